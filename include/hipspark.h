@@ -1,0 +1,279 @@
+/* hipspark.h - C ABI of libhipspark.so: the MI355X (gfx950) operator library behind
+ * minispark_amd.execution.HipExecutionEngine.
+ *
+ * Every entry point replaces one operator loop of the reference (david-westreicher/minispark); the
+ * reference file:line each one stands in for is cited on the declaration.  The reference's only
+ * native boundary is a per-query generated Zig program fed jobs over stdin
+ * (src/mini_spark/execution.py:182-219, zig-src/src/job.zig:3-57); this ABI is what a maintainer would
+ * bind instead (ctypes stub: INTEGRATION.md).
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes; no C++ / torch types cross the boundary.
+ *  - All data pointers are DEVICE pointers unless a parameter is named host_*.  The caller owns all
+ *    memory (inputs, outputs, workspaces); the library never allocates, never synchronises the
+ *    device and never copies to the host, so every call can be captured into a hipGraph.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *  - Return value: 0 = launched ok, nonzero = HS_E_* (bad arguments; nothing was launched);
+ *    hs_last_error() returns a thread-local message.  Data-dependent failures (division by zero,
+ *    i32/f32 overflow at a quantisation point, dictionary capacity exceeded) are reported
+ *    asynchronously in the caller-provided `flags` word(s), see HS_FLAG_*.
+ *  - Rows of a batch are split into `units`: contiguous row ranges [unit_rows[u], unit_rows[u+1]).
+ *    A unit is the reference's job: one BlockFile block for a scan (plan.py:90-93), one shuffle
+ *    partition after a join (plan.py:99-109).  Partial aggregates are produced per unit because the
+ *    reference quantises them to f32/i32 per job (tasks.py:373 -> io.py:87-94).
+ */
+#ifndef HIPSPARK_H
+#define HIPSPARK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HS_VERSION 1
+
+/* ---- error codes (return values) ---- */
+#define HS_OK 0
+#define HS_E_ARG 1      /* malformed argument (null pointer, bad kind, bad program) */
+#define HS_E_LIMIT 2    /* exceeds a compile-time limit (HS_MAX_*) */
+#define HS_E_LAUNCH 3   /* hipLaunchKernel failed */
+
+/* ---- asynchronous status bits written (atomically OR-ed) into a device `flags` word ---- */
+#define HS_FLAG_DIV_ZERO 0x1u      /* reference: ZeroDivisionError raised by operator.truediv/floordiv/mod */
+#define HS_FLAG_INT_OVERFLOW 0x2u  /* reference: OverflowError in int.to_bytes(4, signed=True), io.py:90 */
+#define HS_FLAG_FLT_OVERFLOW 0x4u  /* reference: OverflowError in struct.pack('<f'), io.py:94 */
+#define HS_FLAG_DICT_FULL 0x8u     /* more distinct group keys than the launch's capacity: retry larger */
+#define HS_FLAG_BAD_PROGRAM 0x10u  /* interpreter met an op it cannot run in this kernel */
+#define HS_FLAG_STR_TOO_LONG 0x20u /* a concatenated string exceeds 255 bytes (BlockFile length byte, io.py:18) */
+
+/* ---- storage kinds of a device column ---- */
+#define HS_I32 0 /* INTEGER as stored in a BlockFile */
+#define HS_F32 1 /* FLOAT as stored in a BlockFile */
+#define HS_I64 2 /* TIMESTAMP (us) as stored; also in-flight INTEGER */
+#define HS_F64 3 /* in-flight FLOAT (the reference computes in Python floats) */
+#define HS_STR 4 /* STRING: lens[nrows] + payload bytes + (offs[nrows+1] unless fixed_len >= 0) */
+#define HS_U8 5  /* boolean mask */
+
+typedef struct hs_col {
+    int32_t kind;        /* HS_I32 ... HS_U8 */
+    int32_t fixed_len;   /* HS_STR: byte length shared by every row, or -1 */
+    const void* data;    /* values, or the concatenated string payload */
+    const uint8_t* lens; /* HS_STR: per-row byte length */
+    const int64_t* offs; /* HS_STR with fixed_len < 0: exclusive prefix sum of lens, [nrows+1] */
+} hs_col;
+
+/* ---- expression bytecode ------------------------------------------------------------------------
+ * A stack program over 64-bit cells (f64 or i64; booleans are i64 0/1), produced by
+ * minispark_amd/lowering.py from the reference's expression trees (sql.py:241-303: operator set
+ * + - * / // % == != < <= > >= & |, INT op FLOAT -> FLOAT, '/' always FLOAT; sql.py:166-212 LIKE).
+ * One instruction = 8 bytes: op:8 | sp:8 (stack depth BEFORE the instruction) | a:16 | b:16 | c:16.
+ */
+#define HS_MAX_INS 96
+#define HS_MAX_LIT 32
+#define HS_MAX_POOL 256
+#define HS_MAX_COLS 12
+#define HS_MAX_ACC 16
+#define HS_MAX_STACK 8
+
+enum hs_op {
+    HS_OP_END = 0,
+    HS_OP_LD = 1,       /* a = column slot; push its row value widened to f64 / i64 */
+    HS_OP_LIT = 2,      /* a = literal index; push lit[a] */
+    HS_OP_ADD_F = 3, HS_OP_SUB_F = 4, HS_OP_MUL_F = 5, HS_OP_DIV_F = 6, HS_OP_FLOORDIV_F = 7, HS_OP_MOD_F = 8,
+    HS_OP_ADD_I = 9, HS_OP_SUB_I = 10, HS_OP_MUL_I = 11, HS_OP_FLOORDIV_I = 12, HS_OP_MOD_I = 13,
+    HS_OP_LT_F = 14, HS_OP_LE_F = 15, HS_OP_GT_F = 16, HS_OP_GE_F = 17, HS_OP_EQ_F = 18, HS_OP_NE_F = 19,
+    HS_OP_LT_I = 20, HS_OP_LE_I = 21, HS_OP_GT_I = 22, HS_OP_GE_I = 23, HS_OP_EQ_I = 24, HS_OP_NE_I = 25,
+    HS_OP_AND = 26, HS_OP_OR = 27,
+    HS_OP_I2F = 28,     /* a = 0: convert top of stack i64->f64, a = 1: the cell below it */
+    HS_OP_STRCMP_LIT = 29, /* a = column slot, b = literal index of (pool_off<<32|len), c = cmp (0 lt,1 le,2 gt,3 ge,4 eq,5 ne); push bool */
+    HS_OP_STRCMP_COL = 30, /* a, b = column slots, c = cmp; push bool */
+    HS_OP_LIKE = 31,       /* a = column slot, b = literal index of (pool_off<<32|len) of the LIKE pattern; push bool */
+    HS_OP_FILTER = 32,  /* pop; the row survives iff nonzero (tasks.py:167-177) */
+    HS_OP_AGG = 33,     /* pop; fold into accumulator a (tasks.py:295-310) */
+    HS_OP_OUT = 34,     /* pop; store as output a (hs_eval) */
+    HS_OP_KEY = 35      /* resolve the GROUP BY slot of the surviving rows (between filters and AGGs) */
+};
+
+typedef struct hs_program {
+    uint32_t n_ins;
+    uint32_t n_lit;
+    uint64_t ins[HS_MAX_INS];
+    uint64_t lit[HS_MAX_LIT];
+    uint8_t pool[HS_MAX_POOL]; /* string literals / LIKE patterns */
+} hs_program;
+
+/* ---- aggregate descriptors ---- */
+#define HS_AGG_SUM 0 /* acc = acc + x from 0           (tasks.py:299-302) */
+#define HS_AGG_MIN 1 /* acc = min(acc, x) from MAX_INT (tasks.py:303-306) */
+#define HS_AGG_MAX 2 /* acc = max(acc, x) from MIN_INT (tasks.py:307-310) */
+
+typedef struct hs_agg_spec {
+    int32_t n_acc;
+    uint8_t op[HS_MAX_ACC];     /* HS_AGG_* */
+    uint8_t is_int[HS_MAX_ACC]; /* 1: i64 accumulator (INTEGER aggregate), 0: f64 */
+} hs_agg_spec;
+
+const char* hs_last_error(void);
+int hs_version(void);
+
+/* =================================================================================================
+ * A1  BlockFile decode helpers (reference io.py:112-153: STRING = nrows length bytes + payload)
+ * ===============================================================================================*/
+
+/* Exclusive prefix sum of u8 lengths -> i64 offsets[nrows+1]; also min/max length (for fixed_len
+ * detection) into minmax[2].  ws: hs_scan_ws_bytes(nrows) bytes. */
+size_t hs_scan_ws_bytes(int64_t nrows);
+int hs_str_offsets(void* stream, const uint8_t* lens, int64_t nrows, int64_t* offs, int32_t* minmax, void* ws);
+
+/* =================================================================================================
+ * A4  Expression evaluation (reference tasks.py:32-35 project_column + sql.py:262-266 execute_row)
+ * ===============================================================================================*/
+
+/* Evaluate `prog` for every row; each HS_OP_OUT a stores into outs[a] with kind out_kinds[a]
+ * (HS_F64, HS_I64 or HS_U8 for booleans).  If `sel` != NULL only rows sel[0..nrows) of the input
+ * are evaluated (output row i <- input row sel[i]). */
+int hs_eval(void* stream, const hs_col* cols, int32_t n_cols, const hs_program* prog, const int64_t* sel,
+            int64_t nrows, void* const* outs, const int32_t* out_kinds, int32_t n_outs, uint32_t* flags);
+
+/* =================================================================================================
+ * A3  Filter = stream compaction (reference tasks.py:167-177; zig task_utils.zig:9-51)
+ * ===============================================================================================*/
+
+/* mask[nrows] (u8, nonzero = keep) -> ascending row indices sel[0..*count).  Stable.
+ * ws: hs_scan_ws_bytes(nrows). count is a device int64. */
+int hs_compact(void* stream, const uint8_t* mask, int64_t nrows, int64_t* sel, int64_t* count, void* ws);
+
+/* out[i] = src[idx[i]] for a fixed-width column (elem_bytes in {1,4,8}). */
+int hs_gather_fixed(void* stream, const void* src, int32_t elem_bytes, const int64_t* idx, int64_t n, void* dst);
+/* STRING gather, two steps around an offsets scan: lengths first ... */
+int hs_gather_str_lens(void* stream, const hs_col* src, const int64_t* idx, int64_t n, uint8_t* out_lens);
+/* ... then payload bytes to out_data at out_offs (from hs_str_offsets over out_lens). */
+int hs_gather_str_bytes(void* stream, const hs_col* src, const int64_t* idx, int64_t n, const int64_t* out_offs,
+                        uint8_t* out_data);
+
+/* STRING '+' (reference sql.py:262-266 with operator.add on str; zig utils.zig:118-131).
+ * parts: n_parts columns (HS_STR) or literals (kind = -1, data = host-copied into the launch: the
+ * literal bytes pointer is a DEVICE pointer, fixed_len = its length).  Step 1 lengths, step 2 bytes. */
+int hs_concat_lens(void* stream, const hs_col* parts, int32_t n_parts, int64_t nrows, uint8_t* out_lens,
+                   uint32_t* flags);
+int hs_concat_bytes(void* stream, const hs_col* parts, int32_t n_parts, int64_t nrows, const int64_t* out_offs,
+                    uint8_t* out_data);
+
+/* =================================================================================================
+ * A5/A6  Partial hash aggregate per unit, fused with scan + WHERE + aggregate-argument evaluation
+ *        (reference tasks.py:167-177 + 270-310 before_shuffle branch; quantisation io.py:87-94)
+ * ===============================================================================================*/
+
+/* Geometry of one hs_agg_partial launch (host-side helper, pure arithmetic). */
+typedef struct hs_agg_geom {
+    int32_t group_cap;   /* per-workgroup / per-unit dictionary capacity (power of two) */
+    int32_t chunk_rows;  /* rows per workgroup */
+    int64_t n_chunks;    /* grid size */
+    size_t lds_bytes;    /* dynamic LDS of the main kernel */
+    size_t ws_bytes;     /* workspace bytes */
+} hs_agg_geom;
+
+/* host_unit_rows: HOST copy of the unit boundaries [n_units+1].  Returns HS_E_LIMIT when
+ * group_cap * (n_acc+1) private tables do not fit in LDS (caller then uses hs_agg_partial_global). */
+int hs_agg_partial_geom(const int64_t* host_unit_rows, int64_t n_units, int32_t n_acc, int32_t group_cap,
+                        hs_agg_geom* out);
+
+/* prog: [filter ops ... HS_OP_FILTER]* then [value ops ... HS_OP_AGG a]* ; cols[key_col] is the
+ * GROUP BY column.  unit_rows / unit_chunk0: device arrays [n_units+1] (row boundaries, first chunk of
+ * each unit).  Outputs, all [n_units * group_cap] slot-major per unit:
+ *   out_rep   : a row index holding the slot's key, or -1 for an empty slot
+ *   out_acc   : [n_units * group_cap * n_acc] 64-bit cells, ALREADY QUANTISED like a shuffle-file
+ *               write (FLOAT aggregates rounded to f32 and widened back, INTEGER range-checked)
+ *   out_ngroups[n_units] : occupied slots per unit
+ */
+int hs_agg_partial(void* stream, const hs_col* cols, int32_t n_cols, int32_t key_col, const hs_program* prog,
+                   const hs_agg_spec* spec, const int64_t* unit_rows, const int64_t* unit_chunk0, int64_t n_units,
+                   const hs_agg_geom* geom, int64_t* out_rep, uint64_t* out_acc, int32_t* out_ngroups, void* ws,
+                   uint32_t* flags);
+
+/* Dense pack of the slot arrays: rows of unit u go to [pack_start[u], pack_start[u+1]).
+ * out_cols[a] receives accumulator a as HS_F32 / HS_I32 storage (acc_kinds[a]) = the reference's
+ * shuffle-file column; out_rep the representative rows (gather the key column with them). */
+int hs_agg_pack(void* stream, const int64_t* rep, const uint64_t* acc, const int32_t* ngroups, int64_t n_units,
+                int32_t group_cap, const hs_agg_spec* spec, int64_t* pack_start, int64_t* out_rep,
+                void* const* out_cols, const int32_t* acc_kinds, void* ws);
+
+/* =================================================================================================
+ * A7  Final merge of partial rows (reference tasks.py:290-292 after-shuffle branch)
+ * ===============================================================================================*/
+
+/* Input: a batch of partial rows: key column `key`, accumulator columns acc_cols[n_acc] (HS_F32 /
+ * HS_I32 / HS_F64 / HS_I64), rows grouped by producing unit: unit u = rows [unit_rows[u], unit_rows[u+1]),
+ * keys distinct within a unit.  Partials of a key are folded in unit order in fp64 / i64 (exactly the
+ * reference's order: block order of the shuffle file).  Outputs are DENSE (group i = i-th occupied
+ * dictionary slot) and column-major: out_rep[i] = smallest input row of group i, out_acc[a * cap + i]
+ * = un-rounded 64-bit cell of aggregate a, *out_ngroups = number of groups (<= cap).
+ * ws: hs_agg_merge_ws_bytes(). */
+size_t hs_agg_merge_ws_bytes(int64_t n_rows, int64_t n_units, int32_t cap);
+int hs_agg_merge(void* stream, const hs_col* key, const hs_col* acc_cols, const hs_agg_spec* spec,
+                 const int64_t* unit_rows, int64_t n_units, int64_t n_rows, int32_t cap, int64_t* out_rep,
+                 uint64_t* out_acc, int32_t* out_ngroups, void* ws, uint32_t* flags);
+
+/* =================================================================================================
+ * A6/A9  Hash partitioning (reference tasks.py:347-375 WriteToShufflePartitions.write)
+ * ===============================================================================================*/
+
+/* part[i] = python_hash(key[i]) % n_parts for INTEGER / TIMESTAMP keys (hash(int) = int, -1 -> -2,
+ * floor-mod: tasks.py:362); STRING keys use a fixed 64-bit FNV-1a (the reference's str hash is
+ * seed-randomised, any choice is a valid outcome). */
+int hs_partition_ids(void* stream, const hs_col* key, const int64_t* sel, int64_t nrows, int32_t n_parts,
+                     uint8_t* part);
+/* Stable counting sort of row indices by part id: perm[part_start[p] .. part_start[p+1]) = rows of
+ * partition p in ascending row order.  part_start: device int64[n_parts+1].  ws: hs_partition_ws_bytes. */
+size_t hs_partition_ws_bytes(int64_t nrows, int32_t n_parts);
+int hs_partition_perm(void* stream, const uint8_t* part, int64_t nrows, int32_t n_parts, int64_t* perm,
+                      int64_t* part_start, void* ws);
+
+/* =================================================================================================
+ * A8  Hash join (reference tasks.py:201-240 BroadcastHashJoinTask.generate_chunks)
+ * ===============================================================================================*/
+
+/* Build: open-addressing dictionary over the LEFT key column (table_cap = power of two >= 2*n_left):
+ * table_keys[cap] (u64 key words), table_reps[cap] (a left row holding the slot's key; used to
+ * compare long strings), plus CSR row lists: the left rows of slot s are
+ * rows[slot_start[s] .. slot_start[s+1]) in ASCENDING row order - the reference appends row indices
+ * in row order (tasks.py:216-217).  slot_start: [cap+1].  ws: hs_join_build_ws_bytes(). */
+size_t hs_join_build_ws_bytes(int64_t n_left, int64_t table_cap);
+int hs_join_build(void* stream, const hs_col* left_key, int64_t n_left, int64_t table_cap, uint64_t* table_keys,
+                  int64_t* table_reps, int64_t* slot_start, int64_t* rows, void* ws, uint32_t* flags);
+/* Probe pass 1: match count per right row -> counts[n_right]. */
+int hs_join_count(void* stream, const hs_col* left_key, const hs_col* right_key, int64_t n_right,
+                  int64_t table_cap, const uint64_t* table_keys, const int64_t* table_reps,
+                  const int64_t* slot_start, int64_t* counts);
+/* Probe pass 2 (after an exclusive scan of counts into out_start[n_right+1]): emit (left,right) row
+ * pairs in the reference's order: right rows ascending, for each its left matches ascending
+ * (tasks.py:224-240). */
+int hs_join_fill(void* stream, const hs_col* left_key, const hs_col* right_key, int64_t n_right,
+                 int64_t table_cap, const uint64_t* table_keys, const int64_t* table_reps,
+                 const int64_t* slot_start, const int64_t* rows, const int64_t* out_start, int64_t* out_left,
+                 int64_t* out_right);
+/* Exclusive scan of int64 counts -> start[n+1] (start[n] = total).  ws: hs_scan_ws_bytes(n). */
+int hs_exclusive_scan_i64(void* stream, const int64_t* counts, int64_t n, int64_t* start, void* ws);
+
+/* =================================================================================================
+ * A6/K12  Quantisation at a file write (reference io.py:87-94)
+ * ===============================================================================================*/
+
+/* f64 -> f32 (RNE; finite overflow sets HS_FLAG_FLT_OVERFLOW) or i64 -> i32 (range check sets
+ * HS_FLAG_INT_OVERFLOW).  src_kind in {HS_F64, HS_I64}. */
+int hs_quantise(void* stream, const void* src, int32_t src_kind, int64_t n, void* dst, uint32_t* flags);
+
+/* =================================================================================================
+ * Synthetic TPC-H-shaped data (bench / tests only).  Counter-based: the value of
+ * row i depends only on (seed, column, i), so any row range can be generated independently.
+ * ===============================================================================================*/
+int hs_gen_lineitem(void* stream, uint64_t seed, int64_t row0, int64_t nrows, float* quantity, float* extendedprice,
+                    float* discount, float* tax, int64_t* shipdate, uint8_t* returnflag, uint8_t* flag_lens,
+                    int32_t* orderkey, uint8_t* shipmode_code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIPSPARK_H */

@@ -1,0 +1,783 @@
+// hs_agg.hip - hash group-by / aggregate on gfx950.
+//
+//   k_agg_main   scan + WHERE + aggregate-argument evaluation + per-workgroup partial aggregate
+//                (reference: FilterTask.execute tasks.py:167-177, AggregateTask.execute before_shuffle
+//                branch tasks.py:284-289, fill_aggregators tasks.py:295-310)
+//   k_agg_unit   fixed-order combine of a unit's workgroup partials + quantisation to the shuffle-file
+//                types (reference: is_last emission tasks.py:272-278 -> WriteToShufflePartitions.write
+//                tasks.py:373 -> io.py:87-94)
+//   k_agg_pack   dense partial rows (the reference's shuffle file content)
+//   k_agg_merge_small  final merge of partial rows in unit order (reference: after-shuffle branch
+//                tasks.py:290-292)
+//
+// Design (HBM-bound, no MFMA): every lane streams HS_V=4 consecutive rows per step with 16-byte loads
+// (f32 x4, 2x i64 x2, u8 x4), consecutive lanes take consecutive row quads, so a wave reads 1 KiB
+// per f32 column per instruction.  Group keys are resolved in a per-workgroup LDS dictionary; every
+// lane owns a private accumulator table in LDS laid out [slot][acc][lane] (conflict-free ds_read_b64 /
+// ds_write_b64, no atomics), reduced at the end in a fixed order -> bitwise reproducible results.
+#include "hs_device.h"
+
+#define HS_FUSED_COLS 8 /* numeric column slots preloaded per step */
+
+struct AggMainArgs {
+    HsCols cols;
+    hs_program prog;
+    hs_agg_spec spec;
+    int32_t key_col;
+    int32_t group_cap;
+    int32_t chunk_rows;
+    int32_t pad;
+    const int64_t* unit_rows;
+    const int64_t* unit_chunk0;
+    int64_t n_units;
+    uint64_t* part_keys;  // [n_chunks][GC]
+    int64_t* part_rep;    // [n_chunks][GC]
+    uint64_t* part_acc;   // [n_chunks][GC][n_acc]
+    uint32_t* flags;
+};
+
+// 16-byte global loads ------------------------------------------------------------------------------
+__device__ __forceinline__ void hs_load_quad(const hs_col& c, int64_t row0, uint64_t (&cell)[HS_V]) {
+    switch (c.kind) {
+        case HS_I32: {
+            const int4 v = *reinterpret_cast<const int4*>((const int32_t*)c.data + row0);
+            cell[0] = (uint64_t)(int64_t)v.x;
+            cell[1] = (uint64_t)(int64_t)v.y;
+            cell[2] = (uint64_t)(int64_t)v.z;
+            cell[3] = (uint64_t)(int64_t)v.w;
+            break;
+        }
+        case HS_F32: {
+            const float4 v = *reinterpret_cast<const float4*>((const float*)c.data + row0);
+            cell[0] = hs_d2u((double)v.x);
+            cell[1] = hs_d2u((double)v.y);
+            cell[2] = hs_d2u((double)v.z);
+            cell[3] = hs_d2u((double)v.w);
+            break;
+        }
+        case HS_I64:
+        case HS_F64: {
+            const ulonglong2 v0 = *reinterpret_cast<const ulonglong2*>((const uint64_t*)c.data + row0);
+            const ulonglong2 v1 = *reinterpret_cast<const ulonglong2*>((const uint64_t*)c.data + row0 + 2);
+            cell[0] = v0.x;
+            cell[1] = v0.y;
+            cell[2] = v1.x;
+            cell[3] = v1.y;
+            break;
+        }
+        case HS_U8: {
+            const uint32_t v = *reinterpret_cast<const uint32_t*>((const uint8_t*)c.data + row0);
+            cell[0] = v & 0xff;
+            cell[1] = (v >> 8) & 0xff;
+            cell[2] = (v >> 16) & 0xff;
+            cell[3] = v >> 24;
+            break;
+        }
+        case HS_STR: {
+            // only the GROUP BY column is preloaded, and only when it packs with a power-of-two width
+            if (c.fixed_len == 1) {
+                const uint32_t v = *reinterpret_cast<const uint32_t*>((const uint8_t*)c.data + row0);
+                cell[0] = (1ull << 56) | (v & 0xff);
+                cell[1] = (1ull << 56) | ((v >> 8) & 0xff);
+                cell[2] = (1ull << 56) | ((v >> 16) & 0xff);
+                cell[3] = (1ull << 56) | (v >> 24);
+            } else if (c.fixed_len == 2) {
+                const uint2 v = *reinterpret_cast<const uint2*>((const uint8_t*)c.data + row0 * 2);
+                cell[0] = (2ull << 56) | (v.x & 0xffff);
+                cell[1] = (2ull << 56) | (v.x >> 16);
+                cell[2] = (2ull << 56) | (v.y & 0xffff);
+                cell[3] = (2ull << 56) | (v.y >> 16);
+            } else if (c.fixed_len == 4) {
+                const uint4 v = *reinterpret_cast<const uint4*>((const uint8_t*)c.data + row0 * 4);
+                cell[0] = (4ull << 56) | v.x;
+                cell[1] = (4ull << 56) | v.y;
+                cell[2] = (4ull << 56) | v.z;
+                cell[3] = (4ull << 56) | v.w;
+            }
+            break;
+        }
+        default: break;
+    }
+}
+
+__device__ __forceinline__ bool hs_str_preloads(const hs_col& c) {
+    return c.kind == HS_STR && (c.fixed_len == 1 || c.fixed_len == 2 || c.fixed_len == 4);
+}
+
+template <bool HASHED>
+struct AggSink {
+    const AggMainArgs& A;
+    uint64_t cell[HS_FUSED_COLS][HS_V];
+    int64_t row0;
+    bool alive[HS_V];
+    int slot[HS_V];
+    uint64_t* dkeys;
+    int64_t* dreps;
+    uint64_t* tbl;
+    uint32_t tid, nthr;
+    uint32_t err;
+
+    __device__ __forceinline__ AggSink(const AggMainArgs& a) : A(a) {}
+
+    __device__ __forceinline__ void load(uint32_t s, uint64_t (&dst)[HS_V]) const {
+        switch (s) {
+#define HS_CASE(K)                                                      \
+    case K:                                                             \
+        _Pragma("unroll") for (int j = 0; j < HS_V; ++j) dst[j] = cell[K][j]; \
+        break;
+            HS_CASE(0) HS_CASE(1) HS_CASE(2) HS_CASE(3) HS_CASE(4) HS_CASE(5) HS_CASE(6) HS_CASE(7)
+#undef HS_CASE
+            default: break;
+        }
+    }
+    __device__ __forceinline__ uint64_t load(uint32_t s, int j) const {
+        uint64_t tmp[HS_V];
+        load(s, tmp);
+        return tmp[j];
+    }
+    __device__ __forceinline__ bool live(int j) const { return alive[j]; }
+    __device__ __forceinline__ int64_t row(int j) const { return row0 + j; }
+    __device__ __forceinline__ void filter(int j, bool keep) { alive[j] = alive[j] && keep; }
+    __device__ __forceinline__ void out(uint32_t, int, uint64_t) {}
+
+    __device__ __forceinline__ void key() {
+        const hs_col& kc = A.cols.c[A.key_col];
+        uint64_t kcell[HS_V];
+        const bool pre = (kc.kind != HS_STR) || hs_str_preloads(kc);
+        if (pre) load((uint32_t)A.key_col, kcell);
+        const uint32_t mask = (uint32_t)A.group_cap - 1;
+#pragma unroll
+        for (int j = 0; j < HS_V; ++j) {
+            slot[j] = 0;
+            if (alive[j]) {
+                int s;
+                if constexpr (HASHED) {
+                    s = hs_dict_upsert_rows(dreps, mask, kc, hs_key_at(kc, row0 + j), row0 + j);
+                } else {
+                    uint64_t k;
+                    if (kc.kind == HS_STR)
+                        k = pre ? kcell[j] : hs_key_at(kc, row0 + j);
+                    else
+                        k = hs_key_from_cell(kc.kind, kcell[j]);
+                    s = hs_dict_upsert_word(dkeys, dreps, mask, k, row0 + j);
+                }
+                if (s < 0) {
+                    err |= HS_FLAG_DICT_FULL;
+                    alive[j] = false;
+                    s = 0;
+                }
+                slot[j] = s;
+            }
+        }
+    }
+
+    __device__ __forceinline__ void agg(uint32_t a, int j, uint64_t x) {
+        if (alive[j]) {
+            const uint32_t idx = ((uint32_t)slot[j] * (uint32_t)A.spec.n_acc + a) * nthr + tid;
+            tbl[idx] = hs_acc_fold(A.spec.op[a], A.spec.is_int[a] != 0, tbl[idx], x);
+        }
+    }
+};
+
+template <int D, typename Sink>
+__device__ __forceinline__ void hs_run_quad(const hs_program& P, const HsCols& C, Sink& sink, uint32_t& err) {
+    // same interpreter as hs_run, but LD moves the whole row quad with one slot switch
+    uint64_t st[D][HS_V];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+        for (int j = 0; j < HS_V; ++j) st[d][j] = 0;
+    for (uint32_t pc = 0; pc < P.n_ins; ++pc) {
+        const uint64_t w = P.ins[pc];
+        const uint32_t sp = hs_ins_sp(w);
+        if (hs_ins_op(w) == HS_OP_LD) {
+            uint64_t tmp[HS_V];
+            sink.load(hs_ins_a(w), tmp);
+            switch (sp) {
+#define HS_PUSH(K)                                                        \
+    case K:                                                               \
+        if constexpr (K < D) {                                            \
+            _Pragma("unroll") for (int j = 0; j < HS_V; ++j) st[K][j] = tmp[j]; \
+        }                                                                 \
+        break;
+                HS_PUSH(0) HS_PUSH(1) HS_PUSH(2) HS_PUSH(3) HS_PUSH(4) HS_PUSH(5) HS_PUSH(6) HS_PUSH(7)
+#undef HS_PUSH
+                default: err |= HS_FLAG_BAD_PROGRAM; break;
+            }
+            continue;
+        }
+        switch (sp) {
+            case 0: hs_exec_at<0, D, HS_V>(w, P, C, st, sink, err); break;
+            case 1: hs_exec_at<1, D, HS_V>(w, P, C, st, sink, err); break;
+            case 2: hs_exec_at<2, D, HS_V>(w, P, C, st, sink, err); break;
+            case 3: hs_exec_at<3, D, HS_V>(w, P, C, st, sink, err); break;
+            case 4: hs_exec_at<4, D, HS_V>(w, P, C, st, sink, err); break;
+            default:
+                if constexpr (D > 4) {
+                    switch (sp) {
+                        case 5: hs_exec_at<5, D, HS_V>(w, P, C, st, sink, err); break;
+                        case 6: hs_exec_at<6, D, HS_V>(w, P, C, st, sink, err); break;
+                        case 7: hs_exec_at<7, D, HS_V>(w, P, C, st, sink, err); break;
+                        case 8: hs_exec_at<8, D, HS_V>(w, P, C, st, sink, err); break;
+                        default: err |= HS_FLAG_BAD_PROGRAM; break;
+                    }
+                } else {
+                    err |= HS_FLAG_BAD_PROGRAM;
+                }
+                break;
+        }
+    }
+}
+
+// 64-bit wave shuffle-down
+__device__ __forceinline__ uint64_t hs_shfl_down64(uint64_t v, int delta) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl_down(lo, delta, HS_WAVE);
+    hi = __shfl_down(hi, delta, HS_WAVE);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+template <bool HASHED, int D>
+__global__ void __launch_bounds__(256) k_agg_main(const AggMainArgs A_kernarg) {
+    HS_KERNARG(AggMainArgs, A);
+    extern __shared__ __align__(16) uint64_t lds[];
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+    const int GC = A.group_cap;
+    const int NA = A.spec.n_acc;
+    uint64_t* dkeys = lds;
+    int64_t* dreps = (int64_t*)(lds + GC);
+    uint64_t* tbl = lds + 2 * GC;
+
+    // which unit does this chunk belong to?  (binary search over the first-chunk table)
+    const int64_t chunk = blockIdx.x;
+    int64_t lo = 0, hi = A.n_units;  // invariant: unit_chunk0[lo] <= chunk < unit_chunk0[hi]
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (A.unit_chunk0[mid] <= chunk) lo = mid; else hi = mid;
+    }
+    const int64_t u = lo;
+    const int64_t us = A.unit_rows[u], ue = A.unit_rows[u + 1];
+    const int64_t anchor = us & ~(int64_t)(HS_V - 1);
+    const int64_t c0 = anchor + (chunk - A.unit_chunk0[u]) * (int64_t)A.chunk_rows;
+    int64_t c1 = c0 + A.chunk_rows;
+    if (c1 > ue) c1 = ue;
+
+    for (int i = tid; i < GC; i += nthr) {
+        dkeys[i] = HS_EMPTY_KEY;
+        dreps[i] = -1;
+    }
+    for (int cellid = 0; cellid < GC * NA; ++cellid)
+        tbl[(uint32_t)cellid * nthr + tid] = hs_acc_identity(A.spec.op[cellid % NA], A.spec.is_int[cellid % NA] != 0);
+    __syncthreads();
+
+    AggSink<HASHED> sink(A);
+    sink.dkeys = dkeys;
+    sink.dreps = dreps;
+    sink.tbl = tbl;
+    sink.tid = tid;
+    sink.nthr = nthr;
+    sink.err = 0;
+    uint32_t err = 0;
+
+    const int ncols = A.cols.n < HS_FUSED_COLS ? A.cols.n : HS_FUSED_COLS;
+    for (int64_t base = c0 + (int64_t)tid * HS_V; base < c1; base += (int64_t)nthr * HS_V) {
+#pragma unroll
+        for (int c = 0; c < HS_FUSED_COLS; ++c) {
+            if (c < ncols) {
+                const hs_col& col = A.cols.c[c];
+                if (col.kind != HS_STR || (c == A.key_col && hs_str_preloads(col))) hs_load_quad(col, base, sink.cell[c]);
+            }
+        }
+        sink.row0 = base;
+#pragma unroll
+        for (int j = 0; j < HS_V; ++j) {
+            const int64_t r = base + j;
+            sink.alive[j] = (r >= us) && (r < c1);
+            sink.slot[j] = 0;
+        }
+        hs_run_quad<D>(A.prog, A.cols, sink, err);
+    }
+    err |= sink.err;
+    __syncthreads();
+
+    // fixed-order reduction of the private tables: lanes stride the workgroup, then a shuffle tree
+    const uint32_t wave = tid / HS_WAVE, lane = tid % HS_WAVE, nwaves = nthr / HS_WAVE;
+    for (uint32_t cellid = wave; cellid < (uint32_t)(GC * NA); cellid += nwaves) {
+        const uint32_t s = cellid / NA, a = cellid % NA;
+        if (dreps[s] < 0) continue;  // wave-uniform
+        const uint32_t op = A.spec.op[a];
+        const bool is_int = A.spec.is_int[a] != 0;
+        uint64_t v = hs_acc_identity(op, is_int);
+        for (uint32_t t = lane; t < nthr; t += HS_WAVE) v = hs_acc_fold(op, is_int, v, tbl[cellid * nthr + t]);
+#pragma unroll
+        for (int d = HS_WAVE / 2; d >= 1; d >>= 1) v = hs_acc_fold(op, is_int, v, hs_shfl_down64(v, d));
+        if (lane == 0) A.part_acc[((int64_t)chunk * GC + s) * NA + a] = v;
+    }
+    for (int i = tid; i < GC; i += nthr) {
+        A.part_keys[chunk * GC + i] = dkeys[i];
+        A.part_rep[chunk * GC + i] = dreps[i];
+    }
+    if (err) atomicOr(A.flags, err);
+}
+
+// --------------------------------------------------------------------------------------------------
+struct AggUnitArgs {
+    hs_col key;
+    hs_agg_spec spec;
+    int32_t group_cap;
+    int32_t hashed;
+    const int64_t* unit_chunk0;
+    const uint64_t* part_keys;
+    const int64_t* part_rep;
+    const uint64_t* part_acc;
+    int64_t* out_rep;      // [n_units][GC]
+    uint64_t* out_acc;     // [n_units][GC][NA] quantised
+    int32_t* out_ngroups;  // [n_units]
+    uint32_t* flags;
+};
+
+__global__ void __launch_bounds__(256) k_agg_unit(const AggUnitArgs A_kernarg) {
+    HS_KERNARG(AggUnitArgs, A);
+    extern __shared__ __align__(16) uint64_t lds[];
+    const int GC = A.group_cap, NA = A.spec.n_acc;
+    uint64_t* ukeys = lds;
+    int64_t* ureps = (int64_t*)(lds + GC);
+    uint64_t* uacc = lds + 2 * GC;
+    int* map = (int*)(uacc + GC * NA);
+    __shared__ int s_count;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int64_t u = blockIdx.x;
+    uint32_t err = 0;
+
+    for (int i = tid; i < GC; i += nthr) {
+        ukeys[i] = HS_EMPTY_KEY;
+        ureps[i] = -1;
+    }
+    for (int i = tid; i < GC * NA; i += nthr) uacc[i] = hs_acc_identity(A.spec.op[i % NA], A.spec.is_int[i % NA] != 0);
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+
+    const uint32_t mask = (uint32_t)GC - 1;
+    for (int64_t c = A.unit_chunk0[u]; c < A.unit_chunk0[u + 1]; ++c) {  // chunk order = row order: fixed
+        for (int s = tid; s < GC; s += nthr) {
+            const int64_t rep = A.part_rep[c * GC + s];
+            int m = -1;
+            if (rep >= 0) {
+                m = A.hashed ? hs_dict_upsert_rows(ureps, mask, A.key, hs_key_at(A.key, rep), rep)
+                             : hs_dict_upsert_word(ukeys, ureps, mask, A.part_keys[c * GC + s], rep);
+                if (m < 0) err |= HS_FLAG_DICT_FULL;
+            }
+            map[s] = m;
+        }
+        __syncthreads();
+        for (int i = tid; i < GC * NA; i += nthr) {
+            const int s = i / NA, a = i % NA;
+            const int m = map[s];
+            if (m >= 0)
+                uacc[m * NA + a] = hs_acc_fold(A.spec.op[a], A.spec.is_int[a] != 0, uacc[m * NA + a],
+                                               A.part_acc[(c * GC + s) * NA + a]);
+        }
+        __syncthreads();
+    }
+    for (int s = tid; s < GC; s += nthr) {
+        const int64_t rep = ureps[s];
+        A.out_rep[u * GC + s] = rep;
+        if (rep >= 0) atomicAdd(&s_count, 1);
+    }
+    for (int i = tid; i < GC * NA; i += nthr) {
+        const int a = i % NA;
+        A.out_acc[u * (int64_t)GC * NA + i] = hs_quantise_cell(A.spec.is_int[a] != 0, uacc[i], err);
+    }
+    __syncthreads();
+    if (tid == 0) A.out_ngroups[u] = s_count;
+    // only report quantisation overflow for occupied slots: empty slots hold identities, never overflow
+    if (err) atomicOr(A.flags, err);
+}
+
+// --------------------------------------------------------------------------------------------------
+struct AggPackArgs {
+    const int64_t* rep;
+    const uint64_t* acc;
+    const int32_t* ngroups;
+    int64_t n_units;
+    int32_t group_cap;
+    int32_t n_acc;
+    int64_t* pack_start;  // [n_units+1]
+    int64_t* out_rep;
+    void* out_cols[HS_MAX_ACC];
+    int32_t acc_kinds[HS_MAX_ACC];
+};
+
+// single workgroup: scan of per-unit group counts, then every thread packs whole units
+__global__ void __launch_bounds__(256) k_agg_pack(const AggPackArgs A_kernarg) {
+    HS_KERNARG(AggPackArgs, A);
+    __shared__ int64_t s_scan[256];
+    __shared__ int64_t s_base;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int64_t u0 = 0; u0 < A.n_units; u0 += 256) {
+        const int64_t u = u0 + tid;
+        const int64_t n = u < A.n_units ? A.ngroups[u] : 0;
+        s_scan[tid] = n;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {  // Hillis-Steele inclusive scan
+            const int64_t v = tid >= d ? s_scan[tid - d] : 0;
+            __syncthreads();
+            s_scan[tid] += v;
+            __syncthreads();
+        }
+        const int64_t start = s_base + s_scan[tid] - n;
+        if (u < A.n_units) {
+            A.pack_start[u] = start;
+            int64_t o = start;
+            for (int s = 0; s < A.group_cap; ++s) {
+                const int64_t rep = A.rep[u * A.group_cap + s];
+                if (rep < 0) continue;
+                A.out_rep[o] = rep;
+                for (int a = 0; a < A.n_acc; ++a) {
+                    const uint64_t cell = A.acc[(u * A.group_cap + s) * A.n_acc + a];
+                    switch (A.acc_kinds[a]) {
+                        case HS_F32: ((float*)A.out_cols[a])[o] = (float)hs_u2d(cell); break;
+                        case HS_I32: ((int32_t*)A.out_cols[a])[o] = (int32_t)(int64_t)cell; break;
+                        default: ((uint64_t*)A.out_cols[a])[o] = cell; break;
+                    }
+                }
+                ++o;
+            }
+        }
+        __syncthreads();
+        if (tid == 255) s_base += s_scan[255];
+        __syncthreads();
+    }
+    if (tid == 0) A.pack_start[A.n_units] = s_base;
+}
+
+// --------------------------------------------------------------------------------------------------
+struct AggMergeArgs {
+    hs_col key;
+    hs_col acc_cols[HS_MAX_ACC];
+    hs_agg_spec spec;
+    int64_t n_rows;
+    int32_t cap;
+    int32_t hashed;
+    int64_t* out_rep;
+    uint64_t* out_acc;
+    int32_t* out_ngroups;
+    uint32_t* flags;
+};
+
+// Final merge, everything staged in LDS: rows ascend in unit order, so folding the rows of a slot in
+// ascending row order IS the reference's order (0 + p_block0 + p_block1 + ... in fp64).
+// Outputs are dense (occupied slots in ascending slot order) and column-major: out_acc[a * cap + i].
+__global__ void __launch_bounds__(1024) k_agg_merge_small(const AggMergeArgs A_kernarg) {
+    HS_KERNARG(AggMergeArgs, A);
+    extern __shared__ __align__(16) uint64_t lds[];
+    const int NA = A.spec.n_acc;
+    const int cap = A.cap;
+    const int64_t n = A.n_rows;
+    uint64_t* dkeys = lds;
+    int64_t* dreps = (int64_t*)(lds + cap);
+    uint64_t* cells = lds + 2 * cap;              // [n][NA]
+    int32_t* rslot = (int32_t*)(cells + n * NA);  // [n]
+    int32_t* dense = rslot + n;                   // [cap] slot -> dense output row
+    __shared__ int s_scan[1024];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    uint32_t err = 0;
+
+    for (int i = tid; i < cap; i += nthr) {
+        dkeys[i] = HS_EMPTY_KEY;
+        dreps[i] = -1;
+    }
+    __syncthreads();
+    const uint32_t mask = (uint32_t)cap - 1;
+    for (int64_t r = tid; r < n; r += nthr) {
+        const uint64_t k = hs_key_at(A.key, r);
+        int s = A.hashed ? hs_dict_upsert_rows(dreps, mask, A.key, k, r) : hs_dict_upsert_word(dkeys, dreps, mask, k, r);
+        if (s < 0) {
+            err |= HS_FLAG_DICT_FULL;
+            s = -1;
+        }
+        rslot[r] = s;
+        for (int a = 0; a < NA; ++a) cells[r * NA + a] = hs_load_cell(A.acc_cols[a], r);
+    }
+    __syncthreads();
+    // dense numbering of the occupied slots (ascending slot order): per-thread ranges + block scan
+    const int per = (cap + nthr - 1) / nthr;
+    const int s0 = tid * per, s1 = (s0 + per) < cap ? (s0 + per) : cap;
+    int mine = 0;
+    for (int s = s0; s < s1; ++s) mine += dreps[s] >= 0;
+    s_scan[tid] = mine;
+    __syncthreads();
+    for (int d = 1; d < nthr; d <<= 1) {
+        const int t = tid >= d ? s_scan[tid - d] : 0;
+        __syncthreads();
+        s_scan[tid] += t;
+        __syncthreads();
+    }
+    int run = s_scan[tid] - mine;
+    for (int s = s0; s < s1; ++s) dense[s] = dreps[s] >= 0 ? run++ : -1;
+    __syncthreads();
+    if (tid == 0) *A.out_ngroups = s_scan[nthr - 1];
+
+    for (int i = tid; i < cap * NA; i += nthr) {
+        const int s = i / NA, a = i % NA;
+        if (dense[s] < 0) continue;
+        const uint32_t op = A.spec.op[a];
+        const bool is_int = A.spec.is_int[a] != 0;
+        uint64_t v = hs_acc_identity(op, is_int);
+        for (int64_t r = 0; r < n; ++r)
+            if (rslot[r] == s) v = hs_acc_fold(op, is_int, v, cells[r * NA + a]);
+        A.out_acc[(int64_t)a * cap + dense[s]] = v;
+    }
+    for (int s = tid; s < cap; s += nthr) {
+        if (dense[s] < 0) continue;
+        // representative = the smallest row of the slot, so the output does not depend on insert races
+        int64_t rep = -1;
+        for (int64_t r = 0; r < n; ++r)
+            if (rslot[r] == s) {
+                rep = r;
+                break;
+            }
+        A.out_rep[dense[s]] = rep;
+    }
+    if (err) atomicOr(A.flags, err);
+}
+
+// ==================================================================================================
+// host launchers (C ABI)
+// ==================================================================================================
+extern thread_local char g_hs_err[256];
+void hs_set_error(const char* fmt, ...);
+
+static int fill_cols(HsCols& dst, const hs_col* cols, int32_t n) {
+    if (n < 0 || n > HS_MAX_COLS) {
+        hs_set_error("n_cols=%d exceeds HS_MAX_COLS=%d", n, HS_MAX_COLS);
+        return HS_E_LIMIT;
+    }
+    dst.n = n;
+    dst.pad = 0;
+    for (int i = 0; i < n; ++i) dst.c[i] = cols[i];
+    for (int i = n; i < HS_MAX_COLS; ++i) dst.c[i] = hs_col{HS_U8, -1, nullptr, nullptr, nullptr};
+    return HS_OK;
+}
+
+static int program_depth(const hs_program* p) {
+    int d = 0;
+    for (uint32_t i = 0; i < p->n_ins; ++i) {
+        int sp = (int)((p->ins[i] >> 8) & 0xff);
+        int op = (int)(p->ins[i] & 0xff);
+        int after = sp;
+        if (op == HS_OP_LD || op == HS_OP_LIT || op == HS_OP_STRCMP_LIT || op == HS_OP_STRCMP_COL || op == HS_OP_LIKE)
+            after = sp + 1;
+        if (after > d) d = after;
+        if (sp > d) d = sp;
+    }
+    return d;
+}
+
+static constexpr int HS_AGG_WG = 256;
+static constexpr size_t HS_LDS_BUDGET = 64 * 1024;  // dynamic LDS per workgroup kept <= 64 KiB (>= 2 WG / CU)
+
+extern "C" int hs_agg_partial_geom(const int64_t* host_unit_rows, int64_t n_units, int32_t n_acc, int32_t group_cap,
+                                   hs_agg_geom* out) {
+    if (!host_unit_rows || !out || n_units < 0 || n_acc < 0 || n_acc > HS_MAX_ACC || group_cap < 1 ||
+        (group_cap & (group_cap - 1))) {
+        hs_set_error("hs_agg_partial_geom: bad arguments");
+        return HS_E_ARG;
+    }
+    const size_t lds = (size_t)group_cap * 16 + (size_t)group_cap * (size_t)n_acc * HS_AGG_WG * 8;
+    if (lds > HS_LDS_BUDGET) {
+        hs_set_error("hs_agg_partial_geom: group_cap=%d x n_acc=%d private tables need %zu B LDS (> %zu)", group_cap,
+                     n_acc, lds, HS_LDS_BUDGET);
+        return HS_E_LIMIT;
+    }
+    int64_t max_rows = 0, total = 0;
+    for (int64_t u = 0; u < n_units; ++u) {
+        const int64_t r = host_unit_rows[u + 1] - host_unit_rows[u];
+        if (r < 0) {
+            hs_set_error("hs_agg_partial_geom: unit_rows not ascending at %lld", (long long)u);
+            return HS_E_ARG;
+        }
+        if (r > max_rows) max_rows = r;
+        total += r;
+    }
+    // rows per workgroup: a multiple of WG*V; ~16 steps per lane when there is enough data to fill the
+    // chip (256 CUs x 2 WGs) several times over, fewer for small inputs
+    const int64_t step = (int64_t)HS_AGG_WG * HS_V;
+    int64_t chunk = step * 16;
+    while (chunk > step && total / chunk < 2048) chunk /= 2;
+    int64_t n_chunks = 0;
+    for (int64_t u = 0; u < n_units; ++u) {
+        const int64_t anchor = host_unit_rows[u] & ~(int64_t)(HS_V - 1);
+        const int64_t span = host_unit_rows[u + 1] - anchor;
+        n_chunks += span > 0 ? (span + chunk - 1) / chunk : 0;
+    }
+    out->group_cap = group_cap;
+    out->chunk_rows = (int32_t)chunk;
+    out->n_chunks = n_chunks;
+    out->lds_bytes = lds;
+    const size_t slots = (size_t)n_chunks * group_cap;
+    out->ws_bytes = slots * 16 + slots * (size_t)n_acc * 8 + 256;
+    return HS_OK;
+}
+
+extern "C" int hs_agg_partial(void* stream, const hs_col* cols, int32_t n_cols, int32_t key_col,
+                              const hs_program* prog, const hs_agg_spec* spec, const int64_t* unit_rows,
+                              const int64_t* unit_chunk0, int64_t n_units, const hs_agg_geom* geom, int64_t* out_rep,
+                              uint64_t* out_acc, int32_t* out_ngroups, void* ws, uint32_t* flags) {
+    if (!cols || !prog || !spec || !unit_rows || !unit_chunk0 || !geom || !out_rep || !out_acc || !out_ngroups ||
+        !ws || !flags || key_col < 0 || key_col >= n_cols) {
+        hs_set_error("hs_agg_partial: null or out-of-range argument");
+        return HS_E_ARG;
+    }
+    if (prog->n_ins > HS_MAX_INS || prog->n_lit > HS_MAX_LIT) {
+        hs_set_error("hs_agg_partial: program too long");
+        return HS_E_LIMIT;
+    }
+    if (n_units == 0 || geom->n_chunks == 0) return HS_OK;
+    AggMainArgs A;
+    int rc = fill_cols(A.cols, cols, n_cols);
+    if (rc) return rc;
+    // numeric columns and a preloaded key must sit in the first HS_FUSED_COLS slots
+    for (int i = HS_FUSED_COLS; i < n_cols; ++i) {
+        if (cols[i].kind != HS_STR || i == key_col) {
+            hs_set_error("hs_agg_partial: more than %d numeric column slots", HS_FUSED_COLS);
+            return HS_E_LIMIT;
+        }
+    }
+    A.prog = *prog;
+    A.spec = *spec;
+    A.key_col = key_col;
+    A.group_cap = geom->group_cap;
+    A.chunk_rows = geom->chunk_rows;
+    A.pad = 0;
+    A.unit_rows = unit_rows;
+    A.unit_chunk0 = unit_chunk0;
+    A.n_units = n_units;
+    const size_t slots = (size_t)geom->n_chunks * geom->group_cap;
+    A.part_keys = (uint64_t*)ws;
+    A.part_rep = (int64_t*)((char*)ws + slots * 8);
+    A.part_acc = (uint64_t*)((char*)ws + slots * 16);
+    A.flags = flags;
+    const bool hashed = !hs_col_packs(cols[key_col]);
+    const int depth = program_depth(prog);
+    if (depth > HS_MAX_STACK) {
+        hs_set_error("hs_agg_partial: expression stack depth %d > %d", depth, HS_MAX_STACK);
+        return HS_E_LIMIT;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)geom->n_chunks), block(HS_AGG_WG);
+    if (geom->n_chunks > 0x7fffffffll) {
+        hs_set_error("hs_agg_partial: too many chunks");
+        return HS_E_LIMIT;
+    }
+    if (hashed) {
+        hipLaunchKernelGGL((k_agg_main<true, 8>), grid, block, geom->lds_bytes, s, A);
+    } else if (depth <= 4) {
+        hipLaunchKernelGGL((k_agg_main<false, 4>), grid, block, geom->lds_bytes, s, A);
+    } else {
+        hipLaunchKernelGGL((k_agg_main<false, 8>), grid, block, geom->lds_bytes, s, A);
+    }
+    AggUnitArgs U;
+    U.key = cols[key_col];
+    U.spec = *spec;
+    U.group_cap = geom->group_cap;
+    U.hashed = hashed ? 1 : 0;
+    U.unit_chunk0 = unit_chunk0;
+    U.part_keys = A.part_keys;
+    U.part_rep = A.part_rep;
+    U.part_acc = A.part_acc;
+    U.out_rep = out_rep;
+    U.out_acc = out_acc;
+    U.out_ngroups = out_ngroups;
+    U.flags = flags;
+    const size_t ulds = (size_t)geom->group_cap * 16 + (size_t)geom->group_cap * spec->n_acc * 8 + (size_t)geom->group_cap * 4;
+    hipLaunchKernelGGL(k_agg_unit, dim3((unsigned)n_units), dim3(256), ulds, s, U);
+    if (hipGetLastError() != hipSuccess) {
+        hs_set_error("hs_agg_partial: kernel launch failed");
+        return HS_E_LAUNCH;
+    }
+    return HS_OK;
+}
+
+extern "C" int hs_agg_pack(void* stream, const int64_t* rep, const uint64_t* acc, const int32_t* ngroups,
+                           int64_t n_units, int32_t group_cap, const hs_agg_spec* spec, int64_t* pack_start,
+                           int64_t* out_rep, void* const* out_cols, const int32_t* acc_kinds, void* ws) {
+    (void)ws;
+    if (!rep || !acc || !ngroups || !spec || !pack_start || !out_rep || (spec->n_acc > 0 && (!out_cols || !acc_kinds))) {
+        hs_set_error("hs_agg_pack: null argument");
+        return HS_E_ARG;
+    }
+    AggPackArgs A;
+    A.rep = rep;
+    A.acc = acc;
+    A.ngroups = ngroups;
+    A.n_units = n_units;
+    A.group_cap = group_cap;
+    A.n_acc = spec->n_acc;
+    A.pack_start = pack_start;
+    A.out_rep = out_rep;
+    for (int a = 0; a < HS_MAX_ACC; ++a) {
+        A.out_cols[a] = a < spec->n_acc ? out_cols[a] : nullptr;
+        A.acc_kinds[a] = a < spec->n_acc ? acc_kinds[a] : HS_F64;
+    }
+    hipLaunchKernelGGL(k_agg_pack, dim3(1), dim3(256), 0, (hipStream_t)stream, A);
+    if (hipGetLastError() != hipSuccess) {
+        hs_set_error("hs_agg_pack: kernel launch failed");
+        return HS_E_LAUNCH;
+    }
+    return HS_OK;
+}
+
+static constexpr size_t HS_MERGE_LDS_MAX = 150 * 1024;
+
+extern "C" size_t hs_agg_merge_ws_bytes(int64_t n_rows, int64_t n_units, int32_t cap) {
+    (void)n_rows;
+    (void)n_units;
+    (void)cap;
+    return 256;
+}
+
+extern "C" int hs_agg_merge(void* stream, const hs_col* key, const hs_col* acc_cols, const hs_agg_spec* spec,
+                            const int64_t* unit_rows, int64_t n_units, int64_t n_rows, int32_t cap, int64_t* out_rep,
+                            uint64_t* out_acc, int32_t* out_ngroups, void* ws, uint32_t* flags) {
+    (void)unit_rows;
+    (void)n_units;
+    (void)ws;
+    if (!key || !spec || !out_rep || !out_acc || !out_ngroups || !flags || cap < 1 || (cap & (cap - 1)) ||
+        (spec->n_acc > 0 && !acc_cols)) {
+        hs_set_error("hs_agg_merge: bad arguments");
+        return HS_E_ARG;
+    }
+    const size_t lds = (size_t)cap * 16 + (size_t)n_rows * spec->n_acc * 8 + (size_t)n_rows * 4 + (size_t)cap * 4 + 16;
+    if (lds > HS_MERGE_LDS_MAX) {
+        hs_set_error("hs_agg_merge: %lld partial rows x %d accumulators need %zu B LDS (> %zu): use the unit-stepped merge",
+                     (long long)n_rows, spec->n_acc, lds, HS_MERGE_LDS_MAX);
+        return HS_E_LIMIT;
+    }
+    AggMergeArgs A;
+    A.key = *key;
+    for (int a = 0; a < HS_MAX_ACC; ++a)
+        A.acc_cols[a] = a < spec->n_acc ? acc_cols[a] : hs_col{HS_U8, -1, nullptr, nullptr, nullptr};
+    A.spec = *spec;
+    A.n_rows = n_rows;
+    A.cap = cap;
+    A.hashed = hs_col_packs(*key) ? 0 : 1;
+    A.out_rep = out_rep;
+    A.out_acc = out_acc;
+    A.out_ngroups = out_ngroups;
+    A.flags = flags;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)k_agg_merge_small, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)HS_MERGE_LDS_MAX);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_agg_merge_small, dim3(1), dim3(1024), lds, (hipStream_t)stream, A);
+    if (hipGetLastError() != hipSuccess) {
+        hs_set_error("hs_agg_merge: kernel launch failed");
+        return HS_E_LAUNCH;
+    }
+    return HS_OK;
+}

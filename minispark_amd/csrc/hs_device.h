@@ -1,0 +1,514 @@
+// hs_device.h - device-side building blocks shared by the gfx950 kernels of libhipspark:
+//   * raw column access (BlockFile storage kinds -> 64-bit in-flight cells),
+//   * the expression interpreter (stack program, see include/hipspark.h),
+//   * group-key words and the LDS dictionary.
+//
+// Semantics follow the reference's row evaluator: values are widened to Python float (fp64) /
+// Python int (i64 here) when read (src/mini_spark/io.py:129-149), operators are Python's
+// (src/mini_spark/sql.py:215-231,262-266), booleans are 0/1.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hipspark.h"
+
+#define HS_WAVE 64
+#define HS_V 4 /* rows per lane per step in the vectorised kernels */
+
+static constexpr uint64_t HS_EMPTY_KEY = 0x8000000000000000ull;
+
+// Big by-value kernel arguments (programs, column tables) are indexed dynamically.  hipcc copies a
+// by-value struct argument into private (scratch) memory as soon as it is indexed with a run-time
+// value, so kernels read their single struct argument straight from the kernarg segment instead:
+// explicit arguments start at offset 0 of that segment, and uniform reads of it become s_load.
+#define HS_KERNARG(T, name) \
+    (void)name##_kernarg;   \
+    const T& name = *(const T*)__builtin_amdgcn_kernarg_segment_ptr()
+
+struct HsCols {
+    int32_t n;
+    int32_t pad;
+    hs_col c[HS_MAX_COLS];
+};
+
+__device__ __forceinline__ double hs_u2d(uint64_t u) { return __longlong_as_double((long long)u); }
+__device__ __forceinline__ uint64_t hs_d2u(double d) { return (uint64_t)__double_as_longlong(d); }
+
+// ---- instruction fields --------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t hs_ins_op(uint64_t w) { return (uint32_t)(w & 0xff); }
+__device__ __forceinline__ uint32_t hs_ins_sp(uint64_t w) { return (uint32_t)((w >> 8) & 0xff); }
+__device__ __forceinline__ uint32_t hs_ins_a(uint64_t w) { return (uint32_t)((w >> 16) & 0xffff); }
+__device__ __forceinline__ uint32_t hs_ins_b(uint64_t w) { return (uint32_t)((w >> 32) & 0xffff); }
+__device__ __forceinline__ uint32_t hs_ins_c(uint64_t w) { return (uint32_t)((w >> 48) & 0xffff); }
+
+// ---- one row of a fixed-width column, widened to a 64-bit cell ---------------------------------------
+__device__ __forceinline__ uint64_t hs_load_cell(const hs_col& c, int64_t row) {
+    switch (c.kind) {
+        case HS_I32: return (uint64_t)(int64_t)((const int32_t*)c.data)[row];
+        case HS_F32: return hs_d2u((double)((const float*)c.data)[row]);
+        case HS_I64: return (uint64_t)((const int64_t*)c.data)[row];
+        case HS_F64: return hs_d2u(((const double*)c.data)[row]);
+        case HS_U8: return (uint64_t)((const uint8_t*)c.data)[row];
+        default: return 0;
+    }
+}
+
+// widen a raw (as stored) 32/64-bit pattern to the in-flight cell of its kind
+__device__ __forceinline__ uint64_t hs_widen(int32_t kind, uint64_t raw) {
+    switch (kind) {
+        case HS_I32: return (uint64_t)(int64_t)(int32_t)(uint32_t)raw;
+        case HS_F32: return hs_d2u((double)__uint_as_float((uint32_t)raw));
+        case HS_U8: return raw & 0xff;
+        default: return raw;
+    }
+}
+
+// ---- strings -------------------------------------------------------------------------------------
+struct HsStr {
+    const uint8_t* p;
+    uint32_t len;
+};
+
+__device__ __forceinline__ HsStr hs_str_at(const hs_col& c, int64_t row) {
+    HsStr s;
+    if (c.fixed_len >= 0) {
+        s.len = (uint32_t)c.fixed_len;
+        s.p = (const uint8_t*)c.data + row * (int64_t)c.fixed_len;
+    } else {
+        s.len = c.lens[row];
+        s.p = (const uint8_t*)c.data + c.offs[row];
+    }
+    return s;
+}
+
+// memcmp-style three-way compare (Python str ordering == byte ordering for ASCII)
+__device__ __forceinline__ int hs_str_cmp(HsStr a, HsStr b) {
+    uint32_t n = a.len < b.len ? a.len : b.len;
+    for (uint32_t i = 0; i < n; ++i) {
+        int d = (int)a.p[i] - (int)b.p[i];
+        if (d) return d;
+    }
+    return (int)a.len - (int)b.len;
+}
+
+__device__ __forceinline__ bool hs_cmp_result(int d, uint32_t cmp) {
+    switch (cmp) {
+        case 0: return d < 0;
+        case 1: return d <= 0;
+        case 2: return d > 0;
+        case 3: return d >= 0;
+        case 4: return d == 0;
+        default: return d != 0;
+    }
+}
+
+// SQL LIKE with % (any run) and _ (any one byte), anchored both ends; iterative with one
+// backtrack point (classic wildcard matcher).  Reference: re.match("^...$") on the translated
+// pattern, sql.py:178-179,192-194.  '.' does not match '\n' in the reference's regex.
+__device__ __forceinline__ bool hs_like(HsStr s, const uint8_t* pat, uint32_t plen) {
+    uint32_t si = 0, pi = 0;
+    int64_t star_p = -1;
+    uint32_t star_s = 0;
+    while (si < s.len) {
+        if (pi < plen && pat[pi] == '%') {
+            star_p = pi++;
+            star_s = si;
+        } else if (pi < plen && ((pat[pi] == '_' && s.p[si] != '\n') || (pat[pi] != '_' && pat[pi] == s.p[si]))) {
+            ++pi;
+            ++si;
+        } else if (star_p >= 0 && s.p[star_s] != '\n') {
+            pi = (uint32_t)star_p + 1;
+            si = ++star_s;
+        } else {
+            return false;
+        }
+    }
+    while (pi < plen && pat[pi] == '%') ++pi;
+    return pi == plen;
+}
+
+// ---- Python arithmetic -----------------------------------------------------------------------------
+__device__ __forceinline__ int64_t hs_floordiv_i(int64_t a, int64_t b) {
+    int64_t q = a / b;
+    if ((a % b != 0) && ((a < 0) != (b < 0))) --q;
+    return q;
+}
+__device__ __forceinline__ int64_t hs_mod_i(int64_t a, int64_t b) {
+    int64_t m = a % b;
+    if (m != 0 && ((m < 0) != (b < 0))) m += b;
+    return m;
+}
+// CPython float_divmod (Objects/floatobject.c)
+__device__ __forceinline__ void hs_divmod_f(double vx, double wx, double& floordiv, double& mod) {
+    mod = fmod(vx, wx);
+    double div = (vx - mod) / wx;
+    if (mod != 0.0) {
+        if ((wx < 0) != (mod < 0)) {
+            mod += wx;
+            div -= 1.0;
+        }
+    } else {
+        mod = copysign(0.0, wx);
+    }
+    if (div != 0.0) {
+        floordiv = floor(div);
+        if (div - floordiv > 0.5) floordiv += 1.0;
+    } else {
+        floordiv = copysign(0.0, vx / wx);
+    }
+}
+
+// ---- interpreter ---------------------------------------------------------------------------------
+// The program is straight-line, so the stack depth before every instruction is known when it is
+// lowered and travels in the instruction (sp).  Dispatch is two wave-uniform switches (sp, then op)
+// whose bodies index the stack with compile-time constants: the stack lives in VGPRs, nothing is
+// spilled and nothing diverges.
+//
+// Sink concept:
+//   uint64_t load(uint32_t slot, int j)               value of column slot for row j (already widened)
+//   bool     live(int j)                              row j still takes part (valid & passed filters)
+//   void     filter(int j, bool keep)
+//   void     agg(uint32_t acc, int j, uint64_t cell)
+//   void     out(uint32_t o, int j, uint64_t cell)
+//   int64_t  row(int j)                               row index (string ops read memory with it)
+//   void     key()                                    HS_OP_KEY: resolve the group slot of live rows
+
+
+template <int SP, int D, int V, typename Sink>
+__device__ __forceinline__ void hs_exec_at(uint64_t w, const hs_program& P, const HsCols& C, uint64_t (&st)[D][V],
+                                           Sink& sink, uint32_t& err) {
+    const uint32_t op = hs_ins_op(w);
+    const uint32_t a = hs_ins_a(w);
+    constexpr int T = SP >= 1 ? SP - 1 : 0;  // top
+    constexpr int S = SP >= 2 ? SP - 2 : 0;  // second
+    constexpr int N = SP < D ? SP : D - 1;   // next free
+
+#define HS_BIN_F(EXPR)                                   \
+    if constexpr (SP >= 2) {                             \
+        _Pragma("unroll") for (int j = 0; j < V; ++j) {  \
+            double x = hs_u2d(st[S][j]), y = hs_u2d(st[T][j]); \
+            (void)x; (void)y;                            \
+            st[S][j] = (EXPR);                           \
+        }                                                \
+    }
+#define HS_BIN_I(EXPR)                                   \
+    if constexpr (SP >= 2) {                             \
+        _Pragma("unroll") for (int j = 0; j < V; ++j) {  \
+            int64_t x = (int64_t)st[S][j], y = (int64_t)st[T][j]; \
+            (void)x; (void)y;                            \
+            st[S][j] = (uint64_t)(EXPR);                 \
+        }                                                \
+    }
+
+    switch (op) {
+        case HS_OP_LD:
+            if constexpr (SP < D) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) st[N][j] = sink.load(a, j);
+            }
+            break;
+        case HS_OP_LIT:
+            if constexpr (SP < D) {
+                const uint64_t lit = P.lit[a];
+#pragma unroll
+                for (int j = 0; j < V; ++j) st[N][j] = lit;
+            }
+            break;
+        case HS_OP_ADD_F: HS_BIN_F(hs_d2u(x + y)); break;
+        case HS_OP_SUB_F: HS_BIN_F(hs_d2u(x - y)); break;
+        case HS_OP_MUL_F: HS_BIN_F(hs_d2u(x * y)); break;
+        case HS_OP_DIV_F:
+            if constexpr (SP >= 2) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    double x = hs_u2d(st[S][j]), y = hs_u2d(st[T][j]);
+                    if (y == 0.0 && sink.live(j)) err |= HS_FLAG_DIV_ZERO;
+                    st[S][j] = hs_d2u(x / y);
+                }
+            }
+            break;
+        case HS_OP_FLOORDIV_F:
+        case HS_OP_MOD_F:
+            if constexpr (SP >= 2) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    double x = hs_u2d(st[S][j]), y = hs_u2d(st[T][j]);
+                    double fd = 0.0, md = 0.0;
+                    if (y == 0.0) {
+                        if (sink.live(j)) err |= HS_FLAG_DIV_ZERO;
+                    } else {
+                        hs_divmod_f(x, y, fd, md);
+                    }
+                    st[S][j] = hs_d2u(op == HS_OP_FLOORDIV_F ? fd : md);
+                }
+            }
+            break;
+        case HS_OP_ADD_I: HS_BIN_I(x + y); break;
+        case HS_OP_SUB_I: HS_BIN_I(x - y); break;
+        case HS_OP_MUL_I: HS_BIN_I(x * y); break;
+        case HS_OP_FLOORDIV_I:
+        case HS_OP_MOD_I:
+            if constexpr (SP >= 2) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    int64_t x = (int64_t)st[S][j], y = (int64_t)st[T][j];
+                    int64_t r = 0;
+                    if (y == 0) {
+                        if (sink.live(j)) err |= HS_FLAG_DIV_ZERO;
+                    } else {
+                        r = op == HS_OP_FLOORDIV_I ? hs_floordiv_i(x, y) : hs_mod_i(x, y);
+                    }
+                    st[S][j] = (uint64_t)r;
+                }
+            }
+            break;
+        case HS_OP_LT_F: HS_BIN_F((uint64_t)(x < y)); break;
+        case HS_OP_LE_F: HS_BIN_F((uint64_t)(x <= y)); break;
+        case HS_OP_GT_F: HS_BIN_F((uint64_t)(x > y)); break;
+        case HS_OP_GE_F: HS_BIN_F((uint64_t)(x >= y)); break;
+        case HS_OP_EQ_F: HS_BIN_F((uint64_t)(x == y)); break;
+        case HS_OP_NE_F: HS_BIN_F((uint64_t)(x != y)); break;
+        case HS_OP_LT_I: HS_BIN_I(x < y); break;
+        case HS_OP_LE_I: HS_BIN_I(x <= y); break;
+        case HS_OP_GT_I: HS_BIN_I(x > y); break;
+        case HS_OP_GE_I: HS_BIN_I(x >= y); break;
+        case HS_OP_EQ_I: HS_BIN_I(x == y); break;
+        case HS_OP_NE_I: HS_BIN_I(x != y); break;
+        case HS_OP_AND: HS_BIN_I(x & y); break;
+        case HS_OP_OR: HS_BIN_I(x | y); break;
+        case HS_OP_I2F:
+            if constexpr (SP >= 1) {
+                if (a == 0) {
+#pragma unroll
+                    for (int j = 0; j < V; ++j) st[T][j] = hs_d2u((double)(int64_t)st[T][j]);
+                } else if constexpr (SP >= 2) {
+#pragma unroll
+                    for (int j = 0; j < V; ++j) st[S][j] = hs_d2u((double)(int64_t)st[S][j]);
+                }
+            }
+            break;
+        case HS_OP_STRCMP_LIT:
+            if constexpr (SP < D) {
+                const uint64_t ref = P.lit[hs_ins_b(w)];
+                HsStr lit;
+                lit.p = P.pool + (uint32_t)(ref >> 32);
+                lit.len = (uint32_t)ref;
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    bool r = false;
+                    if (sink.live(j)) r = hs_cmp_result(hs_str_cmp(hs_str_at(C.c[a], sink.row(j)), lit), hs_ins_c(w));
+                    st[N][j] = (uint64_t)r;
+                }
+            }
+            break;
+        case HS_OP_STRCMP_COL:
+            if constexpr (SP < D) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    bool r = false;
+                    if (sink.live(j))
+                        r = hs_cmp_result(
+                            hs_str_cmp(hs_str_at(C.c[a], sink.row(j)), hs_str_at(C.c[hs_ins_b(w)], sink.row(j))),
+                            hs_ins_c(w));
+                    st[N][j] = (uint64_t)r;
+                }
+            }
+            break;
+        case HS_OP_LIKE:
+            if constexpr (SP < D) {
+                const uint64_t ref = P.lit[hs_ins_b(w)];
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    bool r = false;
+                    if (sink.live(j))
+                        r = hs_like(hs_str_at(C.c[a], sink.row(j)), P.pool + (uint32_t)(ref >> 32), (uint32_t)ref);
+                    st[N][j] = (uint64_t)r;
+                }
+            }
+            break;
+        case HS_OP_FILTER:
+            if constexpr (SP >= 1) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) sink.filter(j, st[T][j] != 0);
+            }
+            break;
+        case HS_OP_AGG:
+            if constexpr (SP >= 1) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) sink.agg(a, j, st[T][j]);
+            }
+            break;
+        case HS_OP_OUT:
+            if constexpr (SP >= 1) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) sink.out(a, j, st[T][j]);
+            }
+            break;
+        case HS_OP_KEY: sink.key(); break;
+        default: err |= HS_FLAG_BAD_PROGRAM; break;
+    }
+#undef HS_BIN_F
+#undef HS_BIN_I
+}
+
+template <int D, int V, typename Sink>
+__device__ __forceinline__ void hs_run(const hs_program& P, const HsCols& C, uint32_t first, uint32_t last, Sink& sink,
+                                       uint32_t& err) {
+    uint64_t st[D][V];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+        for (int j = 0; j < V; ++j) st[d][j] = 0;
+    for (uint32_t pc = first; pc < last; ++pc) {
+        const uint64_t w = P.ins[pc];
+        const uint32_t sp = hs_ins_sp(w);
+        switch (sp) {
+            case 0: hs_exec_at<0, D, V>(w, P, C, st, sink, err); break;
+            case 1: hs_exec_at<1, D, V>(w, P, C, st, sink, err); break;
+            case 2: hs_exec_at<2, D, V>(w, P, C, st, sink, err); break;
+            case 3: hs_exec_at<3, D, V>(w, P, C, st, sink, err); break;
+            case 4: hs_exec_at<4, D, V>(w, P, C, st, sink, err); break;
+            default:
+                if constexpr (D > 4) {
+                    switch (sp) {
+                        case 5: hs_exec_at<5, D, V>(w, P, C, st, sink, err); break;
+                        case 6: hs_exec_at<6, D, V>(w, P, C, st, sink, err); break;
+                        case 7: hs_exec_at<7, D, V>(w, P, C, st, sink, err); break;
+                        case 8: hs_exec_at<8, D, V>(w, P, C, st, sink, err); break;
+                        default: err |= HS_FLAG_BAD_PROGRAM; break;
+                    }
+                } else {
+                    err |= HS_FLAG_BAD_PROGRAM;
+                }
+                break;
+        }
+    }
+}
+
+// ---- group keys ------------------------------------------------------------------------------------
+// A key word identifies a group within one launch.  Numeric keys are their own word; a string of <= 7
+// bytes is packed (bytes little-endian, length in the top byte) and so is exact.  Longer strings use
+// "hashed mode": the word only picks the probe start, equality is decided by comparing the bytes of
+// the candidate row with the slot's representative row.
+__device__ __forceinline__ uint64_t hs_mix64(uint64_t x) {
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdull;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ull;
+    x ^= x >> 33;
+    return x;
+}
+
+__device__ __forceinline__ uint64_t hs_fnv1a(const uint8_t* p, uint32_t n) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (uint32_t i = 0; i < n; ++i) {
+        h ^= p[i];
+        h *= 0x100000001b3ull;
+    }
+    return h;
+}
+
+// numeric cell (already widened) -> key word.  Python: 0.0 == -0.0 are one dict key.
+__device__ __forceinline__ uint64_t hs_key_from_cell(int32_t kind, uint64_t cell) {
+    if (kind == HS_F32 || kind == HS_F64) {
+        if (hs_u2d(cell) == 0.0) cell = 0;
+    }
+    return cell == HS_EMPTY_KEY ? HS_EMPTY_KEY + 1 : cell;
+}
+
+__device__ __forceinline__ uint64_t hs_pack_str(const uint8_t* p, uint32_t len) {
+    uint64_t k = (uint64_t)len << 56;
+    for (uint32_t i = 0; i < len; ++i) k |= (uint64_t)p[i] << (8 * i);
+    return k;
+}
+
+// true when every string of the column packs exactly (<= 7 bytes)
+__host__ __device__ __forceinline__ bool hs_col_packs(const hs_col& c) {
+    return c.kind != HS_STR || (c.fixed_len >= 0 && c.fixed_len <= 7);
+}
+
+__device__ __forceinline__ uint64_t hs_key_at(const hs_col& c, int64_t row) {
+    if (c.kind == HS_STR) {
+        HsStr s = hs_str_at(c, row);
+        if (s.len <= 7) return hs_pack_str(s.p, s.len);
+        return (hs_fnv1a(s.p, s.len) & 0x3fffffffffffffffull) | 0x4000000000000000ull;
+    }
+    return hs_key_from_cell(c.kind, hs_load_cell(c, row));
+}
+
+__device__ __forceinline__ bool hs_rows_equal(const hs_col& c, int64_t r0, int64_t r1) {
+    if (c.kind == HS_STR) return hs_str_cmp(hs_str_at(c, r0), hs_str_at(c, r1)) == 0;
+    return hs_key_at(c, r0) == hs_key_at(c, r1);
+}
+
+// LDS dictionary, exact-word mode.  keys[] initialised to HS_EMPTY_KEY, reps[] to -1.
+// Returns the slot of `k`, inserting it if absent; -1 when the table is full.
+__device__ __forceinline__ int hs_dict_upsert_word(uint64_t* keys, int64_t* reps, uint32_t mask, uint64_t k,
+                                                   int64_t row) {
+    uint32_t h = (uint32_t)hs_mix64(k) & mask;
+    for (uint32_t probe = 0; probe <= mask; ++probe) {
+        uint64_t cur = *(volatile uint64_t*)&keys[h];
+        if (cur == HS_EMPTY_KEY) {
+            cur = atomicCAS((unsigned long long*)&keys[h], (unsigned long long)HS_EMPTY_KEY, (unsigned long long)k);
+            if (cur == HS_EMPTY_KEY) {
+                reps[h] = row;
+                return (int)h;
+            }
+        }
+        if (cur == k) return (int)h;
+        h = (h + 1) & mask;
+    }
+    return -1;
+}
+
+// LDS dictionary, hashed mode: the slot is claimed by CAS on its representative row; equality is a
+// byte compare against that row (immutable global memory, so no ordering hazard).
+__device__ __forceinline__ int hs_dict_upsert_rows(int64_t* reps, uint32_t mask, const hs_col& c, uint64_t k,
+                                                   int64_t row) {
+    uint32_t h = (uint32_t)hs_mix64(k) & mask;
+    for (uint32_t probe = 0; probe <= mask; ++probe) {
+        long long cur = *(volatile long long*)&reps[h];
+        if (cur < 0) {
+            cur = (long long)atomicCAS((unsigned long long*)&reps[h], (unsigned long long)(-1ll),
+                                       (unsigned long long)row);
+            if (cur < 0) return (int)h;
+        }
+        if (hs_rows_equal(c, (int64_t)cur, row)) return (int)h;
+        h = (h + 1) & mask;
+    }
+    return -1;
+}
+
+// ---- accumulator folding -----------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t hs_acc_identity(uint32_t op, bool is_int) {
+    if (op == HS_AGG_SUM) return is_int ? 0ull : hs_d2u(0.0);
+    const int64_t id = (op == HS_AGG_MIN) ? 2147483647ll : -2147483648ll;  // MAX_INT / MIN_INT, constants.py:14-15
+    return is_int ? (uint64_t)id : hs_d2u((double)id);
+}
+
+__device__ __forceinline__ uint64_t hs_acc_fold(uint32_t op, bool is_int, uint64_t acc, uint64_t x) {
+    if (is_int) {
+        int64_t a = (int64_t)acc, b = (int64_t)x;
+        if (op == HS_AGG_SUM) return (uint64_t)(a + b);
+        if (op == HS_AGG_MIN) return (uint64_t)(b < a ? b : a);
+        return (uint64_t)(b > a ? b : a);
+    }
+    double a = hs_u2d(acc), b = hs_u2d(x);
+    if (op == HS_AGG_SUM) return hs_d2u(a + b);
+    if (op == HS_AGG_MIN) return hs_d2u(b < a ? b : a);  // Python min(acc, x): x only if strictly smaller
+    return hs_d2u(b > a ? b : a);
+}
+
+// fp64 -> "what a shuffle/result file holds": f32 rounding (RNE) widened back; finite overflow flagged
+__device__ __forceinline__ uint64_t hs_quantise_cell(bool is_int, uint64_t cell, uint32_t& err) {
+    if (is_int) {
+        int64_t v = (int64_t)cell;
+        if (v > 2147483647ll || v < -2147483648ll) err |= HS_FLAG_INT_OVERFLOW;
+        return cell;
+    }
+    double d = hs_u2d(cell);
+    float f = (float)d;
+    if (isinf(f) && !isinf(d)) err |= HS_FLAG_FLT_OVERFLOW;
+    return hs_d2u((double)f);
+}

@@ -1,0 +1,851 @@
+// hs_ops.hip - the non-aggregate operators of libhipspark on gfx950:
+//   device-wide exclusive scans (string offsets, compaction, join output offsets),
+//   WHERE -> row-index compaction, gathers, string concat, expression evaluation, quantisation,
+//   hash partitioning (stable counting sort), hash join (build: dictionary + CSR row lists; probe:
+//   count -> scan -> fill), and the counter-based synthetic lineitem generator.
+//
+// Everything that reorders or selects rows produces a ROW INDEX LIST; columns are then materialised by
+// gathers.  That keeps one implementation per reference loop (cited at each kernel).
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "hs_device.h"
+
+thread_local char g_hs_err[256] = {0};
+
+void hs_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_hs_err, sizeof(g_hs_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* hs_last_error(void) { return g_hs_err; }
+extern "C" int hs_version(void) { return HS_VERSION; }
+
+#define HS_CHECK_LAUNCH(name)                                \
+    do {                                                     \
+        if (hipGetLastError() != hipSuccess) {               \
+            hs_set_error("%s: kernel launch failed", name);  \
+            return HS_E_LAUNCH;                              \
+        }                                                    \
+    } while (0)
+
+static constexpr int SCAN_WG = 256;
+static constexpr int SCAN_ITEMS = 8;
+static constexpr int SCAN_TILE = SCAN_WG * SCAN_ITEMS;
+
+// ---- block-level helpers ---------------------------------------------------------------------------
+// exclusive scan of one int64 per thread across a 256-thread workgroup; returns (exclusive, total)
+__device__ __forceinline__ int64_t block_excl_scan(int64_t v, int64_t* s_tmp, int64_t& total) {
+    const int tid = threadIdx.x;
+    s_tmp[tid] = v;
+    __syncthreads();
+    for (int d = 1; d < SCAN_WG; d <<= 1) {
+        const int64_t t = tid >= d ? s_tmp[tid - d] : 0;
+        __syncthreads();
+        s_tmp[tid] += t;
+        __syncthreads();
+    }
+    total = s_tmp[SCAN_WG - 1];
+    const int64_t excl = s_tmp[tid] - v;
+    __syncthreads();
+    return excl;
+}
+
+struct InLens {
+    const uint8_t* p;
+    __device__ __forceinline__ int64_t operator()(int64_t i) const { return p[i]; }
+};
+struct InMask {
+    const uint8_t* p;
+    __device__ __forceinline__ int64_t operator()(int64_t i) const { return p[i] != 0; }
+};
+struct InI64 {
+    const int64_t* p;
+    __device__ __forceinline__ int64_t operator()(int64_t i) const { return p[i]; }
+};
+
+template <typename In>
+__global__ void __launch_bounds__(SCAN_WG) k_scan_reduce(In in, int64_t n, int64_t* tile_sums) {
+    __shared__ int64_t s_tmp[SCAN_WG];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int64_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k)
+        if (base + k < n) sum += in(base + k);
+    int64_t total;
+    block_excl_scan(sum, s_tmp, total);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+
+// single workgroup: in-place exclusive scan of tile sums; tile_sums[ntiles] = grand total
+__global__ void __launch_bounds__(SCAN_WG) k_scan_tiles(int64_t* tile_sums, int64_t ntiles) {
+    __shared__ int64_t s_tmp[SCAN_WG];
+    __shared__ int64_t s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int64_t t0 = 0; t0 < ntiles; t0 += SCAN_WG) {
+        const int64_t t = t0 + threadIdx.x;
+        const int64_t v = t < ntiles ? tile_sums[t] : 0;
+        int64_t total;
+        const int64_t excl = block_excl_scan(v, s_tmp, total);
+        if (t < ntiles) tile_sums[t] = s_carry + excl;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tile_sums[ntiles] = s_carry;
+}
+
+struct EmitOffsets {  // out[i] = exclusive prefix; out[n] = total
+    int64_t* out;
+    __device__ __forceinline__ void operator()(int64_t i, int64_t excl, int64_t) const { out[i] = excl; }
+};
+struct EmitSelected {  // sel[prefix] = i for flagged rows
+    int64_t* sel;
+    __device__ __forceinline__ void operator()(int64_t i, int64_t excl, int64_t v) const {
+        if (v) sel[excl] = i;
+    }
+};
+
+template <typename In, typename Emit>
+__global__ void __launch_bounds__(SCAN_WG) k_scan_down(In in, int64_t n, const int64_t* tile_sums, Emit emit,
+                                                       int64_t* total_out) {
+    __shared__ int64_t s_tmp[SCAN_WG];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int64_t vals[SCAN_ITEMS];
+    int64_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        vals[k] = base + k < n ? in(base + k) : 0;
+        sum += vals[k];
+    }
+    int64_t total;
+    int64_t run = tile_sums[blockIdx.x] + block_excl_scan(sum, s_tmp, total);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (base + k < n) emit(base + k, run, vals[k]);
+        run += vals[k];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && total_out) *total_out = tile_sums[gridDim.x];
+}
+
+extern "C" size_t hs_scan_ws_bytes(int64_t nrows) {
+    const int64_t ntiles = (nrows + SCAN_TILE - 1) / SCAN_TILE;
+    return (size_t)(ntiles + 2) * 8;
+}
+
+template <typename In, typename Emit>
+static int run_scan(hipStream_t s, In in, int64_t n, Emit emit, int64_t* total_out, void* ws, const char* name) {
+    const int64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    int64_t* tiles = (int64_t*)ws;
+    if (ntiles == 0) {
+        // empty input: total = 0
+        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_WG), 0, s, tiles, (int64_t)0);
+        hipLaunchKernelGGL((k_scan_down<In, Emit>), dim3(1), dim3(SCAN_WG), 0, s, in, (int64_t)0, tiles, emit,
+                           total_out);
+        HS_CHECK_LAUNCH(name);
+        return HS_OK;
+    }
+    if (ntiles > 0x7fffffffll) {
+        hs_set_error("%s: input too large", name);
+        return HS_E_LIMIT;
+    }
+    hipLaunchKernelGGL((k_scan_reduce<In>), dim3((unsigned)ntiles), dim3(SCAN_WG), 0, s, in, n, tiles);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_WG), 0, s, tiles, ntiles);
+    hipLaunchKernelGGL((k_scan_down<In, Emit>), dim3((unsigned)ntiles), dim3(SCAN_WG), 0, s, in, n, tiles, emit,
+                       total_out);
+    HS_CHECK_LAUNCH(name);
+    return HS_OK;
+}
+
+// ---- A1: string offsets + fixed-length detection (reference io.py:143-149) -------------------------------
+__global__ void k_minmax_init(int32_t* minmax) {
+    minmax[0] = 256;
+    minmax[1] = -1;
+}
+__global__ void __launch_bounds__(256) k_lens_minmax(const uint8_t* lens, int64_t n, int32_t* minmax) {
+    int mn = 256, mx = -1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int v = lens[i];
+        mn = v < mn ? v : mn;
+        mx = v > mx ? v : mx;
+    }
+    for (int d = HS_WAVE / 2; d >= 1; d >>= 1) {
+        const int omn = __shfl_down(mn, d, HS_WAVE), omx = __shfl_down(mx, d, HS_WAVE);
+        mn = omn < mn ? omn : mn;
+        mx = omx > mx ? omx : mx;
+    }
+    if ((threadIdx.x % HS_WAVE) == 0) {
+        atomicMin(&minmax[0], mn);
+        atomicMax(&minmax[1], mx);
+    }
+}
+
+extern "C" int hs_str_offsets(void* stream, const uint8_t* lens, int64_t nrows, int64_t* offs, int32_t* minmax,
+                              void* ws) {
+    if ((!lens && nrows > 0) || !offs || !ws || nrows < 0) {
+        hs_set_error("hs_str_offsets: bad arguments");
+        return HS_E_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (minmax) {
+        hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(1), 0, s, minmax);
+        if (nrows > 0) {
+            int64_t blocks = (nrows + 256 * 16 - 1) / (256 * 16);
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(k_lens_minmax, dim3((unsigned)blocks), dim3(256), 0, s, lens, nrows, minmax);
+        }
+    }
+    return run_scan(s, InLens{lens}, nrows, EmitOffsets{offs}, offs + nrows, ws, "hs_str_offsets");
+}
+
+extern "C" int hs_exclusive_scan_i64(void* stream, const int64_t* counts, int64_t n, int64_t* start, void* ws) {
+    if ((!counts && n > 0) || !start || !ws || n < 0) {
+        hs_set_error("hs_exclusive_scan_i64: bad arguments");
+        return HS_E_ARG;
+    }
+    return run_scan((hipStream_t)stream, InI64{counts}, n, EmitOffsets{start}, start + n, ws, "hs_exclusive_scan_i64");
+}
+
+// ---- A3: filter = stable compaction to a row index list (reference tasks.py:177) -----------------------
+extern "C" int hs_compact(void* stream, const uint8_t* mask, int64_t nrows, int64_t* sel, int64_t* count, void* ws) {
+    if ((!mask && nrows > 0) || !sel || !count || !ws || nrows < 0) {
+        hs_set_error("hs_compact: bad arguments");
+        return HS_E_ARG;
+    }
+    return run_scan((hipStream_t)stream, InMask{mask}, nrows, EmitSelected{sel}, count, ws, "hs_compact");
+}
+
+// ---- gathers -------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_gather_fixed(const T* src, const int64_t* idx, int64_t n, T* dst) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = src[idx[i]];
+}
+
+static unsigned grid_for(int64_t n, int per_block) {
+    int64_t b = (n + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > 65536) b = 65536;
+    return (unsigned)b;
+}
+
+extern "C" int hs_gather_fixed(void* stream, const void* src, int32_t elem_bytes, const int64_t* idx, int64_t n,
+                               void* dst) {
+    if (n == 0) return HS_OK;
+    if (!src || !idx || !dst || n < 0) {
+        hs_set_error("hs_gather_fixed: bad arguments");
+        return HS_E_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g(grid_for(n, 256)), b(256);
+    switch (elem_bytes) {
+        case 1: hipLaunchKernelGGL(k_gather_fixed<uint8_t>, g, b, 0, s, (const uint8_t*)src, idx, n, (uint8_t*)dst); break;
+        case 4: hipLaunchKernelGGL(k_gather_fixed<uint32_t>, g, b, 0, s, (const uint32_t*)src, idx, n, (uint32_t*)dst); break;
+        case 8: hipLaunchKernelGGL(k_gather_fixed<uint64_t>, g, b, 0, s, (const uint64_t*)src, idx, n, (uint64_t*)dst); break;
+        default: hs_set_error("hs_gather_fixed: elem_bytes=%d", elem_bytes); return HS_E_ARG;
+    }
+    HS_CHECK_LAUNCH("hs_gather_fixed");
+    return HS_OK;
+}
+
+__global__ void __launch_bounds__(256) k_gather_str_lens(const hs_col src, const int64_t* idx, int64_t n,
+                                                         uint8_t* out_lens) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx ? idx[i] : i;
+        out_lens[i] = src.fixed_len >= 0 ? (uint8_t)src.fixed_len : src.lens[r];
+    }
+}
+__global__ void __launch_bounds__(256) k_gather_str_bytes(const hs_col src, const int64_t* idx, int64_t n,
+                                                          const int64_t* out_offs, uint8_t* out_data) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const HsStr s = hs_str_at(src, idx ? idx[i] : i);
+        uint8_t* d = out_data + out_offs[i];
+        for (uint32_t k = 0; k < s.len; ++k) d[k] = s.p[k];
+    }
+}
+
+extern "C" int hs_gather_str_lens(void* stream, const hs_col* src, const int64_t* idx, int64_t n, uint8_t* out_lens) {
+    if (n == 0) return HS_OK;
+    if (!src || src->kind != HS_STR || !out_lens || n < 0) {
+        hs_set_error("hs_gather_str_lens: bad arguments");
+        return HS_E_ARG;
+    }
+    hipLaunchKernelGGL(k_gather_str_lens, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, *src, idx, n,
+                       out_lens);
+    HS_CHECK_LAUNCH("hs_gather_str_lens");
+    return HS_OK;
+}
+extern "C" int hs_gather_str_bytes(void* stream, const hs_col* src, const int64_t* idx, int64_t n,
+                                   const int64_t* out_offs, uint8_t* out_data) {
+    if (n == 0) return HS_OK;
+    if (!src || src->kind != HS_STR || !out_offs || !out_data || n < 0) {
+        hs_set_error("hs_gather_str_bytes: bad arguments");
+        return HS_E_ARG;
+    }
+    hipLaunchKernelGGL(k_gather_str_bytes, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, *src, idx, n,
+                       out_offs, out_data);
+    HS_CHECK_LAUNCH("hs_gather_str_bytes");
+    return HS_OK;
+}
+
+// ---- string '+' (reference sql.py:262-266 operator.add on str; zig utils.zig:118-131) ------------------
+#define HS_MAX_PARTS 8
+struct ConcatArgs {
+    int32_t n_parts;
+    int32_t pad;
+    hs_col parts[HS_MAX_PARTS];
+};
+__device__ __forceinline__ HsStr part_str(const hs_col& p, int64_t row) {
+    if (p.kind == HS_STR) return hs_str_at(p, row);
+    HsStr s;  // literal: data = device bytes, fixed_len = length
+    s.p = (const uint8_t*)p.data;
+    s.len = (uint32_t)p.fixed_len;
+    return s;
+}
+__global__ void __launch_bounds__(256) k_concat_lens(const ConcatArgs A_kernarg, int64_t n, uint8_t* out_lens, uint32_t* flags) {
+    HS_KERNARG(ConcatArgs, A);
+    uint32_t err = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t len = 0;
+        for (int p = 0; p < A.n_parts; ++p) len += part_str(A.parts[p], i).len;
+        if (len > 255) {
+            err |= HS_FLAG_STR_TOO_LONG;
+            len = 255;
+        }
+        out_lens[i] = (uint8_t)len;
+    }
+    if (err && flags) atomicOr(flags, err);
+}
+__global__ void __launch_bounds__(256) k_concat_bytes(const ConcatArgs A_kernarg, int64_t n, const int64_t* out_offs,
+                                                      uint8_t* out_data) {
+    HS_KERNARG(ConcatArgs, A);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        uint8_t* d = out_data + out_offs[i];
+        const int64_t room = out_offs[i + 1] - out_offs[i];
+        int64_t w = 0;
+        for (int p = 0; p < A.n_parts; ++p) {
+            const HsStr s = part_str(A.parts[p], i);
+            for (uint32_t k = 0; k < s.len && w < room; ++k) d[w++] = s.p[k];
+        }
+    }
+}
+static int fill_concat(ConcatArgs& A, const hs_col* parts, int32_t n_parts, const char* name) {
+    if (!parts || n_parts < 1 || n_parts > HS_MAX_PARTS) {
+        hs_set_error("%s: n_parts=%d out of range 1..%d", name, n_parts, HS_MAX_PARTS);
+        return HS_E_LIMIT;
+    }
+    A.n_parts = n_parts;
+    A.pad = 0;
+    for (int i = 0; i < n_parts; ++i) A.parts[i] = parts[i];
+    return HS_OK;
+}
+extern "C" int hs_concat_lens(void* stream, const hs_col* parts, int32_t n_parts, int64_t nrows, uint8_t* out_lens,
+                              uint32_t* flags) {
+    ConcatArgs A;
+    int rc = fill_concat(A, parts, n_parts, "hs_concat_lens");
+    if (rc) return rc;
+    if (nrows == 0) return HS_OK;
+    hipLaunchKernelGGL(k_concat_lens, dim3(grid_for(nrows, 256)), dim3(256), 0, (hipStream_t)stream, A, nrows, out_lens,
+                       flags);
+    HS_CHECK_LAUNCH("hs_concat_lens");
+    return HS_OK;
+}
+extern "C" int hs_concat_bytes(void* stream, const hs_col* parts, int32_t n_parts, int64_t nrows,
+                               const int64_t* out_offs, uint8_t* out_data) {
+    ConcatArgs A;
+    int rc = fill_concat(A, parts, n_parts, "hs_concat_bytes");
+    if (rc) return rc;
+    if (nrows == 0) return HS_OK;
+    hipLaunchKernelGGL(k_concat_bytes, dim3(grid_for(nrows, 256)), dim3(256), 0, (hipStream_t)stream, A, nrows,
+                       out_offs, out_data);
+    HS_CHECK_LAUNCH("hs_concat_bytes");
+    return HS_OK;
+}
+
+// ---- A4: expression evaluation, one row per lane (reference tasks.py:32-35, sql.py:262-266) ----------------
+#define HS_MAX_OUTS 16
+struct EvalArgs {
+    HsCols cols;
+    hs_program prog;
+    const int64_t* sel;
+    int64_t nrows;
+    void* outs[HS_MAX_OUTS];
+    int32_t out_kinds[HS_MAX_OUTS];
+    uint32_t* flags;
+};
+struct EvalSink {
+    const EvalArgs& A;
+    int64_t in_row, out_row;
+    __device__ __forceinline__ EvalSink(const EvalArgs& a) : A(a) {}
+    __device__ __forceinline__ uint64_t load(uint32_t s, int) const { return hs_load_cell(A.cols.c[s], in_row); }
+    __device__ __forceinline__ bool live(int) const { return true; }
+    __device__ __forceinline__ int64_t row(int) const { return in_row; }
+    __device__ __forceinline__ void filter(int, bool) {}
+    __device__ __forceinline__ void agg(uint32_t, int, uint64_t) {}
+    __device__ __forceinline__ void key() {}
+    __device__ __forceinline__ void out(uint32_t o, int, uint64_t cell) {
+        switch (A.out_kinds[o]) {
+            case HS_U8: ((uint8_t*)A.outs[o])[out_row] = cell != 0; break;
+            default: ((uint64_t*)A.outs[o])[out_row] = cell; break;
+        }
+    }
+};
+__global__ void __launch_bounds__(256) k_eval(const EvalArgs A_kernarg) {
+    HS_KERNARG(EvalArgs, A);
+    uint32_t err = 0;
+    EvalSink sink(A);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.nrows; i += (int64_t)gridDim.x * blockDim.x) {
+        sink.out_row = i;
+        sink.in_row = A.sel ? A.sel[i] : i;
+        hs_run<HS_MAX_STACK, 1>(A.prog, A.cols, 0, A.prog.n_ins, sink, err);
+    }
+    if (err) atomicOr(A.flags, err);
+}
+extern "C" int hs_eval(void* stream, const hs_col* cols, int32_t n_cols, const hs_program* prog, const int64_t* sel,
+                       int64_t nrows, void* const* outs, const int32_t* out_kinds, int32_t n_outs, uint32_t* flags) {
+    if (!prog || !flags || (n_cols > 0 && !cols) || n_cols < 0 || n_cols > HS_MAX_COLS || n_outs < 0 ||
+        n_outs > HS_MAX_OUTS || (n_outs > 0 && (!outs || !out_kinds)) || nrows < 0) {
+        hs_set_error("hs_eval: bad arguments");
+        return HS_E_ARG;
+    }
+    if (prog->n_ins > HS_MAX_INS || prog->n_lit > HS_MAX_LIT) {
+        hs_set_error("hs_eval: program too long");
+        return HS_E_LIMIT;
+    }
+    if (nrows == 0) return HS_OK;
+    EvalArgs A;
+    A.cols.n = n_cols;
+    A.cols.pad = 0;
+    for (int i = 0; i < HS_MAX_COLS; ++i) A.cols.c[i] = i < n_cols ? cols[i] : hs_col{HS_U8, -1, nullptr, nullptr, nullptr};
+    A.prog = *prog;
+    A.sel = sel;
+    A.nrows = nrows;
+    for (int i = 0; i < HS_MAX_OUTS; ++i) {
+        A.outs[i] = i < n_outs ? outs[i] : nullptr;
+        A.out_kinds[i] = i < n_outs ? out_kinds[i] : HS_F64;
+    }
+    A.flags = flags;
+    hipLaunchKernelGGL(k_eval, dim3(grid_for(nrows, 256)), dim3(256), 0, (hipStream_t)stream, A);
+    HS_CHECK_LAUNCH("hs_eval");
+    return HS_OK;
+}
+
+// ---- quantisation at a file write (reference io.py:87-94) ---------------------------------------------
+__global__ void __launch_bounds__(256) k_quantise(const void* src, int32_t kind, int64_t n, void* dst, uint32_t* flags) {
+    uint32_t err = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (kind == HS_F64) {
+            const double d = ((const double*)src)[i];
+            const float f = (float)d;
+            if (isinf(f) && !isinf(d)) err |= HS_FLAG_FLT_OVERFLOW;
+            ((float*)dst)[i] = f;
+        } else {
+            const int64_t v = ((const int64_t*)src)[i];
+            if (v > 2147483647ll || v < -2147483648ll) err |= HS_FLAG_INT_OVERFLOW;
+            ((int32_t*)dst)[i] = (int32_t)v;
+        }
+    }
+    if (err) atomicOr(flags, err);
+}
+extern "C" int hs_quantise(void* stream, const void* src, int32_t src_kind, int64_t n, void* dst, uint32_t* flags) {
+    if (n == 0) return HS_OK;
+    if (!src || !dst || !flags || n < 0 || (src_kind != HS_F64 && src_kind != HS_I64)) {
+        hs_set_error("hs_quantise: bad arguments");
+        return HS_E_ARG;
+    }
+    hipLaunchKernelGGL(k_quantise, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, src, src_kind, n, dst,
+                       flags);
+    HS_CHECK_LAUNCH("hs_quantise");
+    return HS_OK;
+}
+
+// ---- A6/A9: hash partitioning (reference tasks.py:353-365) ------------------------------------------------
+__device__ __forceinline__ uint32_t py_int_partition(int64_t v, int32_t n_parts) {
+    // hash(int) == int for |int| < 2**61-1, except hash(-1) == -2; then Python's floor-mod
+    if (v == -1) v = -2;
+    int64_t m = v % n_parts;
+    if (m < 0) m += n_parts;
+    return (uint32_t)m;
+}
+__global__ void __launch_bounds__(256) k_partition_ids(const hs_col key, const int64_t* sel, int64_t n, int32_t n_parts,
+                                                       uint8_t* part) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = sel ? sel[i] : i;
+        uint32_t p;
+        if (key.kind == HS_STR) {
+            const HsStr s = hs_str_at(key, r);
+            p = (uint32_t)(hs_fnv1a(s.p, s.len) % (uint64_t)n_parts);
+        } else if (key.kind == HS_I32 || key.kind == HS_I64) {
+            p = py_int_partition((int64_t)hs_load_cell(key, r), n_parts);
+        } else {
+            const double d = hs_u2d(hs_load_cell(key, r));
+            // integral floats hash like the equal int in Python; others: any fixed hash is a valid outcome
+            if (d == floor(d) && fabs(d) < 9.0e15) p = py_int_partition((int64_t)d, n_parts);
+            else p = (uint32_t)(hs_mix64(hs_d2u(d)) % (uint64_t)n_parts);
+        }
+        part[i] = (uint8_t)p;
+    }
+}
+extern "C" int hs_partition_ids(void* stream, const hs_col* key, const int64_t* sel, int64_t nrows, int32_t n_parts,
+                                uint8_t* part) {
+    if (nrows == 0) return HS_OK;
+    if (!key || !part || nrows < 0 || n_parts < 1 || n_parts > 256) {
+        hs_set_error("hs_partition_ids: bad arguments");
+        return HS_E_ARG;
+    }
+    hipLaunchKernelGGL(k_partition_ids, dim3(grid_for(nrows, 256)), dim3(256), 0, (hipStream_t)stream, *key, sel, nrows,
+                       n_parts, part);
+    HS_CHECK_LAUNCH("hs_partition_ids");
+    return HS_OK;
+}
+
+// stable counting sort by partition id: per-tile histograms -> (partition-major, tile-minor) scan ->
+// per-tile stable scatter.  Tiles = SCAN_TILE rows, each lane owns SCAN_ITEMS consecutive rows.
+#define HS_MAX_PARTS_SORT 32
+__global__ void __launch_bounds__(SCAN_WG) k_part_hist(const uint8_t* part, int64_t n, int32_t n_parts, int64_t ntiles,
+                                                       int64_t* hist /* [n_parts][ntiles] */) {
+    __shared__ int s_hist[HS_MAX_PARTS_SORT];
+    if (threadIdx.x < HS_MAX_PARTS_SORT) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k)
+        if (base + k < n) atomicAdd(&s_hist[part[base + k]], 1);
+    __syncthreads();
+    if ((int)threadIdx.x < n_parts) hist[(int64_t)threadIdx.x * ntiles + blockIdx.x] = s_hist[threadIdx.x];
+}
+__global__ void __launch_bounds__(SCAN_WG) k_part_starts(const int64_t* hist_scanned, int64_t ntiles, int32_t n_parts,
+                                                         int64_t total, int64_t* part_start) {
+    if ((int)threadIdx.x < n_parts) part_start[threadIdx.x] = hist_scanned[(int64_t)threadIdx.x * ntiles];
+    if (threadIdx.x == 0) part_start[n_parts] = total;
+}
+__global__ void __launch_bounds__(SCAN_WG) k_part_scatter(const uint8_t* part, int64_t n, int32_t n_parts,
+                                                          int64_t ntiles, const int64_t* hist_scanned, int64_t* perm) {
+    __shared__ int s_cnt[HS_MAX_PARTS_SORT][SCAN_WG + 1];
+    const int tid = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)tid * SCAN_ITEMS;
+    for (int p = 0; p < n_parts; ++p) s_cnt[p][tid] = 0;
+    uint8_t mine[SCAN_ITEMS];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        mine[k] = base + k < n ? part[base + k] : 255;
+        if (mine[k] != 255) s_cnt[mine[k]][tid] += 1;
+    }
+    __syncthreads();
+    if (tid < n_parts) {  // exclusive scan over lanes for partition `tid`
+        int run = 0;
+        for (int t = 0; t < SCAN_WG; ++t) {
+            const int c = s_cnt[tid][t];
+            s_cnt[tid][t] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (mine[k] != 255) {
+            const int p = mine[k];
+            const int64_t pos = hist_scanned[(int64_t)p * ntiles + blockIdx.x] + s_cnt[p][tid];
+            s_cnt[p][tid] += 1;
+            perm[pos] = base + k;
+        }
+    }
+}
+extern "C" size_t hs_partition_ws_bytes(int64_t nrows, int32_t n_parts) {
+    const int64_t ntiles = (nrows + SCAN_TILE - 1) / SCAN_TILE;
+    const int64_t nhist = ntiles * n_parts;
+    return (size_t)(2 * nhist + 2) * 8 + hs_scan_ws_bytes(nhist) + 64;
+}
+extern "C" int hs_partition_perm(void* stream, const uint8_t* part, int64_t nrows, int32_t n_parts, int64_t* perm,
+                                 int64_t* part_start, void* ws) {
+    if ((!part && nrows > 0) || !perm || !part_start || !ws || nrows < 0 || n_parts < 1 ||
+        n_parts > HS_MAX_PARTS_SORT) {
+        hs_set_error("hs_partition_perm: bad arguments (n_parts <= %d)", HS_MAX_PARTS_SORT);
+        return HS_E_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t ntiles = (nrows + SCAN_TILE - 1) / SCAN_TILE;
+    const int64_t nhist = ntiles * n_parts;
+    int64_t* hist = (int64_t*)ws;
+    int64_t* hist_scanned = hist + nhist + 1;
+    void* scan_ws = hist_scanned + nhist + 1;
+    if (ntiles > 0) {
+        hipLaunchKernelGGL(k_part_hist, dim3((unsigned)ntiles), dim3(SCAN_WG), 0, s, part, nrows, n_parts, ntiles, hist);
+    }
+    int rc = run_scan(s, InI64{hist}, nhist, EmitOffsets{hist_scanned}, hist_scanned + nhist, scan_ws,
+                      "hs_partition_perm");
+    if (rc) return rc;
+    if (ntiles > 0) {
+        hipLaunchKernelGGL(k_part_starts, dim3(1), dim3(SCAN_WG), 0, s, hist_scanned, ntiles, n_parts, nrows, part_start);
+        hipLaunchKernelGGL(k_part_scatter, dim3((unsigned)ntiles), dim3(SCAN_WG), 0, s, part, nrows, n_parts, ntiles,
+                           hist_scanned, perm);
+    } else {
+        hipMemsetAsync(part_start, 0, (size_t)(n_parts + 1) * 8, s);
+    }
+    HS_CHECK_LAUNCH("hs_partition_perm");
+    return HS_OK;
+}
+
+// ---- A8: hash join (reference tasks.py:201-240) ------------------------------------------------------------
+// Build = global-memory dictionary over the left keys (slot per distinct key) + CSR lists of the left
+// rows of every slot in ASCENDING row order (the reference appends row indices in row order,
+// tasks.py:216-217).  Entries never change once claimed, so a stale read can only see "empty" and the
+// CAS that follows arbitrates.
+__global__ void __launch_bounds__(256) k_fill_u64(uint64_t* p, int64_t n, uint64_t v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+__device__ __forceinline__ int64_t gdict_upsert(uint64_t* keys, int64_t* reps, uint64_t mask, const hs_col& c,
+                                                bool hashed, uint64_t k, int64_t row) {
+    uint64_t h = hs_mix64(k) & mask;
+    for (uint64_t probe = 0; probe <= mask; ++probe) {
+        if (hashed) {
+            long long cur = (long long)atomicCAS((unsigned long long*)&reps[h], (unsigned long long)(-1ll),
+                                                 (unsigned long long)row);
+            if (cur < 0) return (int64_t)h;
+            if (hs_rows_equal(c, (int64_t)cur, row)) return (int64_t)h;
+        } else {
+            uint64_t cur = atomicCAS((unsigned long long*)&keys[h], (unsigned long long)HS_EMPTY_KEY,
+                                     (unsigned long long)k);
+            if (cur == HS_EMPTY_KEY || cur == k) return (int64_t)h;
+        }
+        h = (h + 1) & mask;
+    }
+    return -1;
+}
+// read-only lookup after the build kernel has completed
+__device__ __forceinline__ int64_t gdict_find(const uint64_t* keys, const int64_t* reps, uint64_t mask,
+                                              const hs_col& build_col, const hs_col& probe_col, bool hashed,
+                                              uint64_t k, int64_t probe_row) {
+    uint64_t h = hs_mix64(k) & mask;
+    for (uint64_t probe = 0; probe <= mask; ++probe) {
+        if (hashed) {
+            const int64_t rep = reps[h];
+            if (rep < 0) return -1;
+            if (hs_str_cmp(hs_str_at(build_col, rep), hs_str_at(probe_col, probe_row)) == 0) return (int64_t)h;
+        } else {
+            const uint64_t cur = keys[h];
+            if (cur == HS_EMPTY_KEY) return -1;
+            if (cur == k) return (int64_t)h;
+        }
+        h = (h + 1) & mask;
+    }
+    return -1;
+}
+
+__global__ void __launch_bounds__(256) k_join_slots(const hs_col key, int64_t n, int64_t cap, uint64_t* tkeys,
+                                                    int64_t* treps, int64_t* slot_of_row, int64_t* slot_count,
+                                                    uint32_t* flags) {
+    const bool hashed = !hs_col_packs(key);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = gdict_upsert(tkeys, treps, (uint64_t)cap - 1, key, hashed, hs_key_at(key, i), i);
+        slot_of_row[i] = s;
+        if (s < 0) atomicOr(flags, HS_FLAG_DICT_FULL);
+        else atomicAdd((unsigned long long*)&slot_count[s], 1ull);
+    }
+}
+__global__ void __launch_bounds__(256) k_join_rows(const int64_t* slot_of_row, int64_t n, const int64_t* slot_start,
+                                                   int64_t* cursor, int64_t* rows) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = slot_of_row[i];
+        if (s < 0) continue;
+        const int64_t pos = slot_start[s] + (int64_t)atomicAdd((unsigned long long*)&cursor[s], 1ull);
+        rows[pos] = i;
+    }
+}
+// the fill above lands rows of a slot in arrival order; sort each (short) list ascending
+__global__ void __launch_bounds__(256) k_join_sort(const int64_t* slot_start, int64_t cap, int64_t* rows) {
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < cap; s += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t lo = slot_start[s], hi = slot_start[s + 1];
+        for (int64_t i = lo + 1; i < hi; ++i) {
+            const int64_t v = rows[i];
+            int64_t j = i - 1;
+            while (j >= lo && rows[j] > v) {
+                rows[j + 1] = rows[j];
+                --j;
+            }
+            rows[j + 1] = v;
+        }
+    }
+}
+
+extern "C" size_t hs_join_build_ws_bytes(int64_t n_left, int64_t table_cap) {
+    // slot_of_row[n_left] + slot_count[cap] + cursor[cap] + scan ws
+    return (size_t)(n_left + 2 * table_cap + 2) * 8 + hs_scan_ws_bytes(table_cap) + 64;
+}
+
+extern "C" int hs_join_build(void* stream, const hs_col* left_key, int64_t n_left, int64_t table_cap,
+                             uint64_t* table_keys, int64_t* table_reps, int64_t* slot_start, int64_t* rows, void* ws,
+                             uint32_t* flags) {
+    if (!left_key || !table_keys || !table_reps || !slot_start || (!rows && n_left > 0) || !ws || !flags ||
+        n_left < 0 || table_cap < 1 || (table_cap & (table_cap - 1))) {
+        hs_set_error("hs_join_build: bad arguments (table_cap must be a power of two)");
+        return HS_E_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    int64_t* slot_of_row = (int64_t*)ws;
+    int64_t* slot_count = slot_of_row + n_left;
+    int64_t* cursor = slot_count + table_cap;
+    void* scan_ws = cursor + table_cap + 1;
+    hipLaunchKernelGGL(k_fill_u64, dim3(grid_for(table_cap, 256)), dim3(256), 0, s, table_keys, table_cap, HS_EMPTY_KEY);
+    hipLaunchKernelGGL(k_fill_u64, dim3(grid_for(table_cap, 256)), dim3(256), 0, s, (uint64_t*)table_reps, table_cap,
+                       ~0ull);
+    hipMemsetAsync(slot_count, 0, (size_t)table_cap * 16, s);  // slot_count + cursor
+    if (n_left > 0)
+        hipLaunchKernelGGL(k_join_slots, dim3(grid_for(n_left, 256)), dim3(256), 0, s, *left_key, n_left, table_cap,
+                           table_keys, table_reps, slot_of_row, slot_count, flags);
+    int rc = run_scan(s, InI64{slot_count}, table_cap, EmitOffsets{slot_start}, slot_start + table_cap, scan_ws,
+                      "hs_join_build");
+    if (rc) return rc;
+    if (n_left > 0) {
+        hipLaunchKernelGGL(k_join_rows, dim3(grid_for(n_left, 256)), dim3(256), 0, s, slot_of_row, n_left, slot_start,
+                           cursor, rows);
+        hipLaunchKernelGGL(k_join_sort, dim3(grid_for(table_cap, 256)), dim3(256), 0, s, slot_start, table_cap, rows);
+    }
+    HS_CHECK_LAUNCH("hs_join_build");
+    return HS_OK;
+}
+
+struct JoinProbeArgs {
+    hs_col left_key, right_key;
+    int64_t n_right, cap;
+    const uint64_t* tkeys;
+    const int64_t* treps;
+    const int64_t* slot_start;
+    const int64_t* rows;
+};
+__global__ void __launch_bounds__(256) k_join_count(const JoinProbeArgs A, int64_t* counts) {
+    const bool hashed = !hs_col_packs(A.left_key);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.n_right; i += (int64_t)gridDim.x * blockDim.x) {
+        // the key word of a probe row must be computed like a build row's: same kind rules
+        const int64_t s = gdict_find(A.tkeys, A.treps, (uint64_t)A.cap - 1, A.left_key, A.right_key, hashed,
+                                     hs_key_at(A.right_key, i), i);
+        counts[i] = s < 0 ? 0 : A.slot_start[s + 1] - A.slot_start[s];
+    }
+}
+__global__ void __launch_bounds__(256) k_join_fill(const JoinProbeArgs A, const int64_t* out_start, int64_t* out_left,
+                                                   int64_t* out_right) {
+    const bool hashed = !hs_col_packs(A.left_key);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.n_right; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = out_start[i + 1] - out_start[i];
+        if (n == 0) continue;
+        const int64_t s = gdict_find(A.tkeys, A.treps, (uint64_t)A.cap - 1, A.left_key, A.right_key, hashed,
+                                     hs_key_at(A.right_key, i), i);
+        const int64_t lo = A.slot_start[s];
+        int64_t o = out_start[i];
+        for (int64_t k = 0; k < n; ++k, ++o) {
+            out_left[o] = A.rows[lo + k];
+            out_right[o] = i;
+        }
+    }
+}
+static int fill_probe(JoinProbeArgs& A, const hs_col* lk, const hs_col* rk, int64_t n_right, int64_t cap,
+                      const uint64_t* tkeys, const int64_t* treps, const int64_t* slot_start, const int64_t* rows,
+                      const char* name) {
+    if (!lk || !rk || !tkeys || !treps || !slot_start || n_right < 0 || cap < 1 || (cap & (cap - 1))) {
+        hs_set_error("%s: bad arguments", name);
+        return HS_E_ARG;
+    }
+    const bool ls = lk->kind == HS_STR, rs = rk->kind == HS_STR;
+    if (ls != rs) {
+        hs_set_error("%s: join keys must both be strings or both be numeric", name);
+        return HS_E_ARG;
+    }
+    A.left_key = *lk;
+    A.right_key = *rk;
+    A.n_right = n_right;
+    A.cap = cap;
+    A.tkeys = tkeys;
+    A.treps = treps;
+    A.slot_start = slot_start;
+    A.rows = rows;
+    return HS_OK;
+}
+extern "C" int hs_join_count(void* stream, const hs_col* left_key, const hs_col* right_key, int64_t n_right,
+                             int64_t table_cap, const uint64_t* table_keys, const int64_t* table_reps,
+                             const int64_t* slot_start, int64_t* counts) {
+    JoinProbeArgs A;
+    int rc = fill_probe(A, left_key, right_key, n_right, table_cap, table_keys, table_reps, slot_start, nullptr,
+                        "hs_join_count");
+    if (rc) return rc;
+    if (n_right == 0) return HS_OK;
+    hipLaunchKernelGGL(k_join_count, dim3(grid_for(n_right, 256)), dim3(256), 0, (hipStream_t)stream, A, counts);
+    HS_CHECK_LAUNCH("hs_join_count");
+    return HS_OK;
+}
+extern "C" int hs_join_fill(void* stream, const hs_col* left_key, const hs_col* right_key, int64_t n_right,
+                            int64_t table_cap, const uint64_t* table_keys, const int64_t* table_reps,
+                            const int64_t* slot_start, const int64_t* rows, const int64_t* out_start,
+                            int64_t* out_left, int64_t* out_right) {
+    JoinProbeArgs A;
+    int rc = fill_probe(A, left_key, right_key, n_right, table_cap, table_keys, table_reps, slot_start, rows,
+                        "hs_join_fill");
+    if (rc) return rc;
+    if (n_right == 0) return HS_OK;
+    hipLaunchKernelGGL(k_join_fill, dim3(grid_for(n_right, 256)), dim3(256), 0, (hipStream_t)stream, A, out_start,
+                       out_left, out_right);
+    HS_CHECK_LAUNCH("hs_join_fill");
+    return HS_OK;
+}
+
+// ---- synthetic TPC-H-shaped lineitem --------------------------------------------------
+// value(row i, column c) = f(splitmix64(seed ^ c*GOLDEN + i)).  oracle/q1_oracle.c holds the CPU twin.
+__host__ __device__ __forceinline__ uint64_t hs_splitmix(uint64_t x) {
+    x += 0x9e3779b97f4a7c15ull;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+}
+__host__ __device__ __forceinline__ uint64_t hs_rand(uint64_t seed, uint32_t col, int64_t i) {
+    return hs_splitmix(hs_splitmix(seed + 0x632be59bd9b4e019ull * (col + 1)) + (uint64_t)i);
+}
+struct GenArgs {
+    uint64_t seed;
+    int64_t row0, nrows;
+    float *quantity, *extendedprice, *discount, *tax;
+    int64_t* shipdate;
+    uint8_t *returnflag, *flag_lens;
+    int32_t* orderkey;
+    uint8_t* shipmode_code;
+};
+__global__ void __launch_bounds__(256) k_gen_lineitem(const GenArgs A) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < A.nrows; k += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = A.row0 + k;
+        const uint32_t qty = 1 + (uint32_t)(hs_rand(A.seed, 0, i) % 50);
+        if (A.quantity) A.quantity[k] = (float)qty;
+        if (A.extendedprice) {
+            const uint32_t cents = 90000 + (uint32_t)(hs_rand(A.seed, 1, i) % 110001);
+            A.extendedprice[k] = (float)((double)qty * (double)cents / 100.0);
+        }
+        if (A.discount) A.discount[k] = (float)((double)(hs_rand(A.seed, 2, i) % 11) / 100.0);
+        if (A.tax) A.tax[k] = (float)((double)(hs_rand(A.seed, 3, i) % 9) / 100.0);
+        if (A.shipdate) {
+            // 1992-01-02 00:00:00 UTC = 694310400 s; + U{0..2525} days  (max = 1998-12-01)
+            const int64_t days = (int64_t)(hs_rand(A.seed, 4, i) % 2526);
+            A.shipdate[k] = (694310400ll + days * 86400ll) * 1000000ll;
+        }
+        if (A.returnflag) {
+            const uint32_t r = (uint32_t)(hs_rand(A.seed, 5, i) % 4);
+            A.returnflag[k] = r == 0 ? 'A' : (r == 3 ? 'R' : 'N');
+        }
+        if (A.flag_lens) A.flag_lens[k] = 1;
+        if (A.orderkey) {
+            const int64_t o = i / 4;
+            A.orderkey[k] = (int32_t)(32 * (o / 8) + (o % 8) + 1);
+        }
+        if (A.shipmode_code) A.shipmode_code[k] = (uint8_t)(hs_rand(A.seed, 6, i) % 7);
+    }
+}
+extern "C" int hs_gen_lineitem(void* stream, uint64_t seed, int64_t row0, int64_t nrows, float* quantity,
+                               float* extendedprice, float* discount, float* tax, int64_t* shipdate,
+                               uint8_t* returnflag, uint8_t* flag_lens, int32_t* orderkey, uint8_t* shipmode_code) {
+    if (nrows <= 0) return HS_OK;
+    GenArgs A{seed, row0, nrows, quantity, extendedprice, discount, tax, shipdate, returnflag, flag_lens, orderkey,
+              shipmode_code};
+    hipLaunchKernelGGL(k_gen_lineitem, dim3(grid_for(nrows, 1024)), dim3(256), 0, (hipStream_t)stream, A);
+    HS_CHECK_LAUNCH("hs_gen_lineitem");
+    return HS_OK;
+}

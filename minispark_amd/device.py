@@ -1,0 +1,470 @@
+"""Device-resident columns / batches and the operator calls on them.
+
+torch supplies device memory, the current HIP stream and (in :mod:`minispark_amd.distributed`) the
+RCCL process group - plumbing only.  Every operator below is one or a few calls into libhipspark.so;
+there is no torch arithmetic on the data path and no CPU fallback.
+
+Layout in HBM: one contiguous buffer per referenced column spanning all rows of the
+batch; STRING columns are ``lens`` (u8 per row) + ``data`` (payload bytes) + ``offs`` (i64 exclusive
+offsets, omitted when every row has the same length - ``fixed_len``).  Buffers are over-allocated by
+``PAD`` bytes so the 16-byte row-quad loads of the fused kernels may run past the last row.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Any, Sequence
+
+import numpy as np
+import torch
+
+from . import hipspark as hs
+from .constants import ColumnType, Schema
+from .io import StrCol
+from .lowering import AggregateLowering, ProgramBuilder, StringParts, lower_aggregate
+
+PAD = 64  # bytes of slack behind every buffer
+
+_TORCH_DTYPE = {hs.I32: torch.int32, hs.F32: torch.float32, hs.I64: torch.int64, hs.F64: torch.float64,
+                hs.U8: torch.uint8}
+FILE_KIND = {ColumnType.INTEGER: hs.I32, ColumnType.FLOAT: hs.F32, ColumnType.TIMESTAMP: hs.I64,
+             ColumnType.STRING: hs.STR}
+INFLIGHT_KIND = {ColumnType.INTEGER: hs.I64, ColumnType.FLOAT: hs.F64, ColumnType.TIMESTAMP: hs.I64,
+                 ColumnType.STRING: hs.STR}
+
+
+@dataclass
+class DCol:
+    kind: int
+    data: torch.Tensor
+    n: int
+    lens: torch.Tensor | None = None
+    offs: torch.Tensor | None = None
+    fixed_len: int = -1
+
+    def as_hs(self) -> hs.hs_col:
+        c = hs.hs_col()
+        c.kind = self.kind
+        c.fixed_len = self.fixed_len
+        c.data = self.data.data_ptr()
+        c.lens = self.lens.data_ptr() if self.lens is not None else None
+        c.offs = self.offs.data_ptr() if self.offs is not None else None
+        return c
+
+    def nbytes(self) -> int:
+        total = self.data.numel() * self.data.element_size()
+        if self.lens is not None:
+            total += self.lens.numel()
+        return total
+
+
+@dataclass
+class DBatch:
+    schema: Schema
+    cols: list[DCol]
+    nrows: int
+    unit_rows: list[int] = field(default_factory=list)  # host copy of the unit boundaries [n_units+1]
+
+    def __post_init__(self) -> None:
+        if not self.unit_rows:
+            self.unit_rows = [0, self.nrows]
+
+    @property
+    def kinds(self) -> list[int]:
+        return [c.kind for c in self.cols]
+
+    @property
+    def n_units(self) -> int:
+        return len(self.unit_rows) - 1
+
+    def column_index(self, name: str) -> int:
+        for i, (col_name, _) in enumerate(self.schema):
+            if col_name == name:
+                return i
+        raise ValueError(f'Column "{name}" not found in schema {self.schema}')
+
+
+class DeviceError(RuntimeError):
+    pass
+
+
+class Device:
+    """One GPU + the loaded operator library."""
+
+    def __init__(self, index: int = 0) -> None:
+        self.lib = hs.load_library()
+        if not torch.cuda.is_available():
+            raise DeviceError(
+                "HipExecutionEngine needs an AMD GPU (torch.cuda.is_available() is False); "
+                "there is no CPU execution path in minispark_amd"
+            )
+        self.index = index
+        self.device = torch.device("cuda", index)
+        torch.cuda.set_device(self.device)
+        self.flags = torch.zeros(4, dtype=torch.int32, device=self.device)
+
+    # ---- plumbing ------------------------------------------------------------------------------------
+    @property
+    def stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def empty(self, n: int, dtype: torch.dtype) -> torch.Tensor:
+        esize = torch.empty((), dtype=dtype).element_size()
+        pad = (PAD + esize - 1) // esize
+        return torch.empty(int(n) + pad, dtype=dtype, device=self.device)[: int(n)]
+
+    def zeros(self, n: int, dtype: torch.dtype) -> torch.Tensor:
+        t = self.empty(n, dtype)
+        t.zero_()
+        return t
+
+    def workspace(self, nbytes: int) -> torch.Tensor:
+        return torch.empty(max(int(nbytes), 256) + PAD, dtype=torch.uint8, device=self.device)
+
+    def to_device(self, arr: np.ndarray, dtype: torch.dtype | None = None) -> torch.Tensor:
+        src = torch.from_numpy(np.ascontiguousarray(arr))
+        dst = self.empty(src.numel(), dtype or src.dtype)
+        dst.copy_(src, non_blocking=False)
+        return dst
+
+    def reset_flags(self) -> None:
+        self.flags.zero_()
+
+    def read_flags(self) -> int:
+        return int(self.flags[0].item()) & 0xFFFFFFFF
+
+    def raise_for_flags(self, flags: int) -> None:
+        """Data-dependent failures surface as the exception the reference's Python raises."""
+        if flags & hs.FLAG_DIV_ZERO:
+            raise ZeroDivisionError("division by zero")  # operator.truediv & co. in sql.py:262-266
+        if flags & hs.FLAG_INT_OVERFLOW:
+            raise OverflowError("int too big to convert")  # io.py:90
+        if flags & hs.FLAG_FLT_OVERFLOW:
+            raise OverflowError("float too large to pack with f format")  # io.py:94
+        if flags & hs.FLAG_STR_TOO_LONG:
+            raise ValueError("string longer than 255 bytes cannot be stored in a BlockFile")
+        if flags & hs.FLAG_BAD_PROGRAM:
+            raise DeviceError("internal error: device interpreter rejected the program")
+
+    # ---- columns ---------------------------------------------------------------------------------
+    def fixed_col(self, kind: int, arr: np.ndarray) -> DCol:
+        t = self.to_device(arr, _TORCH_DTYPE[kind])
+        return DCol(kind, t, int(t.numel()))
+
+    def string_col(self, lens: torch.Tensor, data: torch.Tensor, n: int) -> DCol:
+        """Finish a STRING column: offsets scan + fixed-length detection (one tiny D2H)."""
+        offs = self.empty(n + 1, torch.int64)
+        minmax = self.empty(2, torch.int32)
+        ws = self.workspace(self.lib.hs_scan_ws_bytes(n))
+        hs.check(self.lib.hs_str_offsets(self.stream, lens.data_ptr(), n, offs.data_ptr(), minmax.data_ptr(),
+                                         ws.data_ptr()), "hs_str_offsets")
+        mn, mx = minmax.tolist()
+        fixed = mn if (n > 0 and mn == mx) else (0 if n == 0 else -1)
+        return DCol(hs.STR, data, n, lens=lens, offs=None if fixed >= 0 else offs, fixed_len=fixed)
+
+    def upload_raw(self, raw: Any, col_type: ColumnType) -> DCol:
+        if col_type == ColumnType.STRING:
+            lens = self.to_device(raw.lens, torch.uint8)
+            data = self.to_device(raw.data, torch.uint8)
+            return self.string_col(lens, data, len(raw))
+        return self.fixed_col(FILE_KIND[col_type], raw)
+
+    def download(self, col: DCol, col_type: ColumnType) -> Any:
+        """Device column (already in file storage kinds) -> raw numpy column."""
+        if col.kind == hs.STR:
+            n = col.n
+            lens = col.lens[:n].cpu().numpy()
+            total = int(lens.sum(dtype=np.int64)) if col.fixed_len < 0 else n * col.fixed_len
+            return StrCol(lens.astype(np.uint8), col.data[:total].cpu().numpy().astype(np.uint8))
+        return col.data[: col.n].cpu().numpy()
+
+    # ---- expression evaluation (A4) ---------------------------------------------------------------------
+    def _cols_array(self, batch: DBatch, order: Sequence[int]):
+        arr = (hs.hs_col * max(len(order), 1))()
+        for s, idx in enumerate(order):
+            arr[s] = batch.cols[idx].as_hs()
+        return arr
+
+    def eval_numeric(self, batch: DBatch, exprs: Sequence[Any], sel: torch.Tensor | None = None,
+                     n: int | None = None) -> list[tuple[DCol, str]]:
+        """Evaluate numeric / boolean expressions -> in-flight columns (F64 / I64 / U8 mask)."""
+        n = batch.nrows if n is None else n
+        b = ProgramBuilder(batch.schema, batch.kinds)
+        tags = [b.emit_out(i, e) for i, e in enumerate(exprs)]
+        prog = b.finish()
+        out_kinds = [hs.F64 if t == "F" else (hs.U8 if t == "B" else hs.I64) for t in tags]
+        outs = [self.empty(n, _TORCH_DTYPE[k]) for k in out_kinds]
+        if n > 0:
+            cols = self._cols_array(batch, prog.columns)
+            out_ptrs = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
+            kinds = (C.c_int32 * len(outs))(*out_kinds)
+            pstruct = prog.to_struct()
+            hs.check(self.lib.hs_eval(self.stream, cols, len(prog.columns), C.byref(pstruct),
+                                      sel.data_ptr() if sel is not None else None, n, out_ptrs, kinds, len(outs),
+                                      self.flags.data_ptr()), "hs_eval")
+        return [(DCol(k, o, n), t) for k, o, t in zip(out_kinds, outs, tags)]
+
+    # ---- filter (A3) -----------------------------------------------------------------------------------
+    def filter_select(self, batch: DBatch, conds: Sequence[Any]) -> tuple[torch.Tensor, int]:
+        """WHERE -> ascending indices of the surviving rows (+ their number; one D2H)."""
+        n = batch.nrows
+        cond = conds[0]
+        for extra in conds[1:]:
+            cond = cond & extra
+        (mask, tag), = self.eval_numeric(batch, [cond])
+        if tag not in ("B",):
+            (mask, _), = self.eval_numeric(batch, [cond != 0])
+        sel = self.empty(n, torch.int64)
+        count = self.empty(1, torch.int64)
+        ws = self.workspace(self.lib.hs_scan_ws_bytes(n))
+        hs.check(self.lib.hs_compact(self.stream, mask.data.data_ptr(), n, sel.data_ptr(), count.data_ptr(),
+                                     ws.data_ptr()), "hs_compact")
+        return sel, int(count.item())
+
+    # ---- gathers -------------------------------------------------------------------------------------
+    def gather_col(self, col: DCol, idx: torch.Tensor, n: int) -> DCol:
+        if col.kind == hs.STR:
+            src = col.as_hs()
+            lens = self.empty(n, torch.uint8)
+            hs.check(self.lib.hs_gather_str_lens(self.stream, C.byref(src), idx.data_ptr(), n, lens.data_ptr()),
+                     "hs_gather_str_lens")
+            offs = self.empty(n + 1, torch.int64)
+            minmax = self.empty(2, torch.int32)
+            ws = self.workspace(self.lib.hs_scan_ws_bytes(n))
+            hs.check(self.lib.hs_str_offsets(self.stream, lens.data_ptr(), n, offs.data_ptr(), minmax.data_ptr(),
+                                             ws.data_ptr()), "hs_str_offsets")
+            total = int(offs[n].item()) if n > 0 else 0
+            mn, mx = minmax.tolist()
+            data = self.empty(total, torch.uint8)
+            hs.check(self.lib.hs_gather_str_bytes(self.stream, C.byref(src), idx.data_ptr(), n, offs.data_ptr(),
+                                                  data.data_ptr()), "hs_gather_str_bytes")
+            fixed = mn if (n > 0 and mn == mx) else (0 if n == 0 else -1)
+            return DCol(hs.STR, data, n, lens=lens, offs=None if fixed >= 0 else offs, fixed_len=fixed)
+        out = self.empty(n, _TORCH_DTYPE[col.kind])
+        hs.check(self.lib.hs_gather_fixed(self.stream, col.data.data_ptr(), hs.KIND_BYTES[col.kind], idx.data_ptr(), n,
+                                          out.data_ptr()), "hs_gather_fixed")
+        return DCol(col.kind, out, n)
+
+    def gather_batch(self, batch: DBatch, idx: torch.Tensor, n: int, unit_rows: list[int] | None = None) -> DBatch:
+        return DBatch(list(batch.schema), [self.gather_col(c, idx, n) for c in batch.cols], n,
+                      unit_rows or [0, n])
+
+    # ---- string concat -------------------------------------------------------------------------------
+    def concat_strings(self, batch: DBatch, parts: StringParts, n: int) -> DCol:
+        if len(parts.parts) > hs.HS_MAX_PARTS:
+            raise NotImplementedError(f"string concatenation of more than {hs.HS_MAX_PARTS} parts")
+        arr = (hs.hs_col * len(parts.parts))()
+        keep = []
+        for i, (what, value) in enumerate(parts.parts):
+            if what == "col":
+                arr[i] = batch.cols[value].as_hs()
+            else:
+                lit = self.to_device(np.frombuffer(value or b"\0", dtype=np.uint8), torch.uint8)
+                keep.append(lit)
+                c = hs.hs_col()
+                c.kind = -1
+                c.fixed_len = len(value)
+                c.data = lit.data_ptr()
+                arr[i] = c
+        lens = self.empty(n, torch.uint8)
+        hs.check(self.lib.hs_concat_lens(self.stream, arr, len(parts.parts), n, lens.data_ptr(), self.flags.data_ptr()),
+                 "hs_concat_lens")
+        offs = self.empty(n + 1, torch.int64)
+        minmax = self.empty(2, torch.int32)
+        ws = self.workspace(self.lib.hs_scan_ws_bytes(n))
+        hs.check(self.lib.hs_str_offsets(self.stream, lens.data_ptr(), n, offs.data_ptr(), minmax.data_ptr(),
+                                         ws.data_ptr()), "hs_str_offsets")
+        total = int(offs[n].item()) if n > 0 else 0
+        mn, mx = minmax.tolist()
+        data = self.empty(total, torch.uint8)
+        hs.check(self.lib.hs_concat_bytes(self.stream, arr, len(parts.parts), n, offs.data_ptr(), data.data_ptr()),
+                 "hs_concat_bytes")
+        fixed = mn if (n > 0 and mn == mx) else (0 if n == 0 else -1)
+        return DCol(hs.STR, data, n, lens=lens, offs=None if fixed >= 0 else offs, fixed_len=fixed)
+
+    # ---- quantisation (A6 / K12) -------------------------------------------------------------------------
+    def quantise_col(self, col: DCol, col_type: ColumnType) -> DCol:
+        """In-flight column -> the storage kind a BlockFile holds (f64->f32, i64->i32)."""
+        want = FILE_KIND[col_type]
+        if col.kind == want or col.kind == hs.STR:
+            return col
+        if col.kind == hs.U8:
+            raise AssertionError("a boolean column cannot be written to a BlockFile")  # reference: io.py:89 assert
+        if (col.kind, want) in ((hs.F64, hs.F32), (hs.I64, hs.I32)):
+            out = self.empty(col.n, _TORCH_DTYPE[want])
+            hs.check(self.lib.hs_quantise(self.stream, col.data.data_ptr(), col.kind, col.n, out.data_ptr(),
+                                          self.flags.data_ptr()), "hs_quantise")
+            return DCol(want, out, col.n)
+        if (col.kind, want) == (hs.I64, hs.I64):
+            return col
+        raise AssertionError(f"column of kind {col.kind} cannot be stored as {col_type}")
+
+    # ---- partial aggregate (A5/A6) -------------------------------------------------------------------------
+    def aggregate_partial(self, batch: DBatch, filters: Sequence[Any], group_by: Any, agg_columns: Sequence[Any],
+                          out_schema: Schema, group_cap_hint: int = 4) -> DBatch:
+        """Fused scan + WHERE + aggregate arguments + per-unit partial aggregate.
+
+        Returns the partial rows exactly as the reference would have written them to its shuffle
+        file: key column + one column per aggregate, FLOAT partials rounded to f32, INTEGER partials
+        range-checked to i32, rows grouped by unit."""
+        low = lower_aggregate(batch.schema, batch.kinds, filters, group_by, agg_columns)
+        if low.numeric_slots > hs.HS_FUSED_COLS:
+            raise NotImplementedError(f"aggregate reads more than {hs.HS_FUSED_COLS} numeric columns")
+        n_units = batch.n_units
+        n_acc = len(low.acc_ops)
+        spec = low.spec()
+        pstruct = low.program.to_struct()
+        cols = self._cols_array(batch, low.program.columns)
+        host_units = (C.c_int64 * (n_units + 1))(*batch.unit_rows)
+        cap = max(1, int(group_cap_hint))
+        while True:
+            geom = hs.hs_agg_geom()
+            rc = self.lib.hs_agg_partial_geom(host_units, n_units, n_acc, cap, C.byref(geom))
+            if rc == 2:
+                raise NotImplementedError(
+                    f"GROUP BY with more than {cap // 2} groups per unit x {n_acc} aggregates exceeds the LDS tier: "
+                    + self.lib.hs_last_error().decode()
+                )
+            hs.check(rc, "hs_agg_partial_geom")
+            # first chunk of every unit (host arithmetic mirrors hs_agg_partial_geom)
+            chunk0 = np.zeros(n_units + 1, dtype=np.int64)
+            ur = np.asarray(batch.unit_rows, dtype=np.int64)
+            span = ur[1:] - (ur[:-1] & ~np.int64(3))
+            chunk0[1:] = np.cumsum(np.where(span > 0, (span + geom.chunk_rows - 1) // geom.chunk_rows, 0))
+            if int(chunk0[-1]) != geom.n_chunks:
+                raise DeviceError("chunk geometry mismatch between host and library")
+            d_units = self.to_device(ur)
+            d_chunk0 = self.to_device(chunk0)
+            slots = n_units * cap
+            out_rep = self.empty(slots, torch.int64)
+            out_acc = self.empty(max(slots * n_acc, 1), torch.int64)
+            ngroups = self.empty(max(n_units, 1), torch.int32)
+            ws = self.workspace(geom.ws_bytes)
+            hs.check(self.lib.hs_agg_partial(self.stream, cols, len(low.program.columns), low.key_slot,
+                                             C.byref(pstruct), C.byref(spec), d_units.data_ptr(), d_chunk0.data_ptr(),
+                                             n_units, C.byref(geom), out_rep.data_ptr(), out_acc.data_ptr(),
+                                             ngroups.data_ptr(), ws.data_ptr(), self.flags.data_ptr()),
+                     "hs_agg_partial")
+            # dense pack: one column per accumulator in the shuffle-file storage kind
+            acc_kinds = [hs.I32 if is_int else hs.F32 for is_int in low.acc_is_int]
+            pack_start = self.empty(n_units + 1, torch.int64)
+            dense_rep = self.empty(max(slots, 1), torch.int64)
+            acc_bufs = [self.empty(max(slots, 1), _TORCH_DTYPE[k]) for k in acc_kinds]
+            out_ptrs = (C.c_void_p * max(n_acc, 1))(*[t.data_ptr() for t in acc_bufs])
+            kinds_arr = (C.c_int32 * max(n_acc, 1))(*acc_kinds)
+            hs.check(self.lib.hs_agg_pack(self.stream, out_rep.data_ptr(), out_acc.data_ptr(), ngroups.data_ptr(),
+                                          n_units, cap, C.byref(spec), pack_start.data_ptr(), dense_rep.data_ptr(),
+                                          out_ptrs, kinds_arr, None), "hs_agg_pack")
+            flags = self.read_flags()  # D2H sync #1 of the hot path
+            if flags & hs.FLAG_DICT_FULL:
+                self.flags.zero_()
+                cap *= 4
+                continue
+            self.raise_for_flags(flags)
+            break
+        starts = pack_start.tolist()
+        n_rows = int(starts[-1])
+        key_idx = low.program.columns[low.key_slot]
+        key_col = self.gather_col(batch.cols[key_idx], dense_rep, n_rows)
+        out_cols = [key_col]
+        for acc in low.agg_to_acc:
+            buf = acc_bufs[acc]
+            out_cols.append(DCol(acc_kinds[acc], buf[:n_rows], n_rows))
+        self.last_group_cap = cap
+        return DBatch(list(out_schema), out_cols, n_rows, [int(s) for s in starts])
+
+    # ---- final merge (A7) ------------------------------------------------------------------------------
+    def aggregate_merge(self, batch: DBatch, agg_columns: Sequence[Any], out_schema: Schema) -> DBatch:
+        """Merge partial rows by key in unit order; column i+1 is folded with aggregate i's function
+        (reference tasks.py:290-292).  Output columns are in-flight (f64 / i64), not rounded."""
+        n_acc = len(agg_columns)
+        if n_acc > hs.HS_MAX_ACC:
+            raise NotImplementedError(f"more than {hs.HS_MAX_ACC} aggregates")
+        spec = hs.hs_agg_spec()
+        spec.n_acc = n_acc
+        is_int = []
+        for i, agg in enumerate(agg_columns):
+            spec.op[i] = {"sum": hs.AGG_SUM, "min": hs.AGG_MIN, "max": hs.AGG_MAX}[agg.type]
+            integer = batch.cols[i + 1].kind in (hs.I32, hs.I64)
+            spec.is_int[i] = 1 if integer else 0
+            is_int.append(integer)
+        n = batch.nrows
+        cap = 4
+        while cap < 2 * max(n, 1) and cap < 4096:
+            cap *= 2
+        key = batch.cols[0].as_hs()
+        acc_arr = (hs.hs_col * max(n_acc, 1))()
+        for i in range(n_acc):
+            acc_arr[i] = batch.cols[i + 1].as_hs()
+        out_rep = self.empty(cap, torch.int64)
+        out_acc = self.empty(max(cap * n_acc, 1), torch.int64)
+        ngroups = self.empty(1, torch.int32)
+        d_units = self.to_device(np.asarray(batch.unit_rows, dtype=np.int64))
+        rc = self.lib.hs_agg_merge(self.stream, C.byref(key), acc_arr, C.byref(spec), d_units.data_ptr(), batch.n_units,
+                                   n, cap, out_rep.data_ptr(), out_acc.data_ptr(), ngroups.data_ptr(), None,
+                                   self.flags.data_ptr())
+        if rc == 2:
+            raise NotImplementedError("final merge exceeds the LDS tier: " + self.lib.hs_last_error().decode())
+        hs.check(rc, "hs_agg_merge")
+        ng = int(ngroups.item())  # D2H sync #2
+        flags = self.read_flags()
+        if flags & hs.FLAG_DICT_FULL:
+            raise NotImplementedError("final merge: more distinct groups than the LDS tier holds")
+        self.raise_for_flags(flags)
+        key_col = self.gather_col(batch.cols[0], out_rep, ng)
+        cols = [key_col]
+        for i in range(n_acc):
+            raw = out_acc[i * cap: i * cap + ng]
+            if is_int[i]:
+                cols.append(DCol(hs.I64, raw, ng))
+            else:
+                cols.append(DCol(hs.F64, raw.view(torch.float64), ng))
+        return DBatch(list(out_schema), cols, ng, [0, ng])
+
+    # ---- hash partitioning (A6/A9) -------------------------------------------------------------------------
+    def partition(self, batch: DBatch, key_index: int, n_parts: int) -> tuple[torch.Tensor, list[int]]:
+        """Stable partition of the batch's rows by ``hash(key) % n_parts`` -> (perm, part_start)."""
+        n = batch.nrows
+        part = self.empty(n, torch.uint8)
+        key = batch.cols[key_index].as_hs()
+        hs.check(self.lib.hs_partition_ids(self.stream, C.byref(key), None, n, n_parts, part.data_ptr()),
+                 "hs_partition_ids")
+        perm = self.empty(n, torch.int64)
+        part_start = self.empty(n_parts + 1, torch.int64)
+        ws = self.workspace(self.lib.hs_partition_ws_bytes(n, n_parts))
+        hs.check(self.lib.hs_partition_perm(self.stream, part.data_ptr(), n, n_parts, perm.data_ptr(),
+                                            part_start.data_ptr(), ws.data_ptr()), "hs_partition_perm")
+        return perm, [int(v) for v in part_start.tolist()]
+
+    # ---- hash join (A8) --------------------------------------------------------------------------------
+    def join_indices(self, left_key: DCol, right_key: DCol) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, int]:
+        """Inner equi-join -> (left_rows, right_rows, out_start, n_out): pairs ordered by right row,
+        then by left row (the reference's emission order, tasks.py:224-240)."""
+        n_left, n_right = left_key.n, right_key.n
+        cap = 16
+        while cap < 2 * max(n_left, 1):
+            cap *= 2
+        tkeys = self.empty(cap, torch.int64)
+        treps = self.empty(cap, torch.int64)
+        slot_start = self.empty(cap + 1, torch.int64)
+        rows = self.empty(max(n_left, 1), torch.int64)
+        ws = self.workspace(self.lib.hs_join_build_ws_bytes(n_left, cap))
+        lk, rk = left_key.as_hs(), right_key.as_hs()
+        hs.check(self.lib.hs_join_build(self.stream, C.byref(lk), n_left, cap, tkeys.data_ptr(), treps.data_ptr(),
+                                        slot_start.data_ptr(), rows.data_ptr(), ws.data_ptr(), self.flags.data_ptr()),
+                 "hs_join_build")
+        counts = self.empty(max(n_right, 1), torch.int64)
+        hs.check(self.lib.hs_join_count(self.stream, C.byref(lk), C.byref(rk), n_right, cap, tkeys.data_ptr(),
+                                        treps.data_ptr(), slot_start.data_ptr(), counts.data_ptr()), "hs_join_count")
+        out_start = self.empty(n_right + 1, torch.int64)
+        ws2 = self.workspace(self.lib.hs_scan_ws_bytes(n_right))
+        hs.check(self.lib.hs_exclusive_scan_i64(self.stream, counts.data_ptr(), n_right, out_start.data_ptr(),
+                                                ws2.data_ptr()), "hs_exclusive_scan_i64")
+        n_out = int(out_start[n_right].item())
+        out_left = self.empty(max(n_out, 1), torch.int64)
+        out_right = self.empty(max(n_out, 1), torch.int64)
+        hs.check(self.lib.hs_join_fill(self.stream, C.byref(lk), C.byref(rk), n_right, cap, tkeys.data_ptr(),
+                                       treps.data_ptr(), slot_start.data_ptr(), rows.data_ptr(), out_start.data_ptr(),
+                                       out_left.data_ptr(), out_right.data_ptr()), "hs_join_fill")
+        return out_left, out_right, out_start, n_out

@@ -1,0 +1,293 @@
+"""Engine plug-in surface + the HIP engine (reference: src/mini_spark/execution.py:35-93).
+
+``ExecutionEngine`` mirrors the reference's abstract base: ``execute_full_task(Task) -> list[JobResult]``
+is the one method an engine must provide; ``collect_results`` reads the returned ``OutputFile``s back as
+row dicts.  ``HipExecutionEngine`` is the drop-in: it accepts a task chain built either by
+:mod:`minispark_amd.dataframe` or by the reference's own ``DataFrame`` (tasks are inspected by class and
+attribute *names*), plans it with the matching planner, and runs every stage on one MI355X through
+libhipspark.so.  Results are written as BlockFiles it owns and deletes in ``__exit__``.
+
+Stage execution keeps the reference's semantics-bearing structure:
+
+* scan stage: one partial-aggregation unit per file block; partials are quantised to f32/i32 exactly
+  where the reference writes its shuffle file;
+* join stage: one unit per shuffle partition ``hash(key) % 10``;
+* final stage: partial rows of a key are merged in unit order in fp64, AVG is ``sum / count`` on the
+  un-rounded merged sum, the result file rounds to f32 again.
+
+Inter-stage "shuffle files" stay in HBM as device batches (already quantised to the file types).
+"""
+
+from __future__ import annotations
+
+import math
+import os
+import shutil
+import uuid
+from abc import ABC, abstractmethod
+from contextlib import AbstractContextManager
+from pathlib import Path
+from typing import Any, Iterable, Iterator, Sequence
+
+from . import constants
+from .constants import ColumnType, Row, Schema
+from .io import BlockFile
+from .jobs import JobResult, OutputFile
+
+
+class ExecutionError(Exception):
+    def __init__(self, message: str = "Execution failed") -> None:
+        super().__init__(message)
+
+
+class ExecutionEngine(AbstractContextManager, ABC):
+    @abstractmethod
+    def execute_full_task(self, full_task: Any) -> list[JobResult]: ...
+
+    def generate_physical_plan(self, full_task: Any) -> Any:
+        # a task chain built by the reference is planned by the reference's planner (drop-in use);
+        # otherwise by this package's counterpart
+        if type(full_task).__module__.startswith("mini_spark."):
+            from mini_spark.plan import PhysicalPlan as ReferencePlan  # type: ignore[import-not-found]  # noqa: PLC0415
+
+            return ReferencePlan.generate_physical_plan(full_task)
+        from .plan import PhysicalPlan  # noqa: PLC0415
+
+        return PhysicalPlan.generate_physical_plan(full_task)
+
+    def collect_results(self, results: list[JobResult], limit: float = math.inf) -> Iterator[Row]:
+        output_files = {file for result in results for file in result.output_files}
+        for file in output_files:
+            for row in BlockFile(file.file_path).read_data_rows():
+                yield row
+                limit -= 1
+                if limit <= 0:
+                    return
+
+    def sql(self, query: str) -> Any:
+        raise NotImplementedError(
+            "the SQL front-end is outside the accelerated path (SURVEY.md section 8f N3); build the query with DataFrame"
+        )
+
+
+def _cls(obj: Any) -> str:
+    return type(obj).__name__
+
+
+def _plain_names(expr: Any) -> list[str]:
+    return [c.name for c in expr.all_nested_columns if _cls(c) in ("Col", "SchemaCol")]
+
+
+class HipExecutionEngine(ExecutionEngine):
+    """Runs query stages on an MI355X.  Zero-argument constructible like the reference's engines."""
+
+    def __init__(self, device: int | None = None, work_folder: Path | None = None) -> None:
+        from .device import Device  # noqa: PLC0415 - loads libhipspark.so and needs a GPU: fail loudly here
+
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dev = Device(device)
+        self._work_folder = work_folder
+        self._tables: dict[str, Any] = {}
+        self._owned_dirs: set[Path] = set()
+        self.group_cap_hint = 4
+        self.last_stats: dict[str, Any] = {}
+
+    # ---- context manager -------------------------------------------------------------------------------
+    def __exit__(self, exc_type, exc_value, traceback) -> None:  # noqa: ANN001
+        for d in self._owned_dirs:
+            shutil.rmtree(d, ignore_errors=True)
+        self._owned_dirs.clear()
+
+    # ---- tables --------------------------------------------------------------------------------------
+    def attach_device_table(self, path: str | Path, table: Any) -> None:
+        """Register columns that already live in HBM (synthetic data) as the table stored at ``path``.
+        ``path`` must hold a BlockFile header with the same schema (its blocks are not read)."""
+        self._tables[str(Path(path).resolve())] = table
+
+    def _table(self, path: Path) -> Any:
+        from . import table as tbl  # noqa: PLC0415
+
+        key = str(Path(path).resolve())
+        cached = self._tables.get(key)
+        if cached is not None and (cached.stamp == () or cached.stamp == tbl.file_stamp(Path(path))):
+            return cached
+        opened = tbl.open_table(Path(path))
+        self._tables[key] = opened
+        return opened
+
+    # ---- the plug-in entry point ---------------------------------------------------------------------------
+    def execute_full_task(self, full_task: Any) -> list[JobResult]:
+        from .device import DeviceError  # noqa: PLC0415
+        from .hipspark import HipSparkError  # noqa: PLC0415
+
+        plan = self.generate_physical_plan(full_task)
+        self.dev.reset_flags()
+        outputs: dict[int, Any] = {}
+        results: list[JobResult] = []
+        try:
+            for stage in plan.stages:
+                results = self._run_stage(stage, outputs)
+                stage.job_results.extend(results)
+        except (HipSparkError, DeviceError) as e:
+            raise ExecutionError(str(e)) from e
+        return results
+
+    # ---- stage execution -------------------------------------------------------------------------------
+    def _run_stage(self, stage: Any, outputs: dict[int, Any]) -> list[JobResult]:
+        producer, consumers, writer = stage.producer, list(stage.consumers), stage.writer
+        kind = _cls(producer)
+        if kind == "LoadTableBlockTask":
+            batch = self._scan(producer, consumers, writer)
+        elif kind == "LoadShuffleFilesTask":
+            batch = outputs[id(stage.dependencies[0])]
+        elif kind == "BroadcastHashJoinTask":
+            batch = self._join(producer, outputs[id(stage.dependencies[0])], outputs[id(stage.dependencies[1])])
+        else:
+            raise NotImplementedError(f"Job creation not implemented for {type(producer)}")
+
+        pending: list[Any] = []  # WHERE conditions not yet applied to `batch`
+        for task in consumers:
+            tname = _cls(task)
+            if tname == "FilterTask":
+                pending.append(task.condition)
+            elif tname == "ProjectTask":
+                batch = self._project(batch, pending, task)
+                pending = []
+            elif tname == "AggregateTask":
+                if task.before_shuffle:
+                    batch = self.dev.aggregate_partial(batch, pending, task.group_by_column, task.agg_columns,
+                                                       task.inferred_schema, self.group_cap_hint)
+                    self.group_cap_hint = max(self.group_cap_hint, getattr(self.dev, "last_group_cap", 4))
+                    pending = []
+                else:
+                    batch = self._materialise(batch, pending)
+                    pending = []
+                    batch = self.dev.aggregate_merge(batch, task.agg_columns, task.inferred_schema)
+            else:
+                raise NotImplementedError(f"consumer {tname}")
+        batch = self._materialise(batch, pending)
+
+        wname = _cls(writer)
+        schema = writer.inferred_schema
+        if wname == "WriteToShufflePartitions":
+            outputs[id(stage)] = self._quantise_batch(batch, schema)
+            self.dev.raise_for_flags(self.dev.read_flags())
+            return [JobResult(str(uuid.uuid4()), f"hip:{self.dev.index}", [])]
+        if wname == "WriteToLocalFileTask":
+            return [self._write_result(batch, schema, stage.stage_id)]
+        raise NotImplementedError(f"writer {wname}")
+
+    # ---- producers -------------------------------------------------------------------------------------
+    def _scan(self, producer: Any, consumers: Sequence[Any], writer: Any) -> Any:
+        from . import table as tbl  # noqa: PLC0415
+
+        table = self._table(producer.file_path)
+        prefix = f"{producer.alias}." if producer.alias else ""
+        names = [prefix + n for n, _ in table.schema]
+        needed: list[str] | None = []
+        for task in consumers:
+            tname = _cls(task)
+            if tname == "FilterTask":
+                needed += _plain_names(task.condition)
+            elif tname == "ProjectTask":
+                for col in task.columns:
+                    needed += _plain_names(col)
+                break
+            elif tname == "AggregateTask":
+                needed += _plain_names(task.group_by_column)
+                for agg in task.agg_columns:
+                    needed += _plain_names(agg)
+                break
+        else:
+            needed = None  # rows reach the writer unprojected: every column is needed
+        col_ids = list(range(len(names))) if needed is None else sorted({names.index(n) for n in needed})
+        if not col_ids:
+            col_ids = [0]
+        tbl.load_columns(self.dev, table, col_ids)
+        return tbl.table_batch(table, col_ids, producer.alias)
+
+    def _join(self, task: Any, left: Any, right: Any) -> Any:
+        """Partitioned inner hash join; output rows grouped by ``hash(key) % SHUFFLE_PARTITIONS`` so
+        that a following partial aggregate sees the reference's JoinJob units (plan.py:99-109)."""
+        from .device import DBatch  # noqa: PLC0415
+
+        lkey = left.column_index(task.left_key.name)
+        rkey = right.column_index(task.right_key.name)
+        perm, part_start = self.dev.partition(right, rkey, constants.SHUFFLE_PARTITIONS)
+        right = self.dev.gather_batch(right, perm, right.nrows, part_start)
+        out_left, out_right, out_start, n_out = self.dev.join_indices(left.cols[lkey], right.cols[rkey])
+        starts = out_start.tolist() if right.nrows <= 4096 else None
+        if starts is None:
+            import torch  # noqa: PLC0415
+
+            idx = torch.tensor(part_start, dtype=torch.int64, device=out_start.device)
+            unit_rows = [int(v) for v in out_start[idx].tolist()]
+        else:
+            unit_rows = [int(starts[p]) for p in part_start]
+        cols = [self.dev.gather_col(c, out_left, n_out) for c in left.cols]
+        cols += [self.dev.gather_col(c, out_right, n_out) for c in right.cols]
+        return DBatch(list(left.schema) + list(right.schema), cols, n_out, unit_rows)
+
+    # ---- consumers -------------------------------------------------------------------------------------
+    def _materialise(self, batch: Any, pending: Sequence[Any]) -> Any:
+        """Apply deferred WHERE conditions: compaction to a row list, then gather every column."""
+        if not pending:
+            return batch
+        import torch  # noqa: PLC0415
+
+        sel, count = self.dev.filter_select(batch, pending)
+        bounds = torch.tensor(batch.unit_rows, dtype=torch.int64, device=sel.device)
+        unit_rows = [int(v) for v in torch.searchsorted(sel[:count].contiguous(), bounds).tolist()]
+        return self.dev.gather_batch(batch, sel, count, unit_rows)
+
+    def _project(self, batch: Any, pending: Sequence[Any], task: Any) -> Any:
+        from . import hipspark as hs  # noqa: PLC0415
+        from .device import DBatch  # noqa: PLC0415
+        from .lowering import ProgramBuilder, unalias  # noqa: PLC0415
+
+        batch = self._materialise(batch, pending)
+        n = batch.nrows
+        helper = ProgramBuilder(batch.schema, batch.kinds)
+        out_cols: list[Any] = [None] * len(task.columns)
+        numeric: list[tuple[int, Any]] = []
+        for i, col in enumerate(task.columns):
+            bare = unalias(col)
+            if _cls(bare) in ("Col", "SchemaCol"):
+                out_cols[i] = batch.cols[batch.column_index(bare.name)]  # pass-through keeps the stored values
+            elif helper.string_tag(bare):
+                out_cols[i] = self.dev.concat_strings(batch, helper.string_parts(bare), n)
+            else:
+                numeric.append((i, col))
+        if numeric:
+            evaluated = self.dev.eval_numeric(batch, [c for _, c in numeric])
+            for (i, _), (dcol, tag) in zip(numeric, evaluated):
+                if tag == "B":
+                    raise AssertionError("a comparison cannot be selected as a column (the reference has no BOOL type)")
+                out_cols[i] = dcol
+        _ = hs
+        return DBatch(list(task.inferred_schema), out_cols, n, list(batch.unit_rows))
+
+    # ---- writers ---------------------------------------------------------------------------------------
+    def _quantise_batch(self, batch: Any, schema: Schema) -> Any:
+        from .device import DBatch  # noqa: PLC0415
+
+        if len(schema) != len(batch.cols):
+            raise ExecutionError(f"writer schema {schema} does not match batch {batch.schema}")
+        cols = [self.dev.quantise_col(c, t) for c, (_, t) in zip(batch.cols, schema)]
+        return DBatch(list(schema), cols, batch.nrows, list(batch.unit_rows))
+
+    def _write_result(self, batch: Any, schema: Schema, stage_id: str) -> JobResult:
+        job_id = str(uuid.uuid4())
+        quantised = self._quantise_batch(batch, schema)
+        raw = [self.dev.download(c, t) for c, (_, t) in zip(quantised.cols, schema)]  # D2H (synchronises)
+        self.dev.raise_for_flags(self.dev.read_flags())
+        if batch.nrows == 0:
+            return JobResult(job_id, f"hip:{self.dev.index}", [])  # the reference writes no file (tasks.py:405)
+        root = self._work_folder or (constants.SHUFFLE_FOLDER / f"hip-{uuid.uuid4().hex[:12]}")
+        out_dir = Path(root) / str(stage_id)
+        out_dir.mkdir(parents=True, exist_ok=True)
+        self._owned_dirs.add(Path(root))
+        out_file = out_dir / "result.bin"
+        BlockFile(out_file, list(schema)).write_raw(list(schema), raw)
+        return JobResult(job_id, f"hip:{self.dev.index}", [OutputFile(out_file)])

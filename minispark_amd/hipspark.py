@@ -1,0 +1,162 @@
+"""ctypes binding of libhipspark.so (the C ABI declared in include/hipspark.h).
+
+Thin by design: structures mirror the header field for field, every function gets its argtypes, and
+``check()`` turns a nonzero return into :class:`HipSparkError`.  There is no fallback: if the shared
+object cannot be built or loaded, importing the engine fails loudly.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+HS_MAX_INS = 96
+HS_MAX_LIT = 32
+HS_MAX_POOL = 256
+HS_MAX_COLS = 12
+HS_MAX_ACC = 16
+HS_MAX_STACK = 8
+HS_MAX_OUTS = 16
+HS_MAX_PARTS = 8
+HS_FUSED_COLS = 8
+
+# storage kinds
+I32, F32, I64, F64, STR, U8 = 0, 1, 2, 3, 4, 5
+KIND_BYTES = {I32: 4, F32: 4, I64: 8, F64: 8, U8: 1}
+
+# flags
+FLAG_DIV_ZERO = 0x1
+FLAG_INT_OVERFLOW = 0x2
+FLAG_FLT_OVERFLOW = 0x4
+FLAG_DICT_FULL = 0x8
+FLAG_BAD_PROGRAM = 0x10
+FLAG_STR_TOO_LONG = 0x20
+
+AGG_SUM, AGG_MIN, AGG_MAX = 0, 1, 2
+
+# opcodes
+OP_END, OP_LD, OP_LIT = 0, 1, 2
+OP_ADD_F, OP_SUB_F, OP_MUL_F, OP_DIV_F, OP_FLOORDIV_F, OP_MOD_F = 3, 4, 5, 6, 7, 8
+OP_ADD_I, OP_SUB_I, OP_MUL_I, OP_FLOORDIV_I, OP_MOD_I = 9, 10, 11, 12, 13
+OP_LT_F, OP_LE_F, OP_GT_F, OP_GE_F, OP_EQ_F, OP_NE_F = 14, 15, 16, 17, 18, 19
+OP_LT_I, OP_LE_I, OP_GT_I, OP_GE_I, OP_EQ_I, OP_NE_I = 20, 21, 22, 23, 24, 25
+OP_AND, OP_OR, OP_I2F = 26, 27, 28
+OP_STRCMP_LIT, OP_STRCMP_COL, OP_LIKE = 29, 30, 31
+OP_FILTER, OP_AGG, OP_OUT, OP_KEY = 32, 33, 34, 35
+
+
+class HipSparkError(RuntimeError):
+    pass
+
+
+class hs_col(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("fixed_len", C.c_int32),
+        ("data", C.c_void_p),
+        ("lens", C.c_void_p),
+        ("offs", C.c_void_p),
+    ]
+
+
+class hs_program(C.Structure):
+    _fields_ = [
+        ("n_ins", C.c_uint32),
+        ("n_lit", C.c_uint32),
+        ("ins", C.c_uint64 * HS_MAX_INS),
+        ("lit", C.c_uint64 * HS_MAX_LIT),
+        ("pool", C.c_uint8 * HS_MAX_POOL),
+    ]
+
+
+class hs_agg_spec(C.Structure):
+    _fields_ = [
+        ("n_acc", C.c_int32),
+        ("op", C.c_uint8 * HS_MAX_ACC),
+        ("is_int", C.c_uint8 * HS_MAX_ACC),
+    ]
+
+
+class hs_agg_geom(C.Structure):
+    _fields_ = [
+        ("group_cap", C.c_int32),
+        ("chunk_rows", C.c_int32),
+        ("n_chunks", C.c_int64),
+        ("lds_bytes", C.c_size_t),
+        ("ws_bytes", C.c_size_t),
+    ]
+
+
+_P = C.c_void_p
+_I64 = C.c_int64
+_I32 = C.c_int32
+_COLP = C.POINTER(hs_col)
+_PROGP = C.POINTER(hs_program)
+_SPECP = C.POINTER(hs_agg_spec)
+_GEOMP = C.POINTER(hs_agg_geom)
+
+# name -> (restype, argtypes); every symbol include/hipspark.h declares
+SIGNATURES: dict[str, tuple] = {
+    "hs_last_error": (C.c_char_p, []),
+    "hs_version": (C.c_int, []),
+    "hs_scan_ws_bytes": (C.c_size_t, [_I64]),
+    "hs_str_offsets": (C.c_int, [_P, _P, _I64, _P, _P, _P]),
+    "hs_eval": (C.c_int, [_P, _COLP, _I32, _PROGP, _P, _I64, C.POINTER(_P), C.POINTER(_I32), _I32, _P]),
+    "hs_compact": (C.c_int, [_P, _P, _I64, _P, _P, _P]),
+    "hs_gather_fixed": (C.c_int, [_P, _P, _I32, _P, _I64, _P]),
+    "hs_gather_str_lens": (C.c_int, [_P, _COLP, _P, _I64, _P]),
+    "hs_gather_str_bytes": (C.c_int, [_P, _COLP, _P, _I64, _P, _P]),
+    "hs_concat_lens": (C.c_int, [_P, _COLP, _I32, _I64, _P, _P]),
+    "hs_concat_bytes": (C.c_int, [_P, _COLP, _I32, _I64, _P, _P]),
+    "hs_agg_partial_geom": (C.c_int, [C.POINTER(_I64), _I64, _I32, _I32, _GEOMP]),
+    "hs_agg_partial": (
+        C.c_int,
+        [_P, _COLP, _I32, _I32, _PROGP, _SPECP, _P, _P, _I64, _GEOMP, _P, _P, _P, _P, _P],
+    ),
+    "hs_agg_pack": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _SPECP, _P, _P, C.POINTER(_P), C.POINTER(_I32), _P]),
+    "hs_agg_merge_ws_bytes": (C.c_size_t, [_I64, _I64, _I32]),
+    "hs_agg_merge": (C.c_int, [_P, _COLP, _COLP, _SPECP, _P, _I64, _I64, _I32, _P, _P, _P, _P, _P]),
+    "hs_partition_ids": (C.c_int, [_P, _COLP, _P, _I64, _I32, _P]),
+    "hs_partition_ws_bytes": (C.c_size_t, [_I64, _I32]),
+    "hs_partition_perm": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P]),
+    "hs_join_build_ws_bytes": (C.c_size_t, [_I64, _I64]),
+    "hs_join_build": (C.c_int, [_P, _COLP, _I64, _I64, _P, _P, _P, _P, _P, _P]),
+    "hs_join_count": (C.c_int, [_P, _COLP, _COLP, _I64, _I64, _P, _P, _P, _P]),
+    "hs_join_fill": (C.c_int, [_P, _COLP, _COLP, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),
+    "hs_exclusive_scan_i64": (C.c_int, [_P, _P, _I64, _P, _P]),
+    "hs_quantise": (C.c_int, [_P, _P, _I32, _I64, _P, _P]),
+    "hs_gen_lineitem": (C.c_int, [_P, C.c_uint64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+}
+
+_lib: C.CDLL | None = None
+
+
+def library_path() -> Path:
+    return Path(__file__).resolve().parent / "libhipspark.so"
+
+
+def load_library(build_if_missing: bool = True) -> C.CDLL:
+    """Load (building first if needed) libhipspark.so and bind every declared symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if build_if_missing:
+        from . import _build  # noqa: PLC0415
+
+        path = _build.build()
+    if not path.exists():
+        raise HipSparkError(f"{path} is missing: run `python -m minispark_amd._build` (needs hipcc)")
+    lib = C.CDLL(str(path))
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = the library does not export a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load_library().hs_last_error()
+        raise HipSparkError(f"{what or 'libhipspark'} failed (code {rc}): {msg.decode() if msg else ''}")

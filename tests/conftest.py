@@ -1,0 +1,92 @@
+"""Shared test plumbing: markers, TZ pin (BlockFile timestamps are naive local datetimes - the fixtures
+were made under TZ=UTC), scratch folders, golden-fixture helpers."""
+
+from __future__ import annotations
+
+import json
+import os
+import struct
+import sys
+import time
+from datetime import datetime
+from pathlib import Path
+
+import pytest
+
+os.environ["TZ"] = "UTC"
+time.tzset()
+
+ROOT = Path(__file__).resolve().parent.parent
+GOLDEN = ROOT / "tests" / "golden"
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(autouse=True)
+def scratch_folders(tmp_path, monkeypatch):
+    """Engines write result files under constants.SHUFFLE_FOLDER: point it into tmp_path."""
+    from minispark_amd import constants
+
+    monkeypatch.setattr(constants, "SHUFFLE_FOLDER", tmp_path / "shuffle")
+    monkeypatch.setattr(constants, "GLOBAL_TEMP_FOLDER", tmp_path / "tmp")
+
+
+def f32(x: float) -> float:
+    return struct.unpack("<f", struct.pack("<f", x))[0]
+
+
+def decode_golden_value(v):
+    if isinstance(v, dict) and "f" in v:
+        return float.fromhex(v["f"])
+    if isinstance(v, dict) and "t" in v:
+        return datetime.fromisoformat(v["t"])
+    return v
+
+
+def load_golden(name: str) -> dict:
+    data = json.loads((GOLDEN / f"{name}.json").read_text())
+    if "rows" in data:
+        data["rows"] = [{k: decode_golden_value(v) for k, v in row.items()} for row in data["rows"]]
+    data["paths"] = {t: str(GOLDEN / f) for t, f in data["tables"].items()}
+    return data
+
+
+def sort_rows(rows: list[dict]) -> list[dict]:
+    return sorted(rows, key=lambda r: tuple((type(v).__name__, v) for v in r.values()))
+
+
+def f32_ulps(a: float, b: float) -> int:
+    """Distance in f32 units in the last place between two f32-representable values."""
+    def key(x: float) -> int:
+        (i,) = struct.unpack("<i", struct.pack("<f", x))
+        return i if i >= 0 else -(i & 0x7FFFFFFF)
+    return abs(key(a) - key(b))
+
+
+def assert_rows_match(got: list[dict], want: list[dict], *, max_ulps: int = 0) -> int:
+    """Multiset equality of result rows (row order is unspecified in the reference,
+    execution.py:49): ints / strings / datetimes bit-exact; FLOAT columns equal as f32 - or, with
+    max_ulps=1, at most one f32 ulp apart (a re-associated fp64 sum can land on the other side of
+    an f32 rounding boundary).  Returns the number of values that differed by an ulp."""
+    assert len(got) == len(want), f"row count {len(got)} != {len(want)}\n got={got}\nwant={want}"
+    flips = 0
+    # sort on the non-float columns first so a 1-ulp difference cannot reorder rows
+    def stable_key(r):
+        return tuple((type(v).__name__, v) for v in r.values() if type(v) is not float) + tuple(
+            (round(v, 3),) for v in r.values() if type(v) is float)
+    for g, w in zip(sorted(got, key=stable_key), sorted(want, key=stable_key)):
+        assert list(g.keys()) == list(w.keys()), f"columns {list(g.keys())} != {list(w.keys())}"
+        for k in g:
+            gv, wv = g[k], w[k]
+            assert type(gv) is type(wv), f"{k}: type {type(gv).__name__} != {type(wv).__name__} ({gv!r} vs {wv!r})"
+            if type(gv) is float:
+                d = f32_ulps(f32(gv), f32(wv))
+                assert d <= max_ulps, f"{k}: {gv!r} vs {wv!r} differ by {d} f32 ulps"
+                flips += d != 0
+            else:
+                assert gv == wv, f"{k}: {gv!r} != {wv!r}"
+    return flips
