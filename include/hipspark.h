@@ -170,6 +170,8 @@ int hs_concat_bytes(void* stream, const hs_col* parts, int32_t n_parts, int64_t 
 typedef struct hs_agg_geom {
     int32_t group_cap;   /* per-workgroup / per-unit dictionary capacity (power of two) */
     int32_t chunk_rows;  /* rows per workgroup */
+    int32_t wg_threads;  /* lanes per workgroup: 256, 128 or 64 (each lane owns a private LDS table) */
+    int32_t pad;
     int64_t n_chunks;    /* grid size */
     size_t lds_bytes;    /* dynamic LDS of the main kernel */
     size_t ws_bytes;     /* workspace bytes */

@@ -576,8 +576,12 @@ static int program_depth(const hs_program* p) {
     return d;
 }
 
-static constexpr int HS_AGG_WG = 256;
-static constexpr size_t HS_LDS_BUDGET = 64 * 1024;  // dynamic LDS per workgroup kept <= 64 KiB (>= 2 WG / CU)
+static constexpr size_t HS_LDS_SOFT = 64 * 1024;   // keeps >= 2 workgroups per CU resident
+static constexpr size_t HS_LDS_HARD = 144 * 1024;  // one workgroup per CU (gfx950: 160 KiB per CU)
+
+static size_t agg_main_lds(int32_t group_cap, int32_t n_acc, int wg) {
+    return (size_t)group_cap * 16 + (size_t)group_cap * (size_t)n_acc * (size_t)wg * 8;
+}
 
 extern "C" int hs_agg_partial_geom(const int64_t* host_unit_rows, int64_t n_units, int32_t n_acc, int32_t group_cap,
                                    hs_agg_geom* out) {
@@ -586,25 +590,36 @@ extern "C" int hs_agg_partial_geom(const int64_t* host_unit_rows, int64_t n_unit
         hs_set_error("hs_agg_partial_geom: bad arguments");
         return HS_E_ARG;
     }
-    const size_t lds = (size_t)group_cap * 16 + (size_t)group_cap * (size_t)n_acc * HS_AGG_WG * 8;
-    if (lds > HS_LDS_BUDGET) {
-        hs_set_error("hs_agg_partial_geom: group_cap=%d x n_acc=%d private tables need %zu B LDS (> %zu)", group_cap,
-                     n_acc, lds, HS_LDS_BUDGET);
+    // every lane owns a private [group_cap][n_acc] table in LDS: pick the widest workgroup that fits
+    int wg = 0;
+    size_t lds = 0;
+    const int widths[3] = {256, 128, 64};
+    for (int pass = 0; pass < 2 && !wg; ++pass) {
+        for (int k = 0; k < 3; ++k) {
+            lds = agg_main_lds(group_cap, n_acc, widths[k]);
+            if (lds <= (pass == 0 ? HS_LDS_SOFT : HS_LDS_HARD)) {
+                wg = widths[k];
+                break;
+            }
+        }
+    }
+    if (!wg) {
+        hs_set_error("hs_agg_partial_geom: group_cap=%d x n_acc=%d private tables need %zu B LDS even at 64 lanes (> %zu)",
+                     group_cap, n_acc, agg_main_lds(group_cap, n_acc, 64), HS_LDS_HARD);
         return HS_E_LIMIT;
     }
-    int64_t max_rows = 0, total = 0;
+    int64_t total = 0;
     for (int64_t u = 0; u < n_units; ++u) {
         const int64_t r = host_unit_rows[u + 1] - host_unit_rows[u];
         if (r < 0) {
             hs_set_error("hs_agg_partial_geom: unit_rows not ascending at %lld", (long long)u);
             return HS_E_ARG;
         }
-        if (r > max_rows) max_rows = r;
         total += r;
     }
-    // rows per workgroup: a multiple of WG*V; ~16 steps per lane when there is enough data to fill the
+    // rows per workgroup: a multiple of wg*V; ~16 steps per lane when there is enough data to fill the
     // chip (256 CUs x 2 WGs) several times over, fewer for small inputs
-    const int64_t step = (int64_t)HS_AGG_WG * HS_V;
+    const int64_t step = (int64_t)wg * HS_V;
     int64_t chunk = step * 16;
     while (chunk > step && total / chunk < 2048) chunk /= 2;
     int64_t n_chunks = 0;
@@ -615,11 +630,18 @@ extern "C" int hs_agg_partial_geom(const int64_t* host_unit_rows, int64_t n_unit
     }
     out->group_cap = group_cap;
     out->chunk_rows = (int32_t)chunk;
+    out->wg_threads = wg;
+    out->pad = 0;
     out->n_chunks = n_chunks;
     out->lds_bytes = lds;
     const size_t slots = (size_t)n_chunks * group_cap;
     out->ws_bytes = slots * 16 + slots * (size_t)n_acc * 8 + 256;
     return HS_OK;
+}
+
+template <typename K>
+static void allow_big_lds(K kernel) {
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HS_LDS_HARD);
 }
 
 extern "C" int hs_agg_partial(void* stream, const hs_col* cols, int32_t n_cols, int32_t key_col,
@@ -667,7 +689,18 @@ extern "C" int hs_agg_partial(void* stream, const hs_col* cols, int32_t n_cols, 
         return HS_E_LIMIT;
     }
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((unsigned)geom->n_chunks), block(HS_AGG_WG);
+    if (geom->wg_threads != 64 && geom->wg_threads != 128 && geom->wg_threads != 256) {
+        hs_set_error("hs_agg_partial: geometry not made by hs_agg_partial_geom");
+        return HS_E_ARG;
+    }
+    dim3 grid((unsigned)geom->n_chunks), block((unsigned)geom->wg_threads);
+    static bool attrs_set = false;
+    if (!attrs_set) {
+        allow_big_lds(k_agg_main<true, 8>);
+        allow_big_lds(k_agg_main<false, 4>);
+        allow_big_lds(k_agg_main<false, 8>);
+        attrs_set = true;
+    }
     if (geom->n_chunks > 0x7fffffffll) {
         hs_set_error("hs_agg_partial: too many chunks");
         return HS_E_LIMIT;

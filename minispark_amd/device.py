@@ -323,7 +323,7 @@ class Device:
             rc = self.lib.hs_agg_partial_geom(host_units, n_units, n_acc, cap, C.byref(geom))
             if rc == 2:
                 raise NotImplementedError(
-                    f"GROUP BY with more than {cap // 2} groups per unit x {n_acc} aggregates exceeds the LDS tier: "
+                    f"GROUP BY with more than {cap // 2} groups per workgroup x {n_acc} aggregates exceeds the LDS tier: "
                     + self.lib.hs_last_error().decode()
                 )
             hs.check(rc, "hs_agg_partial_geom")
@@ -359,7 +359,7 @@ class Device:
             flags = self.read_flags()  # D2H sync #1 of the hot path
             if flags & hs.FLAG_DICT_FULL:
                 self.flags.zero_()
-                cap *= 4
+                cap *= 2
                 continue
             self.raise_for_flags(flags)
             break

@@ -81,6 +81,8 @@ class hs_agg_geom(C.Structure):
     _fields_ = [
         ("group_cap", C.c_int32),
         ("chunk_rows", C.c_int32),
+        ("wg_threads", C.c_int32),
+        ("pad", C.c_int32),
         ("n_chunks", C.c_int64),
         ("lds_bytes", C.c_size_t),
         ("ws_bytes", C.c_size_t),
