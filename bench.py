@@ -1,0 +1,189 @@
+"""bench.py - TPC-H Q1 (the reference's benchmark query, README.md:141-158) on synthetic lineitem through
+HipExecutionEngine, N GPUs of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--sf SF]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path: ``DataFrame.collect()`` of Q1 with the referenced columns already
+resident in HBM (block b on rank b % N) -> result rows on the host of rank 0.  Strong scaling: the
+table (default sf=100 = 600 037 902 rows, 287 blocks) is fixed and split across the ranks.
+Rank 0 prints ONE JSON line (see DESIGN.md section 6 for every field).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+from datetime import datetime
+from pathlib import Path
+
+os.environ.setdefault("TZ", "UTC")
+time.tzset()
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s)
+CUTOFF = "1998-12-01"
+
+
+def q1_frame(engine, table_path: str):
+    from minispark_amd.dataframe import DataFrame
+    from minispark_amd.sql import Col, Functions, Lit
+    from tests.queries import api_namespace, q1
+
+    return q1(api_namespace(lambda: DataFrame(engine), Col, Functions, Lit), table_path, CUTOFF)
+
+
+def cpu_baseline(engine, table, sample_blocks: int, gpu_rows_for_sample):
+    """The C port of the reference's algorithm (oracle/q1_oracle.c) timed on the host cores over the
+    first ``sample_blocks`` blocks of the same table; also checks the GPU's rows for that sample."""
+    import numpy as np
+
+    from oracle import blockfile as bfio
+    from oracle import q1_native
+    from tests.conftest import assert_rows_match
+
+    sizes = table.block_rows[:sample_blocks]
+    n = sum(sizes)
+    names = {1: "l_quantity", 2: "l_extendedprice", 3: "l_discount", 4: "l_tax", 5: "l_returnflag", 6: "l_shipdate"}
+    cols = {name: table.columns[cid].data[:n].cpu().numpy() for cid, name in names.items()}
+    cutoff_us = bfio.to_us(datetime.fromisoformat(CUTOFF))
+    threads = q1_native.host_threads()
+    q1_native.run(cols, sizes, cutoff_us, threads=threads)  # warm-up (page in, build)
+    t0 = time.perf_counter()
+    passes_mt = 0
+    while time.perf_counter() - t0 < 6.0 or passes_mt < 2:
+        want = q1_native.run(cols, sizes, cutoff_us, threads=threads)
+        passes_mt += 1
+    t_mt = (time.perf_counter() - t0) / passes_mt
+    t0 = time.perf_counter()
+    passes_1 = 0
+    while time.perf_counter() - t0 < 6.0 or passes_1 < 1:
+        want1 = q1_native.run(cols, sizes, cutoff_us, threads=1)
+        passes_1 += 1
+    t_1 = (time.perf_counter() - t0) / passes_1
+    assert want == want1, "C oracle: threaded and scalar runs differ"
+    flips = assert_rows_match(gpu_rows_for_sample, want, max_ulps=1)
+    return {
+        "value": n / t_mt, "unit": "rows/s", "cores": threads, "kind": "port",
+        "sample": f"first {sample_blocks} blocks ({n} rows) of the same table; {passes_mt} passes on {threads} threads, "
+                  f"{passes_1} on 1 thread",
+        "value_1core": n / t_1,
+        "gpu_matches_oracle_on_sample": True, "f32_ulp_flips_on_sample": flips,
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--sf", type=float, default=100.0)
+    ap.add_argument("--sample-blocks", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from minispark_amd import constants, synth
+    from minispark_amd.execution import HipExecutionEngine
+
+    scratch = Path(tempfile.mkdtemp(prefix=f"hipspark_bench_r{rank}_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None))
+    constants.SHUFFLE_FOLDER = scratch / "shuffle"
+    total_rows = synth.lineitem_rows(args.sf)
+    engine = HipExecutionEngine(device=local_rank)
+    if world > 1:
+        engine.enable_distributed(dist)
+    table_path = scratch / f"lineitem_sf{args.sf:g}.bin"
+    table = synth.make_lineitem(engine.dev, table_path, total_rows, rank=rank, world=world)
+    engine.attach_device_table(table_path, table)
+    frame = q1_frame(engine, str(table_path))
+    engine.dev.time_scan_kernel(True)
+
+    def step():
+        return frame.collect()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    rows = None
+    for _ in range(args.warmup):
+        rows = step()
+    fence()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rows = step()
+        kernel_ms.append(engine.dev.scan_kernel_ms())  # the step ended with a D2H sync: events are complete
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        k = torch.tensor([sum(kernel_ms) / len(kernel_ms)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(k, op=dist.ReduceOp.MAX)
+        kernel_avg_ms = float(k.item())
+    else:
+        kernel_avg_ms = sum(kernel_ms) / len(kernel_ms)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        local_rows = table.nrows
+        scan = engine.dev.last_scan
+        achieved = synth.Q1_BYTES_PER_ROW * local_rows / (kernel_avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "TPC-H Q1 lineitem rows/sec", "value": total_rows / (elapsed / args.steps), "unit": "rows/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": f"TPC-H Q1 variant (8 aggregates, WHERE l_shipdate <= '{CUTOFF}', GROUP BY l_returnflag) "
+                            f"on synthetic lineitem sf={args.sf:g}",
+                "rows": total_rows, "blocks": len(synth.block_sizes(total_rows)), "rows_per_block": constants.ROWS_PER_BLOCK,
+                "bytes_per_row": synth.Q1_BYTES_PER_ROW, "groups": len(rows or []), "placement": "block b on rank b % n_gpus",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "k_agg_main", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel_ms": kernel_avg_ms,
+                "rows_per_launch": local_rows, "launch": scan,
+            },
+            "whole_step_GBps_per_gpu": synth.Q1_BYTES_PER_ROW * local_rows / (elapsed / args.steps) / 1e9,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            blocks = min(args.sample_blocks, len(table.block_rows))
+            sample = synth.make_lineitem(engine.dev, scratch / "sample.bin", sum(table.block_rows[:blocks]))
+            engine.attach_device_table(scratch / "sample.bin", sample)
+            gpu_sample_rows = q1_frame(engine, str(scratch / "sample.bin")).collect()
+            out["cpu_baseline"] = cpu_baseline(engine, table, blocks, gpu_sample_rows)
+        print(json.dumps(out), flush=True)
+    engine.__exit__(None, None, None)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    import shutil
+
+    shutil.rmtree(scratch, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

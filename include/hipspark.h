@@ -189,11 +189,13 @@ int hs_agg_partial_geom(const int64_t* host_unit_rows, int64_t n_units, int32_t 
  *   out_acc   : [n_units * group_cap * n_acc] 64-bit cells, ALREADY QUANTISED like a shuffle-file
  *               write (FLOAT aggregates rounded to f32 and widened back, INTEGER range-checked)
  *   out_ngroups[n_units] : occupied slots per unit
+ * ev_begin / ev_end: optional hipEvent_t recorded on `stream` immediately before / after the main
+ * scan kernel (NULL = none) - how bench.py measures the kernel's duration live.
  */
 int hs_agg_partial(void* stream, const hs_col* cols, int32_t n_cols, int32_t key_col, const hs_program* prog,
                    const hs_agg_spec* spec, const int64_t* unit_rows, const int64_t* unit_chunk0, int64_t n_units,
                    const hs_agg_geom* geom, int64_t* out_rep, uint64_t* out_acc, int32_t* out_ngroups, void* ws,
-                   uint32_t* flags);
+                   uint32_t* flags, void* ev_begin, void* ev_end);
 
 /* Dense pack of the slot arrays: rows of unit u go to [pack_start[u], pack_start[u+1]).
  * out_cols[a] receives accumulator a as HS_F32 / HS_I32 storage (acc_kinds[a]) = the reference's

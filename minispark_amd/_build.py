@@ -19,7 +19,7 @@ LIB = PKG / "libhipspark.so"
 STAMP = PKG / ".libhipspark.stamp"
 SOURCES = ["hs_agg.hip", "hs_ops.hip"]
 HEADERS = [CSRC / "hs_device.h", PKG.parent / "include" / "hipspark.h"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unused-value"]
 
 
 def _digest() -> str:

@@ -647,7 +647,8 @@ static void allow_big_lds(K kernel) {
 extern "C" int hs_agg_partial(void* stream, const hs_col* cols, int32_t n_cols, int32_t key_col,
                               const hs_program* prog, const hs_agg_spec* spec, const int64_t* unit_rows,
                               const int64_t* unit_chunk0, int64_t n_units, const hs_agg_geom* geom, int64_t* out_rep,
-                              uint64_t* out_acc, int32_t* out_ngroups, void* ws, uint32_t* flags) {
+                              uint64_t* out_acc, int32_t* out_ngroups, void* ws, uint32_t* flags, void* ev_begin,
+                              void* ev_end) {
     if (!cols || !prog || !spec || !unit_rows || !unit_chunk0 || !geom || !out_rep || !out_acc || !out_ngroups ||
         !ws || !flags || key_col < 0 || key_col >= n_cols) {
         hs_set_error("hs_agg_partial: null or out-of-range argument");
@@ -705,6 +706,7 @@ extern "C" int hs_agg_partial(void* stream, const hs_col* cols, int32_t n_cols, 
         hs_set_error("hs_agg_partial: too many chunks");
         return HS_E_LIMIT;
     }
+    if (ev_begin) (void)hipEventRecord((hipEvent_t)ev_begin, s);
     if (hashed) {
         hipLaunchKernelGGL((k_agg_main<true, 8>), grid, block, geom->lds_bytes, s, A);
     } else if (depth <= 4) {
@@ -712,6 +714,7 @@ extern "C" int hs_agg_partial(void* stream, const hs_col* cols, int32_t n_cols, 
     } else {
         hipLaunchKernelGGL((k_agg_main<false, 8>), grid, block, geom->lds_bytes, s, A);
     }
+    if (ev_end) (void)hipEventRecord((hipEvent_t)ev_end, s);
     AggUnitArgs U;
     U.key = cols[key_col];
     U.spec = *spec;

@@ -105,6 +105,23 @@ class Device:
         self.flags = torch.zeros(4, dtype=torch.int32, device=self.device)
 
     # ---- plumbing ------------------------------------------------------------------------------------
+    def time_scan_kernel(self, enable: bool = True) -> None:
+        """Bracket the main scan kernel of every following aggregate_partial with HIP events (recorded
+        by the library on the launch stream); read with scan_kernel_ms() after a synchronise."""
+        if enable:
+            self.scan_events = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+            for ev in self.scan_events:
+                ev.record()  # creates the underlying hipEvent_t
+        else:
+            self.scan_events = None
+
+    def _event_handle(self, i: int):
+        ev = getattr(self, "scan_events", None)
+        return None if ev is None else ev[i].cuda_event
+
+    def scan_kernel_ms(self) -> float:
+        return self.scan_events[0].elapsed_time(self.scan_events[1])
+
     @property
     def stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -344,8 +361,11 @@ class Device:
             hs.check(self.lib.hs_agg_partial(self.stream, cols, len(low.program.columns), low.key_slot,
                                              C.byref(pstruct), C.byref(spec), d_units.data_ptr(), d_chunk0.data_ptr(),
                                              n_units, C.byref(geom), out_rep.data_ptr(), out_acc.data_ptr(),
-                                             ngroups.data_ptr(), ws.data_ptr(), self.flags.data_ptr()),
+                                             ngroups.data_ptr(), ws.data_ptr(), self.flags.data_ptr(),
+                                             self._event_handle(0), self._event_handle(1)),
                      "hs_agg_partial")
+            self.last_scan = {"rows": batch.nrows, "chunks": int(geom.n_chunks), "chunk_rows": int(geom.chunk_rows),
+                              "wg_threads": int(geom.wg_threads), "group_cap": cap, "lds_bytes": int(geom.lds_bytes)}
             # dense pack: one column per accumulator in the shuffle-file storage kind
             acc_kinds = [hs.I32 if is_int else hs.F32 for is_int in low.acc_is_int]
             pack_start = self.empty(n_units + 1, torch.int64)

@@ -113,7 +113,7 @@ SIGNATURES: dict[str, tuple] = {
     "hs_agg_partial_geom": (C.c_int, [C.POINTER(_I64), _I64, _I32, _I32, _GEOMP]),
     "hs_agg_partial": (
         C.c_int,
-        [_P, _COLP, _I32, _I32, _PROGP, _SPECP, _P, _P, _I64, _GEOMP, _P, _P, _P, _P, _P],
+        [_P, _COLP, _I32, _I32, _PROGP, _SPECP, _P, _P, _I64, _GEOMP, _P, _P, _P, _P, _P, _P, _P],
     ),
     "hs_agg_pack": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _SPECP, _P, _P, C.POINTER(_P), C.POINTER(_I32), _P]),
     "hs_agg_merge_ws_bytes": (C.c_size_t, [_I64, _I64, _I32]),

@@ -38,6 +38,8 @@ class DeviceTable:
     block_rows: list[int]
     columns: dict[int, DCol] = field(default_factory=dict)
     stamp: tuple = ()
+    global_blocks: list[int] | None = None  # multi-GPU: file block ids of the local blocks
+    total_blocks: int | None = None
 
     @property
     def nrows(self) -> int:
