@@ -25,8 +25,10 @@
 #ifndef HIPSPARK_H
 #define HIPSPARK_H
 
+#ifndef HS_JIT_BUILD /* the run-time compiler (hiprtc) brings its own fixed-width types */
 #include <stddef.h>
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -268,6 +270,23 @@ int hs_exclusive_scan_i64(void* stream, const int64_t* counts, int64_t n, int64_
 /* f64 -> f32 (RNE; finite overflow sets HS_FLAG_FLT_OVERFLOW) or i64 -> i32 (range check sets
  * HS_FLAG_INT_OVERFLOW).  src_kind in {HS_F64, HS_I64}. */
 int hs_quantise(void* stream, const void* src, int32_t src_kind, int64_t n, void* dst, uint32_t* flags);
+
+/* =================================================================================================
+ * Run-time specialisation (reference: codegen.py:230-247 compiles every query with `zig build`).
+ * hs_agg_partial translates its bytecode to straight-line code inside the hand-written kernel skeleton,
+ * compiles it with hiprtc for the running GPU and caches it per program; on any failure it launches the
+ * ahead-of-time interpreter kernel instead (still on the GPU).  Env HIPSPARK_JIT=0 disables it.
+ * ===============================================================================================*/
+void hs_jit_set_enabled(int enabled);
+int hs_jit_get_enabled(void);
+/* counters[0] = programs compiled, [1] = launches of compiled programs, [2] = compile failures */
+void hs_jit_stats(int32_t* counters);
+const char* hs_jit_last_log(void);
+/* Translate + compile only (needs no GPU): proves the generated source builds for `arch`
+ * (NULL = "gfx950"); optionally returns the generated source text. */
+int hs_jit_compile_check(const hs_col* cols, int32_t n_cols, int32_t key_col, const hs_program* prog,
+                         const hs_agg_spec* spec, const char* arch, int64_t* code_bytes, char* src_out,
+                         int64_t src_cap);
 
 /* =================================================================================================
  * Synthetic TPC-H-shaped data (bench / tests only).  Counter-based: the value of

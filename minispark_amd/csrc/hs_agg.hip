@@ -1,8 +1,7 @@
 // hs_agg.hip - hash group-by / aggregate on gfx950.
 //
-//   k_agg_main   scan + WHERE + aggregate-argument evaluation + per-workgroup partial aggregate
-//                (reference: FilterTask.execute tasks.py:167-177, AggregateTask.execute before_shuffle
-//                branch tasks.py:284-289, fill_aggregators tasks.py:295-310)
+//   k_agg_main   scan + WHERE + aggregate-argument evaluation + per-workgroup partial aggregate: body in
+//                hs_agg_kernel.h (interpreter instantiated here, JIT-compiled programs in hs_jit.cpp)
 //   k_agg_unit   fixed-order combine of a unit's workgroup partials + quantisation to the shuffle-file
 //                types (reference: is_last emission tasks.py:272-278 -> WriteToShufflePartitions.write
 //                tasks.py:373 -> io.py:87-94)
@@ -15,309 +14,14 @@
 // per f32 column per instruction.  Group keys are resolved in a per-workgroup LDS dictionary; every
 // lane owns a private accumulator table in LDS laid out [slot][acc][lane] (conflict-free ds_read_b64 /
 // ds_write_b64, no atomics), reduced at the end in a fixed order -> bitwise reproducible results.
-#include "hs_device.h"
+#include "hs_agg_kernel.h"
 
-#define HS_FUSED_COLS 8 /* numeric column slots preloaded per step */
-
-struct AggMainArgs {
-    HsCols cols;
-    hs_program prog;
-    hs_agg_spec spec;
-    int32_t key_col;
-    int32_t group_cap;
-    int32_t chunk_rows;
-    int32_t pad;
-    const int64_t* unit_rows;
-    const int64_t* unit_chunk0;
-    int64_t n_units;
-    uint64_t* part_keys;  // [n_chunks][GC]
-    int64_t* part_rep;    // [n_chunks][GC]
-    uint64_t* part_acc;   // [n_chunks][GC][n_acc]
-    uint32_t* flags;
-};
-
-// 16-byte global loads ------------------------------------------------------------------------------
-__device__ __forceinline__ void hs_load_quad(const hs_col& c, int64_t row0, uint64_t (&cell)[HS_V]) {
-    switch (c.kind) {
-        case HS_I32: {
-            const int4 v = *reinterpret_cast<const int4*>((const int32_t*)c.data + row0);
-            cell[0] = (uint64_t)(int64_t)v.x;
-            cell[1] = (uint64_t)(int64_t)v.y;
-            cell[2] = (uint64_t)(int64_t)v.z;
-            cell[3] = (uint64_t)(int64_t)v.w;
-            break;
-        }
-        case HS_F32: {
-            const float4 v = *reinterpret_cast<const float4*>((const float*)c.data + row0);
-            cell[0] = hs_d2u((double)v.x);
-            cell[1] = hs_d2u((double)v.y);
-            cell[2] = hs_d2u((double)v.z);
-            cell[3] = hs_d2u((double)v.w);
-            break;
-        }
-        case HS_I64:
-        case HS_F64: {
-            const ulonglong2 v0 = *reinterpret_cast<const ulonglong2*>((const uint64_t*)c.data + row0);
-            const ulonglong2 v1 = *reinterpret_cast<const ulonglong2*>((const uint64_t*)c.data + row0 + 2);
-            cell[0] = v0.x;
-            cell[1] = v0.y;
-            cell[2] = v1.x;
-            cell[3] = v1.y;
-            break;
-        }
-        case HS_U8: {
-            const uint32_t v = *reinterpret_cast<const uint32_t*>((const uint8_t*)c.data + row0);
-            cell[0] = v & 0xff;
-            cell[1] = (v >> 8) & 0xff;
-            cell[2] = (v >> 16) & 0xff;
-            cell[3] = v >> 24;
-            break;
-        }
-        case HS_STR: {
-            // only the GROUP BY column is preloaded, and only when it packs with a power-of-two width
-            if (c.fixed_len == 1) {
-                const uint32_t v = *reinterpret_cast<const uint32_t*>((const uint8_t*)c.data + row0);
-                cell[0] = (1ull << 56) | (v & 0xff);
-                cell[1] = (1ull << 56) | ((v >> 8) & 0xff);
-                cell[2] = (1ull << 56) | ((v >> 16) & 0xff);
-                cell[3] = (1ull << 56) | (v >> 24);
-            } else if (c.fixed_len == 2) {
-                const uint2 v = *reinterpret_cast<const uint2*>((const uint8_t*)c.data + row0 * 2);
-                cell[0] = (2ull << 56) | (v.x & 0xffff);
-                cell[1] = (2ull << 56) | (v.x >> 16);
-                cell[2] = (2ull << 56) | (v.y & 0xffff);
-                cell[3] = (2ull << 56) | (v.y >> 16);
-            } else if (c.fixed_len == 4) {
-                const uint4 v = *reinterpret_cast<const uint4*>((const uint8_t*)c.data + row0 * 4);
-                cell[0] = (4ull << 56) | v.x;
-                cell[1] = (4ull << 56) | v.y;
-                cell[2] = (4ull << 56) | v.z;
-                cell[3] = (4ull << 56) | v.w;
-            }
-            break;
-        }
-        default: break;
-    }
-}
-
-__device__ __forceinline__ bool hs_str_preloads(const hs_col& c) {
-    return c.kind == HS_STR && (c.fixed_len == 1 || c.fixed_len == 2 || c.fixed_len == 4);
-}
-
-template <bool HASHED>
-struct AggSink {
-    const AggMainArgs& A;
-    uint64_t cell[HS_FUSED_COLS][HS_V];
-    int64_t row0;
-    bool alive[HS_V];
-    int slot[HS_V];
-    uint64_t* dkeys;
-    int64_t* dreps;
-    uint64_t* tbl;
-    uint32_t tid, nthr;
-    uint32_t err;
-
-    __device__ __forceinline__ AggSink(const AggMainArgs& a) : A(a) {}
-
-    __device__ __forceinline__ void load(uint32_t s, uint64_t (&dst)[HS_V]) const {
-        switch (s) {
-#define HS_CASE(K)                                                      \
-    case K:                                                             \
-        _Pragma("unroll") for (int j = 0; j < HS_V; ++j) dst[j] = cell[K][j]; \
-        break;
-            HS_CASE(0) HS_CASE(1) HS_CASE(2) HS_CASE(3) HS_CASE(4) HS_CASE(5) HS_CASE(6) HS_CASE(7)
-#undef HS_CASE
-            default: break;
-        }
-    }
-    __device__ __forceinline__ uint64_t load(uint32_t s, int j) const {
-        uint64_t tmp[HS_V];
-        load(s, tmp);
-        return tmp[j];
-    }
-    __device__ __forceinline__ bool live(int j) const { return alive[j]; }
-    __device__ __forceinline__ int64_t row(int j) const { return row0 + j; }
-    __device__ __forceinline__ void filter(int j, bool keep) { alive[j] = alive[j] && keep; }
-    __device__ __forceinline__ void out(uint32_t, int, uint64_t) {}
-
-    __device__ __forceinline__ void key() {
-        const hs_col& kc = A.cols.c[A.key_col];
-        uint64_t kcell[HS_V];
-        const bool pre = (kc.kind != HS_STR) || hs_str_preloads(kc);
-        if (pre) load((uint32_t)A.key_col, kcell);
-        const uint32_t mask = (uint32_t)A.group_cap - 1;
-#pragma unroll
-        for (int j = 0; j < HS_V; ++j) {
-            slot[j] = 0;
-            if (alive[j]) {
-                int s;
-                if constexpr (HASHED) {
-                    s = hs_dict_upsert_rows(dreps, mask, kc, hs_key_at(kc, row0 + j), row0 + j);
-                } else {
-                    uint64_t k;
-                    if (kc.kind == HS_STR)
-                        k = pre ? kcell[j] : hs_key_at(kc, row0 + j);
-                    else
-                        k = hs_key_from_cell(kc.kind, kcell[j]);
-                    s = hs_dict_upsert_word(dkeys, dreps, mask, k, row0 + j);
-                }
-                if (s < 0) {
-                    err |= HS_FLAG_DICT_FULL;
-                    alive[j] = false;
-                    s = 0;
-                }
-                slot[j] = s;
-            }
-        }
-    }
-
-    __device__ __forceinline__ void agg(uint32_t a, int j, uint64_t x) {
-        if (alive[j]) {
-            const uint32_t idx = ((uint32_t)slot[j] * (uint32_t)A.spec.n_acc + a) * nthr + tid;
-            tbl[idx] = hs_acc_fold(A.spec.op[a], A.spec.is_int[a] != 0, tbl[idx], x);
-        }
-    }
-};
-
-template <int D, typename Sink>
-__device__ __forceinline__ void hs_run_quad(const hs_program& P, const HsCols& C, Sink& sink, uint32_t& err) {
-    // same interpreter as hs_run, but LD moves the whole row quad with one slot switch
-    uint64_t st[D][HS_V];
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-#pragma unroll
-        for (int j = 0; j < HS_V; ++j) st[d][j] = 0;
-    for (uint32_t pc = 0; pc < P.n_ins; ++pc) {
-        const uint64_t w = P.ins[pc];
-        const uint32_t sp = hs_ins_sp(w);
-        if (hs_ins_op(w) == HS_OP_LD) {
-            uint64_t tmp[HS_V];
-            sink.load(hs_ins_a(w), tmp);
-            switch (sp) {
-#define HS_PUSH(K)                                                        \
-    case K:                                                               \
-        if constexpr (K < D) {                                            \
-            _Pragma("unroll") for (int j = 0; j < HS_V; ++j) st[K][j] = tmp[j]; \
-        }                                                                 \
-        break;
-                HS_PUSH(0) HS_PUSH(1) HS_PUSH(2) HS_PUSH(3) HS_PUSH(4) HS_PUSH(5) HS_PUSH(6) HS_PUSH(7)
-#undef HS_PUSH
-                default: err |= HS_FLAG_BAD_PROGRAM; break;
-            }
-            continue;
-        }
-        switch (sp) {
-            case 0: hs_exec_at<0, D, HS_V>(w, P, C, st, sink, err); break;
-            case 1: hs_exec_at<1, D, HS_V>(w, P, C, st, sink, err); break;
-            case 2: hs_exec_at<2, D, HS_V>(w, P, C, st, sink, err); break;
-            case 3: hs_exec_at<3, D, HS_V>(w, P, C, st, sink, err); break;
-            case 4: hs_exec_at<4, D, HS_V>(w, P, C, st, sink, err); break;
-            default:
-                if constexpr (D > 4) {
-                    switch (sp) {
-                        case 5: hs_exec_at<5, D, HS_V>(w, P, C, st, sink, err); break;
-                        case 6: hs_exec_at<6, D, HS_V>(w, P, C, st, sink, err); break;
-                        case 7: hs_exec_at<7, D, HS_V>(w, P, C, st, sink, err); break;
-                        case 8: hs_exec_at<8, D, HS_V>(w, P, C, st, sink, err); break;
-                        default: err |= HS_FLAG_BAD_PROGRAM; break;
-                    }
-                } else {
-                    err |= HS_FLAG_BAD_PROGRAM;
-                }
-                break;
-        }
-    }
-}
-
-// 64-bit wave shuffle-down
-__device__ __forceinline__ uint64_t hs_shfl_down64(uint64_t v, int delta) {
-    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-    lo = __shfl_down(lo, delta, HS_WAVE);
-    hi = __shfl_down(hi, delta, HS_WAVE);
-    return ((uint64_t)hi << 32) | lo;
-}
-
+// ahead-of-time instantiations: the bytecode interpreter (always available; also the reference point
+// the JIT-compiled programs are tested against)
 template <bool HASHED, int D>
 __global__ void __launch_bounds__(256) k_agg_main(const AggMainArgs A_kernarg) {
     HS_KERNARG(AggMainArgs, A);
-    extern __shared__ __align__(16) uint64_t lds[];
-    const uint32_t tid = threadIdx.x, nthr = blockDim.x;
-    const int GC = A.group_cap;
-    const int NA = A.spec.n_acc;
-    uint64_t* dkeys = lds;
-    int64_t* dreps = (int64_t*)(lds + GC);
-    uint64_t* tbl = lds + 2 * GC;
-
-    // which unit does this chunk belong to?  (binary search over the first-chunk table)
-    const int64_t chunk = blockIdx.x;
-    int64_t lo = 0, hi = A.n_units;  // invariant: unit_chunk0[lo] <= chunk < unit_chunk0[hi]
-    while (hi - lo > 1) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (A.unit_chunk0[mid] <= chunk) lo = mid; else hi = mid;
-    }
-    const int64_t u = lo;
-    const int64_t us = A.unit_rows[u], ue = A.unit_rows[u + 1];
-    const int64_t anchor = us & ~(int64_t)(HS_V - 1);
-    const int64_t c0 = anchor + (chunk - A.unit_chunk0[u]) * (int64_t)A.chunk_rows;
-    int64_t c1 = c0 + A.chunk_rows;
-    if (c1 > ue) c1 = ue;
-
-    for (int i = tid; i < GC; i += nthr) {
-        dkeys[i] = HS_EMPTY_KEY;
-        dreps[i] = -1;
-    }
-    for (int cellid = 0; cellid < GC * NA; ++cellid)
-        tbl[(uint32_t)cellid * nthr + tid] = hs_acc_identity(A.spec.op[cellid % NA], A.spec.is_int[cellid % NA] != 0);
-    __syncthreads();
-
-    AggSink<HASHED> sink(A);
-    sink.dkeys = dkeys;
-    sink.dreps = dreps;
-    sink.tbl = tbl;
-    sink.tid = tid;
-    sink.nthr = nthr;
-    sink.err = 0;
-    uint32_t err = 0;
-
-    const int ncols = A.cols.n < HS_FUSED_COLS ? A.cols.n : HS_FUSED_COLS;
-    for (int64_t base = c0 + (int64_t)tid * HS_V; base < c1; base += (int64_t)nthr * HS_V) {
-#pragma unroll
-        for (int c = 0; c < HS_FUSED_COLS; ++c) {
-            if (c < ncols) {
-                const hs_col& col = A.cols.c[c];
-                if (col.kind != HS_STR || (c == A.key_col && hs_str_preloads(col))) hs_load_quad(col, base, sink.cell[c]);
-            }
-        }
-        sink.row0 = base;
-#pragma unroll
-        for (int j = 0; j < HS_V; ++j) {
-            const int64_t r = base + j;
-            sink.alive[j] = (r >= us) && (r < c1);
-            sink.slot[j] = 0;
-        }
-        hs_run_quad<D>(A.prog, A.cols, sink, err);
-    }
-    err |= sink.err;
-    __syncthreads();
-
-    // fixed-order reduction of the private tables: lanes stride the workgroup, then a shuffle tree
-    const uint32_t wave = tid / HS_WAVE, lane = tid % HS_WAVE, nwaves = nthr / HS_WAVE;
-    for (uint32_t cellid = wave; cellid < (uint32_t)(GC * NA); cellid += nwaves) {
-        const uint32_t s = cellid / NA, a = cellid % NA;
-        if (dreps[s] < 0) continue;  // wave-uniform
-        const uint32_t op = A.spec.op[a];
-        const bool is_int = A.spec.is_int[a] != 0;
-        uint64_t v = hs_acc_identity(op, is_int);
-        for (uint32_t t = lane; t < nthr; t += HS_WAVE) v = hs_acc_fold(op, is_int, v, tbl[cellid * nthr + t]);
-#pragma unroll
-        for (int d = HS_WAVE / 2; d >= 1; d >>= 1) v = hs_acc_fold(op, is_int, v, hs_shfl_down64(v, d));
-        if (lane == 0) A.part_acc[((int64_t)chunk * GC + s) * NA + a] = v;
-    }
-    for (int i = tid; i < GC; i += nthr) {
-        A.part_keys[chunk * GC + i] = dkeys[i];
-        A.part_rep[chunk * GC + i] = dreps[i];
-    }
-    if (err) atomicOr(A.flags, err);
+    hs_agg_main_body<InterpProg<HASHED, D>>(A);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -549,6 +253,9 @@ __global__ void __launch_bounds__(1024) k_agg_merge_small(const AggMergeArgs A_k
 // ==================================================================================================
 extern thread_local char g_hs_err[256];
 void hs_set_error(const char* fmt, ...);
+// hs_jit.cpp: HS_OK = a kernel compiled for this program was launched; anything else = not launched
+int hs_jit_launch_agg_main(const AggMainArgs* args, bool hashed, unsigned grid, unsigned block, size_t lds_bytes,
+                           hipStream_t stream);
 
 static int fill_cols(HsCols& dst, const hs_col* cols, int32_t n) {
     if (n < 0 || n > HS_MAX_COLS) {
@@ -707,7 +414,10 @@ extern "C" int hs_agg_partial(void* stream, const hs_col* cols, int32_t n_cols, 
         return HS_E_LIMIT;
     }
     if (ev_begin) (void)hipEventRecord((hipEvent_t)ev_begin, s);
-    if (hashed) {
+    const int jit_rc = hs_jit_launch_agg_main(&A, hashed, grid.x, block.x, geom->lds_bytes, s);
+    if (jit_rc == HS_OK) {
+        // launched the program compiled for exactly this bytecode
+    } else if (hashed) {
         hipLaunchKernelGGL((k_agg_main<true, 8>), grid, block, geom->lds_bytes, s, A);
     } else if (depth <= 4) {
         hipLaunchKernelGGL((k_agg_main<false, 4>), grid, block, geom->lds_bytes, s, A);

@@ -1,0 +1,371 @@
+// hs_agg_kernel.h - body of the fused scan + WHERE + aggregate-argument + partial-aggregate kernel,
+// templated on a `Prog` that says how one row quad is loaded and evaluated:
+//
+//   * InterpProg<HASHED, D>  (compiled ahead of time in hs_agg.hip): runs the stack bytecode;
+//   * a generated JitProg    (compiled at run time by hs_jit.cpp through hiprtc): the same bytecode
+//                            translated to straight-line code with typed loads - the MI355X-native
+//                            counterpart of the reference compiling every query (codegen.py:230-247).
+//
+// Both share this skeleton, the operator semantics (hs_bin<>) and the dictionary / accumulator code, so
+// they produce bit-identical results (tests/test_gpu_kernels.py runs every case through both).
+//
+// Reference loops replaced: FilterTask.execute tasks.py:167-177, AggregateTask.execute (before_shuffle)
+// tasks.py:284-289, fill_aggregators tasks.py:295-310.
+//
+// Design (HBM-bound; no MFMA - there is no contraction in this workload): every lane streams HS_V = 4
+// consecutive rows per step with 16-byte loads, consecutive lanes take consecutive quads (a wave reads
+// 1 KiB per f32 column per instruction); the next quad's loads are issued before the current quad is
+// evaluated.  Group keys are resolved in a per-workgroup LDS dictionary; every lane owns a private
+// accumulator table in LDS laid out [slot][acc][lane] (conflict-free ds_read_b64 / ds_write_b64, no
+// atomics), reduced at the end in a fixed order -> bitwise reproducible.
+#pragma once
+
+#include "hs_device.h"
+
+#define HS_FUSED_COLS 8 /* numeric column slots preloaded per step */
+
+struct AggMainArgs {
+    HsCols cols;
+    hs_program prog;
+    hs_agg_spec spec;
+    int32_t key_col;
+    int32_t group_cap;
+    int32_t chunk_rows;
+    int32_t pad;
+    const int64_t* unit_rows;
+    const int64_t* unit_chunk0;
+    int64_t n_units;
+    uint64_t* part_keys;  // [n_chunks][GC]
+    int64_t* part_rep;    // [n_chunks][GC]
+    uint64_t* part_acc;   // [n_chunks][GC][n_acc]
+    uint32_t* flags;
+};
+
+// 64-bit wave shuffle-down
+__device__ __forceinline__ uint64_t hs_shfl_down64(uint64_t v, int delta) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl_down(lo, delta, HS_WAVE);
+    hi = __shfl_down(hi, delta, HS_WAVE);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ bool hs_str_preloads(const hs_col& c) {
+    return c.kind == HS_STR && (c.fixed_len == 1 || c.fixed_len == 2 || c.fixed_len == 4);
+}
+
+// packed key words of a fixed-width (1 / 2 / 4 byte) string column for one row quad
+template <int LEN>
+__device__ __forceinline__ void hs_load_packed_quad(const hs_col& c, int64_t row0, uint64_t (&cell)[HS_V]) {
+    if constexpr (LEN == 1) {
+        const uint32_t v = *reinterpret_cast<const uint32_t*>((const uint8_t*)c.data + row0);
+        cell[0] = (1ull << 56) | (v & 0xff);
+        cell[1] = (1ull << 56) | ((v >> 8) & 0xff);
+        cell[2] = (1ull << 56) | ((v >> 16) & 0xff);
+        cell[3] = (1ull << 56) | (v >> 24);
+    } else if constexpr (LEN == 2) {
+        const uint2 v = *reinterpret_cast<const uint2*>((const uint8_t*)c.data + row0 * 2);
+        cell[0] = (2ull << 56) | (v.x & 0xffff);
+        cell[1] = (2ull << 56) | (v.x >> 16);
+        cell[2] = (2ull << 56) | (v.y & 0xffff);
+        cell[3] = (2ull << 56) | (v.y >> 16);
+    } else {
+        const uint4 v = *reinterpret_cast<const uint4*>((const uint8_t*)c.data + row0 * 4);
+        cell[0] = (4ull << 56) | v.x;
+        cell[1] = (4ull << 56) | v.y;
+        cell[2] = (4ull << 56) | v.z;
+        cell[3] = (4ull << 56) | v.w;
+    }
+}
+
+// one row quad of a column, widened to 64-bit cells (run-time kind: the interpreter's loader)
+__device__ __forceinline__ void hs_load_quad(const hs_col& c, int64_t row0, uint64_t (&cell)[HS_V]) {
+    switch (c.kind) {
+        case HS_I32: {
+            const int4 v = *reinterpret_cast<const int4*>((const int32_t*)c.data + row0);
+            cell[0] = (uint64_t)(int64_t)v.x;
+            cell[1] = (uint64_t)(int64_t)v.y;
+            cell[2] = (uint64_t)(int64_t)v.z;
+            cell[3] = (uint64_t)(int64_t)v.w;
+            break;
+        }
+        case HS_F32: {
+            const float4 v = *reinterpret_cast<const float4*>((const float*)c.data + row0);
+            cell[0] = hs_d2u((double)v.x);
+            cell[1] = hs_d2u((double)v.y);
+            cell[2] = hs_d2u((double)v.z);
+            cell[3] = hs_d2u((double)v.w);
+            break;
+        }
+        case HS_I64:
+        case HS_F64: {
+            const ulonglong2 v0 = *reinterpret_cast<const ulonglong2*>((const uint64_t*)c.data + row0);
+            const ulonglong2 v1 = *reinterpret_cast<const ulonglong2*>((const uint64_t*)c.data + row0 + 2);
+            cell[0] = v0.x;
+            cell[1] = v0.y;
+            cell[2] = v1.x;
+            cell[3] = v1.y;
+            break;
+        }
+        case HS_U8: {
+            const uint32_t v = *reinterpret_cast<const uint32_t*>((const uint8_t*)c.data + row0);
+            cell[0] = v & 0xff;
+            cell[1] = (v >> 8) & 0xff;
+            cell[2] = (v >> 16) & 0xff;
+            cell[3] = v >> 24;
+            break;
+        }
+        case HS_STR:
+            // only the GROUP BY column is preloaded, and only when it packs with a power-of-two width
+            if (c.fixed_len == 1) hs_load_packed_quad<1>(c, row0, cell);
+            else if (c.fixed_len == 2) hs_load_packed_quad<2>(c, row0, cell);
+            else if (c.fixed_len == 4) hs_load_packed_quad<4>(c, row0, cell);
+            break;
+        default: break;
+    }
+}
+
+// Per-lane state of the fused kernel: liveness of the quad's rows, their group slots, the workgroup's
+// dictionary and the lane's private accumulator table.
+struct AggCtx {
+    int64_t row0;
+    bool alive[HS_V];
+    int slot[HS_V];
+    uint64_t* dkeys;
+    int64_t* dreps;
+    uint64_t* tbl;
+    uint32_t tid, nthr, mask;
+    int32_t n_acc;
+    uint32_t err;
+
+    // slot of key word `k` held by `row`; marks the row dead and flags overflow when the table is full
+    template <bool HASHED>
+    __device__ __forceinline__ int find(const hs_col& key_col, uint64_t k, int64_t row, bool& live) {
+        int s = 0;
+        if (live) {
+            if constexpr (HASHED) s = hs_dict_upsert_rows(dreps, mask, key_col, k, row);
+            else s = hs_dict_upsert_word(dkeys, dreps, mask, k, row);
+            if (s < 0) {
+                err |= HS_FLAG_DICT_FULL;
+                live = false;
+                s = 0;
+            }
+        }
+        return s;
+    }
+
+    // fold with run-time aggregate description (interpreter)
+    __device__ __forceinline__ void fold(const hs_agg_spec& spec, uint32_t a, int s, bool live, uint64_t x) {
+        if (live) {
+            const uint32_t idx = ((uint32_t)s * (uint32_t)n_acc + a) * nthr + tid;
+            tbl[idx] = hs_acc_fold(spec.op[a], spec.is_int[a] != 0, tbl[idx], x);
+        }
+    }
+
+    // fold with compile-time aggregate description (JIT): dead rows fold the identity into slot 0,
+    // which leaves every accumulator unchanged, so there is no branch
+    template <int NA, int A, int OP, bool IS_INT>
+    __device__ __forceinline__ void fold_c(int s, bool live, uint64_t x) {
+        const uint32_t idx = ((uint32_t)(live ? s : 0) * (uint32_t)NA + (uint32_t)A) * nthr + tid;
+        const uint64_t v = live ? x : hs_acc_identity(OP, IS_INT);
+        tbl[idx] = hs_acc_fold(OP, IS_INT, tbl[idx], v);
+    }
+};
+
+// ---- the interpreter as a Prog ------------------------------------------------------------------------
+template <bool HASHED_, int D>
+struct InterpProg {
+    static constexpr bool HASHED = HASHED_;
+    struct Cells {
+        uint64_t cell[HS_FUSED_COLS][HS_V];
+    };
+
+    static __device__ __forceinline__ void load(const AggMainArgs& A, int64_t base, Cells& x) {
+        const int ncols = A.cols.n < HS_FUSED_COLS ? A.cols.n : HS_FUSED_COLS;
+#pragma unroll
+        for (int c = 0; c < HS_FUSED_COLS; ++c) {
+            if (c < ncols) {
+                const hs_col& col = A.cols.c[c];
+                if (col.kind != HS_STR || (c == A.key_col && hs_str_preloads(col))) hs_load_quad(col, base, x.cell[c]);
+            }
+        }
+    }
+
+    struct Sink {
+        const AggMainArgs& A;
+        const Cells& x;
+        AggCtx& ctx;
+        __device__ __forceinline__ Sink(const AggMainArgs& a, const Cells& c, AggCtx& k) : A(a), x(c), ctx(k) {}
+        __device__ __forceinline__ void load(uint32_t s, uint64_t (&dst)[HS_V]) const {
+            switch (s) {
+#define HS_CASE(K)                                                          \
+    case K:                                                                 \
+        _Pragma("unroll") for (int j = 0; j < HS_V; ++j) dst[j] = x.cell[K][j]; \
+        break;
+                HS_CASE(0) HS_CASE(1) HS_CASE(2) HS_CASE(3) HS_CASE(4) HS_CASE(5) HS_CASE(6) HS_CASE(7)
+#undef HS_CASE
+                default: break;
+            }
+        }
+        __device__ __forceinline__ uint64_t load(uint32_t s, int j) const {
+            uint64_t tmp[HS_V];
+            load(s, tmp);
+            return tmp[j];
+        }
+        __device__ __forceinline__ bool live(int j) const { return ctx.alive[j]; }
+        __device__ __forceinline__ int64_t row(int j) const { return ctx.row0 + j; }
+        __device__ __forceinline__ void filter(int j, bool keep) { ctx.alive[j] = ctx.alive[j] && keep; }
+        __device__ __forceinline__ void out(uint32_t, int, uint64_t) {}
+        __device__ __forceinline__ void key() {
+            const hs_col& kc = A.cols.c[A.key_col];
+            uint64_t kcell[HS_V];
+            const bool pre = (kc.kind != HS_STR) || hs_str_preloads(kc);
+            if (pre) load((uint32_t)A.key_col, kcell);
+#pragma unroll
+            for (int j = 0; j < HS_V; ++j) {
+                uint64_t k = 0;
+                if (ctx.alive[j]) {
+                    if (kc.kind == HS_STR) k = pre ? kcell[j] : hs_key_at(kc, ctx.row0 + j);
+                    else k = hs_key_from_cell(kc.kind, kcell[j]);
+                }
+                ctx.slot[j] = ctx.template find<HASHED>(kc, k, ctx.row0 + j, ctx.alive[j]);
+            }
+        }
+        __device__ __forceinline__ void agg(uint32_t a, int j, uint64_t v) {
+            ctx.fold(A.spec, a, ctx.slot[j], ctx.alive[j], v);
+        }
+    };
+
+    static __device__ __forceinline__ void run(const AggMainArgs& A, const Cells& x, AggCtx& ctx) {
+        Sink sink(A, x, ctx);
+        const hs_program& P = A.prog;
+        uint64_t st[D][HS_V];
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int j = 0; j < HS_V; ++j) st[d][j] = 0;
+        for (uint32_t pc = 0; pc < P.n_ins; ++pc) {
+            const uint64_t w = P.ins[pc];
+            const uint32_t sp = hs_ins_sp(w);
+            if (hs_ins_op(w) == HS_OP_LD) {  // LD moves the whole quad with one slot switch
+                uint64_t tmp[HS_V];
+                sink.load(hs_ins_a(w), tmp);
+                switch (sp) {
+#define HS_PUSH(K)                                                            \
+    case K:                                                                   \
+        if constexpr (K < D) {                                                \
+            _Pragma("unroll") for (int j = 0; j < HS_V; ++j) st[K][j] = tmp[j]; \
+        }                                                                     \
+        break;
+                    HS_PUSH(0) HS_PUSH(1) HS_PUSH(2) HS_PUSH(3) HS_PUSH(4) HS_PUSH(5) HS_PUSH(6) HS_PUSH(7)
+#undef HS_PUSH
+                    default: ctx.err |= HS_FLAG_BAD_PROGRAM; break;
+                }
+                continue;
+            }
+            switch (sp) {
+                case 0: hs_exec_at<0, D, HS_V>(w, P, A.cols, st, sink, ctx.err); break;
+                case 1: hs_exec_at<1, D, HS_V>(w, P, A.cols, st, sink, ctx.err); break;
+                case 2: hs_exec_at<2, D, HS_V>(w, P, A.cols, st, sink, ctx.err); break;
+                case 3: hs_exec_at<3, D, HS_V>(w, P, A.cols, st, sink, ctx.err); break;
+                case 4: hs_exec_at<4, D, HS_V>(w, P, A.cols, st, sink, ctx.err); break;
+                default:
+                    if constexpr (D > 4) {
+                        switch (sp) {
+                            case 5: hs_exec_at<5, D, HS_V>(w, P, A.cols, st, sink, ctx.err); break;
+                            case 6: hs_exec_at<6, D, HS_V>(w, P, A.cols, st, sink, ctx.err); break;
+                            case 7: hs_exec_at<7, D, HS_V>(w, P, A.cols, st, sink, ctx.err); break;
+                            case 8: hs_exec_at<8, D, HS_V>(w, P, A.cols, st, sink, ctx.err); break;
+                            default: ctx.err |= HS_FLAG_BAD_PROGRAM; break;
+                        }
+                    } else {
+                        ctx.err |= HS_FLAG_BAD_PROGRAM;
+                    }
+                    break;
+            }
+        }
+    }
+};
+
+// ---- the kernel body ---------------------------------------------------------------------------------
+template <class Prog>
+__device__ __forceinline__ void hs_agg_main_body(const AggMainArgs& A) {
+    extern __shared__ __align__(16) uint64_t hs_lds[];
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+    const int GC = A.group_cap;
+    const int NA = A.spec.n_acc;
+    uint64_t* dkeys = hs_lds;
+    int64_t* dreps = (int64_t*)(hs_lds + GC);
+    uint64_t* tbl = hs_lds + 2 * GC;
+
+    // which unit does this chunk belong to?  (binary search over the first-chunk table)
+    const int64_t chunk = blockIdx.x;
+    int64_t lo = 0, hi = A.n_units;  // invariant: unit_chunk0[lo] <= chunk < unit_chunk0[hi]
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (A.unit_chunk0[mid] <= chunk) lo = mid; else hi = mid;
+    }
+    const int64_t u = lo;
+    const int64_t us = A.unit_rows[u], ue = A.unit_rows[u + 1];
+    const int64_t anchor = us & ~(int64_t)(HS_V - 1);
+    const int64_t c0 = anchor + (chunk - A.unit_chunk0[u]) * (int64_t)A.chunk_rows;
+    int64_t c1 = c0 + A.chunk_rows;
+    if (c1 > ue) c1 = ue;
+
+    for (int i = tid; i < GC; i += nthr) {
+        dkeys[i] = HS_EMPTY_KEY;
+        dreps[i] = -1;
+    }
+    for (int cellid = 0; cellid < GC * NA; ++cellid)
+        tbl[(uint32_t)cellid * nthr + tid] = hs_acc_identity(A.spec.op[cellid % NA], A.spec.is_int[cellid % NA] != 0);
+    __syncthreads();
+
+    AggCtx ctx;
+    ctx.dkeys = dkeys;
+    ctx.dreps = dreps;
+    ctx.tbl = tbl;
+    ctx.tid = tid;
+    ctx.nthr = nthr;
+    ctx.mask = (uint32_t)GC - 1;
+    ctx.n_acc = NA;
+    ctx.err = 0;
+
+    // software pipeline: the loads of step i+1 are in flight while step i is evaluated
+    const int64_t stride = (int64_t)nthr * HS_V;
+    int64_t base = c0 + (int64_t)tid * HS_V;
+    typename Prog::Cells cur, nxt;
+    if (base < c1) Prog::load(A, base, nxt);
+    while (base < c1) {
+        cur = nxt;
+        const int64_t next_base = base + stride;
+        if (next_base < c1) Prog::load(A, next_base, nxt);
+        ctx.row0 = base;
+#pragma unroll
+        for (int j = 0; j < HS_V; ++j) {
+            const int64_t r = base + j;
+            ctx.alive[j] = (r >= us) && (r < c1);
+            ctx.slot[j] = 0;
+        }
+        Prog::run(A, cur, ctx);
+        base = next_base;
+    }
+    __syncthreads();
+
+    // fixed-order reduction of the private tables: lanes stride the workgroup, then a shuffle tree
+    const uint32_t wave = tid / HS_WAVE, lane = tid % HS_WAVE, nwaves = nthr / HS_WAVE;
+    for (uint32_t cellid = wave; cellid < (uint32_t)(GC * NA); cellid += nwaves) {
+        const uint32_t s = cellid / NA, a = cellid % NA;
+        if (dreps[s] < 0) continue;  // wave-uniform
+        const uint32_t op = A.spec.op[a];
+        const bool is_int = A.spec.is_int[a] != 0;
+        uint64_t v = hs_acc_identity(op, is_int);
+        for (uint32_t t = lane; t < nthr; t += HS_WAVE) v = hs_acc_fold(op, is_int, v, tbl[cellid * nthr + t]);
+#pragma unroll
+        for (int d = HS_WAVE / 2; d >= 1; d >>= 1) v = hs_acc_fold(op, is_int, v, hs_shfl_down64(v, d));
+        if (lane == 0) A.part_acc[((int64_t)chunk * GC + s) * NA + a] = v;
+    }
+    for (int i = tid; i < GC; i += nthr) {
+        A.part_keys[chunk * GC + i] = dkeys[i];
+        A.part_rep[chunk * GC + i] = dreps[i];
+    }
+    if (ctx.err) atomicOr(A.flags, ctx.err);
+}

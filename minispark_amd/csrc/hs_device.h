@@ -9,9 +9,24 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#ifndef HS_JIT_BUILD
 #include <stdint.h>
+#endif
 
+#ifdef HS_JIT_BUILD
+/* hiprtc keeps its fixed-width types in a namespace: publish the ones the headers use */
+typedef signed char int8_t;
+typedef unsigned char uint8_t;
+typedef short int16_t;
+typedef unsigned short uint16_t;
+typedef int int32_t;
+typedef unsigned int uint32_t;
+typedef long long int64_t;
+typedef unsigned long long uint64_t;
+#include "hipspark.h" /* supplied to hiprtc as an in-memory header */
+#else
 #include "../../include/hipspark.h"
+#endif
 
 #define HS_WAVE 64
 #define HS_V 4 /* rows per lane per step in the vectorised kernels */
@@ -159,6 +174,70 @@ __device__ __forceinline__ void hs_divmod_f(double vx, double wx, double& floord
     }
 }
 
+// ---- binary operators: ONE definition shared by the interpreter and by JIT-generated code -------------------
+// x = second-from-top cell, y = top cell; `live` gates data-dependent error reporting (rows that failed
+// the WHERE clause are never evaluated by the reference and must not raise).
+template <int OP>
+__device__ __forceinline__ uint64_t hs_bin(uint64_t xs, uint64_t ys, bool live, uint32_t& err) {
+    if constexpr (OP == HS_OP_ADD_F) return hs_d2u(hs_u2d(xs) + hs_u2d(ys));
+    else if constexpr (OP == HS_OP_SUB_F) return hs_d2u(hs_u2d(xs) - hs_u2d(ys));
+    else if constexpr (OP == HS_OP_MUL_F) return hs_d2u(hs_u2d(xs) * hs_u2d(ys));
+    else if constexpr (OP == HS_OP_DIV_F) {
+        if (hs_u2d(ys) == 0.0 && live) err |= HS_FLAG_DIV_ZERO;
+        return hs_d2u(hs_u2d(xs) / hs_u2d(ys));
+    } else if constexpr (OP == HS_OP_FLOORDIV_F || OP == HS_OP_MOD_F) {
+        double fd = 0.0, md = 0.0;
+        if (hs_u2d(ys) == 0.0) {
+            if (live) err |= HS_FLAG_DIV_ZERO;
+        } else {
+            hs_divmod_f(hs_u2d(xs), hs_u2d(ys), fd, md);
+        }
+        return hs_d2u(OP == HS_OP_FLOORDIV_F ? fd : md);
+    } else if constexpr (OP == HS_OP_ADD_I) return (uint64_t)((int64_t)xs + (int64_t)ys);
+    else if constexpr (OP == HS_OP_SUB_I) return (uint64_t)((int64_t)xs - (int64_t)ys);
+    else if constexpr (OP == HS_OP_MUL_I) return (uint64_t)((int64_t)xs * (int64_t)ys);
+    else if constexpr (OP == HS_OP_FLOORDIV_I || OP == HS_OP_MOD_I) {
+        int64_t r = 0;
+        if ((int64_t)ys == 0) {
+            if (live) err |= HS_FLAG_DIV_ZERO;
+        } else {
+            r = OP == HS_OP_FLOORDIV_I ? hs_floordiv_i((int64_t)xs, (int64_t)ys) : hs_mod_i((int64_t)xs, (int64_t)ys);
+        }
+        return (uint64_t)r;
+    } else if constexpr (OP == HS_OP_LT_F) return (uint64_t)(hs_u2d(xs) < hs_u2d(ys));
+    else if constexpr (OP == HS_OP_LE_F) return (uint64_t)(hs_u2d(xs) <= hs_u2d(ys));
+    else if constexpr (OP == HS_OP_GT_F) return (uint64_t)(hs_u2d(xs) > hs_u2d(ys));
+    else if constexpr (OP == HS_OP_GE_F) return (uint64_t)(hs_u2d(xs) >= hs_u2d(ys));
+    else if constexpr (OP == HS_OP_EQ_F) return (uint64_t)(hs_u2d(xs) == hs_u2d(ys));
+    else if constexpr (OP == HS_OP_NE_F) return (uint64_t)(hs_u2d(xs) != hs_u2d(ys));
+    else if constexpr (OP == HS_OP_LT_I) return (uint64_t)((int64_t)xs < (int64_t)ys);
+    else if constexpr (OP == HS_OP_LE_I) return (uint64_t)((int64_t)xs <= (int64_t)ys);
+    else if constexpr (OP == HS_OP_GT_I) return (uint64_t)((int64_t)xs > (int64_t)ys);
+    else if constexpr (OP == HS_OP_GE_I) return (uint64_t)((int64_t)xs >= (int64_t)ys);
+    else if constexpr (OP == HS_OP_EQ_I) return (uint64_t)(xs == ys);
+    else if constexpr (OP == HS_OP_NE_I) return (uint64_t)(xs != ys);
+    else if constexpr (OP == HS_OP_AND) return xs & ys;
+    else if constexpr (OP == HS_OP_OR) return xs | ys;
+    else return 0;
+}
+
+// string predicates, shared likewise
+__device__ __forceinline__ uint64_t hs_strcmp_lit(const hs_program& P, const hs_col& c, int64_t row, uint32_t lit_idx,
+                                                  uint32_t cmp) {
+    const uint64_t ref = P.lit[lit_idx];
+    HsStr lit;
+    lit.p = P.pool + (uint32_t)(ref >> 32);
+    lit.len = (uint32_t)ref;
+    return (uint64_t)hs_cmp_result(hs_str_cmp(hs_str_at(c, row), lit), cmp);
+}
+__device__ __forceinline__ uint64_t hs_strcmp_col(const hs_col& a, const hs_col& b, int64_t row, uint32_t cmp) {
+    return (uint64_t)hs_cmp_result(hs_str_cmp(hs_str_at(a, row), hs_str_at(b, row)), cmp);
+}
+__device__ __forceinline__ uint64_t hs_like_lit(const hs_program& P, const hs_col& c, int64_t row, uint32_t lit_idx) {
+    const uint64_t ref = P.lit[lit_idx];
+    return (uint64_t)hs_like(hs_str_at(c, row), P.pool + (uint32_t)(ref >> 32), (uint32_t)ref);
+}
+
 // ---- interpreter ---------------------------------------------------------------------------------
 // The program is straight-line, so the stack depth before every instruction is known when it is
 // lowered and travels in the instruction (sp).  Dispatch is two wave-uniform switches (sp, then op)
@@ -184,22 +263,13 @@ __device__ __forceinline__ void hs_exec_at(uint64_t w, const hs_program& P, cons
     constexpr int S = SP >= 2 ? SP - 2 : 0;  // second
     constexpr int N = SP < D ? SP : D - 1;   // next free
 
-#define HS_BIN_F(EXPR)                                   \
-    if constexpr (SP >= 2) {                             \
-        _Pragma("unroll") for (int j = 0; j < V; ++j) {  \
-            double x = hs_u2d(st[S][j]), y = hs_u2d(st[T][j]); \
-            (void)x; (void)y;                            \
-            st[S][j] = (EXPR);                           \
-        }                                                \
-    }
-#define HS_BIN_I(EXPR)                                   \
-    if constexpr (SP >= 2) {                             \
-        _Pragma("unroll") for (int j = 0; j < V; ++j) {  \
-            int64_t x = (int64_t)st[S][j], y = (int64_t)st[T][j]; \
-            (void)x; (void)y;                            \
-            st[S][j] = (uint64_t)(EXPR);                 \
-        }                                                \
-    }
+#define HS_BIN(OPC)                                                                  \
+    case OPC:                                                                        \
+        if constexpr (SP >= 2) {                                                     \
+            _Pragma("unroll") for (int j = 0; j < V; ++j)                            \
+                st[S][j] = hs_bin<OPC>(st[S][j], st[T][j], sink.live(j), err);       \
+        }                                                                            \
+        break;
 
     switch (op) {
         case HS_OP_LD:
@@ -215,68 +285,12 @@ __device__ __forceinline__ void hs_exec_at(uint64_t w, const hs_program& P, cons
                 for (int j = 0; j < V; ++j) st[N][j] = lit;
             }
             break;
-        case HS_OP_ADD_F: HS_BIN_F(hs_d2u(x + y)); break;
-        case HS_OP_SUB_F: HS_BIN_F(hs_d2u(x - y)); break;
-        case HS_OP_MUL_F: HS_BIN_F(hs_d2u(x * y)); break;
-        case HS_OP_DIV_F:
-            if constexpr (SP >= 2) {
-#pragma unroll
-                for (int j = 0; j < V; ++j) {
-                    double x = hs_u2d(st[S][j]), y = hs_u2d(st[T][j]);
-                    if (y == 0.0 && sink.live(j)) err |= HS_FLAG_DIV_ZERO;
-                    st[S][j] = hs_d2u(x / y);
-                }
-            }
-            break;
-        case HS_OP_FLOORDIV_F:
-        case HS_OP_MOD_F:
-            if constexpr (SP >= 2) {
-#pragma unroll
-                for (int j = 0; j < V; ++j) {
-                    double x = hs_u2d(st[S][j]), y = hs_u2d(st[T][j]);
-                    double fd = 0.0, md = 0.0;
-                    if (y == 0.0) {
-                        if (sink.live(j)) err |= HS_FLAG_DIV_ZERO;
-                    } else {
-                        hs_divmod_f(x, y, fd, md);
-                    }
-                    st[S][j] = hs_d2u(op == HS_OP_FLOORDIV_F ? fd : md);
-                }
-            }
-            break;
-        case HS_OP_ADD_I: HS_BIN_I(x + y); break;
-        case HS_OP_SUB_I: HS_BIN_I(x - y); break;
-        case HS_OP_MUL_I: HS_BIN_I(x * y); break;
-        case HS_OP_FLOORDIV_I:
-        case HS_OP_MOD_I:
-            if constexpr (SP >= 2) {
-#pragma unroll
-                for (int j = 0; j < V; ++j) {
-                    int64_t x = (int64_t)st[S][j], y = (int64_t)st[T][j];
-                    int64_t r = 0;
-                    if (y == 0) {
-                        if (sink.live(j)) err |= HS_FLAG_DIV_ZERO;
-                    } else {
-                        r = op == HS_OP_FLOORDIV_I ? hs_floordiv_i(x, y) : hs_mod_i(x, y);
-                    }
-                    st[S][j] = (uint64_t)r;
-                }
-            }
-            break;
-        case HS_OP_LT_F: HS_BIN_F((uint64_t)(x < y)); break;
-        case HS_OP_LE_F: HS_BIN_F((uint64_t)(x <= y)); break;
-        case HS_OP_GT_F: HS_BIN_F((uint64_t)(x > y)); break;
-        case HS_OP_GE_F: HS_BIN_F((uint64_t)(x >= y)); break;
-        case HS_OP_EQ_F: HS_BIN_F((uint64_t)(x == y)); break;
-        case HS_OP_NE_F: HS_BIN_F((uint64_t)(x != y)); break;
-        case HS_OP_LT_I: HS_BIN_I(x < y); break;
-        case HS_OP_LE_I: HS_BIN_I(x <= y); break;
-        case HS_OP_GT_I: HS_BIN_I(x > y); break;
-        case HS_OP_GE_I: HS_BIN_I(x >= y); break;
-        case HS_OP_EQ_I: HS_BIN_I(x == y); break;
-        case HS_OP_NE_I: HS_BIN_I(x != y); break;
-        case HS_OP_AND: HS_BIN_I(x & y); break;
-        case HS_OP_OR: HS_BIN_I(x | y); break;
+        HS_BIN(HS_OP_ADD_F) HS_BIN(HS_OP_SUB_F) HS_BIN(HS_OP_MUL_F) HS_BIN(HS_OP_DIV_F)
+        HS_BIN(HS_OP_FLOORDIV_F) HS_BIN(HS_OP_MOD_F)
+        HS_BIN(HS_OP_ADD_I) HS_BIN(HS_OP_SUB_I) HS_BIN(HS_OP_MUL_I) HS_BIN(HS_OP_FLOORDIV_I) HS_BIN(HS_OP_MOD_I)
+        HS_BIN(HS_OP_LT_F) HS_BIN(HS_OP_LE_F) HS_BIN(HS_OP_GT_F) HS_BIN(HS_OP_GE_F) HS_BIN(HS_OP_EQ_F) HS_BIN(HS_OP_NE_F)
+        HS_BIN(HS_OP_LT_I) HS_BIN(HS_OP_LE_I) HS_BIN(HS_OP_GT_I) HS_BIN(HS_OP_GE_I) HS_BIN(HS_OP_EQ_I) HS_BIN(HS_OP_NE_I)
+        HS_BIN(HS_OP_AND) HS_BIN(HS_OP_OR)
         case HS_OP_I2F:
             if constexpr (SP >= 1) {
                 if (a == 0) {
@@ -290,41 +304,23 @@ __device__ __forceinline__ void hs_exec_at(uint64_t w, const hs_program& P, cons
             break;
         case HS_OP_STRCMP_LIT:
             if constexpr (SP < D) {
-                const uint64_t ref = P.lit[hs_ins_b(w)];
-                HsStr lit;
-                lit.p = P.pool + (uint32_t)(ref >> 32);
-                lit.len = (uint32_t)ref;
 #pragma unroll
-                for (int j = 0; j < V; ++j) {
-                    bool r = false;
-                    if (sink.live(j)) r = hs_cmp_result(hs_str_cmp(hs_str_at(C.c[a], sink.row(j)), lit), hs_ins_c(w));
-                    st[N][j] = (uint64_t)r;
-                }
+                for (int j = 0; j < V; ++j)
+                    st[N][j] = sink.live(j) ? hs_strcmp_lit(P, C.c[a], sink.row(j), hs_ins_b(w), hs_ins_c(w)) : 0;
             }
             break;
         case HS_OP_STRCMP_COL:
             if constexpr (SP < D) {
 #pragma unroll
-                for (int j = 0; j < V; ++j) {
-                    bool r = false;
-                    if (sink.live(j))
-                        r = hs_cmp_result(
-                            hs_str_cmp(hs_str_at(C.c[a], sink.row(j)), hs_str_at(C.c[hs_ins_b(w)], sink.row(j))),
-                            hs_ins_c(w));
-                    st[N][j] = (uint64_t)r;
-                }
+                for (int j = 0; j < V; ++j)
+                    st[N][j] = sink.live(j) ? hs_strcmp_col(C.c[a], C.c[hs_ins_b(w)], sink.row(j), hs_ins_c(w)) : 0;
             }
             break;
         case HS_OP_LIKE:
             if constexpr (SP < D) {
-                const uint64_t ref = P.lit[hs_ins_b(w)];
 #pragma unroll
-                for (int j = 0; j < V; ++j) {
-                    bool r = false;
-                    if (sink.live(j))
-                        r = hs_like(hs_str_at(C.c[a], sink.row(j)), P.pool + (uint32_t)(ref >> 32), (uint32_t)ref);
-                    st[N][j] = (uint64_t)r;
-                }
+                for (int j = 0; j < V; ++j)
+                    st[N][j] = sink.live(j) ? hs_like_lit(P, C.c[a], sink.row(j), hs_ins_b(w)) : 0;
             }
             break;
         case HS_OP_FILTER:
@@ -348,8 +344,7 @@ __device__ __forceinline__ void hs_exec_at(uint64_t w, const hs_program& P, cons
         case HS_OP_KEY: sink.key(); break;
         default: err |= HS_FLAG_BAD_PROGRAM; break;
     }
-#undef HS_BIN_F
-#undef HS_BIN_I
+#undef HS_BIN
 }
 
 template <int D, int V, typename Sink>
@@ -442,11 +437,17 @@ __device__ __forceinline__ bool hs_rows_equal(const hs_col& c, int64_t r0, int64
     return hs_key_at(c, r0) == hs_key_at(c, r1);
 }
 
+// probe start for the small LDS dictionaries: one 32-bit multiply (the 64-bit mixer above is for the
+// big global tables)
+__device__ __forceinline__ uint32_t hs_slot_hash(uint64_t k) {
+    return ((uint32_t)k ^ (uint32_t)(k >> 32)) * 0x9E3779B1u >> 12;
+}
+
 // LDS dictionary, exact-word mode.  keys[] initialised to HS_EMPTY_KEY, reps[] to -1.
 // Returns the slot of `k`, inserting it if absent; -1 when the table is full.
 __device__ __forceinline__ int hs_dict_upsert_word(uint64_t* keys, int64_t* reps, uint32_t mask, uint64_t k,
                                                    int64_t row) {
-    uint32_t h = (uint32_t)hs_mix64(k) & mask;
+    uint32_t h = hs_slot_hash(k) & mask;
     for (uint32_t probe = 0; probe <= mask; ++probe) {
         uint64_t cur = *(volatile uint64_t*)&keys[h];
         if (cur == HS_EMPTY_KEY) {
@@ -466,7 +467,7 @@ __device__ __forceinline__ int hs_dict_upsert_word(uint64_t* keys, int64_t* reps
 // byte compare against that row (immutable global memory, so no ordering hazard).
 __device__ __forceinline__ int hs_dict_upsert_rows(int64_t* reps, uint32_t mask, const hs_col& c, uint64_t k,
                                                    int64_t row) {
-    uint32_t h = (uint32_t)hs_mix64(k) & mask;
+    uint32_t h = hs_slot_hash(k) & mask;
     for (uint32_t probe = 0; probe <= mask; ++probe) {
         long long cur = *(volatile long long*)&reps[h];
         if (cur < 0) {
