@@ -133,11 +133,15 @@ int hs_str_offsets(void* stream, const uint8_t* lens, int64_t nrows, int64_t* of
  * A4  Expression evaluation (reference tasks.py:32-35 project_column + sql.py:262-266 execute_row)
  * ===============================================================================================*/
 
-/* Evaluate `prog` for every row; each HS_OP_OUT a stores into outs[a] with kind out_kinds[a]
+/* Everywhere below, a `*_dev` row count (device int64, may be NULL) caps the host-side count: rows at or
+ * beyond it are not touched.  It lets operators run on a batch whose size is only known on the device.
+ *
+ * Evaluate `prog` for every row; each HS_OP_OUT a stores into outs[a] with kind out_kinds[a]
  * (HS_F64, HS_I64 or HS_U8 for booleans).  If `sel` != NULL only rows sel[0..nrows) of the input
  * are evaluated (output row i <- input row sel[i]). */
 int hs_eval(void* stream, const hs_col* cols, int32_t n_cols, const hs_program* prog, const int64_t* sel,
-            int64_t nrows, void* const* outs, const int32_t* out_kinds, int32_t n_outs, uint32_t* flags);
+            int64_t nrows, const int64_t* nrows_dev, void* const* outs, const int32_t* out_kinds, int32_t n_outs,
+            uint32_t* flags);
 
 /* =================================================================================================
  * A3  Filter = stream compaction (reference tasks.py:167-177; zig task_utils.zig:9-51)
@@ -148,7 +152,8 @@ int hs_eval(void* stream, const hs_col* cols, int32_t n_cols, const hs_program* 
 int hs_compact(void* stream, const uint8_t* mask, int64_t nrows, int64_t* sel, int64_t* count, void* ws);
 
 /* out[i] = src[idx[i]] for a fixed-width column (elem_bytes in {1,4,8}). */
-int hs_gather_fixed(void* stream, const void* src, int32_t elem_bytes, const int64_t* idx, int64_t n, void* dst);
+int hs_gather_fixed(void* stream, const void* src, int32_t elem_bytes, const int64_t* idx, int64_t n,
+                    const int64_t* n_dev, void* dst);
 /* STRING gather, two steps around an offsets scan: lengths first ... */
 int hs_gather_str_lens(void* stream, const hs_col* src, const int64_t* idx, int64_t n, uint8_t* out_lens);
 /* ... then payload bytes to out_data at out_offs (from hs_str_offsets over out_lens). */
@@ -216,11 +221,13 @@ int hs_agg_pack(void* stream, const int64_t* rep, const uint64_t* acc, const int
  * reference's order: block order of the shuffle file).  Outputs are DENSE (group i = i-th occupied
  * dictionary slot) and column-major: out_rep[i] = smallest input row of group i, out_acc[a * cap + i]
  * = un-rounded 64-bit cell of aggregate a, *out_ngroups = number of groups (<= cap).
+ * n_rows is an upper bound when n_rows_dev != NULL (then *n_rows_dev, a device int64, is the exact
+ * count): lets a whole query run without a host round trip between its kernels.
  * ws: hs_agg_merge_ws_bytes(). */
 size_t hs_agg_merge_ws_bytes(int64_t n_rows, int64_t n_units, int32_t cap);
 int hs_agg_merge(void* stream, const hs_col* key, const hs_col* acc_cols, const hs_agg_spec* spec,
-                 const int64_t* unit_rows, int64_t n_units, int64_t n_rows, int32_t cap, int64_t* out_rep,
-                 uint64_t* out_acc, int32_t* out_ngroups, void* ws, uint32_t* flags);
+                 const int64_t* unit_rows, int64_t n_units, int64_t n_rows, const int64_t* n_rows_dev, int32_t cap,
+                 int64_t* out_rep, uint64_t* out_acc, int64_t* out_ngroups, void* ws, uint32_t* flags);
 
 /* =================================================================================================
  * A6/A9  Hash partitioning (reference tasks.py:347-375 WriteToShufflePartitions.write)
@@ -269,7 +276,8 @@ int hs_exclusive_scan_i64(void* stream, const int64_t* counts, int64_t n, int64_
 
 /* f64 -> f32 (RNE; finite overflow sets HS_FLAG_FLT_OVERFLOW) or i64 -> i32 (range check sets
  * HS_FLAG_INT_OVERFLOW).  src_kind in {HS_F64, HS_I64}. */
-int hs_quantise(void* stream, const void* src, int32_t src_kind, int64_t n, void* dst, uint32_t* flags);
+int hs_quantise(void* stream, const void* src, int32_t src_kind, int64_t n, const int64_t* n_dev, void* dst,
+                uint32_t* flags);
 
 /* =================================================================================================
  * Run-time specialisation (reference: codegen.py:230-247 compiles every query with `zig build`).

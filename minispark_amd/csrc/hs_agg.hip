@@ -40,14 +40,20 @@ struct AggUnitArgs {
     uint32_t* flags;
 };
 
+// One workgroup per unit.  Phase 1: every (chunk, slot) entry of the unit is inserted into the unit's
+// dictionary in parallel (the SET of keys does not depend on insertion races) and remembers its unit
+// slot.  Phase 2: one lane per (unit slot, accumulator) folds that key's chunk partials in ascending
+// chunk order = row order, without barriers.  Chunks are staged through LDS in batches.
+#define HS_UNIT_BATCH 64 /* chunks per LDS batch */
 __global__ void __launch_bounds__(256) k_agg_unit(const AggUnitArgs A_kernarg) {
     HS_KERNARG(AggUnitArgs, A);
     extern __shared__ __align__(16) uint64_t lds[];
     const int GC = A.group_cap, NA = A.spec.n_acc;
-    uint64_t* ukeys = lds;
-    int64_t* ureps = (int64_t*)(lds + GC);
-    uint64_t* uacc = lds + 2 * GC;
-    int* map = (int*)(uacc + GC * NA);
+    uint64_t* ukeys = lds;                                  // [GC]
+    int64_t* ureps = (int64_t*)(lds + GC);                  // [GC]
+    uint64_t* uacc = lds + 2 * GC;                          // [GC][NA]
+    uint64_t* pacc = uacc + GC * NA;                        // [BATCH][GC][NA] staged chunk partials
+    int* map = (int*)(pacc + (size_t)HS_UNIT_BATCH * GC * NA);  // [BATCH][GC] chunk slot -> unit slot
     __shared__ int s_count;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int64_t u = blockIdx.x;
@@ -62,30 +68,40 @@ __global__ void __launch_bounds__(256) k_agg_unit(const AggUnitArgs A_kernarg) {
     __syncthreads();
 
     const uint32_t mask = (uint32_t)GC - 1;
-    for (int64_t c = A.unit_chunk0[u]; c < A.unit_chunk0[u + 1]; ++c) {  // chunk order = row order: fixed
-        for (int s = tid; s < GC; s += nthr) {
-            const int64_t rep = A.part_rep[c * GC + s];
+    const int64_t cbeg = A.unit_chunk0[u], cend = A.unit_chunk0[u + 1];
+    for (int64_t b0 = cbeg; b0 < cend; b0 += HS_UNIT_BATCH) {
+        const int nb = (int)((cend - b0) < HS_UNIT_BATCH ? (cend - b0) : HS_UNIT_BATCH);
+        for (int i = tid; i < nb * GC; i += nthr) {
+            const int64_t c = b0 + i / GC;
+            const int sl = i % GC;
+            const int64_t rep = A.part_rep[c * GC + sl];
             int m = -1;
             if (rep >= 0) {
                 m = A.hashed ? hs_dict_upsert_rows(ureps, mask, A.key, hs_key_at(A.key, rep), rep)
-                             : hs_dict_upsert_word(ukeys, ureps, mask, A.part_keys[c * GC + s], rep);
+                             : hs_dict_upsert_word(ukeys, ureps, mask, A.part_keys[c * GC + sl], rep);
                 if (m < 0) err |= HS_FLAG_DICT_FULL;
             }
-            map[s] = m;
+            map[i] = m;
         }
+        for (int i = tid; i < nb * GC * NA; i += nthr) pacc[i] = A.part_acc[b0 * GC * NA + i];
         __syncthreads();
         for (int i = tid; i < GC * NA; i += nthr) {
-            const int s = i / NA, a = i % NA;
-            const int m = map[s];
-            if (m >= 0)
-                uacc[m * NA + a] = hs_acc_fold(A.spec.op[a], A.spec.is_int[a] != 0, uacc[m * NA + a],
-                                               A.part_acc[(c * GC + s) * NA + a]);
+            const int us = i / NA, a = i % NA;
+            const uint32_t op = A.spec.op[a];
+            const bool is_int = A.spec.is_int[a] != 0;
+            uint64_t v = uacc[i];
+            for (int c = 0; c < nb; ++c)
+                for (int sl = 0; sl < GC; ++sl)
+                    if (map[c * GC + sl] == us) v = hs_acc_fold(op, is_int, v, pacc[(c * GC + sl) * NA + a]);
+            uacc[i] = v;
         }
         __syncthreads();
     }
-    for (int s = tid; s < GC; s += nthr) {
-        const int64_t rep = ureps[s];
-        A.out_rep[u * GC + s] = rep;
+    for (int sl = tid; sl < GC; sl += nthr) {
+        // representative = smallest row index seen for the slot would need a second pass; any row of the
+        // key is equivalent (same key bytes), so keep the one that won the insert
+        const int64_t rep = ureps[sl];
+        A.out_rep[u * GC + sl] = rep;
         if (rep >= 0) atomicAdd(&s_count, 1);
     }
     for (int i = tid; i < GC * NA; i += nthr) {
@@ -94,7 +110,6 @@ __global__ void __launch_bounds__(256) k_agg_unit(const AggUnitArgs A_kernarg) {
     }
     __syncthreads();
     if (tid == 0) A.out_ngroups[u] = s_count;
-    // only report quantisation overflow for occupied slots: empty slots hold identities, never overflow
     if (err) atomicOr(A.flags, err);
 }
 
@@ -162,29 +177,39 @@ struct AggMergeArgs {
     hs_col key;
     hs_col acc_cols[HS_MAX_ACC];
     hs_agg_spec spec;
-    int64_t n_rows;
+    int64_t n_rows;            // upper bound (sizes LDS)
+    const int64_t* n_rows_dev; // optional exact row count on the device
     int32_t cap;
     int32_t hashed;
     int64_t* out_rep;
     uint64_t* out_acc;
-    int32_t* out_ngroups;
+    int64_t* out_ngroups;
     uint32_t* flags;
 };
 
-// Final merge, everything staged in LDS: rows ascend in unit order, so folding the rows of a slot in
-// ascending row order IS the reference's order (0 + p_block0 + p_block1 + ... in fp64).
-// Outputs are dense (occupied slots in ascending slot order) and column-major: out_acc[a * cap + i].
+// Final merge, everything staged in LDS.  Rows ascend in unit order, so folding the rows of a group in
+// ascending row order IS the reference's order (0 + p_block0 + p_block1 + ... in fp64).  Rows are
+// bucketed by group with a stable rank (number of earlier rows of the same group) so the ordered fold
+// reads contiguous LDS.  Outputs are dense (groups in ascending dictionary-slot order) and
+// column-major: out_acc[a * cap + i].
 __global__ void __launch_bounds__(1024) k_agg_merge_small(const AggMergeArgs A_kernarg) {
     HS_KERNARG(AggMergeArgs, A);
     extern __shared__ __align__(16) uint64_t lds[];
     const int NA = A.spec.n_acc;
     const int cap = A.cap;
-    const int64_t n = A.n_rows;
-    uint64_t* dkeys = lds;
-    int64_t* dreps = (int64_t*)(lds + cap);
-    uint64_t* cells = lds + 2 * cap;              // [n][NA]
-    int32_t* rslot = (int32_t*)(cells + n * NA);  // [n]
-    int32_t* dense = rslot + n;                   // [cap] slot -> dense output row
+    const int64_t nmax = A.n_rows;
+    int64_t n = nmax;
+    if (A.n_rows_dev) {
+        const int64_t nd = *A.n_rows_dev;
+        n = nd < nmax ? nd : nmax;
+    }
+    uint64_t* dkeys = lds;                                // [cap]
+    int64_t* dreps = (int64_t*)(lds + cap);               // [cap]
+    uint64_t* sorted = lds + 2 * cap;                     // [nmax][NA] cells bucketed by group
+    int32_t* rslot = (int32_t*)(sorted + nmax * NA);      // [nmax]
+    int32_t* dense = rslot + nmax;                        // [cap] slot -> dense output row
+    int32_t* cnt = dense + cap;                           // [cap] rows per slot
+    int32_t* start = cnt + cap;                           // [cap] first bucket position of the slot
     __shared__ int s_scan[1024];
     const int tid = threadIdx.x, nthr = blockDim.x;
     uint32_t err = 0;
@@ -192,25 +217,26 @@ __global__ void __launch_bounds__(1024) k_agg_merge_small(const AggMergeArgs A_k
     for (int i = tid; i < cap; i += nthr) {
         dkeys[i] = HS_EMPTY_KEY;
         dreps[i] = -1;
+        cnt[i] = 0;
     }
     __syncthreads();
     const uint32_t mask = (uint32_t)cap - 1;
     for (int64_t r = tid; r < n; r += nthr) {
         const uint64_t k = hs_key_at(A.key, r);
-        int s = A.hashed ? hs_dict_upsert_rows(dreps, mask, A.key, k, r) : hs_dict_upsert_word(dkeys, dreps, mask, k, r);
-        if (s < 0) {
-            err |= HS_FLAG_DICT_FULL;
-            s = -1;
-        }
-        rslot[r] = s;
-        for (int a = 0; a < NA; ++a) cells[r * NA + a] = hs_load_cell(A.acc_cols[a], r);
+        int sl = A.hashed ? hs_dict_upsert_rows(dreps, mask, A.key, k, r) : hs_dict_upsert_word(dkeys, dreps, mask, k, r);
+        if (sl < 0) err |= HS_FLAG_DICT_FULL;
+        else atomicAdd(&cnt[sl], 1);
+        rslot[r] = sl;
     }
     __syncthreads();
-    // dense numbering of the occupied slots (ascending slot order): per-thread ranges + block scan
+    // per-thread slot ranges + block scans: dense group numbering and bucket starts
     const int per = (cap + nthr - 1) / nthr;
     const int s0 = tid * per, s1 = (s0 + per) < cap ? (s0 + per) : cap;
-    int mine = 0;
-    for (int s = s0; s < s1; ++s) mine += dreps[s] >= 0;
+    int mine = 0, mine_rows = 0;
+    for (int sl = s0; sl < s1; ++sl) {
+        mine += cnt[sl] > 0;
+        mine_rows += cnt[sl];
+    }
     s_scan[tid] = mine;
     __syncthreads();
     for (int d = 1; d < nthr; d <<= 1) {
@@ -220,30 +246,44 @@ __global__ void __launch_bounds__(1024) k_agg_merge_small(const AggMergeArgs A_k
         __syncthreads();
     }
     int run = s_scan[tid] - mine;
-    for (int s = s0; s < s1; ++s) dense[s] = dreps[s] >= 0 ? run++ : -1;
+    const int ngroups = s_scan[nthr - 1];
     __syncthreads();
-    if (tid == 0) *A.out_ngroups = s_scan[nthr - 1];
-
+    for (int sl = s0; sl < s1; ++sl) dense[sl] = cnt[sl] > 0 ? run++ : -1;
+    s_scan[tid] = mine_rows;
+    __syncthreads();
+    for (int d = 1; d < nthr; d <<= 1) {
+        const int t = tid >= d ? s_scan[tid - d] : 0;
+        __syncthreads();
+        s_scan[tid] += t;
+        __syncthreads();
+    }
+    int pos = s_scan[tid] - mine_rows;
+    for (int sl = s0; sl < s1; ++sl) {
+        start[sl] = pos;
+        pos += cnt[sl];
+    }
+    __syncthreads();
+    if (tid == 0) *A.out_ngroups = ngroups;
+    // stable rank of every row inside its group, then scatter its cells into the group's bucket
+    for (int64_t r = tid; r < n; r += nthr) {
+        const int sl = rslot[r];
+        if (sl < 0) continue;
+        int rank = 0;
+        for (int64_t q = 0; q < r; ++q) rank += rslot[q] == sl;
+        const int at = start[sl] + rank;
+        for (int a = 0; a < NA; ++a) sorted[(int64_t)at * NA + a] = hs_load_cell(A.acc_cols[a], r);
+        if (rank == 0) A.out_rep[dense[sl]] = r;  // smallest row of the group: independent of insert races
+    }
+    __syncthreads();
     for (int i = tid; i < cap * NA; i += nthr) {
-        const int s = i / NA, a = i % NA;
-        if (dense[s] < 0) continue;
+        const int sl = i / NA, a = i % NA;
+        if (dense[sl] < 0) continue;
         const uint32_t op = A.spec.op[a];
         const bool is_int = A.spec.is_int[a] != 0;
         uint64_t v = hs_acc_identity(op, is_int);
-        for (int64_t r = 0; r < n; ++r)
-            if (rslot[r] == s) v = hs_acc_fold(op, is_int, v, cells[r * NA + a]);
-        A.out_acc[(int64_t)a * cap + dense[s]] = v;
-    }
-    for (int s = tid; s < cap; s += nthr) {
-        if (dense[s] < 0) continue;
-        // representative = the smallest row of the slot, so the output does not depend on insert races
-        int64_t rep = -1;
-        for (int64_t r = 0; r < n; ++r)
-            if (rslot[r] == s) {
-                rep = r;
-                break;
-            }
-        A.out_rep[dense[s]] = rep;
+        const int b = start[sl], e = b + cnt[sl];
+        for (int q = b; q < e; ++q) v = hs_acc_fold(op, is_int, v, sorted[(int64_t)q * NA + a]);
+        A.out_acc[(int64_t)a * cap + dense[sl]] = v;
     }
     if (err) atomicOr(A.flags, err);
 }
@@ -438,7 +478,17 @@ extern "C" int hs_agg_partial(void* stream, const hs_col* cols, int32_t n_cols, 
     U.out_acc = out_acc;
     U.out_ngroups = out_ngroups;
     U.flags = flags;
-    const size_t ulds = (size_t)geom->group_cap * 16 + (size_t)geom->group_cap * spec->n_acc * 8 + (size_t)geom->group_cap * 4;
+    const size_t ulds = (size_t)geom->group_cap * 16 + (size_t)geom->group_cap * spec->n_acc * 8 +
+                        (size_t)HS_UNIT_BATCH * geom->group_cap * spec->n_acc * 8 + (size_t)HS_UNIT_BATCH * geom->group_cap * 4;
+    if (ulds > HS_LDS_HARD) {
+        hs_set_error("hs_agg_partial: unit combine needs %zu B LDS", ulds);
+        return HS_E_LIMIT;
+    }
+    static bool unit_attr = false;
+    if (!unit_attr) {
+        allow_big_lds(k_agg_unit);
+        unit_attr = true;
+    }
     hipLaunchKernelGGL(k_agg_unit, dim3((unsigned)n_units), dim3(256), ulds, s, U);
     if (hipGetLastError() != hipSuccess) {
         hs_set_error("hs_agg_partial: kernel launch failed");
@@ -486,8 +536,9 @@ extern "C" size_t hs_agg_merge_ws_bytes(int64_t n_rows, int64_t n_units, int32_t
 }
 
 extern "C" int hs_agg_merge(void* stream, const hs_col* key, const hs_col* acc_cols, const hs_agg_spec* spec,
-                            const int64_t* unit_rows, int64_t n_units, int64_t n_rows, int32_t cap, int64_t* out_rep,
-                            uint64_t* out_acc, int32_t* out_ngroups, void* ws, uint32_t* flags) {
+                            const int64_t* unit_rows, int64_t n_units, int64_t n_rows, const int64_t* n_rows_dev,
+                            int32_t cap, int64_t* out_rep, uint64_t* out_acc, int64_t* out_ngroups, void* ws,
+                            uint32_t* flags) {
     (void)unit_rows;
     (void)n_units;
     (void)ws;
@@ -496,7 +547,7 @@ extern "C" int hs_agg_merge(void* stream, const hs_col* key, const hs_col* acc_c
         hs_set_error("hs_agg_merge: bad arguments");
         return HS_E_ARG;
     }
-    const size_t lds = (size_t)cap * 16 + (size_t)n_rows * spec->n_acc * 8 + (size_t)n_rows * 4 + (size_t)cap * 4 + 16;
+    const size_t lds = (size_t)cap * 16 + (size_t)n_rows * spec->n_acc * 8 + (size_t)n_rows * 4 + (size_t)cap * 12 + 16;
     if (lds > HS_MERGE_LDS_MAX) {
         hs_set_error("hs_agg_merge: %lld partial rows x %d accumulators need %zu B LDS (> %zu): use the unit-stepped merge",
                      (long long)n_rows, spec->n_acc, lds, HS_MERGE_LDS_MAX);
@@ -508,6 +559,7 @@ extern "C" int hs_agg_merge(void* stream, const hs_col* key, const hs_col* acc_c
         A.acc_cols[a] = a < spec->n_acc ? acc_cols[a] : hs_col{HS_U8, -1, nullptr, nullptr, nullptr};
     A.spec = *spec;
     A.n_rows = n_rows;
+    A.n_rows_dev = n_rows_dev;
     A.cap = cap;
     A.hashed = hs_col_packs(*key) ? 0 : 1;
     A.out_rep = out_rep;

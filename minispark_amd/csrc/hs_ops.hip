@@ -219,8 +219,16 @@ extern "C" int hs_compact(void* stream, const uint8_t* mask, int64_t nrows, int6
 }
 
 // ---- gathers -------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t capped(int64_t n, const int64_t* n_dev) {
+    if (!n_dev) return n;
+    const int64_t d = *n_dev;
+    return d < n ? d : n;
+}
+
 template <typename T>
-__global__ void __launch_bounds__(256) k_gather_fixed(const T* src, const int64_t* idx, int64_t n, T* dst) {
+__global__ void __launch_bounds__(256) k_gather_fixed(const T* src, const int64_t* idx, int64_t n, const int64_t* n_dev,
+                                                      T* dst) {
+    n = capped(n, n_dev);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         dst[i] = src[idx[i]];
 }
@@ -233,7 +241,7 @@ static unsigned grid_for(int64_t n, int per_block) {
 }
 
 extern "C" int hs_gather_fixed(void* stream, const void* src, int32_t elem_bytes, const int64_t* idx, int64_t n,
-                               void* dst) {
+                               const int64_t* n_dev, void* dst) {
     if (n == 0) return HS_OK;
     if (!src || !idx || !dst || n < 0) {
         hs_set_error("hs_gather_fixed: bad arguments");
@@ -242,9 +250,10 @@ extern "C" int hs_gather_fixed(void* stream, const void* src, int32_t elem_bytes
     hipStream_t s = (hipStream_t)stream;
     const dim3 g(grid_for(n, 256)), b(256);
     switch (elem_bytes) {
-        case 1: hipLaunchKernelGGL(k_gather_fixed<uint8_t>, g, b, 0, s, (const uint8_t*)src, idx, n, (uint8_t*)dst); break;
-        case 4: hipLaunchKernelGGL(k_gather_fixed<uint32_t>, g, b, 0, s, (const uint32_t*)src, idx, n, (uint32_t*)dst); break;
-        case 8: hipLaunchKernelGGL(k_gather_fixed<uint64_t>, g, b, 0, s, (const uint64_t*)src, idx, n, (uint64_t*)dst); break;
+        case 1: hipLaunchKernelGGL(k_gather_fixed<uint8_t>, g, b, 0, s, (const uint8_t*)src, idx, n, n_dev, (uint8_t*)dst); break;
+        case 2: hipLaunchKernelGGL(k_gather_fixed<uint16_t>, g, b, 0, s, (const uint16_t*)src, idx, n, n_dev, (uint16_t*)dst); break;
+        case 4: hipLaunchKernelGGL(k_gather_fixed<uint32_t>, g, b, 0, s, (const uint32_t*)src, idx, n, n_dev, (uint32_t*)dst); break;
+        case 8: hipLaunchKernelGGL(k_gather_fixed<uint64_t>, g, b, 0, s, (const uint64_t*)src, idx, n, n_dev, (uint64_t*)dst); break;
         default: hs_set_error("hs_gather_fixed: elem_bytes=%d", elem_bytes); return HS_E_ARG;
     }
     HS_CHECK_LAUNCH("hs_gather_fixed");
@@ -372,6 +381,7 @@ struct EvalArgs {
     hs_program prog;
     const int64_t* sel;
     int64_t nrows;
+    const int64_t* nrows_dev;
     void* outs[HS_MAX_OUTS];
     int32_t out_kinds[HS_MAX_OUTS];
     uint32_t* flags;
@@ -397,7 +407,8 @@ __global__ void __launch_bounds__(256) k_eval(const EvalArgs A_kernarg) {
     HS_KERNARG(EvalArgs, A);
     uint32_t err = 0;
     EvalSink sink(A);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.nrows; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t nrows = capped(A.nrows, A.nrows_dev);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nrows; i += (int64_t)gridDim.x * blockDim.x) {
         sink.out_row = i;
         sink.in_row = A.sel ? A.sel[i] : i;
         hs_run<HS_MAX_STACK, 1>(A.prog, A.cols, 0, A.prog.n_ins, sink, err);
@@ -405,7 +416,8 @@ __global__ void __launch_bounds__(256) k_eval(const EvalArgs A_kernarg) {
     if (err) atomicOr(A.flags, err);
 }
 extern "C" int hs_eval(void* stream, const hs_col* cols, int32_t n_cols, const hs_program* prog, const int64_t* sel,
-                       int64_t nrows, void* const* outs, const int32_t* out_kinds, int32_t n_outs, uint32_t* flags) {
+                       int64_t nrows, const int64_t* nrows_dev, void* const* outs, const int32_t* out_kinds,
+                       int32_t n_outs, uint32_t* flags) {
     if (!prog || !flags || (n_cols > 0 && !cols) || n_cols < 0 || n_cols > HS_MAX_COLS || n_outs < 0 ||
         n_outs > HS_MAX_OUTS || (n_outs > 0 && (!outs || !out_kinds)) || nrows < 0) {
         hs_set_error("hs_eval: bad arguments");
@@ -423,6 +435,7 @@ extern "C" int hs_eval(void* stream, const hs_col* cols, int32_t n_cols, const h
     A.prog = *prog;
     A.sel = sel;
     A.nrows = nrows;
+    A.nrows_dev = nrows_dev;
     for (int i = 0; i < HS_MAX_OUTS; ++i) {
         A.outs[i] = i < n_outs ? outs[i] : nullptr;
         A.out_kinds[i] = i < n_outs ? out_kinds[i] : HS_F64;
@@ -434,8 +447,10 @@ extern "C" int hs_eval(void* stream, const hs_col* cols, int32_t n_cols, const h
 }
 
 // ---- quantisation at a file write (reference io.py:87-94) ---------------------------------------------
-__global__ void __launch_bounds__(256) k_quantise(const void* src, int32_t kind, int64_t n, void* dst, uint32_t* flags) {
+__global__ void __launch_bounds__(256) k_quantise(const void* src, int32_t kind, int64_t n, const int64_t* n_dev,
+                                                  void* dst, uint32_t* flags) {
     uint32_t err = 0;
+    n = capped(n, n_dev);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         if (kind == HS_F64) {
             const double d = ((const double*)src)[i];
@@ -450,14 +465,15 @@ __global__ void __launch_bounds__(256) k_quantise(const void* src, int32_t kind,
     }
     if (err) atomicOr(flags, err);
 }
-extern "C" int hs_quantise(void* stream, const void* src, int32_t src_kind, int64_t n, void* dst, uint32_t* flags) {
+extern "C" int hs_quantise(void* stream, const void* src, int32_t src_kind, int64_t n, const int64_t* n_dev, void* dst,
+                           uint32_t* flags) {
     if (n == 0) return HS_OK;
     if (!src || !dst || !flags || n < 0 || (src_kind != HS_F64 && src_kind != HS_I64)) {
         hs_set_error("hs_quantise: bad arguments");
         return HS_E_ARG;
     }
-    hipLaunchKernelGGL(k_quantise, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, src, src_kind, n, dst,
-                       flags);
+    hipLaunchKernelGGL(k_quantise, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, src, src_kind, n, n_dev,
+                       dst, flags);
     HS_CHECK_LAUNCH("hs_quantise");
     return HS_OK;
 }

@@ -61,28 +61,48 @@ class DCol:
 
 @dataclass
 class DBatch:
+    """Columns + row count + unit boundaries.
+
+    ``nrows`` is exact unless ``nrows_dev`` is set: then it is an upper bound (buffers are that large) and
+    the exact count lives on the device in ``nrows_dev[0]`` (int64).  Operators pass that pointer to the
+    kernels, so a query can run end to end without the host learning intermediate sizes."""
+
     schema: Schema
     cols: list[DCol]
     nrows: int
-    unit_rows: list[int] = field(default_factory=list)  # host copy of the unit boundaries [n_units+1]
+    unit_rows: list[int] | None = field(default_factory=list)  # host copy of the unit boundaries [n_units+1]
+    nrows_dev: torch.Tensor | None = None
 
     def __post_init__(self) -> None:
-        if not self.unit_rows:
-            self.unit_rows = [0, self.nrows]
+        if self.nrows_dev is None and not self.unit_rows:
+            self.unit_rows = [0, self.nrows]  # exact batch without explicit units: one unit
 
     @property
     def kinds(self) -> list[int]:
         return [c.kind for c in self.cols]
 
     @property
+    def lazy(self) -> bool:
+        return self.nrows_dev is not None
+
+    @property
     def n_units(self) -> int:
-        return len(self.unit_rows) - 1
+        return len(self.unit_rows) - 1 if self.unit_rows is not None else 1
+
+    @property
+    def n_dev_ptr(self):
+        return self.nrows_dev.data_ptr() if self.nrows_dev is not None else None
 
     def column_index(self, name: str) -> int:
         for i, (col_name, _) in enumerate(self.schema):
             if col_name == name:
                 return i
         raise ValueError(f'Column "{name}" not found in schema {self.schema}')
+
+
+class RetryWithLargerDictionary(Exception):
+    """A launch met more distinct group keys than its dictionary capacity (noticed at the query's single
+    host round trip); the engine re-runs the query with larger capacities."""
 
 
 class DeviceError(RuntimeError):
@@ -196,6 +216,48 @@ class Device:
             return StrCol(lens.astype(np.uint8), col.data[:total].cpu().numpy().astype(np.uint8))
         return col.data[: col.n].cpu().numpy()
 
+    def download_batch(self, batch: DBatch, schema: Schema) -> tuple[list[Any], int, int]:
+        """All columns (already in file storage kinds) + the exact row count + the status flags in ONE
+        device->host copy.  Returns (raw numpy columns, nrows, flags)."""
+        parts: list[torch.Tensor] = []
+        layout: list[tuple[str, int, int, Any]] = []
+        pos = 0
+
+        def add(tag: str, t: torch.Tensor, extra: Any = None) -> None:
+            nonlocal pos
+            b = t.contiguous().view(torch.uint8)
+            parts.append(b)
+            layout.append((tag, pos, b.numel(), extra))
+            pos += b.numel()
+
+        add("flags", self.flags[:1])
+        if batch.nrows_dev is not None:
+            add("nrows", batch.nrows_dev[:1])
+        for c in batch.cols:
+            if c.kind == hs.STR:
+                add("lens", c.lens[: c.n])
+                add("sdata", c.data, c)
+            else:
+                add("col", c.data[: c.n], c)
+        host = torch.cat(parts).cpu().numpy()  # the single synchronising copy
+        flags = int(host[0:4].view(np.uint32)[0])
+        n = batch.nrows
+        for tag, off, size, _ in layout:
+            if tag == "nrows":
+                n = min(n, int(host[off: off + size].view(np.int64)[0]))
+        raw: list[Any] = []
+        pending_lens = None
+        np_dtype = {hs.I32: np.int32, hs.F32: np.float32, hs.I64: np.int64, hs.F64: np.float64, hs.U8: np.uint8}
+        for tag, off, size, c in layout:
+            if tag == "lens":
+                pending_lens = host[off: off + size][:n].copy()
+            elif tag == "sdata":
+                total = int(pending_lens.sum(dtype=np.int64))
+                raw.append(StrCol(pending_lens, host[off: off + size][:total].copy()))
+            elif tag == "col":
+                raw.append(host[off: off + size].view(np_dtype[c.kind])[:n].copy())
+        return raw, n, flags
+
     # ---- expression evaluation (A4) ---------------------------------------------------------------------
     def _cols_array(self, batch: DBatch, order: Sequence[int]):
         arr = (hs.hs_col * max(len(order), 1))()
@@ -218,13 +280,15 @@ class Device:
             kinds = (C.c_int32 * len(outs))(*out_kinds)
             pstruct = prog.to_struct()
             hs.check(self.lib.hs_eval(self.stream, cols, len(prog.columns), C.byref(pstruct),
-                                      sel.data_ptr() if sel is not None else None, n, out_ptrs, kinds, len(outs),
+                                      sel.data_ptr() if sel is not None else None, n,
+                                      batch.n_dev_ptr if sel is None else None, out_ptrs, kinds, len(outs),
                                       self.flags.data_ptr()), "hs_eval")
         return [(DCol(k, o, n), t) for k, o, t in zip(out_kinds, outs, tags)]
 
     # ---- filter (A3) -----------------------------------------------------------------------------------
     def filter_select(self, batch: DBatch, conds: Sequence[Any]) -> tuple[torch.Tensor, int]:
         """WHERE -> ascending indices of the surviving rows (+ their number; one D2H)."""
+        batch = self.resolve(batch)
         n = batch.nrows
         cond = conds[0]
         for extra in conds[1:]:
@@ -240,8 +304,21 @@ class Device:
         return sel, int(count.item())
 
     # ---- gathers -------------------------------------------------------------------------------------
-    def gather_col(self, col: DCol, idx: torch.Tensor, n: int) -> DCol:
+    def gather_col(self, col: DCol, idx: torch.Tensor, n: int, n_dev: torch.Tensor | None = None) -> DCol:
+        """out[i] = col[idx[i]], i < n (and < n_dev[0] when given).  Variable-length strings need the
+        exact count (their payload size comes from a scan), fixed-length ones do not."""
+        n_dev_ptr = n_dev.data_ptr() if n_dev is not None else None
+        if col.kind == hs.STR and col.fixed_len in (1, 2, 4, 8):
+            width = col.fixed_len
+            data = self.empty(n * width, torch.uint8)
+            hs.check(self.lib.hs_gather_fixed(self.stream, col.data.data_ptr(), width, idx.data_ptr(), n, n_dev_ptr,
+                                              data.data_ptr()), "hs_gather_fixed")
+            lens = self.empty(n, torch.uint8)
+            lens.fill_(width)
+            return DCol(hs.STR, data, n, lens=lens, offs=None, fixed_len=width)
         if col.kind == hs.STR:
+            if n_dev is not None:
+                n = min(n, int(n_dev[0].item()))
             src = col.as_hs()
             lens = self.empty(n, torch.uint8)
             hs.check(self.lib.hs_gather_str_lens(self.stream, C.byref(src), idx.data_ptr(), n, lens.data_ptr()),
@@ -260,8 +337,22 @@ class Device:
             return DCol(hs.STR, data, n, lens=lens, offs=None if fixed >= 0 else offs, fixed_len=fixed)
         out = self.empty(n, _TORCH_DTYPE[col.kind])
         hs.check(self.lib.hs_gather_fixed(self.stream, col.data.data_ptr(), hs.KIND_BYTES[col.kind], idx.data_ptr(), n,
-                                          out.data_ptr()), "hs_gather_fixed")
+                                          n_dev_ptr, out.data_ptr()), "hs_gather_fixed")
         return DCol(col.kind, out, n)
+
+    def resolve(self, batch: DBatch) -> DBatch:
+        """Make a lazily-sized batch exact (one D2H of the row count)."""
+        if not batch.lazy:
+            return batch
+        n = min(batch.nrows, int(batch.nrows_dev[0].item()))
+        cols = []
+        for c in batch.cols:
+            if c.kind == hs.STR:
+                cols.append(DCol(hs.STR, c.data, n, lens=c.lens[:n] if c.lens is not None else None,
+                                 offs=c.offs[: n + 1] if c.offs is not None else None, fixed_len=c.fixed_len))
+            else:
+                cols.append(DCol(c.kind, c.data[:n], n))
+        return DBatch(list(batch.schema), cols, n, [0, n])
 
     def gather_batch(self, batch: DBatch, idx: torch.Tensor, n: int, unit_rows: list[int] | None = None) -> DBatch:
         return DBatch(list(batch.schema), [self.gather_col(c, idx, n) for c in batch.cols], n,
@@ -301,7 +392,7 @@ class Device:
         return DCol(hs.STR, data, n, lens=lens, offs=None if fixed >= 0 else offs, fixed_len=fixed)
 
     # ---- quantisation (A6 / K12) -------------------------------------------------------------------------
-    def quantise_col(self, col: DCol, col_type: ColumnType) -> DCol:
+    def quantise_col(self, col: DCol, col_type: ColumnType, n_dev_ptr=None) -> DCol:
         """In-flight column -> the storage kind a BlockFile holds (f64->f32, i64->i32)."""
         want = FILE_KIND[col_type]
         if col.kind == want or col.kind == hs.STR:
@@ -310,7 +401,7 @@ class Device:
             raise AssertionError("a boolean column cannot be written to a BlockFile")  # reference: io.py:89 assert
         if (col.kind, want) in ((hs.F64, hs.F32), (hs.I64, hs.I32)):
             out = self.empty(col.n, _TORCH_DTYPE[want])
-            hs.check(self.lib.hs_quantise(self.stream, col.data.data_ptr(), col.kind, col.n, out.data_ptr(),
+            hs.check(self.lib.hs_quantise(self.stream, col.data.data_ptr(), col.kind, col.n, n_dev_ptr, out.data_ptr(),
                                           self.flags.data_ptr()), "hs_quantise")
             return DCol(want, out, col.n)
         if (col.kind, want) == (hs.I64, hs.I64):
@@ -325,6 +416,7 @@ class Device:
         Returns the partial rows exactly as the reference would have written them to its shuffle
         file: key column + one column per aggregate, FLOAT partials rounded to f32, INTEGER partials
         range-checked to i32, rows grouped by unit."""
+        batch = self.resolve(batch)  # units are row ranges: the row count must be exact
         low = lower_aggregate(batch.schema, batch.kinds, filters, group_by, agg_columns)
         if low.numeric_slots > hs.HS_FUSED_COLS:
             raise NotImplementedError(f"aggregate reads more than {hs.HS_FUSED_COLS} numeric columns")
@@ -376,28 +468,27 @@ class Device:
             hs.check(self.lib.hs_agg_pack(self.stream, out_rep.data_ptr(), out_acc.data_ptr(), ngroups.data_ptr(),
                                           n_units, cap, C.byref(spec), pack_start.data_ptr(), dense_rep.data_ptr(),
                                           out_ptrs, kinds_arr, None), "hs_agg_pack")
-            flags = self.read_flags()  # D2H sync #1 of the hot path
-            if flags & hs.FLAG_DICT_FULL:
-                self.flags.zero_()
-                cap *= 2
-                continue
-            self.raise_for_flags(flags)
             break
-        starts = pack_start.tolist()
-        n_rows = int(starts[-1])
+        # No host round trip here: the number of partial rows stays on the device (pack_start[n_units]);
+        # a dictionary overflow is noticed at the query's final read-back and the query re-run.
+        n_max = slots
+        n_dev = pack_start[n_units:]
         key_idx = low.program.columns[low.key_slot]
-        key_col = self.gather_col(batch.cols[key_idx], dense_rep, n_rows)
+        key_col = self.gather_col(batch.cols[key_idx], dense_rep, n_max, n_dev)
+        if key_col.n != n_max:  # variable-length string keys made the count exact
+            n_max, n_dev = key_col.n, None
         out_cols = [key_col]
         for acc in low.agg_to_acc:
-            buf = acc_bufs[acc]
-            out_cols.append(DCol(acc_kinds[acc], buf[:n_rows], n_rows))
+            out_cols.append(DCol(acc_kinds[acc], acc_bufs[acc][:n_max], n_max))
         self.last_group_cap = cap
-        return DBatch(list(out_schema), out_cols, n_rows, [int(s) for s in starts])
+        return DBatch(list(out_schema), out_cols, n_max, None, n_dev)
 
     # ---- final merge (A7) ------------------------------------------------------------------------------
-    def aggregate_merge(self, batch: DBatch, agg_columns: Sequence[Any], out_schema: Schema) -> DBatch:
-        """Merge partial rows by key in unit order; column i+1 is folded with aggregate i's function
-        (reference tasks.py:290-292).  Output columns are in-flight (f64 / i64), not rounded."""
+    def aggregate_merge(self, batch: DBatch, agg_columns: Sequence[Any], out_schema: Schema,
+                        cap_hint: int = 16) -> DBatch:
+        """Merge partial rows by key in row (= unit) order; column i+1 is folded with aggregate i's function
+        (reference tasks.py:290-292).  Output columns are in-flight (f64 / i64), not rounded; the number
+        of groups stays on the device."""
         n_acc = len(agg_columns)
         if n_acc > hs.HS_MAX_ACC:
             raise NotImplementedError(f"more than {hs.HS_MAX_ACC} aggregates")
@@ -411,7 +502,7 @@ class Device:
             is_int.append(integer)
         n = batch.nrows
         cap = 4
-        while cap < 2 * max(n, 1) and cap < 4096:
+        while cap < cap_hint:
             cap *= 2
         key = batch.cols[0].as_hs()
         acc_arr = (hs.hs_col * max(n_acc, 1))()
@@ -419,28 +510,25 @@ class Device:
             acc_arr[i] = batch.cols[i + 1].as_hs()
         out_rep = self.empty(cap, torch.int64)
         out_acc = self.empty(max(cap * n_acc, 1), torch.int64)
-        ngroups = self.empty(1, torch.int32)
-        d_units = self.to_device(np.asarray(batch.unit_rows, dtype=np.int64))
-        rc = self.lib.hs_agg_merge(self.stream, C.byref(key), acc_arr, C.byref(spec), d_units.data_ptr(), batch.n_units,
-                                   n, cap, out_rep.data_ptr(), out_acc.data_ptr(), ngroups.data_ptr(), None,
+        ngroups = self.empty(1, torch.int64)
+        rc = self.lib.hs_agg_merge(self.stream, C.byref(key), acc_arr, C.byref(spec), None, 1, n, batch.n_dev_ptr, cap,
+                                   out_rep.data_ptr(), out_acc.data_ptr(), ngroups.data_ptr(), None,
                                    self.flags.data_ptr())
         if rc == 2:
             raise NotImplementedError("final merge exceeds the LDS tier: " + self.lib.hs_last_error().decode())
         hs.check(rc, "hs_agg_merge")
-        ng = int(ngroups.item())  # D2H sync #2
-        flags = self.read_flags()
-        if flags & hs.FLAG_DICT_FULL:
-            raise NotImplementedError("final merge: more distinct groups than the LDS tier holds")
-        self.raise_for_flags(flags)
-        key_col = self.gather_col(batch.cols[0], out_rep, ng)
+        self.last_merge_cap = cap
+        n_out = min(cap, n)
+        key_col = self.gather_col(batch.cols[0], out_rep, n_out, ngroups)
+        if key_col.n != n_out:
+            n_out, ngroups_dev = key_col.n, None
+        else:
+            ngroups_dev = ngroups
         cols = [key_col]
         for i in range(n_acc):
-            raw = out_acc[i * cap: i * cap + ng]
-            if is_int[i]:
-                cols.append(DCol(hs.I64, raw, ng))
-            else:
-                cols.append(DCol(hs.F64, raw.view(torch.float64), ng))
-        return DBatch(list(out_schema), cols, ng, [0, ng])
+            raw = out_acc[i * cap: i * cap + n_out]
+            cols.append(DCol(hs.I64, raw, n_out) if is_int[i] else DCol(hs.F64, raw.view(torch.float64), n_out))
+        return DBatch(list(out_schema), cols, n_out, None, ngroups_dev)
 
     # ---- hash partitioning (A6/A9) -------------------------------------------------------------------------
     def partition(self, batch: DBatch, key_index: int, n_parts: int) -> tuple[torch.Tensor, list[int]]:

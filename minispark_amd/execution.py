@@ -90,7 +90,10 @@ class HipExecutionEngine(ExecutionEngine):
         self._work_folder = work_folder
         self._tables: dict[str, Any] = {}
         self._owned_dirs: set[Path] = set()
-        self.group_cap_hint = 4
+        self._result_root: Path | None = None
+        self._made_dirs: set[Path] = set()
+        self.group_cap_hint = 4   # dictionary capacity per workgroup of the partial aggregate (grows on overflow)
+        self.merge_cap_hint = 16  # dictionary capacity of the final merge (grows on overflow)
         self.last_stats: dict[str, Any] = {}
 
     # ---- context manager -------------------------------------------------------------------------------
@@ -98,6 +101,8 @@ class HipExecutionEngine(ExecutionEngine):
         for d in self._owned_dirs:
             shutil.rmtree(d, ignore_errors=True)
         self._owned_dirs.clear()
+        self._made_dirs.clear()
+        self._result_root = None
 
     # ---- tables --------------------------------------------------------------------------------------
     def attach_device_table(self, path: str | Path, table: Any) -> None:
@@ -121,17 +126,25 @@ class HipExecutionEngine(ExecutionEngine):
         from .device import DeviceError  # noqa: PLC0415
         from .hipspark import HipSparkError  # noqa: PLC0415
 
-        plan = self.generate_physical_plan(full_task)
-        self.dev.reset_flags()
-        outputs: dict[int, Any] = {}
-        results: list[JobResult] = []
-        try:
-            for stage in plan.stages:
-                results = self._run_stage(stage, outputs)
-                stage.job_results.extend(results)
-        except (HipSparkError, DeviceError) as e:
-            raise ExecutionError(str(e)) from e
-        return results
+        from .device import RetryWithLargerDictionary  # noqa: PLC0415
+
+        for _attempt in range(12):
+            plan = self.generate_physical_plan(full_task)
+            self.dev.reset_flags()
+            outputs: dict[int, Any] = {}
+            results: list[JobResult] = []
+            try:
+                for stage in plan.stages:
+                    results = self._run_stage(stage, outputs)
+                    stage.job_results.extend(results)
+                return results
+            except RetryWithLargerDictionary:
+                # more distinct GROUP BY keys than the dictionaries were sized for: grow and re-run
+                self.group_cap_hint *= 2
+                self.merge_cap_hint = min(self.merge_cap_hint * 4, 4096)
+            except (HipSparkError, DeviceError) as e:
+                raise ExecutionError(str(e)) from e
+        raise ExecutionError("GROUP BY cardinality exceeds the on-chip aggregation tiers")
 
     # ---- stage execution -------------------------------------------------------------------------------
     def _run_stage(self, stage: Any, outputs: dict[int, Any]) -> list[JobResult]:
@@ -163,7 +176,7 @@ class HipExecutionEngine(ExecutionEngine):
                 else:
                     batch = self._materialise(batch, pending)
                     pending = []
-                    batch = self.dev.aggregate_merge(batch, task.agg_columns, task.inferred_schema)
+                    batch = self.dev.aggregate_merge(batch, task.agg_columns, task.inferred_schema, self.merge_cap_hint)
             else:
                 raise NotImplementedError(f"consumer {tname}")
         batch = self._materialise(batch, pending)
@@ -171,8 +184,8 @@ class HipExecutionEngine(ExecutionEngine):
         wname = _cls(writer)
         schema = writer.inferred_schema
         if wname == "WriteToShufflePartitions":
+            # the "shuffle file" stays in HBM; data-dependent errors surface at the query's final read-back
             outputs[id(stage)] = self._quantise_batch(batch, schema)
-            self.dev.raise_for_flags(self.dev.read_flags())
             return [JobResult(str(uuid.uuid4()), f"hip:{self.dev.index}", [])]
         if wname == "WriteToLocalFileTask":
             return [self._write_result(batch, schema, stage.stage_id)]
@@ -212,6 +225,7 @@ class HipExecutionEngine(ExecutionEngine):
         that a following partial aggregate sees the reference's JoinJob units (plan.py:99-109)."""
         from .device import DBatch  # noqa: PLC0415
 
+        left, right = self.dev.resolve(left), self.dev.resolve(right)
         lkey = left.column_index(task.left_key.name)
         rkey = right.column_index(task.right_key.name)
         perm, part_start = self.dev.partition(right, rkey, constants.SHUFFLE_PARTITIONS)
@@ -236,6 +250,7 @@ class HipExecutionEngine(ExecutionEngine):
             return batch
         import torch  # noqa: PLC0415
 
+        batch = self.dev.resolve(batch)
         sel, count = self.dev.filter_select(batch, pending)
         bounds = torch.tensor(batch.unit_rows, dtype=torch.int64, device=sel.device)
         unit_rows = [int(v) for v in torch.searchsorted(sel[:count].contiguous(), bounds).tolist()]
@@ -247,8 +262,10 @@ class HipExecutionEngine(ExecutionEngine):
         from .lowering import ProgramBuilder, unalias  # noqa: PLC0415
 
         batch = self._materialise(batch, pending)
-        n = batch.nrows
         helper = ProgramBuilder(batch.schema, batch.kinds)
+        if any(helper.string_tag(unalias(c)) and _cls(unalias(c)) not in ("Col", "SchemaCol") for c in task.columns):
+            batch = self.dev.resolve(batch)  # string concatenation sizes its output from the exact row count
+        n = batch.nrows
         out_cols: list[Any] = [None] * len(task.columns)
         numeric: list[tuple[int, Any]] = []
         for i, col in enumerate(task.columns):
@@ -266,7 +283,8 @@ class HipExecutionEngine(ExecutionEngine):
                     raise AssertionError("a comparison cannot be selected as a column (the reference has no BOOL type)")
                 out_cols[i] = dcol
         _ = hs
-        return DBatch(list(task.inferred_schema), out_cols, n, list(batch.unit_rows))
+        return DBatch(list(task.inferred_schema), out_cols, n, list(batch.unit_rows) if batch.unit_rows else None,
+                      batch.nrows_dev)
 
     # ---- writers ---------------------------------------------------------------------------------------
     def _quantise_batch(self, batch: Any, schema: Schema) -> Any:
@@ -274,20 +292,29 @@ class HipExecutionEngine(ExecutionEngine):
 
         if len(schema) != len(batch.cols):
             raise ExecutionError(f"writer schema {schema} does not match batch {batch.schema}")
-        cols = [self.dev.quantise_col(c, t) for c, (_, t) in zip(batch.cols, schema)]
-        return DBatch(list(schema), cols, batch.nrows, list(batch.unit_rows))
+        cols = [self.dev.quantise_col(c, t, batch.n_dev_ptr) for c, (_, t) in zip(batch.cols, schema)]
+        return DBatch(list(schema), cols, batch.nrows, list(batch.unit_rows) if batch.unit_rows else None,
+                      batch.nrows_dev)
 
     def _write_result(self, batch: Any, schema: Schema, stage_id: str) -> JobResult:
+        from . import hipspark as hs  # noqa: PLC0415
+        from .device import RetryWithLargerDictionary  # noqa: PLC0415
+
         job_id = str(uuid.uuid4())
         quantised = self._quantise_batch(batch, schema)
-        raw = [self.dev.download(c, t) for c, (_, t) in zip(quantised.cols, schema)]  # D2H (synchronises)
-        self.dev.raise_for_flags(self.dev.read_flags())
-        if batch.nrows == 0:
+        raw, nrows, flags = self.dev.download_batch(quantised, schema)  # the query's one host round trip
+        if flags & hs.FLAG_DICT_FULL:
+            raise RetryWithLargerDictionary
+        self.dev.raise_for_flags(flags)
+        if nrows == 0:
             return JobResult(job_id, f"hip:{self.dev.index}", [])  # the reference writes no file (tasks.py:405)
-        root = self._work_folder or (constants.SHUFFLE_FOLDER / f"hip-{uuid.uuid4().hex[:12]}")
-        out_dir = Path(root) / str(stage_id)
-        out_dir.mkdir(parents=True, exist_ok=True)
-        self._owned_dirs.add(Path(root))
+        if self._result_root is None:
+            self._result_root = Path(self._work_folder or (constants.SHUFFLE_FOLDER / f"hip-{uuid.uuid4().hex[:12]}"))
+            self._owned_dirs.add(self._result_root)
+        out_dir = self._result_root / str(stage_id)
+        if out_dir not in self._made_dirs:
+            out_dir.mkdir(parents=True, exist_ok=True)
+            self._made_dirs.add(out_dir)
         out_file = out_dir / "result.bin"
         BlockFile(out_file, list(schema)).write_raw(list(schema), raw)
         return JobResult(job_id, f"hip:{self.dev.index}", [OutputFile(out_file)])
