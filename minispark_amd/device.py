@@ -123,6 +123,7 @@ class Device:
         self.device = torch.device("cuda", index)
         torch.cuda.set_device(self.device)
         self.flags = torch.zeros(4, dtype=torch.int32, device=self.device)
+        self._partial_prepared: dict[Any, dict] = {}
 
     # ---- plumbing ------------------------------------------------------------------------------------
     def time_scan_kernel(self, enable: bool = True) -> None:
@@ -410,78 +411,92 @@ class Device:
 
     # ---- partial aggregate (A5/A6) -------------------------------------------------------------------------
     def aggregate_partial(self, batch: DBatch, filters: Sequence[Any], group_by: Any, agg_columns: Sequence[Any],
-                          out_schema: Schema, group_cap_hint: int = 4) -> DBatch:
+                          out_schema: Schema, group_cap_hint: int = 4, cache_key: Any = None) -> DBatch:
         """Fused scan + WHERE + aggregate arguments + per-unit partial aggregate.
 
         Returns the partial rows exactly as the reference would have written them to its shuffle
         file: key column + one column per aggregate, FLOAT partials rounded to f32, INTEGER partials
-        range-checked to i32, rows grouped by unit."""
+        range-checked to i32, rows grouped by unit.  Everything that depends only on (query node, input
+        buffers, capacity) - lowered program, geometry, unit tables, output buffers - is prepared once
+        and re-used by later runs of the same query (``cache_key``)."""
         batch = self.resolve(batch)  # units are row ranges: the row count must be exact
+        cap = max(1, int(group_cap_hint))
+        key = None
+        if cache_key is not None:
+            key = (cache_key, cap, batch.nrows, tuple((c.data.data_ptr(), c.n) for c in batch.cols),
+                   len(batch.unit_rows), batch.unit_rows[-1])
+        prep = self._partial_prepared.get(key) if key is not None else None
+        if prep is None:
+            prep = self._prepare_partial(batch, filters, group_by, agg_columns, cap)
+            if key is not None:
+                if len(self._partial_prepared) >= 8:
+                    self._partial_prepared.pop(next(iter(self._partial_prepared)))
+                self._partial_prepared[key] = prep
+        p = prep
+        hs.check(self.lib.hs_agg_partial(self.stream, p["cols"], p["n_cols"], p["key_slot"], C.byref(p["prog"]),
+                                         C.byref(p["spec"]), p["d_units"].data_ptr(), p["d_chunk0"].data_ptr(),
+                                         p["n_units"], C.byref(p["geom"]), p["out_rep"].data_ptr(),
+                                         p["out_acc"].data_ptr(), p["ngroups"].data_ptr(), p["ws"].data_ptr(),
+                                         self.flags.data_ptr(), self._event_handle(0), self._event_handle(1)),
+                 "hs_agg_partial")
+        self.last_scan = p["info"]
+        hs.check(self.lib.hs_agg_pack(self.stream, p["out_rep"].data_ptr(), p["out_acc"].data_ptr(),
+                                      p["ngroups"].data_ptr(), p["n_units"], cap, C.byref(p["spec"]),
+                                      p["pack_start"].data_ptr(), p["dense_rep"].data_ptr(), p["out_ptrs"],
+                                      p["kinds_arr"], None), "hs_agg_pack")
+        # No host round trip here: the number of partial rows stays on the device (pack_start[n_units]);
+        # a dictionary overflow is noticed at the query's final read-back and the query re-run.
+        n_max = p["slots"]
+        n_dev = p["pack_start"][p["n_units"]:]
+        key_col = self.gather_col(batch.cols[p["key_idx"]], p["dense_rep"], n_max, n_dev)
+        if key_col.n != n_max:  # variable-length string keys made the count exact
+            n_max, n_dev = key_col.n, None
+        out_cols = [key_col]
+        for acc in p["agg_to_acc"]:
+            out_cols.append(DCol(p["acc_kinds"][acc], p["acc_bufs"][acc][:n_max], n_max))
+        self.last_group_cap = cap
+        return DBatch(list(out_schema), out_cols, n_max, None, n_dev)
+
+    def _prepare_partial(self, batch: DBatch, filters: Sequence[Any], group_by: Any, agg_columns: Sequence[Any],
+                         cap: int) -> dict:
         low = lower_aggregate(batch.schema, batch.kinds, filters, group_by, agg_columns)
         if low.numeric_slots > hs.HS_FUSED_COLS:
             raise NotImplementedError(f"aggregate reads more than {hs.HS_FUSED_COLS} numeric columns")
         n_units = batch.n_units
         n_acc = len(low.acc_ops)
-        spec = low.spec()
-        pstruct = low.program.to_struct()
-        cols = self._cols_array(batch, low.program.columns)
         host_units = (C.c_int64 * (n_units + 1))(*batch.unit_rows)
-        cap = max(1, int(group_cap_hint))
-        while True:
-            geom = hs.hs_agg_geom()
-            rc = self.lib.hs_agg_partial_geom(host_units, n_units, n_acc, cap, C.byref(geom))
-            if rc == 2:
-                raise NotImplementedError(
-                    f"GROUP BY with more than {cap // 2} groups per workgroup x {n_acc} aggregates exceeds the LDS tier: "
-                    + self.lib.hs_last_error().decode()
-                )
-            hs.check(rc, "hs_agg_partial_geom")
-            # first chunk of every unit (host arithmetic mirrors hs_agg_partial_geom)
-            chunk0 = np.zeros(n_units + 1, dtype=np.int64)
-            ur = np.asarray(batch.unit_rows, dtype=np.int64)
-            span = ur[1:] - (ur[:-1] & ~np.int64(3))
-            chunk0[1:] = np.cumsum(np.where(span > 0, (span + geom.chunk_rows - 1) // geom.chunk_rows, 0))
-            if int(chunk0[-1]) != geom.n_chunks:
-                raise DeviceError("chunk geometry mismatch between host and library")
-            d_units = self.to_device(ur)
-            d_chunk0 = self.to_device(chunk0)
-            slots = n_units * cap
-            out_rep = self.empty(slots, torch.int64)
-            out_acc = self.empty(max(slots * n_acc, 1), torch.int64)
-            ngroups = self.empty(max(n_units, 1), torch.int32)
-            ws = self.workspace(geom.ws_bytes)
-            hs.check(self.lib.hs_agg_partial(self.stream, cols, len(low.program.columns), low.key_slot,
-                                             C.byref(pstruct), C.byref(spec), d_units.data_ptr(), d_chunk0.data_ptr(),
-                                             n_units, C.byref(geom), out_rep.data_ptr(), out_acc.data_ptr(),
-                                             ngroups.data_ptr(), ws.data_ptr(), self.flags.data_ptr(),
-                                             self._event_handle(0), self._event_handle(1)),
-                     "hs_agg_partial")
-            self.last_scan = {"rows": batch.nrows, "chunks": int(geom.n_chunks), "chunk_rows": int(geom.chunk_rows),
-                              "wg_threads": int(geom.wg_threads), "group_cap": cap, "lds_bytes": int(geom.lds_bytes)}
-            # dense pack: one column per accumulator in the shuffle-file storage kind
-            acc_kinds = [hs.I32 if is_int else hs.F32 for is_int in low.acc_is_int]
-            pack_start = self.empty(n_units + 1, torch.int64)
-            dense_rep = self.empty(max(slots, 1), torch.int64)
-            acc_bufs = [self.empty(max(slots, 1), _TORCH_DTYPE[k]) for k in acc_kinds]
-            out_ptrs = (C.c_void_p * max(n_acc, 1))(*[t.data_ptr() for t in acc_bufs])
-            kinds_arr = (C.c_int32 * max(n_acc, 1))(*acc_kinds)
-            hs.check(self.lib.hs_agg_pack(self.stream, out_rep.data_ptr(), out_acc.data_ptr(), ngroups.data_ptr(),
-                                          n_units, cap, C.byref(spec), pack_start.data_ptr(), dense_rep.data_ptr(),
-                                          out_ptrs, kinds_arr, None), "hs_agg_pack")
-            break
-        # No host round trip here: the number of partial rows stays on the device (pack_start[n_units]);
-        # a dictionary overflow is noticed at the query's final read-back and the query re-run.
-        n_max = slots
-        n_dev = pack_start[n_units:]
-        key_idx = low.program.columns[low.key_slot]
-        key_col = self.gather_col(batch.cols[key_idx], dense_rep, n_max, n_dev)
-        if key_col.n != n_max:  # variable-length string keys made the count exact
-            n_max, n_dev = key_col.n, None
-        out_cols = [key_col]
-        for acc in low.agg_to_acc:
-            out_cols.append(DCol(acc_kinds[acc], acc_bufs[acc][:n_max], n_max))
-        self.last_group_cap = cap
-        return DBatch(list(out_schema), out_cols, n_max, None, n_dev)
+        geom = hs.hs_agg_geom()
+        rc = self.lib.hs_agg_partial_geom(host_units, n_units, n_acc, cap, C.byref(geom))
+        if rc == 2:
+            raise NotImplementedError(
+                f"GROUP BY with more than {cap // 2} groups per workgroup x {n_acc} aggregates exceeds the LDS tier: "
+                + self.lib.hs_last_error().decode()
+            )
+        hs.check(rc, "hs_agg_partial_geom")
+        # first chunk of every unit (host arithmetic mirrors hs_agg_partial_geom)
+        chunk0 = np.zeros(n_units + 1, dtype=np.int64)
+        ur = np.asarray(batch.unit_rows, dtype=np.int64)
+        span = ur[1:] - (ur[:-1] & ~np.int64(3))
+        chunk0[1:] = np.cumsum(np.where(span > 0, (span + geom.chunk_rows - 1) // geom.chunk_rows, 0))
+        if int(chunk0[-1]) != geom.n_chunks:
+            raise DeviceError("chunk geometry mismatch between host and library")
+        slots = n_units * cap
+        acc_kinds = [hs.I32 if is_int else hs.F32 for is_int in low.acc_is_int]
+        acc_bufs = [self.empty(max(slots, 1), _TORCH_DTYPE[k]) for k in acc_kinds]
+        return {
+            "cols": self._cols_array(batch, low.program.columns), "n_cols": len(low.program.columns),
+            "key_slot": low.key_slot, "key_idx": low.program.columns[low.key_slot], "prog": low.program.to_struct(),
+            "spec": low.spec(), "geom": geom, "n_units": n_units, "slots": slots, "agg_to_acc": low.agg_to_acc,
+            "d_units": self.to_device(ur), "d_chunk0": self.to_device(chunk0),
+            "out_rep": self.empty(slots, torch.int64), "out_acc": self.empty(max(slots * n_acc, 1), torch.int64),
+            "ngroups": self.empty(max(n_units, 1), torch.int32), "ws": self.workspace(geom.ws_bytes),
+            "pack_start": self.empty(n_units + 1, torch.int64), "dense_rep": self.empty(max(slots, 1), torch.int64),
+            "acc_kinds": acc_kinds, "acc_bufs": acc_bufs,
+            "out_ptrs": (C.c_void_p * max(n_acc, 1))(*[t.data_ptr() for t in acc_bufs]),
+            "kinds_arr": (C.c_int32 * max(n_acc, 1))(*acc_kinds),
+            "info": {"rows": batch.nrows, "chunks": int(geom.n_chunks), "chunk_rows": int(geom.chunk_rows),
+                     "wg_threads": int(geom.wg_threads), "group_cap": cap, "lds_bytes": int(geom.lds_bytes)},
+        }
 
     # ---- final merge (A7) ------------------------------------------------------------------------------
     def aggregate_merge(self, batch: DBatch, agg_columns: Sequence[Any], out_schema: Schema,

@@ -89,6 +89,7 @@ class HipExecutionEngine(ExecutionEngine):
         self.dev = Device(device)
         self._work_folder = work_folder
         self._tables: dict[str, Any] = {}
+        self._plans: dict[Any, Any] = {}
         self._owned_dirs: set[Path] = set()
         self._result_root: Path | None = None
         self._made_dirs: set[Path] = set()
@@ -129,7 +130,7 @@ class HipExecutionEngine(ExecutionEngine):
         from .device import RetryWithLargerDictionary  # noqa: PLC0415
 
         for _attempt in range(12):
-            plan = self.generate_physical_plan(full_task)
+            plan = self._cached_plan(full_task)
             self.dev.reset_flags()
             outputs: dict[int, Any] = {}
             results: list[JobResult] = []
@@ -145,6 +146,38 @@ class HipExecutionEngine(ExecutionEngine):
             except (HipSparkError, DeviceError) as e:
                 raise ExecutionError(str(e)) from e
         raise ExecutionError("GROUP BY cardinality exceeds the on-chip aggregation tiers")
+
+    def _cached_plan(self, full_task: Any) -> Any:
+        """Planning is pure in (task tree, table headers): keep the physical plan of the last few task
+        trees.  Keyed by the root object (kept alive by the cache, so ids cannot be recycled) plus the
+        stamps of the table files it scans."""
+        stamps = []
+        node, stack = full_task, []
+        while node is not None and _cls(node) != "VoidTask":
+            if _cls(node) == "LoadTableBlockTask":
+                p = Path(node.file_path)
+                try:
+                    st = p.stat()
+                    stamps.append((str(p), node.alias, st.st_mtime_ns, st.st_size))
+                except OSError:
+                    stamps.append((str(p), node.alias, 0, 0))
+            if _cls(node) == "BroadcastHashJoinTask":
+                stack.append(node.right_side_task)
+            node = node.parent_task
+            if (node is None or _cls(node) == "VoidTask") and stack:
+                node = stack.pop()
+        key = (id(full_task), tuple(stamps))
+        hit = self._plans.get(key)
+        if hit is not None and hit[0] is full_task:
+            plan = hit[1]
+            for stage in plan.stages:
+                stage.job_results.clear()
+            return plan
+        plan = self.generate_physical_plan(full_task)
+        if len(self._plans) >= 16:
+            self._plans.pop(next(iter(self._plans)))
+        self._plans[key] = (full_task, plan)
+        return plan
 
     # ---- stage execution -------------------------------------------------------------------------------
     def _run_stage(self, stage: Any, outputs: dict[int, Any]) -> list[JobResult]:
@@ -170,7 +203,7 @@ class HipExecutionEngine(ExecutionEngine):
             elif tname == "AggregateTask":
                 if task.before_shuffle:
                     batch = self.dev.aggregate_partial(batch, pending, task.group_by_column, task.agg_columns,
-                                                       task.inferred_schema, self.group_cap_hint)
+                                                       task.inferred_schema, self.group_cap_hint, cache_key=id(task))
                     self.group_cap_hint = max(self.group_cap_hint, getattr(self.dev, "last_group_cap", 4))
                     pending = []
                 else:
