@@ -206,28 +206,28 @@ int hs_agg_partial(void* stream, const hs_col* cols, int32_t n_cols, int32_t key
 
 /* Dense pack of the slot arrays: rows of unit u go to [pack_start[u], pack_start[u+1]).
  * out_cols[a] receives accumulator a as HS_F32 / HS_I32 storage (acc_kinds[a]) = the reference's
- * shuffle-file column; out_rep the representative rows (gather the key column with them). */
+ * shuffle-file column; out_rep the representative rows (gather the key column with them).
+ * unit_ids / out_unit (both optional): out_unit[row] = unit_ids[u] (or u), the id that orders the final
+ * merge when partial rows of several GPUs meet (multi-GPU: the file block id). */
 int hs_agg_pack(void* stream, const int64_t* rep, const uint64_t* acc, const int32_t* ngroups, int64_t n_units,
                 int32_t group_cap, const hs_agg_spec* spec, int64_t* pack_start, int64_t* out_rep,
-                void* const* out_cols, const int32_t* acc_kinds, void* ws);
+                void* const* out_cols, const int32_t* acc_kinds, const int64_t* unit_ids, int64_t* out_unit);
 
 /* =================================================================================================
  * A7  Final merge of partial rows (reference tasks.py:290-292 after-shuffle branch)
  * ===============================================================================================*/
 
 /* Input: a batch of partial rows: key column `key`, accumulator columns acc_cols[n_acc] (HS_F32 /
- * HS_I32 / HS_F64 / HS_I64), rows grouped by producing unit: unit u = rows [unit_rows[u], unit_rows[u+1]),
- * keys distinct within a unit.  Partials of a key are folded in unit order in fp64 / i64 (exactly the
- * reference's order: block order of the shuffle file).  Outputs are DENSE (group i = i-th occupied
- * dictionary slot) and column-major: out_rep[i] = smallest input row of group i, out_acc[a * cap + i]
- * = un-rounded 64-bit cell of aggregate a, *out_ngroups = number of groups (<= cap).
- * n_rows is an upper bound when n_rows_dev != NULL (then *n_rows_dev, a device int64, is the exact
- * count): lets a whole query run without a host round trip between its kernels.
- * ws: hs_agg_merge_ws_bytes(). */
-size_t hs_agg_merge_ws_bytes(int64_t n_rows, int64_t n_units, int32_t cap);
+ * HS_I32 / HS_F64 / HS_I64).  Partials of a key are folded in fp64 / i64 in ascending (order[row], row)
+ * order - with order == NULL in row order - which is the reference's order: block order of the shuffle
+ * file.  Rows with order[row] < 0 are padding and ignored (fixed-size slabs exchanged between GPUs).
+ * Outputs are DENSE (group i = i-th occupied dictionary slot) and column-major: out_rep[i] = first input
+ * row of group i, out_acc[a * cap + i] = un-rounded 64-bit cell of aggregate a, *out_ngroups = number of
+ * groups (<= cap).  n_rows is an upper bound when n_rows_dev != NULL (then *n_rows_dev, a device int64, is
+ * the exact count): lets a whole query run without a host round trip between its kernels. */
 int hs_agg_merge(void* stream, const hs_col* key, const hs_col* acc_cols, const hs_agg_spec* spec,
-                 const int64_t* unit_rows, int64_t n_units, int64_t n_rows, const int64_t* n_rows_dev, int32_t cap,
-                 int64_t* out_rep, uint64_t* out_acc, int64_t* out_ngroups, void* ws, uint32_t* flags);
+                 const int64_t* order, int64_t n_rows, const int64_t* n_rows_dev, int32_t cap, int64_t* out_rep,
+                 uint64_t* out_acc, int64_t* out_ngroups, uint32_t* flags);
 
 /* =================================================================================================
  * A6/A9  Hash partitioning (reference tasks.py:347-375 WriteToShufflePartitions.write)

@@ -123,6 +123,8 @@ struct AggPackArgs {
     int32_t n_acc;
     int64_t* pack_start;  // [n_units+1]
     int64_t* out_rep;
+    const int64_t* unit_ids;  // optional [n_units]: global id of every local unit (multi-GPU: file block id)
+    int64_t* out_unit;        // optional: unit id of every packed row (orders the final merge across ranks)
     void* out_cols[HS_MAX_ACC];
     int32_t acc_kinds[HS_MAX_ACC];
 };
@@ -154,6 +156,7 @@ __global__ void __launch_bounds__(256) k_agg_pack(const AggPackArgs A_kernarg) {
                 const int64_t rep = A.rep[u * A.group_cap + s];
                 if (rep < 0) continue;
                 A.out_rep[o] = rep;
+                if (A.out_unit) A.out_unit[o] = A.unit_ids ? A.unit_ids[u] : u;
                 for (int a = 0; a < A.n_acc; ++a) {
                     const uint64_t cell = A.acc[(u * A.group_cap + s) * A.n_acc + a];
                     switch (A.acc_kinds[a]) {
@@ -179,6 +182,7 @@ struct AggMergeArgs {
     hs_agg_spec spec;
     int64_t n_rows;            // upper bound (sizes LDS)
     const int64_t* n_rows_dev; // optional exact row count on the device
+    const int64_t* order;      // optional per-row order key (global unit id); rows with order < 0 are padding
     int32_t cap;
     int32_t hashed;
     int64_t* out_rep;
@@ -222,10 +226,13 @@ __global__ void __launch_bounds__(1024) k_agg_merge_small(const AggMergeArgs A_k
     __syncthreads();
     const uint32_t mask = (uint32_t)cap - 1;
     for (int64_t r = tid; r < n; r += nthr) {
-        const uint64_t k = hs_key_at(A.key, r);
-        int sl = A.hashed ? hs_dict_upsert_rows(dreps, mask, A.key, k, r) : hs_dict_upsert_word(dkeys, dreps, mask, k, r);
-        if (sl < 0) err |= HS_FLAG_DICT_FULL;
-        else atomicAdd(&cnt[sl], 1);
+        int sl = -1;
+        if (!A.order || A.order[r] >= 0) {
+            const uint64_t k = hs_key_at(A.key, r);
+            sl = A.hashed ? hs_dict_upsert_rows(dreps, mask, A.key, k, r) : hs_dict_upsert_word(dkeys, dreps, mask, k, r);
+            if (sl < 0) err |= HS_FLAG_DICT_FULL;
+            else atomicAdd(&cnt[sl], 1);
+        }
         rslot[r] = sl;
     }
     __syncthreads();
@@ -269,7 +276,16 @@ __global__ void __launch_bounds__(1024) k_agg_merge_small(const AggMergeArgs A_k
         const int sl = rslot[r];
         if (sl < 0) continue;
         int rank = 0;
-        for (int64_t q = 0; q < r; ++q) rank += rslot[q] == sl;
+        if (A.order) {  // (order key, row) lexicographic: partial rows of all ranks in global unit order
+            const int64_t mine_o = A.order[r];
+            for (int64_t q = 0; q < n; ++q) {
+                if (rslot[q] != sl) continue;
+                const int64_t o = A.order[q];
+                rank += (o < mine_o) || (o == mine_o && q < r);
+            }
+        } else {
+            for (int64_t q = 0; q < r; ++q) rank += rslot[q] == sl;
+        }
         const int at = start[sl] + rank;
         for (int a = 0; a < NA; ++a) sorted[(int64_t)at * NA + a] = hs_load_cell(A.acc_cols[a], r);
         if (rank == 0) A.out_rep[dense[sl]] = r;  // smallest row of the group: independent of insert races
@@ -499,8 +515,8 @@ extern "C" int hs_agg_partial(void* stream, const hs_col* cols, int32_t n_cols, 
 
 extern "C" int hs_agg_pack(void* stream, const int64_t* rep, const uint64_t* acc, const int32_t* ngroups,
                            int64_t n_units, int32_t group_cap, const hs_agg_spec* spec, int64_t* pack_start,
-                           int64_t* out_rep, void* const* out_cols, const int32_t* acc_kinds, void* ws) {
-    (void)ws;
+                           int64_t* out_rep, void* const* out_cols, const int32_t* acc_kinds, const int64_t* unit_ids,
+                           int64_t* out_unit) {
     if (!rep || !acc || !ngroups || !spec || !pack_start || !out_rep || (spec->n_acc > 0 && (!out_cols || !acc_kinds))) {
         hs_set_error("hs_agg_pack: null argument");
         return HS_E_ARG;
@@ -514,6 +530,8 @@ extern "C" int hs_agg_pack(void* stream, const int64_t* rep, const uint64_t* acc
     A.n_acc = spec->n_acc;
     A.pack_start = pack_start;
     A.out_rep = out_rep;
+    A.unit_ids = unit_ids;
+    A.out_unit = out_unit;
     for (int a = 0; a < HS_MAX_ACC; ++a) {
         A.out_cols[a] = a < spec->n_acc ? out_cols[a] : nullptr;
         A.acc_kinds[a] = a < spec->n_acc ? acc_kinds[a] : HS_F64;
@@ -528,20 +546,9 @@ extern "C" int hs_agg_pack(void* stream, const int64_t* rep, const uint64_t* acc
 
 static constexpr size_t HS_MERGE_LDS_MAX = 150 * 1024;
 
-extern "C" size_t hs_agg_merge_ws_bytes(int64_t n_rows, int64_t n_units, int32_t cap) {
-    (void)n_rows;
-    (void)n_units;
-    (void)cap;
-    return 256;
-}
-
 extern "C" int hs_agg_merge(void* stream, const hs_col* key, const hs_col* acc_cols, const hs_agg_spec* spec,
-                            const int64_t* unit_rows, int64_t n_units, int64_t n_rows, const int64_t* n_rows_dev,
-                            int32_t cap, int64_t* out_rep, uint64_t* out_acc, int64_t* out_ngroups, void* ws,
-                            uint32_t* flags) {
-    (void)unit_rows;
-    (void)n_units;
-    (void)ws;
+                            const int64_t* order, int64_t n_rows, const int64_t* n_rows_dev, int32_t cap,
+                            int64_t* out_rep, uint64_t* out_acc, int64_t* out_ngroups, uint32_t* flags) {
     if (!key || !spec || !out_rep || !out_acc || !out_ngroups || !flags || cap < 1 || (cap & (cap - 1)) ||
         (spec->n_acc > 0 && !acc_cols)) {
         hs_set_error("hs_agg_merge: bad arguments");
@@ -560,6 +567,7 @@ extern "C" int hs_agg_merge(void* stream, const hs_col* key, const hs_col* acc_c
     A.spec = *spec;
     A.n_rows = n_rows;
     A.n_rows_dev = n_rows_dev;
+    A.order = order;
     A.cap = cap;
     A.hashed = hs_col_packs(*key) ? 0 : 1;
     A.out_rep = out_rep;

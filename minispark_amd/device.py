@@ -72,6 +72,12 @@ class DBatch:
     nrows: int
     unit_rows: list[int] | None = field(default_factory=list)  # host copy of the unit boundaries [n_units+1]
     nrows_dev: torch.Tensor | None = None
+    unit_ids: list[int] | None = None     # multi-GPU: global id (file block id) of every local unit
+    total_units: int | None = None        # multi-GPU: number of units over all ranks
+    order: torch.Tensor | None = None     # per-row order key for the final merge (global unit id; <0 = padding)
+    slab: torch.Tensor | None = None      # multi-GPU: the exchange slab the columns live in
+    slab_layout: Any = None
+    slab_cols: list[int] | None = None    # slab column holding each batch column (aggregates may share one)
 
     def __post_init__(self) -> None:
         if self.nrows_dev is None and not self.unit_rows:
@@ -217,7 +223,8 @@ class Device:
             return StrCol(lens.astype(np.uint8), col.data[:total].cpu().numpy().astype(np.uint8))
         return col.data[: col.n].cpu().numpy()
 
-    def download_batch(self, batch: DBatch, schema: Schema) -> tuple[list[Any], int, int]:
+    def download_batch(self, batch: DBatch, schema: Schema,
+                       extra_flags: torch.Tensor | None = None) -> tuple[list[Any], int, int]:
         """All columns (already in file storage kinds) + the exact row count + the status flags in ONE
         device->host copy.  Returns (raw numpy columns, nrows, flags)."""
         parts: list[torch.Tensor] = []
@@ -232,6 +239,8 @@ class Device:
             pos += b.numel()
 
         add("flags", self.flags[:1])
+        if extra_flags is not None:
+            add("xflags", extra_flags)
         if batch.nrows_dev is not None:
             add("nrows", batch.nrows_dev[:1])
         for c in batch.cols:
@@ -246,6 +255,9 @@ class Device:
         for tag, off, size, _ in layout:
             if tag == "nrows":
                 n = min(n, int(host[off: off + size].view(np.int64)[0]))
+            elif tag == "xflags":  # status words of the other ranks (came with their slabs)
+                for w in host[off: off + size].view(np.uint32):
+                    flags |= int(w)
         raw: list[Any] = []
         pending_lens = None
         np_dtype = {hs.I32: np.int32, hs.F32: np.float32, hs.I64: np.int64, hs.F64: np.float64, hs.U8: np.uint8}
@@ -305,13 +317,14 @@ class Device:
         return sel, int(count.item())
 
     # ---- gathers -------------------------------------------------------------------------------------
-    def gather_col(self, col: DCol, idx: torch.Tensor, n: int, n_dev: torch.Tensor | None = None) -> DCol:
+    def gather_col(self, col: DCol, idx: torch.Tensor, n: int, n_dev: torch.Tensor | None = None,
+                   out: torch.Tensor | None = None) -> DCol:
         """out[i] = col[idx[i]], i < n (and < n_dev[0] when given).  Variable-length strings need the
         exact count (their payload size comes from a scan), fixed-length ones do not."""
         n_dev_ptr = n_dev.data_ptr() if n_dev is not None else None
         if col.kind == hs.STR and col.fixed_len in (1, 2, 4, 8):
             width = col.fixed_len
-            data = self.empty(n * width, torch.uint8)
+            data = out if out is not None else self.empty(n * width, torch.uint8)
             hs.check(self.lib.hs_gather_fixed(self.stream, col.data.data_ptr(), width, idx.data_ptr(), n, n_dev_ptr,
                                               data.data_ptr()), "hs_gather_fixed")
             lens = self.empty(n, torch.uint8)
@@ -336,7 +349,9 @@ class Device:
                                                   data.data_ptr()), "hs_gather_str_bytes")
             fixed = mn if (n > 0 and mn == mx) else (0 if n == 0 else -1)
             return DCol(hs.STR, data, n, lens=lens, offs=None if fixed >= 0 else offs, fixed_len=fixed)
-        out = self.empty(n, _TORCH_DTYPE[col.kind])
+        if col.kind == hs.STR and out is not None:
+            raise NotImplementedError("variable-length string keys cannot be written into a fixed-size exchange slab")
+        out = out if out is not None else self.empty(n, _TORCH_DTYPE[col.kind])
         hs.check(self.lib.hs_gather_fixed(self.stream, col.data.data_ptr(), hs.KIND_BYTES[col.kind], idx.data_ptr(), n,
                                           n_dev_ptr, out.data_ptr()), "hs_gather_fixed")
         return DCol(col.kind, out, n)
@@ -411,7 +426,8 @@ class Device:
 
     # ---- partial aggregate (A5/A6) -------------------------------------------------------------------------
     def aggregate_partial(self, batch: DBatch, filters: Sequence[Any], group_by: Any, agg_columns: Sequence[Any],
-                          out_schema: Schema, group_cap_hint: int = 4, cache_key: Any = None) -> DBatch:
+                          out_schema: Schema, group_cap_hint: int = 4, cache_key: Any = None,
+                          slab_rows: int | None = None) -> DBatch:
         """Fused scan + WHERE + aggregate arguments + per-unit partial aggregate.
 
         Returns the partial rows exactly as the reference would have written them to its shuffle
@@ -424,10 +440,10 @@ class Device:
         key = None
         if cache_key is not None:
             key = (cache_key, cap, batch.nrows, tuple((c.data.data_ptr(), c.n) for c in batch.cols),
-                   len(batch.unit_rows), batch.unit_rows[-1])
+                   len(batch.unit_rows), batch.unit_rows[-1], slab_rows)
         prep = self._partial_prepared.get(key) if key is not None else None
         if prep is None:
-            prep = self._prepare_partial(batch, filters, group_by, agg_columns, cap)
+            prep = self._prepare_partial(batch, filters, group_by, agg_columns, cap, slab_rows)
             if key is not None:
                 if len(self._partial_prepared) >= 8:
                     self._partial_prepared.pop(next(iter(self._partial_prepared)))
@@ -443,22 +459,28 @@ class Device:
         hs.check(self.lib.hs_agg_pack(self.stream, p["out_rep"].data_ptr(), p["out_acc"].data_ptr(),
                                       p["ngroups"].data_ptr(), p["n_units"], cap, C.byref(p["spec"]),
                                       p["pack_start"].data_ptr(), p["dense_rep"].data_ptr(), p["out_ptrs"],
-                                      p["kinds_arr"], None), "hs_agg_pack")
+                                      p["kinds_arr"], p["d_unit_ids"].data_ptr() if p["d_unit_ids"] is not None else None,
+                                      p["out_unit"].data_ptr() if p["out_unit"] is not None else None), "hs_agg_pack")
         # No host round trip here: the number of partial rows stays on the device (pack_start[n_units]);
         # a dictionary overflow is noticed at the query's final read-back and the query re-run.
         n_max = p["slots"]
         n_dev = p["pack_start"][p["n_units"]:]
-        key_col = self.gather_col(batch.cols[p["key_idx"]], p["dense_rep"], n_max, n_dev)
+        key_col = self.gather_col(batch.cols[p["key_idx"]], p["dense_rep"], n_max, n_dev, out=p["key_out"])
         if key_col.n != n_max:  # variable-length string keys made the count exact
             n_max, n_dev = key_col.n, None
         out_cols = [key_col]
         for acc in p["agg_to_acc"]:
             out_cols.append(DCol(p["acc_kinds"][acc], p["acc_bufs"][acc][:n_max], n_max))
         self.last_group_cap = cap
-        return DBatch(list(out_schema), out_cols, n_max, None, n_dev)
+        if p["slab"] is not None:  # header of the exchange slab: status so far + number of rows
+            p["layout"].flags_view(p["slab"]).copy_(self.flags[:1])
+            p["layout"].count_view(p["slab"]).copy_(p["pack_start"][p["n_units"]: p["n_units"] + 1])
+        return DBatch(list(out_schema), out_cols, n_max, None, n_dev, order=p["out_unit"], slab=p["slab"],
+                      slab_layout=p["layout"], total_units=batch.total_units,
+                      slab_cols=[0] + [1 + acc for acc in p["agg_to_acc"]])
 
     def _prepare_partial(self, batch: DBatch, filters: Sequence[Any], group_by: Any, agg_columns: Sequence[Any],
-                         cap: int) -> dict:
+                         cap: int, slab_rows: int | None = None) -> dict:
         low = lower_aggregate(batch.schema, batch.kinds, filters, group_by, agg_columns)
         if low.numeric_slots > hs.HS_FUSED_COLS:
             raise NotImplementedError(f"aggregate reads more than {hs.HS_FUSED_COLS} numeric columns")
@@ -482,10 +504,37 @@ class Device:
             raise DeviceError("chunk geometry mismatch between host and library")
         slots = n_units * cap
         acc_kinds = [hs.I32 if is_int else hs.F32 for is_int in low.acc_is_int]
-        acc_bufs = [self.empty(max(slots, 1), _TORCH_DTYPE[k]) for k in acc_kinds]
+        key_idx = low.program.columns[low.key_slot]
+        slab = layout = key_out = out_unit = None
+        if slab_rows is not None:
+            # multi-GPU: outputs are written straight into the fixed-size slab that gets all-gathered
+            from .distributed import SlabLayout  # noqa: PLC0415
+
+            if slots > slab_rows:
+                raise DeviceError(f"exchange slab of {slab_rows} rows cannot hold {slots} partial rows")
+            kc = batch.cols[key_idx]
+            if kc.kind == hs.STR:
+                if kc.fixed_len not in (1, 2, 4, 8):
+                    raise NotImplementedError("multi-GPU GROUP BY on variable-length string keys")
+                key_spec = (kc.fixed_len, torch.uint8)
+            else:
+                key_spec = (hs.KIND_BYTES[kc.kind], _TORCH_DTYPE[kc.kind])
+            layout = SlabLayout.build(slab_rows, [key_spec] + [(4, _TORCH_DTYPE[k]) for k in acc_kinds])
+            slab = torch.zeros(layout.nbytes, dtype=torch.uint8, device=self.device)
+            key_out = layout.column_view(slab, 0)
+            acc_bufs = [layout.column_view(slab, 1 + i) for i in range(n_acc)]
+            out_unit = layout.order_view(slab)
+        else:
+            acc_bufs = [self.empty(max(slots, 1), _TORCH_DTYPE[k]) for k in acc_kinds]
+        d_unit_ids = None
+        if batch.unit_ids is not None:
+            d_unit_ids = self.to_device(np.asarray(batch.unit_ids, dtype=np.int64))
+            if out_unit is None:
+                out_unit = self.empty(max(slots, 1), torch.int64)
         return {
+            "slab": slab, "layout": layout, "key_out": key_out, "out_unit": out_unit, "d_unit_ids": d_unit_ids,
             "cols": self._cols_array(batch, low.program.columns), "n_cols": len(low.program.columns),
-            "key_slot": low.key_slot, "key_idx": low.program.columns[low.key_slot], "prog": low.program.to_struct(),
+            "key_slot": low.key_slot, "key_idx": key_idx, "prog": low.program.to_struct(),
             "spec": low.spec(), "geom": geom, "n_units": n_units, "slots": slots, "agg_to_acc": low.agg_to_acc,
             "d_units": self.to_device(ur), "d_chunk0": self.to_device(chunk0),
             "out_rep": self.empty(slots, torch.int64), "out_acc": self.empty(max(slots * n_acc, 1), torch.int64),
@@ -526,9 +575,9 @@ class Device:
         out_rep = self.empty(cap, torch.int64)
         out_acc = self.empty(max(cap * n_acc, 1), torch.int64)
         ngroups = self.empty(1, torch.int64)
-        rc = self.lib.hs_agg_merge(self.stream, C.byref(key), acc_arr, C.byref(spec), None, 1, n, batch.n_dev_ptr, cap,
-                                   out_rep.data_ptr(), out_acc.data_ptr(), ngroups.data_ptr(), None,
-                                   self.flags.data_ptr())
+        rc = self.lib.hs_agg_merge(self.stream, C.byref(key), acc_arr, C.byref(spec),
+                                   batch.order.data_ptr() if batch.order is not None else None, n, batch.n_dev_ptr, cap,
+                                   out_rep.data_ptr(), out_acc.data_ptr(), ngroups.data_ptr(), self.flags.data_ptr())
         if rc == 2:
             raise NotImplementedError("final merge exceeds the LDS tier: " + self.lib.hs_last_error().decode())
         hs.check(rc, "hs_agg_merge")

@@ -1,0 +1,115 @@
+"""Multi-GPU exchange of partial-aggregate rows (the shuffle step between the two aggregation phases).
+
+One process per GPU (``torch.distributed``, backend "nccl" = RCCL over xGMI).  File block ``b`` lives on
+rank ``b % world`` (reference: one ScanJob per block, plan.py:90-93 - independent units), so the scan +
+partial aggregate needs no communication.  The reference then routes every partial row through its
+shuffle files to the final merge (tasks.py:347-375, plan.py:94-98); here the partial rows of all ranks
+meet through ONE collective per query:
+
+* every rank packs its partial rows into a fixed-size *slab*: header (status flags, row count), the
+  global unit id (= file block id) of every row, then the columns, each padded to ``slab_rows`` rows;
+  the producing kernels write straight into the slab, there is no packing pass;
+* ``all_gather_into_tensor`` of the slabs (a few KB per rank: latency-bound, one RCCL call);
+* every rank un-interleaves the columns and runs the same final merge, which folds the partials of a key
+  in ascending (block id, row) order - exactly the order in which the reference's single shuffle file
+  holds them - so the result does not depend on the number of GPUs.  Rank 0 writes the result file.
+
+Fixed-size slabs mean no count exchange and no host round trip before the collective.  This module is
+plain torch tensor plumbing and device-agnostic: tests/test_distributed_cpu.py runs it under gloo.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any
+
+import torch
+
+HEADER_BYTES = 16  # [flags: u32][pad: u32][row count: i64]
+
+
+@dataclass
+class SlabColumn:
+    offset: int  # byte offset inside the slab
+    row_bytes: int  # bytes per row
+    dtype: torch.dtype  # element type of the column view (uint8 for packed strings)
+
+
+@dataclass
+class SlabLayout:
+    """Byte layout of one rank's slab: header | order keys (i64 per row) | columns."""
+
+    slab_rows: int
+    columns: list[SlabColumn] = field(default_factory=list)
+    order_offset: int = HEADER_BYTES
+    nbytes: int = 0
+
+    @staticmethod
+    def build(slab_rows: int, column_specs: list[tuple[int, torch.dtype]]) -> "SlabLayout":
+        """column_specs: (bytes per row, view dtype) per column."""
+        lay = SlabLayout(slab_rows)
+        pos = HEADER_BYTES + 8 * slab_rows
+        for row_bytes, dtype in column_specs:
+            pos = (pos + 15) & ~15
+            lay.columns.append(SlabColumn(pos, row_bytes, dtype))
+            pos += row_bytes * slab_rows
+        lay.nbytes = (pos + 15) & ~15
+        return lay
+
+    # ---- views into a rank's slab --------------------------------------------------------------------
+    def order_view(self, slab: torch.Tensor) -> torch.Tensor:
+        return slab[self.order_offset: self.order_offset + 8 * self.slab_rows].view(torch.int64)
+
+    def column_view(self, slab: torch.Tensor, i: int) -> torch.Tensor:
+        c = self.columns[i]
+        return slab[c.offset: c.offset + c.row_bytes * self.slab_rows].view(c.dtype)
+
+    def flags_view(self, slab: torch.Tensor) -> torch.Tensor:
+        return slab[0:4].view(torch.int32)
+
+    def count_view(self, slab: torch.Tensor) -> torch.Tensor:
+        return slab[8:16].view(torch.int64)
+
+
+def all_gather_slabs(dist: Any, slab: torch.Tensor, world: int, group: Any = None) -> torch.Tensor:
+    """-> uint8 tensor [world, slab_bytes].  RCCL moves device tensors directly; the gloo backend (CPU
+    tests, single-GPU rehearsal) has no device all-gather, so device tensors are staged through the host."""
+    out = torch.empty(world * slab.numel(), dtype=torch.uint8, device=slab.device)
+    backend = dist.get_backend(group)
+    if backend == "gloo" and slab.device.type != "cpu":
+        host_in = slab.cpu()
+        host_out = torch.empty(world * slab.numel(), dtype=torch.uint8)
+        dist.all_gather_into_tensor(host_out, host_in, group=group)
+        out.copy_(host_out)
+    else:
+        dist.all_gather_into_tensor(out, slab, group=group)
+    return out.view(world, slab.numel())
+
+
+def unpack_gathered(gathered: torch.Tensor, layout: SlabLayout) -> tuple[torch.Tensor, torch.Tensor, list[torch.Tensor]]:
+    """[world, slab_bytes] -> (flags int32[world], order int64[world*M] with -1 on padding rows,
+    columns, each contiguous over all world*M rows in rank-major order)."""
+    world = gathered.shape[0]
+    m = layout.slab_rows
+    flags = gathered[:, 0:4].contiguous().view(torch.int32).reshape(world)
+    counts = gathered[:, 8:16].contiguous().view(torch.int64).reshape(world)
+    order = gathered[:, layout.order_offset: layout.order_offset + 8 * m].contiguous().view(torch.int64).reshape(world, m)
+    # rows at or beyond a rank's count are padding: their order key must be negative
+    valid = torch.arange(m, device=gathered.device).unsqueeze(0) < counts.unsqueeze(1)
+    order = torch.where(valid, order, torch.full_like(order, -1)).reshape(world * m)
+    cols = []
+    for c in layout.columns:
+        cols.append(gathered[:, c.offset: c.offset + c.row_bytes * m].contiguous().view(c.dtype).reshape(-1))
+    return flags, order, cols
+
+
+def owner_of_block(block: int, world: int) -> int:
+    return block % world
+
+
+def local_blocks(n_blocks: int, rank: int, world: int) -> list[int]:
+    return [b for b in range(n_blocks) if b % world == rank]
+
+
+def max_local_units(n_blocks: int, world: int) -> int:
+    return (n_blocks + world - 1) // world

@@ -96,6 +96,9 @@ class HipExecutionEngine(ExecutionEngine):
         self.group_cap_hint = 4   # dictionary capacity per workgroup of the partial aggregate (grows on overflow)
         self.merge_cap_hint = 16  # dictionary capacity of the final merge (grows on overflow)
         self.last_stats: dict[str, Any] = {}
+        self.dist: Any = None  # torch.distributed once enable_distributed() was called
+        self.rank, self.world = 0, 1
+        self._remote_flags: Any = None
 
     # ---- context manager -------------------------------------------------------------------------------
     def __exit__(self, exc_type, exc_value, traceback) -> None:  # noqa: ANN001
@@ -104,6 +107,16 @@ class HipExecutionEngine(ExecutionEngine):
         self._owned_dirs.clear()
         self._made_dirs.clear()
         self._result_root = None
+
+    # ---- multi-GPU -------------------------------------------------------------------------------------
+    def enable_distributed(self, dist: Any, group: Any = None) -> None:
+        """One process per GPU: this engine owns the file blocks b with b % world == rank; partial
+        aggregates meet through one all-gather per query (minispark_amd/distributed.py); rank 0 writes
+        the result, the other ranks return no output files."""
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
 
     # ---- tables --------------------------------------------------------------------------------------
     def attach_device_table(self, path: str | Path, table: Any) -> None:
@@ -118,7 +131,7 @@ class HipExecutionEngine(ExecutionEngine):
         cached = self._tables.get(key)
         if cached is not None and (cached.stamp == () or cached.stamp == tbl.file_stamp(Path(path))):
             return cached
-        opened = tbl.open_table(Path(path))
+        opened = tbl.open_table(Path(path), self.rank, self.world)
         self._tables[key] = opened
         return opened
 
@@ -187,7 +200,11 @@ class HipExecutionEngine(ExecutionEngine):
             batch = self._scan(producer, consumers, writer)
         elif kind == "LoadShuffleFilesTask":
             batch = outputs[id(stage.dependencies[0])]
+            if self.dist is not None:
+                batch = self._exchange_partials(batch)
         elif kind == "BroadcastHashJoinTask":
+            if self.dist is not None:
+                raise NotImplementedError("multi-GPU hash join (all-to-all of both inputs) is not built yet")
             batch = self._join(producer, outputs[id(stage.dependencies[0])], outputs[id(stage.dependencies[1])])
         else:
             raise NotImplementedError(f"Job creation not implemented for {type(producer)}")
@@ -202,8 +219,16 @@ class HipExecutionEngine(ExecutionEngine):
                 pending = []
             elif tname == "AggregateTask":
                 if task.before_shuffle:
+                    slab_rows = None
+                    if self.dist is not None:
+                        from .distributed import max_local_units  # noqa: PLC0415
+
+                        if batch.total_units is None:
+                            raise NotImplementedError("multi-GPU aggregation needs a block-partitioned table scan")
+                        slab_rows = max_local_units(batch.total_units, self.world) * self.group_cap_hint
                     batch = self.dev.aggregate_partial(batch, pending, task.group_by_column, task.agg_columns,
-                                                       task.inferred_schema, self.group_cap_hint, cache_key=id(task))
+                                                       task.inferred_schema, self.group_cap_hint, cache_key=id(task),
+                                                       slab_rows=slab_rows)
                     self.group_cap_hint = max(self.group_cap_hint, getattr(self.dev, "last_group_cap", 4))
                     pending = []
                 else:
@@ -276,6 +301,30 @@ class HipExecutionEngine(ExecutionEngine):
         cols += [self.dev.gather_col(c, out_right, n_out) for c in right.cols]
         return DBatch(list(left.schema) + list(right.schema), cols, n_out, unit_rows)
 
+    def _exchange_partials(self, batch: Any) -> Any:
+        """The shuffle between the two aggregation phases on N GPUs: all-gather the fixed-size slabs."""
+        from . import hipspark as hs  # noqa: PLC0415
+        from .device import DBatch, DCol  # noqa: PLC0415
+        from .distributed import all_gather_slabs, unpack_gathered  # noqa: PLC0415
+
+        if batch.slab is None:
+            raise NotImplementedError("multi-GPU exchange of this stage's output is not built yet")
+        layout = batch.slab_layout
+        gathered = all_gather_slabs(self.dist, batch.slab, self.world, self.group)
+        flags, order, cols = unpack_gathered(gathered, layout)
+        self._remote_flags = flags
+        n = self.world * layout.slab_rows
+        out = []
+        for src, slab_col in zip(batch.cols, batch.slab_cols):
+            data = cols[slab_col]
+            if src.kind == hs.STR:
+                lens = self.dev.empty(n, data.dtype)
+                lens.fill_(src.fixed_len)
+                out.append(DCol(hs.STR, data, n, lens=lens, offs=None, fixed_len=src.fixed_len))
+            else:
+                out.append(DCol(src.kind, data, n))
+        return DBatch(list(batch.schema), out, n, [0, n], None, order=order)
+
     # ---- consumers -------------------------------------------------------------------------------------
     def _materialise(self, batch: Any, pending: Sequence[Any]) -> Any:
         """Apply deferred WHERE conditions: compaction to a row list, then gather every column."""
@@ -326,8 +375,11 @@ class HipExecutionEngine(ExecutionEngine):
         if len(schema) != len(batch.cols):
             raise ExecutionError(f"writer schema {schema} does not match batch {batch.schema}")
         cols = [self.dev.quantise_col(c, t, batch.n_dev_ptr) for c, (_, t) in zip(batch.cols, schema)]
+        unchanged = all(a is b for a, b in zip(cols, batch.cols))
         return DBatch(list(schema), cols, batch.nrows, list(batch.unit_rows) if batch.unit_rows else None,
-                      batch.nrows_dev)
+                      batch.nrows_dev, unit_ids=batch.unit_ids, total_units=batch.total_units, order=batch.order,
+                      slab=batch.slab if unchanged else None, slab_layout=batch.slab_layout if unchanged else None,
+                      slab_cols=batch.slab_cols)
 
     def _write_result(self, batch: Any, schema: Schema, stage_id: str) -> JobResult:
         from . import hipspark as hs  # noqa: PLC0415
@@ -335,12 +387,14 @@ class HipExecutionEngine(ExecutionEngine):
 
         job_id = str(uuid.uuid4())
         quantised = self._quantise_batch(batch, schema)
-        raw, nrows, flags = self.dev.download_batch(quantised, schema)  # the query's one host round trip
+        raw, nrows, flags = self.dev.download_batch(quantised, schema, self._remote_flags)  # the one host round trip
+        self._remote_flags = None
         if flags & hs.FLAG_DICT_FULL:
             raise RetryWithLargerDictionary
         self.dev.raise_for_flags(flags)
-        if nrows == 0:
-            return JobResult(job_id, f"hip:{self.dev.index}", [])  # the reference writes no file (tasks.py:405)
+        if nrows == 0 or self.rank != 0:
+            # empty result: the reference writes no file (tasks.py:405); multi-GPU: rank 0 owns the result
+            return JobResult(job_id, f"hip:{self.dev.index}", [])
         if self._result_root is None:
             self._result_root = Path(self._work_folder or (constants.SHUFFLE_FOLDER / f"hip-{uuid.uuid4().hex[:12]}"))
             self._owned_dirs.add(self._result_root)

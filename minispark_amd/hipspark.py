@@ -115,9 +115,8 @@ SIGNATURES: dict[str, tuple] = {
         C.c_int,
         [_P, _COLP, _I32, _I32, _PROGP, _SPECP, _P, _P, _I64, _GEOMP, _P, _P, _P, _P, _P, _P, _P],
     ),
-    "hs_agg_pack": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _SPECP, _P, _P, C.POINTER(_P), C.POINTER(_I32), _P]),
-    "hs_agg_merge_ws_bytes": (C.c_size_t, [_I64, _I64, _I32]),
-    "hs_agg_merge": (C.c_int, [_P, _COLP, _COLP, _SPECP, _P, _I64, _I64, _P, _I32, _P, _P, _P, _P, _P]),
+    "hs_agg_pack": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _SPECP, _P, _P, C.POINTER(_P), C.POINTER(_I32), _P, _P]),
+    "hs_agg_merge": (C.c_int, [_P, _COLP, _COLP, _SPECP, _P, _I64, _P, _I32, _P, _P, _P, _P]),
     "hs_partition_ids": (C.c_int, [_P, _COLP, _P, _I64, _I32, _P]),
     "hs_partition_ws_bytes": (C.c_size_t, [_I64, _I32]),
     "hs_partition_perm": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P]),

@@ -58,9 +58,15 @@ def file_stamp(path: Path) -> tuple:
     return (st.st_mtime_ns, st.st_size)
 
 
-def open_table(path: Path) -> DeviceTable:
+def open_table(path: Path, rank: int = 0, world: int = 1) -> DeviceTable:
+    """Open a BlockFile; with world > 1 this rank owns the blocks b with b % world == rank."""
     bf = BlockFile(path)
-    return DeviceTable(Path(path), list(bf.file_schema), bf.block_rows(), {}, file_stamp(Path(path)))
+    rows = bf.block_rows()
+    if world == 1:
+        return DeviceTable(Path(path), list(bf.file_schema), rows, {}, file_stamp(Path(path)))
+    mine = [b for b in range(len(rows)) if b % world == rank]
+    return DeviceTable(Path(path), list(bf.file_schema), [rows[b] for b in mine], {}, file_stamp(Path(path)),
+                       global_blocks=mine, total_blocks=len(rows))
 
 
 def load_columns(dev: Device, table: DeviceTable, col_ids: list[int]) -> None:
@@ -71,8 +77,9 @@ def load_columns(dev: Device, table: DeviceTable, col_ids: list[int]) -> None:
     bf = BlockFile(table.path)
     nblocks = len(table.block_rows)
     total_rows = table.nrows
+    file_blocks = table.global_blocks if table.global_blocks is not None else list(range(nblocks))
     with table.path.open("rb") as f:
-        layouts = [bf.block_layout(b, f) for b in range(nblocks)]
+        layouts = [bf.block_layout(b, f) for b in file_blocks]
         for cid in missing:
             col_type = table.schema[cid][1]
             if col_type == ColumnType.STRING:
@@ -109,4 +116,5 @@ def load_columns(dev: Device, table: DeviceTable, col_ids: list[int]) -> None:
 def table_batch(table: DeviceTable, col_ids: list[int], alias: str = "") -> DBatch:
     prefix = f"{alias}." if alias else ""
     schema = [(prefix + table.schema[c][0], table.schema[c][1]) for c in col_ids]
-    return DBatch(schema, [table.columns[c] for c in col_ids], table.nrows, table.unit_rows)
+    return DBatch(schema, [table.columns[c] for c in col_ids], table.nrows, table.unit_rows,
+                  unit_ids=table.global_blocks, total_units=table.total_blocks)

@@ -1,0 +1,53 @@
+"""Worker for the multi-process tests: one rank of a world running a catalogue query through
+HipExecutionEngine.enable_distributed (backend gloo = rehearsal on one GPU / CPU plumbing; nccl = RCCL)."""
+
+from __future__ import annotations
+
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+os.environ["TZ"] = "UTC"
+time.tzset()
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+
+def main() -> None:
+    case_name, out_path, backend = sys.argv[1], sys.argv[2], sys.argv[3]
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ["RANK"])
+    world = int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    from minispark_amd import constants
+    from minispark_amd.dataframe import DataFrame
+    from minispark_amd.execution import HipExecutionEngine
+    from minispark_amd.sql import Col, Functions, Lit
+    from tests.conftest import load_golden
+    from tests.queries import api_namespace, case_by_name
+
+    constants.SHUFFLE_FOLDER = Path(out_path).parent / f"shuffle_r{rank}"
+    golden = load_golden(case_name)
+    case = case_by_name(case_name)
+    with HipExecutionEngine(device=int(os.environ.get("LOCAL_RANK", "0"))) as engine:
+        engine.enable_distributed(dist)
+        api = api_namespace(lambda: DataFrame(engine), Col, Functions, Lit)
+        frame = case.build(api, golden["paths"])
+        rows = None
+        for _ in range(2):  # second run exercises the plan / launch caches
+            rows = frame.collect()
+        if rank == 0:
+            enc = [{k: (v.hex() if type(v) is float else v) for k, v in r.items()} for r in rows]
+            Path(out_path).write_text(json.dumps(enc))
+        else:
+            assert rows == [], f"rank {rank} must not own result rows"
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

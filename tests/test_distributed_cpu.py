@@ -1,0 +1,80 @@
+"""N>1 exchange path on CPU (gloo, world_size 2): the slab layout, the all-gather and the un-interleave of
+minispark_amd/distributed.py are device-agnostic torch plumbing, so they are exercised here without a GPU;
+the kernels that consume the result are covered by the GPU tests (tests/test_gpu_distributed.py)."""
+
+from __future__ import annotations
+
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from minispark_amd.distributed import SlabLayout, all_gather_slabs, local_blocks, max_local_units, unpack_gathered
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _make_slab(rank: int, layout: SlabLayout, rows: int) -> torch.Tensor:
+    slab = torch.zeros(layout.nbytes, dtype=torch.uint8)
+    layout.flags_view(slab)[0] = 0x2 if rank == 1 else 0
+    layout.count_view(slab)[0] = rows
+    layout.order_view(slab)[:rows] = torch.arange(rows) * 2 + rank  # block b = 2*i + rank
+    layout.order_view(slab)[rows:] = 777  # garbage beyond the count: must come out as -1
+    layout.column_view(slab, 0)[:rows] = torch.arange(rows, dtype=torch.uint8) + 65 + rank  # 1-byte string key
+    layout.column_view(slab, 1)[:rows] = torch.arange(rows, dtype=torch.float32) + 100 * rank
+    layout.column_view(slab, 2)[:rows] = torch.arange(rows, dtype=torch.int32) - 5 * rank
+    return slab
+
+
+def _worker(rank: int, world: int, port: int, result):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    layout = SlabLayout.build(6, [(1, torch.uint8), (4, torch.float32), (4, torch.int32)])
+    rows = 4 if rank == 0 else 3
+    gathered = all_gather_slabs(dist, _make_slab(rank, layout, rows), world)
+    flags, order, cols = unpack_gathered(gathered, layout)
+    result[rank] = (flags.tolist(), order.tolist(), [c.tolist() for c in cols])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_slab_all_gather_world2():
+    world = 2
+    manager = mp.Manager()
+    result = manager.dict()
+    mp.spawn(_worker, args=(world, _free_port(), result), nprocs=world, join=True)
+    assert result[0] == result[1], "every rank must see the same gathered partial rows"
+    flags, order, cols = result[0]
+    assert flags == [0, 2]
+    #            rank 0: 4 rows, 2 padding       rank 1: 3 rows, 3 padding
+    assert order == [0, 2, 4, 6, -1, -1, 1, 3, 5, -1, -1, -1]
+    assert cols[0][:4] == [65, 66, 67, 68] and cols[0][6:9] == [66, 67, 68]
+    assert cols[1][:4] == [0.0, 1.0, 2.0, 3.0] and cols[1][6:9] == [100.0, 101.0, 102.0]
+    assert cols[2][:4] == [0, 1, 2, 3] and cols[2][6:9] == [-5, -4, -3]
+
+
+def test_slab_layout_alignment_and_views():
+    layout = SlabLayout.build(5, [(2, torch.uint8), (8, torch.int64), (4, torch.float32)])
+    assert layout.nbytes % 16 == 0
+    assert all(c.offset % 16 == 0 for c in layout.columns)
+    slab = torch.zeros(layout.nbytes, dtype=torch.uint8)
+    assert layout.order_view(slab).numel() == 5
+    assert layout.column_view(slab, 0).numel() == 10
+    assert layout.column_view(slab, 1).dtype == torch.int64 and layout.column_view(slab, 1).numel() == 5
+    layout.column_view(slab, 2)[:] = 1.5  # views alias the slab
+    assert slab[layout.columns[2].offset: layout.columns[2].offset + 4].view(torch.float32)[0] == 1.5
+
+
+def test_block_ownership():
+    assert local_blocks(7, 0, 2) == [0, 2, 4, 6]
+    assert local_blocks(7, 1, 2) == [1, 3, 5]
+    assert sorted(b for r in range(8) for b in local_blocks(287, r, 8)) == list(range(287))
+    assert max_local_units(287, 8) == 36 and max_local_units(6, 2) == 3 and max_local_units(1, 8) == 1
