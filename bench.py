@@ -94,13 +94,20 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # rehearsal knobs (one-GPU box): HIPSPARK_DIST_BACKEND=gloo HIPSPARK_FORCE_DEVICE=0 run N ranks on one GPU
+    backend = os.environ.get("HIPSPARK_DIST_BACKEND", "nccl")
+    if "HIPSPARK_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["HIPSPARK_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from minispark_amd import constants, synth
     from minispark_amd.execution import HipExecutionEngine
@@ -161,6 +168,7 @@ def main() -> None:
                             f"on synthetic lineitem sf={args.sf:g}",
                 "rows": total_rows, "blocks": len(synth.block_sizes(total_rows)), "rows_per_block": constants.ROWS_PER_BLOCK,
                 "bytes_per_row": synth.Q1_BYTES_PER_ROW, "groups": len(rows or []), "placement": "block b on rank b % n_gpus",
+                "exchange": "none" if world == 1 else f"one all_gather of partial-row slabs per query ({backend})",
             },
             "roofline": {
                 "bound": "hbm", "kernel": "k_agg_main", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

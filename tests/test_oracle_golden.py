@@ -1,0 +1,87 @@
+"""The oracle is only trustworthy because it is pinned here: every golden fixture under tests/golden/
+was produced by running the REAL reference (PythonExecutionEngine) in the build container
+(tests/golden/make_golden.py); the oracle must reproduce all of them bit for bit - result rows, column
+order, exception types."""
+
+from __future__ import annotations
+
+from datetime import datetime
+
+import numpy as np
+import pytest
+
+from tests.conftest import assert_rows_match, load_golden
+from tests.queries import CASES, api_namespace
+
+
+def _api():
+    from minispark_amd.dataframe import DataFrame
+    from minispark_amd.sql import Col, Functions, Lit
+
+    return api_namespace(lambda: DataFrame(engine=object()), Col, Functions, Lit)
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c.name for c in CASES])
+def test_python_oracle_reproduces_reference(case):
+    from oracle.py_engine import run_query
+
+    golden = load_golden(case.name)
+    frame = case.build(_api(), golden["paths"])
+    if "error" in golden:
+        with pytest.raises(Exception) as info:
+            run_query(frame.task)
+        assert type(info.value).__name__ == golden["error"]
+        return
+    assert_rows_match(run_query(frame.task), golden["rows"], max_ulps=0)
+
+
+Q1_CASES = [("q1_multiblock", "1998-12-01"), ("q1_selective", "1995-06-17"), ("q1_ragged_blocks", "1998-09-02")]
+
+
+def _columns_from_fixture(path):
+    from oracle import blockfile as bfio
+
+    schema, blocks = bfio.read_blockfile(path)
+    names = [n for n, _ in schema]
+
+    def col(name):
+        i = names.index(name)
+        return [v for b in blocks for v in b[i]]
+
+    cols = {k: np.array(col(k), np.float32) for k in ("l_quantity", "l_extendedprice", "l_discount", "l_tax")}
+    cols["l_shipdate"] = np.array([bfio.to_us(v) for v in col("l_shipdate")], np.int64)
+    cols["l_returnflag"] = np.frombuffer("".join(col("l_returnflag")).encode(), np.uint8)
+    return cols, [len(b[0]) for b in blocks]
+
+
+@pytest.mark.parametrize("name,cutoff", Q1_CASES)
+def test_c_oracle_reproduces_reference(name, cutoff):
+    """oracle/q1_oracle.c (the cpu_baseline 'port' and the large-size checker) against the same goldens."""
+    from oracle import blockfile as bfio
+    from oracle import q1_native
+
+    golden = load_golden(name)
+    cols, block_rows = _columns_from_fixture(golden["paths"]["lineitem"])
+    cutoff_us = bfio.to_us(datetime.fromisoformat(cutoff))
+    rows = q1_native.run(cols, block_rows, cutoff_us)
+    assert_rows_match(rows, golden["rows"], max_ulps=0)
+    assert q1_native.run(cols, block_rows, cutoff_us, threads=3) == rows  # block-parallel run: same bits
+
+
+def test_readme_fruit_example_values():
+    """/root/reference/README.md:97-106 prints apple 4.5, banana 9.5, orange 11.2 - the last one is
+    f32(2*f32(1.2) + 4*f32(2.2)), i.e. the result went through the f32 quantisation points."""
+    rows = {r["fruit"]: r["total_price"] for r in load_golden("fruit")["rows"]}
+    assert rows == {"apple": 4.5, "banana": 9.5, "orange": float.fromhex("0x1.666668p+3")}
+
+
+def test_c_generator_is_deterministic_and_blockwise():
+    from oracle import q1_native
+
+    whole = q1_native.gen(20251003, 0, 5000, orderkey=True, shipmode=True)
+    tail = q1_native.gen(20251003, 3000, 2000, orderkey=True, shipmode=True)
+    for k in whole:
+        assert np.array_equal(whole[k][3000:], tail[k]), k  # value depends on (seed, row) only
+    assert set(np.unique(whole["l_returnflag"]).tolist()) <= {ord("A"), ord("N"), ord("R")}
+    assert whole["l_quantity"].min() >= 1 and whole["l_quantity"].max() <= 50
+    assert whole["l_shipdate"].max() <= 912470400 * 1_000_000  # 1998-12-01
