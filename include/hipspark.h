@@ -220,14 +220,16 @@ int hs_agg_pack(void* stream, const int64_t* rep, const uint64_t* acc, const int
 /* Input: a batch of partial rows: key column `key`, accumulator columns acc_cols[n_acc] (HS_F32 /
  * HS_I32 / HS_F64 / HS_I64).  Partials of a key are folded in fp64 / i64 in ascending (order[row], row)
  * order - with order == NULL in row order - which is the reference's order: block order of the shuffle
- * file.  Rows with order[row] < 0 are padding and ignored (fixed-size slabs exchanged between GPUs).
+ * file.  Rows with order[row] < 0 are padding and ignored (fixed-size slabs exchanged between GPUs); valid
+ * order keys lie in [0, n_order) and rows sharing a key are contiguous and ascending in the input (they
+ * come from one producer).
  * Outputs are DENSE (group i = i-th occupied dictionary slot) and column-major: out_rep[i] = first input
  * row of group i, out_acc[a * cap + i] = un-rounded 64-bit cell of aggregate a, *out_ngroups = number of
  * groups (<= cap).  n_rows is an upper bound when n_rows_dev != NULL (then *n_rows_dev, a device int64, is
  * the exact count): lets a whole query run without a host round trip between its kernels. */
 int hs_agg_merge(void* stream, const hs_col* key, const hs_col* acc_cols, const hs_agg_spec* spec,
-                 const int64_t* order, int64_t n_rows, const int64_t* n_rows_dev, int32_t cap, int64_t* out_rep,
-                 uint64_t* out_acc, int64_t* out_ngroups, uint32_t* flags);
+                 const int64_t* order, int64_t n_order, int64_t n_rows, const int64_t* n_rows_dev, int32_t cap,
+                 int64_t* out_rep, uint64_t* out_acc, int64_t* out_ngroups, uint32_t* flags);
 
 /* =================================================================================================
  * A6/A9  Hash partitioning (reference tasks.py:347-375 WriteToShufflePartitions.write)
@@ -278,6 +280,9 @@ int hs_exclusive_scan_i64(void* stream, const int64_t* counts, int64_t n, int64_
  * HS_FLAG_INT_OVERFLOW).  src_kind in {HS_F64, HS_I64}. */
 int hs_quantise(void* stream, const void* src, int32_t src_kind, int64_t n, const int64_t* n_dev, void* dst,
                 uint32_t* flags);
+/* The same for up to 16 columns of one batch in a single launch. */
+int hs_quantise_many(void* stream, int32_t n_cols, void* const* srcs, const int32_t* src_kinds, int64_t n,
+                     const int64_t* n_dev, void* const* dsts, uint32_t* flags);
 
 /* =================================================================================================
  * Run-time specialisation (reference: codegen.py:230-247 compiles every query with `zig build`).

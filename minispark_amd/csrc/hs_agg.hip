@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(256) k_agg_unit(const AggUnitArgs A_kernarg) {
     int64_t* ureps = (int64_t*)(lds + GC);                  // [GC]
     uint64_t* uacc = lds + 2 * GC;                          // [GC][NA]
     uint64_t* pacc = uacc + GC * NA;                        // [BATCH][GC][NA] staged chunk partials
-    int* map = (int*)(pacc + (size_t)HS_UNIT_BATCH * GC * NA);  // [BATCH][GC] chunk slot -> unit slot
+    int* inv = (int*)(pacc + (size_t)HS_UNIT_BATCH * GC * NA);  // [BATCH][GC] unit slot -> chunk slot (or -1)
     __shared__ int s_count;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int64_t u = blockIdx.x;
@@ -71,17 +71,18 @@ __global__ void __launch_bounds__(256) k_agg_unit(const AggUnitArgs A_kernarg) {
     const int64_t cbeg = A.unit_chunk0[u], cend = A.unit_chunk0[u + 1];
     for (int64_t b0 = cbeg; b0 < cend; b0 += HS_UNIT_BATCH) {
         const int nb = (int)((cend - b0) < HS_UNIT_BATCH ? (cend - b0) : HS_UNIT_BATCH);
+        for (int i = tid; i < nb * GC; i += nthr) inv[i] = -1;
+        __syncthreads();
         for (int i = tid; i < nb * GC; i += nthr) {
             const int64_t c = b0 + i / GC;
             const int sl = i % GC;
             const int64_t rep = A.part_rep[c * GC + sl];
-            int m = -1;
             if (rep >= 0) {
-                m = A.hashed ? hs_dict_upsert_rows(ureps, mask, A.key, hs_key_at(A.key, rep), rep)
-                             : hs_dict_upsert_word(ukeys, ureps, mask, A.part_keys[c * GC + sl], rep);
+                const int m = A.hashed ? hs_dict_upsert_rows(ureps, mask, A.key, hs_key_at(A.key, rep), rep)
+                                       : hs_dict_upsert_word(ukeys, ureps, mask, A.part_keys[c * GC + sl], rep);
                 if (m < 0) err |= HS_FLAG_DICT_FULL;
+                else inv[(i / GC) * GC + m] = sl;  // keys are distinct within a chunk: one writer per cell
             }
-            map[i] = m;
         }
         for (int i = tid; i < nb * GC * NA; i += nthr) pacc[i] = A.part_acc[b0 * GC * NA + i];
         __syncthreads();
@@ -90,9 +91,10 @@ __global__ void __launch_bounds__(256) k_agg_unit(const AggUnitArgs A_kernarg) {
             const uint32_t op = A.spec.op[a];
             const bool is_int = A.spec.is_int[a] != 0;
             uint64_t v = uacc[i];
-            for (int c = 0; c < nb; ++c)
-                for (int sl = 0; sl < GC; ++sl)
-                    if (map[c * GC + sl] == us) v = hs_acc_fold(op, is_int, v, pacc[(c * GC + sl) * NA + a]);
+            for (int c = 0; c < nb; ++c) {  // ascending chunk order = row order
+                const int sl = inv[c * GC + us];
+                if (sl >= 0) v = hs_acc_fold(op, is_int, v, pacc[(c * GC + sl) * NA + a]);
+            }
             uacc[i] = v;
         }
         __syncthreads();
@@ -183,6 +185,8 @@ struct AggMergeArgs {
     int64_t n_rows;            // upper bound (sizes LDS)
     const int64_t* n_rows_dev; // optional exact row count on the device
     const int64_t* order;      // optional per-row order key (global unit id); rows with order < 0 are padding
+    int32_t n_order;           // order keys lie in [0, n_order)
+    int32_t pad0;
     int32_t cap;
     int32_t hashed;
     int64_t* out_rep;
@@ -191,30 +195,44 @@ struct AggMergeArgs {
     uint32_t* flags;
 };
 
-// Final merge, everything staged in LDS.  Rows ascend in unit order, so folding the rows of a group in
-// ascending row order IS the reference's order (0 + p_block0 + p_block1 + ... in fp64).  Rows are
-// bucketed by group with a stable rank (number of earlier rows of the same group) so the ordered fold
-// reads contiguous LDS.  Outputs are dense (groups in ascending dictionary-slot order) and
-// column-major: out_acc[a * cap + i].
+// Final merge, everything staged in LDS.  The partials of a group must be folded in the reference's
+// order: ascending (order key, row) - with order == NULL simply ascending row - i.e. block order of the
+// shuffle file (0 + p_block0 + p_block1 + ... in fp64).  All steps are O(n):
+//   1. rows -> dictionary slot (parallel);
+//   2. visiting sequence = rows sorted by (order key, row): a counting sort on the order key (block id);
+//      rows of one block are contiguous in the input, so the position inside a block is r - first_row;
+//   3. one wave walks the sequence 64 rows at a time and ranks the rows of each group with a
+//      ballot / match-any loop (stable);
+//   4. cells are scattered to [group bucket][rank], then one lane per (group, aggregate) folds its
+//      bucket front to back from contiguous LDS.
+// Outputs are dense (groups in ascending dictionary-slot order) and column-major: out_acc[a * cap + i].
 __global__ void __launch_bounds__(1024) k_agg_merge_small(const AggMergeArgs A_kernarg) {
     HS_KERNARG(AggMergeArgs, A);
     extern __shared__ __align__(16) uint64_t lds[];
     const int NA = A.spec.n_acc;
     const int cap = A.cap;
     const int64_t nmax = A.n_rows;
-    int64_t n = nmax;
+    const int nord = A.n_order;  // order keys lie in [0, n_order)
+    int64_t n64 = nmax;
     if (A.n_rows_dev) {
         const int64_t nd = *A.n_rows_dev;
-        n = nd < nmax ? nd : nmax;
+        n64 = nd < nmax ? nd : nmax;
     }
+    const int n = (int)n64;
     uint64_t* dkeys = lds;                                // [cap]
     int64_t* dreps = (int64_t*)(lds + cap);               // [cap]
     uint64_t* sorted = lds + 2 * cap;                     // [nmax][NA] cells bucketed by group
-    int32_t* rslot = (int32_t*)(sorted + nmax * NA);      // [nmax]
-    int32_t* dense = rslot + nmax;                        // [cap] slot -> dense output row
+    int32_t* rslot = (int32_t*)(sorted + nmax * NA);      // [nmax] row -> slot (-1: padding / overflow)
+    int32_t* seq = rslot + nmax;                          // [nmax] visiting sequence: seq[i] = row
+    int32_t* rrank = seq + nmax;                          // [nmax] row -> rank inside its group
+    int32_t* dense = rrank + nmax;                        // [cap] slot -> dense output row
     int32_t* cnt = dense + cap;                           // [cap] rows per slot
     int32_t* start = cnt + cap;                           // [cap] first bucket position of the slot
+    int32_t* run = start + cap;                           // [cap] running rank per slot (step 3)
+    int32_t* ocnt = run + cap;                            // [nord] rows per order key
+    int32_t* ofirst = ocnt + nord;                        // [nord] first row of an order key
     __shared__ int s_scan[1024];
+    __shared__ int s_nvalid;
     const int tid = threadIdx.x, nthr = blockDim.x;
     uint32_t err = 0;
 
@@ -222,21 +240,37 @@ __global__ void __launch_bounds__(1024) k_agg_merge_small(const AggMergeArgs A_k
         dkeys[i] = HS_EMPTY_KEY;
         dreps[i] = -1;
         cnt[i] = 0;
+        run[i] = 0;
     }
+    for (int i = tid; i < nord; i += nthr) {
+        ocnt[i] = 0;
+        ofirst[i] = 0x7fffffff;
+    }
+    if (tid == 0) s_nvalid = 0;
     __syncthreads();
     const uint32_t mask = (uint32_t)cap - 1;
-    for (int64_t r = tid; r < n; r += nthr) {
+    for (int r = tid; r < n; r += nthr) {  // step 1
         int sl = -1;
-        if (!A.order || A.order[r] >= 0) {
+        const int64_t o = A.order ? A.order[r] : 0;
+        if (o >= 0) {
             const uint64_t k = hs_key_at(A.key, r);
             sl = A.hashed ? hs_dict_upsert_rows(dreps, mask, A.key, k, r) : hs_dict_upsert_word(dkeys, dreps, mask, k, r);
             if (sl < 0) err |= HS_FLAG_DICT_FULL;
             else atomicAdd(&cnt[sl], 1);
+            if (A.order && sl >= 0) {
+                if (o >= nord) {
+                    err |= HS_FLAG_BAD_PROGRAM;
+                    sl = -1;
+                } else {
+                    atomicAdd(&ocnt[(int)o], 1);
+                    atomicMin(&ofirst[(int)o], r);
+                }
+            }
         }
         rslot[r] = sl;
     }
     __syncthreads();
-    // per-thread slot ranges + block scans: dense group numbering and bucket starts
+    // dense group numbering + bucket starts: per-thread slot ranges and two block scans
     const int per = (cap + nthr - 1) / nthr;
     const int s0 = tid * per, s1 = (s0 + per) < cap ? (s0 + per) : cap;
     int mine = 0, mine_rows = 0;
@@ -252,10 +286,10 @@ __global__ void __launch_bounds__(1024) k_agg_merge_small(const AggMergeArgs A_k
         s_scan[tid] += t;
         __syncthreads();
     }
-    int run = s_scan[tid] - mine;
+    int drun = s_scan[tid] - mine;
     const int ngroups = s_scan[nthr - 1];
     __syncthreads();
-    for (int sl = s0; sl < s1; ++sl) dense[sl] = cnt[sl] > 0 ? run++ : -1;
+    for (int sl = s0; sl < s1; ++sl) dense[sl] = cnt[sl] > 0 ? drun++ : -1;
     s_scan[tid] = mine_rows;
     __syncthreads();
     for (int d = 1; d < nthr; d <<= 1) {
@@ -271,24 +305,65 @@ __global__ void __launch_bounds__(1024) k_agg_merge_small(const AggMergeArgs A_k
     }
     __syncthreads();
     if (tid == 0) *A.out_ngroups = ngroups;
-    // stable rank of every row inside its group, then scatter its cells into the group's bucket
-    for (int64_t r = tid; r < n; r += nthr) {
+
+    // step 2: visiting sequence
+    int nseq = n;
+    if (A.order) {
+        const int operth = (nord + nthr - 1) / nthr;
+        const int o0 = tid * operth, o1 = (o0 + operth) < nord ? (o0 + operth) : nord;
+        int osum = 0;
+        for (int o = o0; o < o1; ++o) osum += ocnt[o];
+        s_scan[tid] = osum;
+        __syncthreads();
+        for (int d = 1; d < nthr; d <<= 1) {
+            const int t = tid >= d ? s_scan[tid - d] : 0;
+            __syncthreads();
+            s_scan[tid] += t;
+            __syncthreads();
+        }
+        int opos = s_scan[tid] - osum;
+        if (tid == nthr - 1) s_nvalid = s_scan[tid];
+        for (int o = o0; o < o1; ++o) {  // ocnt becomes the start of the block's run in the sequence
+            const int c = ocnt[o];
+            ocnt[o] = opos;
+            opos += c;
+        }
+        __syncthreads();
+        nseq = s_nvalid;
+        for (int r = tid; r < n; r += nthr) {
+            if (rslot[r] < 0) continue;
+            const int o = (int)A.order[r];
+            seq[ocnt[o] + (r - ofirst[o])] = r;
+        }
+        __syncthreads();
+    }
+
+    // step 3: stable rank of every row inside its group, one wave, 64 rows of the sequence at a time
+    if (tid < HS_WAVE) {
+        for (int base = 0; base < nseq; base += HS_WAVE) {
+            const int i = base + tid;
+            const int r = i < nseq ? (A.order ? seq[i] : i) : -1;
+            const int sl = r >= 0 ? rslot[r] : -1;
+            unsigned long long todo = __ballot(sl >= 0);
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const int g = __shfl(sl, leader, HS_WAVE);
+                const unsigned long long same = __ballot(sl == g);
+                if (sl == g) rrank[r] = run[g] + __popcll(same & ((1ull << tid) - 1));
+                if (tid == leader) run[g] += __popcll(same);
+                todo &= ~same;
+            }
+        }
+    }
+    __syncthreads();
+    // step 4: scatter cells into the group buckets, then the ordered fold
+    for (int r = tid; r < n; r += nthr) {
         const int sl = rslot[r];
         if (sl < 0) continue;
-        int rank = 0;
-        if (A.order) {  // (order key, row) lexicographic: partial rows of all ranks in global unit order
-            const int64_t mine_o = A.order[r];
-            for (int64_t q = 0; q < n; ++q) {
-                if (rslot[q] != sl) continue;
-                const int64_t o = A.order[q];
-                rank += (o < mine_o) || (o == mine_o && q < r);
-            }
-        } else {
-            for (int64_t q = 0; q < r; ++q) rank += rslot[q] == sl;
-        }
-        const int at = start[sl] + rank;
+        const int rk = rrank[r];
+        const int at = start[sl] + rk;
         for (int a = 0; a < NA; ++a) sorted[(int64_t)at * NA + a] = hs_load_cell(A.acc_cols[a], r);
-        if (rank == 0) A.out_rep[dense[sl]] = r;  // smallest row of the group: independent of insert races
+        if (rk == 0) A.out_rep[dense[sl]] = r;  // first row of the group in merge order: race-independent
     }
     __syncthreads();
     for (int i = tid; i < cap * NA; i += nthr) {
@@ -547,14 +622,19 @@ extern "C" int hs_agg_pack(void* stream, const int64_t* rep, const uint64_t* acc
 static constexpr size_t HS_MERGE_LDS_MAX = 150 * 1024;
 
 extern "C" int hs_agg_merge(void* stream, const hs_col* key, const hs_col* acc_cols, const hs_agg_spec* spec,
-                            const int64_t* order, int64_t n_rows, const int64_t* n_rows_dev, int32_t cap,
-                            int64_t* out_rep, uint64_t* out_acc, int64_t* out_ngroups, uint32_t* flags) {
+                            const int64_t* order, int64_t n_order, int64_t n_rows, const int64_t* n_rows_dev,
+                            int32_t cap, int64_t* out_rep, uint64_t* out_acc, int64_t* out_ngroups, uint32_t* flags) {
     if (!key || !spec || !out_rep || !out_acc || !out_ngroups || !flags || cap < 1 || (cap & (cap - 1)) ||
         (spec->n_acc > 0 && !acc_cols)) {
         hs_set_error("hs_agg_merge: bad arguments");
         return HS_E_ARG;
     }
-    const size_t lds = (size_t)cap * 16 + (size_t)n_rows * spec->n_acc * 8 + (size_t)n_rows * 4 + (size_t)cap * 12 + 16;
+    if (order && (n_order < 1 || n_order > 65536)) {
+        hs_set_error("hs_agg_merge: n_order=%lld out of range", (long long)n_order);
+        return HS_E_ARG;
+    }
+    const size_t lds = (size_t)cap * 16 + (size_t)n_rows * spec->n_acc * 8 + (size_t)n_rows * 12 + (size_t)cap * 16 +
+                       (order ? (size_t)n_order * 8 : 0) + 16;
     if (lds > HS_MERGE_LDS_MAX) {
         hs_set_error("hs_agg_merge: %lld partial rows x %d accumulators need %zu B LDS (> %zu): use the unit-stepped merge",
                      (long long)n_rows, spec->n_acc, lds, HS_MERGE_LDS_MAX);
@@ -568,6 +648,8 @@ extern "C" int hs_agg_merge(void* stream, const hs_col* key, const hs_col* acc_c
     A.n_rows = n_rows;
     A.n_rows_dev = n_rows_dev;
     A.order = order;
+    A.n_order = order ? (int32_t)n_order : 0;
+    A.pad0 = 0;
     A.cap = cap;
     A.hashed = hs_col_packs(*key) ? 0 : 1;
     A.out_rep = out_rep;

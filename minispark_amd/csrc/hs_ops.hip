@@ -478,6 +478,58 @@ extern "C" int hs_quantise(void* stream, const void* src, int32_t src_kind, int6
     return HS_OK;
 }
 
+struct QuantManyArgs {
+    int32_t n_cols;
+    int32_t kinds[16];
+    const void* srcs[16];
+    void* dsts[16];
+};
+__global__ void __launch_bounds__(256) k_quantise_many(const QuantManyArgs A_kernarg, int64_t n, const int64_t* n_dev,
+                                                       uint32_t* flags) {
+    HS_KERNARG(QuantManyArgs, A);
+    uint32_t err = 0;
+    n = capped(n, n_dev);
+    const int64_t total = n * A.n_cols;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t / n);
+        const int64_t i = t % n;
+        if (A.kinds[c] == HS_F64) {
+            const double d = ((const double*)A.srcs[c])[i];
+            const float f = (float)d;
+            if (isinf(f) && !isinf(d)) err |= HS_FLAG_FLT_OVERFLOW;
+            ((float*)A.dsts[c])[i] = f;
+        } else {
+            const int64_t v = ((const int64_t*)A.srcs[c])[i];
+            if (v > 2147483647ll || v < -2147483648ll) err |= HS_FLAG_INT_OVERFLOW;
+            ((int32_t*)A.dsts[c])[i] = (int32_t)v;
+        }
+    }
+    if (err) atomicOr(flags, err);
+}
+extern "C" int hs_quantise_many(void* stream, int32_t n_cols, void* const* srcs, const int32_t* src_kinds, int64_t n,
+                                const int64_t* n_dev, void* const* dsts, uint32_t* flags) {
+    if (n == 0 || n_cols == 0) return HS_OK;
+    if (n_cols < 0 || n_cols > 16 || !srcs || !src_kinds || !dsts || !flags || n < 0) {
+        hs_set_error("hs_quantise_many: bad arguments");
+        return HS_E_ARG;
+    }
+    QuantManyArgs A;
+    A.n_cols = n_cols;
+    for (int i = 0; i < 16; ++i) {
+        A.kinds[i] = i < n_cols ? src_kinds[i] : HS_I64;
+        A.srcs[i] = i < n_cols ? srcs[i] : nullptr;
+        A.dsts[i] = i < n_cols ? dsts[i] : nullptr;
+        if (i < n_cols && A.kinds[i] != HS_F64 && A.kinds[i] != HS_I64) {
+            hs_set_error("hs_quantise_many: column %d is not an in-flight kind", i);
+            return HS_E_ARG;
+        }
+    }
+    hipLaunchKernelGGL(k_quantise_many, dim3(grid_for(n * n_cols, 256)), dim3(256), 0, (hipStream_t)stream, A, n, n_dev,
+                       flags);
+    HS_CHECK_LAUNCH("hs_quantise_many");
+    return HS_OK;
+}
+
 // ---- A6/A9: hash partitioning (reference tasks.py:353-365) ------------------------------------------------
 __device__ __forceinline__ uint32_t py_int_partition(int64_t v, int32_t n_parts) {
     // hash(int) == int for |int| < 2**61-1, except hash(-1) == -2; then Python's floor-mod

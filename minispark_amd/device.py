@@ -424,6 +424,35 @@ class Device:
             return col
         raise AssertionError(f"column of kind {col.kind} cannot be stored as {col_type}")
 
+    def quantise_cols(self, cols: Sequence[DCol], types: Sequence[ColumnType], n_dev_ptr=None) -> list[DCol]:
+        """quantise_col for a whole batch with ONE launch for all the columns that need converting."""
+        out: list[DCol] = list(cols)
+        todo = []
+        for i, (c, t) in enumerate(zip(cols, types)):
+            want = FILE_KIND[t]
+            if c.kind == want or c.kind == hs.STR or (c.kind, want) == (hs.I64, hs.I64):
+                continue
+            if (c.kind, want) not in ((hs.F64, hs.F32), (hs.I64, hs.I32)):
+                out[i] = self.quantise_col(c, t, n_dev_ptr)  # raises the appropriate error
+                continue
+            todo.append((i, c, want))
+        for lo in range(0, len(todo), 16):
+            part = todo[lo: lo + 16]
+            n = part[0][1].n
+            if any(c.n != n for _, c, _ in part):
+                for i, c, _ in part:
+                    out[i] = self.quantise_col(c, types[i], n_dev_ptr)
+                continue
+            dsts = [self.empty(n, _TORCH_DTYPE[w]) for _, _, w in part]
+            srcs_arr = (C.c_void_p * len(part))(*[c.data.data_ptr() for _, c, _ in part])
+            kinds_arr = (C.c_int32 * len(part))(*[c.kind for _, c, _ in part])
+            dsts_arr = (C.c_void_p * len(part))(*[d.data_ptr() for d in dsts])
+            hs.check(self.lib.hs_quantise_many(self.stream, len(part), srcs_arr, kinds_arr, n, n_dev_ptr, dsts_arr,
+                                               self.flags.data_ptr()), "hs_quantise_many")
+            for (i, _, w), d in zip(part, dsts):
+                out[i] = DCol(w, d, n)
+        return out
+
     # ---- partial aggregate (A5/A6) -------------------------------------------------------------------------
     def aggregate_partial(self, batch: DBatch, filters: Sequence[Any], group_by: Any, agg_columns: Sequence[Any],
                           out_schema: Schema, group_cap_hint: int = 4, cache_key: Any = None,
@@ -576,7 +605,8 @@ class Device:
         out_acc = self.empty(max(cap * n_acc, 1), torch.int64)
         ngroups = self.empty(1, torch.int64)
         rc = self.lib.hs_agg_merge(self.stream, C.byref(key), acc_arr, C.byref(spec),
-                                   batch.order.data_ptr() if batch.order is not None else None, n, batch.n_dev_ptr, cap,
+                                   batch.order.data_ptr() if batch.order is not None else None,
+                                   batch.total_units or 0, n, batch.n_dev_ptr, cap,
                                    out_rep.data_ptr(), out_acc.data_ptr(), ngroups.data_ptr(), self.flags.data_ptr())
         if rc == 2:
             raise NotImplementedError("final merge exceeds the LDS tier: " + self.lib.hs_last_error().decode())

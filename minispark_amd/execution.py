@@ -65,9 +65,18 @@ class ExecutionEngine(AbstractContextManager, ABC):
                     return
 
     def sql(self, query: str) -> Any:
-        raise NotImplementedError(
-            "the SQL front-end is outside the accelerated path (SURVEY.md section 8f N3); build the query with DataFrame"
-        )
+        """SQL text -> DataFrame bound to this engine.  The parser is the reference's (parser.py:391-397,
+        needs `parsimonious`): the SQL front-end is outside the accelerated path."""
+        try:
+            from mini_spark.parser import parse_sql  # type: ignore[import-not-found]  # noqa: PLC0415
+        except ImportError as e:
+            raise NotImplementedError(
+                "no SQL front-end available (the reference's mini_spark.parser is not importable); "
+                "build the query with DataFrame"
+            ) from e
+        df = parse_sql(query)
+        df.engine = self
+        return df
 
 
 def _cls(obj: Any) -> str:
@@ -323,7 +332,7 @@ class HipExecutionEngine(ExecutionEngine):
                 out.append(DCol(hs.STR, data, n, lens=lens, offs=None, fixed_len=src.fixed_len))
             else:
                 out.append(DCol(src.kind, data, n))
-        return DBatch(list(batch.schema), out, n, [0, n], None, order=order)
+        return DBatch(list(batch.schema), out, n, [0, n], None, order=order, total_units=batch.total_units)
 
     # ---- consumers -------------------------------------------------------------------------------------
     def _materialise(self, batch: Any, pending: Sequence[Any]) -> Any:
@@ -374,7 +383,7 @@ class HipExecutionEngine(ExecutionEngine):
 
         if len(schema) != len(batch.cols):
             raise ExecutionError(f"writer schema {schema} does not match batch {batch.schema}")
-        cols = [self.dev.quantise_col(c, t, batch.n_dev_ptr) for c, (_, t) in zip(batch.cols, schema)]
+        cols = self.dev.quantise_cols(batch.cols, [t for _, t in schema], batch.n_dev_ptr)
         unchanged = all(a is b for a, b in zip(cols, batch.cols))
         return DBatch(list(schema), cols, batch.nrows, list(batch.unit_rows) if batch.unit_rows else None,
                       batch.nrows_dev, unit_ids=batch.unit_ids, total_units=batch.total_units, order=batch.order,

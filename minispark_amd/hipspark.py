@@ -116,7 +116,7 @@ SIGNATURES: dict[str, tuple] = {
         [_P, _COLP, _I32, _I32, _PROGP, _SPECP, _P, _P, _I64, _GEOMP, _P, _P, _P, _P, _P, _P, _P],
     ),
     "hs_agg_pack": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _SPECP, _P, _P, C.POINTER(_P), C.POINTER(_I32), _P, _P]),
-    "hs_agg_merge": (C.c_int, [_P, _COLP, _COLP, _SPECP, _P, _I64, _P, _I32, _P, _P, _P, _P]),
+    "hs_agg_merge": (C.c_int, [_P, _COLP, _COLP, _SPECP, _P, _I64, _I64, _P, _I32, _P, _P, _P, _P]),
     "hs_partition_ids": (C.c_int, [_P, _COLP, _P, _I64, _I32, _P]),
     "hs_partition_ws_bytes": (C.c_size_t, [_I64, _I32]),
     "hs_partition_perm": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P]),
@@ -126,6 +126,7 @@ SIGNATURES: dict[str, tuple] = {
     "hs_join_fill": (C.c_int, [_P, _COLP, _COLP, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),
     "hs_exclusive_scan_i64": (C.c_int, [_P, _P, _I64, _P, _P]),
     "hs_quantise": (C.c_int, [_P, _P, _I32, _I64, _P, _P, _P]),
+    "hs_quantise_many": (C.c_int, [_P, _I32, C.POINTER(_P), C.POINTER(_I32), _I64, _P, C.POINTER(_P), _P]),
     "hs_jit_set_enabled": (None, [C.c_int]),
     "hs_jit_get_enabled": (C.c_int, []),
     "hs_jit_stats": (None, [C.POINTER(_I32)]),
