@@ -184,14 +184,26 @@ typedef struct hs_agg_geom {
     size_t ws_bytes;     /* workspace bytes */
 } hs_agg_geom;
 
+/* One workgroup's share of a unit: rows [row_begin, row_end) of unit `unit` (the first quad may start up
+ * to 3 rows before the unit; those rows are masked by unit_begin). */
+typedef struct hs_chunk {
+    int64_t row_begin;   /* multiple of 4 */
+    int64_t row_end;
+    int64_t unit_begin;  /* first row of the unit */
+    int64_t unit;
+} hs_chunk;
+
 /* host_unit_rows: HOST copy of the unit boundaries [n_units+1].  Returns HS_E_LIMIT when
  * group_cap * (n_acc+1) private tables do not fit in LDS (caller then uses hs_agg_partial_global). */
 int hs_agg_partial_geom(const int64_t* host_unit_rows, int64_t n_units, int32_t n_acc, int32_t group_cap,
                         hs_agg_geom* out);
+/* Fill the HOST arrays the launch needs on the device: chunks[geom->n_chunks] and unit_chunk0[n_units+1]
+ * (first chunk of every unit).  Upload them once; they depend only on the unit boundaries and geometry. */
+int hs_agg_partial_chunks(const int64_t* host_unit_rows, int64_t n_units, const hs_agg_geom* geom,
+                          hs_chunk* host_chunks, int64_t* host_unit_chunk0);
 
 /* prog: [filter ops ... HS_OP_FILTER]* then [value ops ... HS_OP_AGG a]* ; cols[key_col] is the
- * GROUP BY column.  unit_rows / unit_chunk0: device arrays [n_units+1] (row boundaries, first chunk of
- * each unit).  Outputs, all [n_units * group_cap] slot-major per unit:
+ * GROUP BY column.  chunks / unit_chunk0: device copies of what hs_agg_partial_chunks produced.  Outputs, all [n_units * group_cap] slot-major per unit:
  *   out_rep   : a row index holding the slot's key, or -1 for an empty slot
  *   out_acc   : [n_units * group_cap * n_acc] 64-bit cells, ALREADY QUANTISED like a shuffle-file
  *               write (FLOAT aggregates rounded to f32 and widened back, INTEGER range-checked)
@@ -200,7 +212,7 @@ int hs_agg_partial_geom(const int64_t* host_unit_rows, int64_t n_units, int32_t 
  * scan kernel (NULL = none) - how bench.py measures the kernel's duration live.
  */
 int hs_agg_partial(void* stream, const hs_col* cols, int32_t n_cols, int32_t key_col, const hs_program* prog,
-                   const hs_agg_spec* spec, const int64_t* unit_rows, const int64_t* unit_chunk0, int64_t n_units,
+                   const hs_agg_spec* spec, const hs_chunk* chunks, const int64_t* unit_chunk0, int64_t n_units,
                    const hs_agg_geom* geom, int64_t* out_rep, uint64_t* out_acc, int32_t* out_ngroups, void* ws,
                    uint32_t* flags, void* ev_begin, void* ev_end);
 

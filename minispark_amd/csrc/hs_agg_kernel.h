@@ -32,7 +32,7 @@ struct AggMainArgs {
     int32_t group_cap;
     int32_t chunk_rows;
     int32_t pad;
-    const int64_t* unit_rows;
+    const hs_chunk* chunks;  // [n_chunks] one descriptor per workgroup
     const int64_t* unit_chunk0;
     int64_t n_units;
     uint64_t* part_keys;  // [n_chunks][GC]
@@ -297,19 +297,16 @@ __device__ __forceinline__ void hs_agg_main_body(const AggMainArgs& A) {
     int64_t* dreps = (int64_t*)(hs_lds + GC);
     uint64_t* tbl = hs_lds + 2 * GC;
 
-    // which unit does this chunk belong to?  (binary search over the first-chunk table)
+    // this workgroup's row range: one 32-byte descriptor (a wave-uniform scalar load)
     const int64_t chunk = blockIdx.x;
-    int64_t lo = 0, hi = A.n_units;  // invariant: unit_chunk0[lo] <= chunk < unit_chunk0[hi]
-    while (hi - lo > 1) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (A.unit_chunk0[mid] <= chunk) lo = mid; else hi = mid;
-    }
-    const int64_t u = lo;
-    const int64_t us = A.unit_rows[u], ue = A.unit_rows[u + 1];
-    const int64_t anchor = us & ~(int64_t)(HS_V - 1);
-    const int64_t c0 = anchor + (chunk - A.unit_chunk0[u]) * (int64_t)A.chunk_rows;
-    int64_t c1 = c0 + A.chunk_rows;
-    if (c1 > ue) c1 = ue;
+    const hs_chunk desc = A.chunks[chunk];
+    const int64_t us = desc.unit_begin, c0 = desc.row_begin, c1 = desc.row_end;
+
+    // the first quad's loads go out before the LDS tables are initialised: their latency hides the init
+    const int64_t stride = (int64_t)nthr * HS_V;
+    int64_t base = c0 + (int64_t)tid * HS_V;
+    typename Prog::Cells cur, nxt;
+    if (base < c1) Prog::load(A, base, nxt);
 
     for (int i = tid; i < GC; i += nthr) {
         dkeys[i] = HS_EMPTY_KEY;
@@ -330,10 +327,6 @@ __device__ __forceinline__ void hs_agg_main_body(const AggMainArgs& A) {
     ctx.err = 0;
 
     // software pipeline: the loads of step i+1 are in flight while step i is evaluated
-    const int64_t stride = (int64_t)nthr * HS_V;
-    int64_t base = c0 + (int64_t)tid * HS_V;
-    typename Prog::Cells cur, nxt;
-    if (base < c1) Prog::load(A, base, nxt);
     while (base < c1) {
         cur = nxt;
         const int64_t next_base = base + stride;
@@ -350,18 +343,39 @@ __device__ __forceinline__ void hs_agg_main_body(const AggMainArgs& A) {
     }
     __syncthreads();
 
-    // fixed-order reduction of the private tables: lanes stride the workgroup, then a shuffle tree
+    // Fixed-order reduction of the private tables.  A wave owns cells wave, wave+nwaves, ...; it folds
+    // each cell's lanes (stride 64), then a shuffle tree.  HS_RED cells are reduced together so that
+    // their shuffle chains (each ~6 dependent cross-lane hops) overlap instead of running back to back.
+    constexpr int HS_RED = 6;
     const uint32_t wave = tid / HS_WAVE, lane = tid % HS_WAVE, nwaves = nthr / HS_WAVE;
-    for (uint32_t cellid = wave; cellid < (uint32_t)(GC * NA); cellid += nwaves) {
-        const uint32_t s = cellid / NA, a = cellid % NA;
-        if (dreps[s] < 0) continue;  // wave-uniform
-        const uint32_t op = A.spec.op[a];
-        const bool is_int = A.spec.is_int[a] != 0;
-        uint64_t v = hs_acc_identity(op, is_int);
-        for (uint32_t t = lane; t < nthr; t += HS_WAVE) v = hs_acc_fold(op, is_int, v, tbl[cellid * nthr + t]);
+    const uint32_t ncells = (uint32_t)(GC * NA);
+    for (uint32_t c0id = wave; c0id < ncells; c0id += nwaves * HS_RED) {
+        uint64_t v[HS_RED];
+        uint32_t ops[HS_RED];
+        bool ints[HS_RED], on[HS_RED];
 #pragma unroll
-        for (int d = HS_WAVE / 2; d >= 1; d >>= 1) v = hs_acc_fold(op, is_int, v, hs_shfl_down64(v, d));
-        if (lane == 0) A.part_acc[((int64_t)chunk * GC + s) * NA + a] = v;
+        for (int k = 0; k < HS_RED; ++k) {
+            const uint32_t cellid = c0id + (uint32_t)k * nwaves;
+            on[k] = cellid < ncells && dreps[cellid / NA] >= 0;  // wave-uniform
+            const uint32_t a = on[k] ? cellid % NA : 0;
+            ops[k] = A.spec.op[a];
+            ints[k] = A.spec.is_int[a] != 0;
+            v[k] = hs_acc_identity(ops[k], ints[k]);
+            if (on[k])
+                for (uint32_t t = lane; t < nthr; t += HS_WAVE) v[k] = hs_acc_fold(ops[k], ints[k], v[k], tbl[cellid * nthr + t]);
+        }
+#pragma unroll
+        for (int d = HS_WAVE / 2; d >= 1; d >>= 1) {
+#pragma unroll
+            for (int k = 0; k < HS_RED; ++k) v[k] = hs_acc_fold(ops[k], ints[k], v[k], hs_shfl_down64(v[k], d));
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < HS_RED; ++k) {
+                const uint32_t cellid = c0id + (uint32_t)k * nwaves;
+                if (on[k]) A.part_acc[((int64_t)chunk * GC + cellid / NA) * NA + cellid % NA] = v[k];
+            }
+        }
     }
     for (int i = tid; i < GC; i += nthr) {
         A.part_keys[chunk * GC + i] = dkeys[i];

@@ -524,13 +524,12 @@ class Device:
                 + self.lib.hs_last_error().decode()
             )
         hs.check(rc, "hs_agg_partial_geom")
-        # first chunk of every unit (host arithmetic mirrors hs_agg_partial_geom)
+        # per-workgroup row ranges + first chunk of every unit, computed by the library, uploaded once
+        chunks = np.zeros((max(int(geom.n_chunks), 1), 4), dtype=np.int64)
         chunk0 = np.zeros(n_units + 1, dtype=np.int64)
-        ur = np.asarray(batch.unit_rows, dtype=np.int64)
-        span = ur[1:] - (ur[:-1] & ~np.int64(3))
-        chunk0[1:] = np.cumsum(np.where(span > 0, (span + geom.chunk_rows - 1) // geom.chunk_rows, 0))
-        if int(chunk0[-1]) != geom.n_chunks:
-            raise DeviceError("chunk geometry mismatch between host and library")
+        hs.check(self.lib.hs_agg_partial_chunks(host_units, n_units, C.byref(geom),
+                                                chunks.ctypes.data_as(C.POINTER(hs.hs_chunk)),
+                                                chunk0.ctypes.data_as(C.POINTER(C.c_int64))), "hs_agg_partial_chunks")
         slots = n_units * cap
         acc_kinds = [hs.I32 if is_int else hs.F32 for is_int in low.acc_is_int]
         key_idx = low.program.columns[low.key_slot]
@@ -565,7 +564,7 @@ class Device:
             "cols": self._cols_array(batch, low.program.columns), "n_cols": len(low.program.columns),
             "key_slot": low.key_slot, "key_idx": key_idx, "prog": low.program.to_struct(),
             "spec": low.spec(), "geom": geom, "n_units": n_units, "slots": slots, "agg_to_acc": low.agg_to_acc,
-            "d_units": self.to_device(ur), "d_chunk0": self.to_device(chunk0),
+            "d_units": self.to_device(chunks.reshape(-1)), "d_chunk0": self.to_device(chunk0),
             "out_rep": self.empty(slots, torch.int64), "out_acc": self.empty(max(slots * n_acc, 1), torch.int64),
             "ngroups": self.empty(max(n_units, 1), torch.int32), "ws": self.workspace(geom.ws_bytes),
             "pack_start": self.empty(n_units + 1, torch.int64), "dense_rep": self.empty(max(slots, 1), torch.int64),

@@ -77,6 +77,10 @@ class hs_agg_spec(C.Structure):
     ]
 
 
+class hs_chunk(C.Structure):
+    _fields_ = [("row_begin", C.c_int64), ("row_end", C.c_int64), ("unit_begin", C.c_int64), ("unit", C.c_int64)]
+
+
 class hs_agg_geom(C.Structure):
     _fields_ = [
         ("group_cap", C.c_int32),
@@ -111,6 +115,7 @@ SIGNATURES: dict[str, tuple] = {
     "hs_concat_lens": (C.c_int, [_P, _COLP, _I32, _I64, _P, _P]),
     "hs_concat_bytes": (C.c_int, [_P, _COLP, _I32, _I64, _P, _P]),
     "hs_agg_partial_geom": (C.c_int, [C.POINTER(_I64), _I64, _I32, _I32, _GEOMP]),
+    "hs_agg_partial_chunks": (C.c_int, [C.POINTER(_I64), _I64, _GEOMP, C.POINTER(hs_chunk), C.POINTER(_I64)]),
     "hs_agg_partial": (
         C.c_int,
         [_P, _COLP, _I32, _I32, _PROGP, _SPECP, _P, _P, _I64, _GEOMP, _P, _P, _P, _P, _P, _P, _P],
