@@ -171,12 +171,19 @@ def main() -> None:
                 "exchange": "none" if world == 1 else f"one all_gather of partial-row slabs per query ({backend})",
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_agg_main", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "bound": "hbm", "kernel": "k_agg_jit (k_agg_main body)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel_ms": kernel_avg_ms,
                 "rows_per_launch": local_rows, "launch": scan,
             },
             "whole_step_GBps_per_gpu": synth.Q1_BYTES_PER_ROW * local_rows / (elapsed / args.steps) / 1e9,
         }
+        # HBM traffic of the scan kernel per launch from the PMC counters: rocprofv3 cannot run inside this
+        # process, so the figure comes from the committed counter passes of this same command (profiles/)
+        pmc = ROOT / "profiles" / "r01_pmc_hbm_traffic_q1_sf100.json"
+        if world == 1 and pmc.exists() and total_rows == 600_037_902:
+            t = json.loads(pmc.read_text())
+            out["roofline"]["traffic"] = t["hbm_read_bytes_per_launch (FETCH_SIZE*1024*2)"] + t["hbm_write_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = "profiles/r01_pmc_hbm_traffic_q1_sf100.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes)"
         if world == 1 and not args.no_cpu_baseline:
             blocks = min(args.sample_blocks, len(table.block_rows))
             sample = synth.make_lineitem(engine.dev, scratch / "sample.bin", sum(table.block_rows[:blocks]))

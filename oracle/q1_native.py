@@ -100,4 +100,13 @@ def run(cols: dict[str, np.ndarray], block_rows: list[int], cutoff_us: int, thre
 
 
 def host_threads() -> int:
-    return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    """Usable host cores: the affinity mask, capped by the cgroup CPU quota when there is one (a GPU box
+    exposes all host cores in the mask but grants this container only a share of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
