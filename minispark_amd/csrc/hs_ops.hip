@@ -211,7 +211,7 @@ extern "C" int hs_exclusive_scan_i64(void* stream, const int64_t* counts, int64_
 
 // ---- A3: filter = stable compaction to a row index list (reference tasks.py:177) -----------------------
 extern "C" int hs_compact(void* stream, const uint8_t* mask, int64_t nrows, int64_t* sel, int64_t* count, void* ws) {
-    if ((!mask && nrows > 0) || !sel || !count || !ws || nrows < 0) {
+    if ((!mask && nrows > 0) || (!sel && nrows > 0) || !count || !ws || nrows < 0) {
         hs_set_error("hs_compact: bad arguments");
         return HS_E_ARG;
     }

@@ -167,7 +167,7 @@ class Device:
         return torch.empty(max(int(nbytes), 256) + PAD, dtype=torch.uint8, device=self.device)
 
     def to_device(self, arr: np.ndarray, dtype: torch.dtype | None = None) -> torch.Tensor:
-        src = torch.from_numpy(np.ascontiguousarray(arr))
+        src = torch.from_numpy(np.require(arr, requirements=["C", "W"]))  # copies read-only views (np.frombuffer)
         dst = self.empty(src.numel(), dtype or src.dtype)
         dst.copy_(src, non_blocking=False)
         return dst
