@@ -270,6 +270,23 @@ int hs_partition_perm(void* stream, const uint8_t* part, int64_t nrows, int32_t 
 size_t hs_join_build_ws_bytes(int64_t n_left, int64_t table_cap);
 int hs_join_build(void* stream, const hs_col* left_key, int64_t n_left, int64_t table_cap, uint64_t* table_keys,
                   int64_t* table_reps, int64_t* slot_start, int64_t* rows, void* ws, uint32_t* flags);
+/* The same build over positions 0..n-1 of an input whose position i is row sel[i] (or row0 + i when sel is
+ * NULL): positions[] receives POSITIONS, ascending inside every slot; table_reps[] holds row ids.
+ * This is the global-memory tier of GROUP BY (any cardinality): see hs_group_fold. */
+int hs_group_build(void* stream, const hs_col* key, const int64_t* sel, int64_t row0, int64_t n, int64_t table_cap,
+                   uint64_t* table_keys, int64_t* table_reps, int64_t* slot_start, int64_t* positions, void* ws,
+                   uint32_t* flags);
+/* mask[s] = 1 for non-empty slots (compact it with hs_compact to get the dense slot list). */
+int hs_group_mask(void* stream, const int64_t* slot_start, int64_t table_cap, uint8_t* mask);
+/* One lane per group folds val_cols[a][position] over the group's positions front to back - the reference's
+ * own order (fill_aggregators, tasks.py:295-310), so fp64 sums are bit-identical to Python's.  Outputs:
+ * out_rep_row[g] = row id of the group's first row, out_acc[a * n_groups_max + g] = 64-bit cell (quantised
+ * like a shuffle-file write when quantise != 0). */
+int hs_group_fold(void* stream, const hs_col* val_cols, const hs_agg_spec* spec, const int64_t* slot_list,
+                  int64_t n_groups_max, const int64_t* n_groups_dev, const int64_t* slot_start,
+                  const int64_t* positions, const int64_t* sel, int64_t row0, int32_t quantise, int64_t* out_rep_row,
+                  uint64_t* out_acc, uint32_t* flags);
+
 /* Probe pass 1: match count per right row -> counts[n_right]. */
 int hs_join_count(void* stream, const hs_col* left_key, const hs_col* right_key, int64_t n_right,
                   int64_t table_cap, const uint64_t* table_keys, const int64_t* table_reps,

@@ -704,12 +704,14 @@ __device__ __forceinline__ int64_t gdict_find(const uint64_t* keys, const int64_
     return -1;
 }
 
-__global__ void __launch_bounds__(256) k_join_slots(const hs_col key, int64_t n, int64_t cap, uint64_t* tkeys,
-                                                    int64_t* treps, int64_t* slot_of_row, int64_t* slot_count,
-                                                    uint32_t* flags) {
+// position i of the build input is row sel[i] (or row0 + i) of the key column
+__global__ void __launch_bounds__(256) k_join_slots(const hs_col key, const int64_t* sel, int64_t row0, int64_t n,
+                                                    int64_t cap, uint64_t* tkeys, int64_t* treps, int64_t* slot_of_row,
+                                                    int64_t* slot_count, uint32_t* flags) {
     const bool hashed = !hs_col_packs(key);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t s = gdict_upsert(tkeys, treps, (uint64_t)cap - 1, key, hashed, hs_key_at(key, i), i);
+        const int64_t row = sel ? sel[i] : row0 + i;
+        const int64_t s = gdict_upsert(tkeys, treps, (uint64_t)cap - 1, key, hashed, hs_key_at(key, row), row);
         slot_of_row[i] = s;
         if (s < 0) atomicOr(flags, HS_FLAG_DICT_FULL);
         else atomicAdd((unsigned long long*)&slot_count[s], 1ull);
@@ -745,9 +747,28 @@ extern "C" size_t hs_join_build_ws_bytes(int64_t n_left, int64_t table_cap) {
     return (size_t)(n_left + 2 * table_cap + 2) * 8 + hs_scan_ws_bytes(table_cap) + 64;
 }
 
+static int group_build(void* stream, const hs_col* left_key, const int64_t* sel, int64_t row0, int64_t n_left,
+                       int64_t table_cap, uint64_t* table_keys, int64_t* table_reps, int64_t* slot_start, int64_t* rows,
+                       void* ws, uint32_t* flags);
+
 extern "C" int hs_join_build(void* stream, const hs_col* left_key, int64_t n_left, int64_t table_cap,
                              uint64_t* table_keys, int64_t* table_reps, int64_t* slot_start, int64_t* rows, void* ws,
                              uint32_t* flags) {
+    return group_build(stream, left_key, nullptr, 0, n_left, table_cap, table_keys, table_reps, slot_start, rows, ws,
+                       flags);
+}
+
+// Group dictionary over positions 0..n-1 of an input whose position i is row sel[i] (or row0 + i): the same
+// build as the join's.  rows[] receives POSITIONS (ascending inside every slot); table_reps[] holds ROW ids.
+extern "C" int hs_group_build(void* stream, const hs_col* key, const int64_t* sel, int64_t row0, int64_t n,
+                              int64_t table_cap, uint64_t* table_keys, int64_t* table_reps, int64_t* slot_start,
+                              int64_t* positions, void* ws, uint32_t* flags) {
+    return group_build(stream, key, sel, row0, n, table_cap, table_keys, table_reps, slot_start, positions, ws, flags);
+}
+
+static int group_build(void* stream, const hs_col* left_key, const int64_t* sel, int64_t row0, int64_t n_left,
+                       int64_t table_cap, uint64_t* table_keys, int64_t* table_reps, int64_t* slot_start, int64_t* rows,
+                       void* ws, uint32_t* flags) {
     if (!left_key || !table_keys || !table_reps || !slot_start || (!rows && n_left > 0) || !ws || !flags ||
         n_left < 0 || table_cap < 1 || (table_cap & (table_cap - 1))) {
         hs_set_error("hs_join_build: bad arguments (table_cap must be a power of two)");
@@ -763,8 +784,8 @@ extern "C" int hs_join_build(void* stream, const hs_col* left_key, int64_t n_lef
                        ~0ull);
     hipMemsetAsync(slot_count, 0, (size_t)table_cap * 16, s);  // slot_count + cursor
     if (n_left > 0)
-        hipLaunchKernelGGL(k_join_slots, dim3(grid_for(n_left, 256)), dim3(256), 0, s, *left_key, n_left, table_cap,
-                           table_keys, table_reps, slot_of_row, slot_count, flags);
+        hipLaunchKernelGGL(k_join_slots, dim3(grid_for(n_left, 256)), dim3(256), 0, s, *left_key, sel, row0, n_left,
+                           table_cap, table_keys, table_reps, slot_of_row, slot_count, flags);
     int rc = run_scan(s, InI64{slot_count}, table_cap, EmitOffsets{slot_start}, slot_start + table_cap, scan_ws,
                       "hs_join_build");
     if (rc) return rc;
@@ -774,6 +795,91 @@ extern "C" int hs_join_build(void* stream, const hs_col* left_key, int64_t n_lef
         hipLaunchKernelGGL(k_join_sort, dim3(grid_for(table_cap, 256)), dim3(256), 0, s, slot_start, table_cap, rows);
     }
     HS_CHECK_LAUNCH("hs_join_build");
+    return HS_OK;
+}
+
+// ---- A5/A7 global-memory tier: fold the value columns of every group in ascending position order --------------
+// (reference fill_aggregators tasks.py:295-310: counter[key] = counter.get(key, identity) op x, row by row - one
+// lane per group walks its row list front to back, so the fp64 additions happen in EXACTLY the reference's order)
+__global__ void __launch_bounds__(256) k_group_mask(const int64_t* slot_start, int64_t cap, uint8_t* mask) {
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < cap; s += (int64_t)gridDim.x * blockDim.x)
+        mask[s] = slot_start[s + 1] > slot_start[s];
+}
+struct GroupFoldArgs {
+    hs_col vals[HS_MAX_ACC];
+    hs_agg_spec spec;
+    const int64_t* slot_list;   // dense list of non-empty slots
+    int64_t n_groups_max;
+    const int64_t* n_groups_dev;
+    const int64_t* slot_start;
+    const int64_t* positions;
+    const int64_t* sel;
+    int64_t row0;
+    int32_t quantise;
+    int32_t pad;
+    int64_t* out_rep_row;  // [n_groups_max] row id of the group's first row
+    uint64_t* out_acc;     // [n_acc][n_groups_max]
+    uint32_t* flags;
+};
+__global__ void __launch_bounds__(256) k_group_fold(const GroupFoldArgs A_kernarg) {
+    HS_KERNARG(GroupFoldArgs, A);
+    uint32_t err = 0;
+    const int64_t ng = capped(A.n_groups_max, A.n_groups_dev);
+    const int NA = A.spec.n_acc;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ng; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = A.slot_list[g];
+        const int64_t b = A.slot_start[s], e = A.slot_start[s + 1];
+        const int64_t first = A.positions[b];
+        A.out_rep_row[g] = A.sel ? A.sel[first] : A.row0 + first;
+        for (int a = 0; a < NA; ++a) {
+            const uint32_t op = A.spec.op[a];
+            const bool is_int = A.spec.is_int[a] != 0;
+            uint64_t v = hs_acc_identity(op, is_int);
+            for (int64_t q = b; q < e; ++q) v = hs_acc_fold(op, is_int, v, hs_load_cell(A.vals[a], A.positions[q]));
+            if (A.quantise) v = hs_quantise_cell(is_int, v, err);
+            A.out_acc[(int64_t)a * A.n_groups_max + g] = v;
+        }
+    }
+    if (err) atomicOr(A.flags, err);
+}
+extern "C" int hs_group_mask(void* stream, const int64_t* slot_start, int64_t table_cap, uint8_t* mask) {
+    if (!slot_start || !mask || table_cap < 1) {
+        hs_set_error("hs_group_mask: bad arguments");
+        return HS_E_ARG;
+    }
+    hipLaunchKernelGGL(k_group_mask, dim3(grid_for(table_cap, 256)), dim3(256), 0, (hipStream_t)stream, slot_start,
+                       table_cap, mask);
+    HS_CHECK_LAUNCH("hs_group_mask");
+    return HS_OK;
+}
+extern "C" int hs_group_fold(void* stream, const hs_col* val_cols, const hs_agg_spec* spec, const int64_t* slot_list,
+                             int64_t n_groups_max, const int64_t* n_groups_dev, const int64_t* slot_start,
+                             const int64_t* positions, const int64_t* sel, int64_t row0, int32_t quantise,
+                             int64_t* out_rep_row, uint64_t* out_acc, uint32_t* flags) {
+    if (n_groups_max == 0) return HS_OK;
+    if (!spec || !slot_list || !slot_start || !positions || !out_rep_row || !out_acc || !flags || n_groups_max < 0 ||
+        spec->n_acc < 0 || spec->n_acc > HS_MAX_ACC || (spec->n_acc > 0 && !val_cols)) {
+        hs_set_error("hs_group_fold: bad arguments");
+        return HS_E_ARG;
+    }
+    GroupFoldArgs A;
+    for (int a = 0; a < HS_MAX_ACC; ++a)
+        A.vals[a] = a < spec->n_acc ? val_cols[a] : hs_col{HS_U8, -1, nullptr, nullptr, nullptr};
+    A.spec = *spec;
+    A.slot_list = slot_list;
+    A.n_groups_max = n_groups_max;
+    A.n_groups_dev = n_groups_dev;
+    A.slot_start = slot_start;
+    A.positions = positions;
+    A.sel = sel;
+    A.row0 = row0;
+    A.quantise = quantise;
+    A.pad = 0;
+    A.out_rep_row = out_rep_row;
+    A.out_acc = out_acc;
+    A.flags = flags;
+    hipLaunchKernelGGL(k_group_fold, dim3(grid_for(n_groups_max, 256)), dim3(256), 0, (hipStream_t)stream, A);
+    HS_CHECK_LAUNCH("hs_group_fold");
     return HS_OK;
 }
 

@@ -106,6 +106,10 @@ class DBatch:
         raise ValueError(f'Column "{name}" not found in schema {self.schema}')
 
 
+class TierExceeded(NotImplementedError):
+    """The on-chip (LDS) aggregation tier cannot hold this launch: the engine switches to the global tier."""
+
+
 class RetryWithLargerDictionary(Exception):
     """A launch met more distinct group keys than its dictionary capacity (noticed at the query's single
     host round trip); the engine re-runs the query with larger capacities."""
@@ -512,14 +516,14 @@ class Device:
                          cap: int, slab_rows: int | None = None) -> dict:
         low = lower_aggregate(batch.schema, batch.kinds, filters, group_by, agg_columns)
         if low.numeric_slots > hs.HS_FUSED_COLS:
-            raise NotImplementedError(f"aggregate reads more than {hs.HS_FUSED_COLS} numeric columns")
+            raise TierExceeded(f"aggregate reads more than {hs.HS_FUSED_COLS} numeric columns")
         n_units = batch.n_units
         n_acc = len(low.acc_ops)
         host_units = (C.c_int64 * (n_units + 1))(*batch.unit_rows)
         geom = hs.hs_agg_geom()
         rc = self.lib.hs_agg_partial_geom(host_units, n_units, n_acc, cap, C.byref(geom))
         if rc == 2:
-            raise NotImplementedError(
+            raise TierExceeded(
                 f"GROUP BY with more than {cap // 2} groups per workgroup x {n_acc} aggregates exceeds the LDS tier: "
                 + self.lib.hs_last_error().decode()
             )
@@ -608,7 +612,7 @@ class Device:
                                    batch.total_units or 0, n, batch.n_dev_ptr, cap,
                                    out_rep.data_ptr(), out_acc.data_ptr(), ngroups.data_ptr(), self.flags.data_ptr())
         if rc == 2:
-            raise NotImplementedError("final merge exceeds the LDS tier: " + self.lib.hs_last_error().decode())
+            raise TierExceeded("final merge exceeds the LDS tier: " + self.lib.hs_last_error().decode())
         hs.check(rc, "hs_agg_merge")
         self.last_merge_cap = cap
         n_out = min(cap, n)
@@ -622,6 +626,148 @@ class Device:
             raw = out_acc[i * cap: i * cap + n_out]
             cols.append(DCol(hs.I64, raw, n_out) if is_int[i] else DCol(hs.F64, raw.view(torch.float64), n_out))
         return DBatch(list(out_schema), cols, n_out, None, ngroups_dev)
+
+    # ---- global-memory aggregation tier (any cardinality) ---------------------------------------------------
+    def concat_cols(self, parts: Sequence[DCol]) -> DCol:
+        """Row-wise concatenation of column pieces (torch.cat = memory plumbing)."""
+        if len(parts) == 1:
+            return parts[0]
+        kind = parts[0].kind
+        n = sum(p.n for p in parts)
+        if kind == hs.STR:
+            lens = torch.cat([p.lens[: p.n] for p in parts])
+            sizes = [int(p.lens[: p.n].sum().item()) if p.fixed_len < 0 else p.n * p.fixed_len for p in parts]
+            data = torch.cat([p.data[:sz] for p, sz in zip(parts, sizes)])
+            padded_l, padded_d = self.empty(n, torch.uint8), self.empty(int(sum(sizes)), torch.uint8)
+            padded_l.copy_(lens)
+            padded_d.copy_(data)
+            return self.string_col(padded_l, padded_d, n)
+        out = self.empty(n, _TORCH_DTYPE[kind])
+        out.copy_(torch.cat([p.data[: p.n] for p in parts]))
+        return DCol(kind, out, n)
+
+    def _group_build(self, key: DCol, sel: torch.Tensor | None, n: int):
+        cap = 16
+        while cap < 2 * max(n, 1):
+            cap *= 2
+        tkeys = self.empty(cap, torch.int64)
+        treps = self.empty(cap, torch.int64)
+        slot_start = self.empty(cap + 1, torch.int64)
+        positions = self.empty(max(n, 1), torch.int64)
+        ws = self.workspace(self.lib.hs_join_build_ws_bytes(n, cap))
+        k = key.as_hs()
+        hs.check(self.lib.hs_group_build(self.stream, C.byref(k), sel.data_ptr() if sel is not None else None, 0, n, cap,
+                                         tkeys.data_ptr(), treps.data_ptr(), slot_start.data_ptr(), positions.data_ptr(),
+                                         ws.data_ptr(), self.flags.data_ptr()), "hs_group_build")
+        mask = self.empty(cap, torch.uint8)
+        hs.check(self.lib.hs_group_mask(self.stream, slot_start.data_ptr(), cap, mask.data_ptr()), "hs_group_mask")
+        slot_list = self.empty(cap, torch.int64)
+        count = self.empty(1, torch.int64)
+        ws2 = self.workspace(self.lib.hs_scan_ws_bytes(cap))
+        hs.check(self.lib.hs_compact(self.stream, mask.data_ptr(), cap, slot_list.data_ptr(), count.data_ptr(),
+                                     ws2.data_ptr()), "hs_compact")
+        return slot_start, positions, slot_list, int(count.item())
+
+    def _group_fold(self, vals: Sequence[DCol], ops: Sequence[int], is_int: Sequence[bool], slot_start, positions,
+                    slot_list, n_groups: int, sel: torch.Tensor | None, quantise: bool):
+        spec = hs.hs_agg_spec()
+        spec.n_acc = len(vals)
+        for i, (op, integer) in enumerate(zip(ops, is_int)):
+            spec.op[i] = op
+            spec.is_int[i] = 1 if integer else 0
+        arr = (hs.hs_col * max(len(vals), 1))()
+        for i, v in enumerate(vals):
+            arr[i] = v.as_hs()
+        rep_row = self.empty(max(n_groups, 1), torch.int64)
+        out_acc = self.empty(max(n_groups * len(vals), 1), torch.int64)
+        hs.check(self.lib.hs_group_fold(self.stream, arr, C.byref(spec), slot_list.data_ptr(), n_groups, None,
+                                        slot_start.data_ptr(), positions.data_ptr(),
+                                        sel.data_ptr() if sel is not None else None, 0, 1 if quantise else 0,
+                                        rep_row.data_ptr(), out_acc.data_ptr(), self.flags.data_ptr()), "hs_group_fold")
+        cols = []
+        for i, integer in enumerate(is_int):
+            raw = out_acc[i * n_groups: (i + 1) * n_groups]
+            cols.append(DCol(hs.I64, raw, n_groups) if integer else DCol(hs.F64, raw.view(torch.float64), n_groups))
+        return rep_row, cols
+
+    def aggregate_partial_global(self, batch: DBatch, filters: Sequence[Any], group_by: Any,
+                                 agg_columns: Sequence[Any], out_schema: Schema) -> DBatch:
+        """Partial aggregate for any number of groups: per unit, an HBM dictionary over the surviving rows'
+        keys with per-group row lists, then one lane per group folds the aggregate arguments in row order
+        (bit-identical to the reference's sequential Python sums).  Used when the on-chip tiers do not fit."""
+        from .lowering import AGG_CODES, expr_key, unalias  # noqa: PLC0415
+
+        batch = self.resolve(batch)
+        key_idx = batch.column_index(unalias(group_by).name)
+        acc_of: dict[tuple, int] = {}
+        args: list[Any] = []
+        ops: list[int] = []
+        agg_to_acc: list[int] = []
+        for agg in agg_columns:
+            ident = (agg.type, expr_key(agg.original_col))
+            if ident not in acc_of:
+                acc_of[ident] = len(args)
+                args.append(agg.original_col)
+                ops.append(AGG_CODES[agg.type])
+            agg_to_acc.append(acc_of[ident])
+        if filters:
+            sel_all, count = self.filter_select(batch, filters)
+            bounds = torch.searchsorted(sel_all[:count].contiguous(),
+                                        torch.tensor(batch.unit_rows, dtype=torch.int64, device=self.device)).tolist()
+        else:
+            sel_all, bounds = None, list(batch.unit_rows)
+        key_parts: list[DCol] = []
+        acc_parts: list[list[DCol]] = [[] for _ in args]
+        unit_rows = [0]
+        for u in range(batch.n_units):
+            lo, hi = int(bounds[u]), int(bounds[u + 1])
+            n = hi - lo
+            if n > 0:
+                sel = sel_all[lo:hi] if sel_all is not None else torch.arange(lo, hi, dtype=torch.int64, device=self.device)
+                sel = sel.contiguous()
+                vals = self.eval_numeric(batch, args, sel=sel, n=n)
+                is_int = [tag in ("I", "B") for _, tag in vals]
+                slot_start, positions, slot_list, ng = self._group_build(batch.cols[key_idx], sel, n)
+                rep_row, cols = self._group_fold([v for v, _ in vals], ops, is_int, slot_start, positions, slot_list, ng,
+                                                 sel, quantise=True)
+                key_parts.append(self.gather_col(batch.cols[key_idx], rep_row, ng))
+                types = [ColumnType.INTEGER if i else ColumnType.FLOAT for i in is_int]
+                for a, col in enumerate(self.quantise_cols(cols, types)):
+                    acc_parts[a].append(col)
+                unit_rows.append(unit_rows[-1] + ng)
+            else:
+                unit_rows.append(unit_rows[-1])
+        total = unit_rows[-1]
+        if total == 0:
+            empty_key = self.gather_col(batch.cols[key_idx], self.empty(0, torch.int64), 0)
+            out_cols = [empty_key] + [DCol(FILE_KIND[t], self.empty(0, _TORCH_DTYPE[FILE_KIND[t]]), 0)
+                                      for _, t in out_schema[1:]]
+            return DBatch(list(out_schema), out_cols, 0, unit_rows)
+        key_col = self.concat_cols(key_parts)
+        accs = [self.concat_cols(parts) for parts in acc_parts]
+        return DBatch(list(out_schema), [key_col] + [accs[a] for a in agg_to_acc], total, unit_rows)
+
+    def aggregate_merge_global(self, batch: DBatch, agg_columns: Sequence[Any], out_schema: Schema) -> DBatch:
+        """Final merge for any number of groups: dictionary over the partial rows' keys, row lists in merge
+        order, one lane per group folds its partials front to back (the reference's order)."""
+        batch = self.resolve(batch)
+        n = batch.nrows
+        sel = None
+        if batch.order is not None:  # multi-GPU: visit rows by (block id, row); padding rows (order < 0) dropped
+            order = batch.order[:n]
+            perm = torch.argsort(order, stable=True)
+            n_pad = int((order < 0).sum().item())
+            sel = perm[n_pad:].contiguous()
+            n = n - n_pad
+        ops = [{"sum": hs.AGG_SUM, "min": hs.AGG_MIN, "max": hs.AGG_MAX}[a.type] for a in agg_columns]
+        vals = batch.cols[1: 1 + len(agg_columns)]
+        is_int = [v.kind in (hs.I32, hs.I64) for v in vals]
+        if sel is not None:  # fold reads values by POSITION: bring them into visiting order
+            vals = [self.gather_col(v, sel, n) for v in vals]
+        slot_start, positions, slot_list, ng = self._group_build(batch.cols[0], sel, n)
+        rep_row, cols = self._group_fold(vals, ops, is_int, slot_start, positions, slot_list, ng, sel, quantise=False)
+        key_col = self.gather_col(batch.cols[0], rep_row, ng)
+        return DBatch(list(out_schema), [key_col] + cols, ng, [0, ng])
 
     # ---- hash partitioning (A6/A9) -------------------------------------------------------------------------
     def partition(self, batch: DBatch, key_index: int, n_parts: int) -> tuple[torch.Tensor, list[int]]:

@@ -104,6 +104,8 @@ class HipExecutionEngine(ExecutionEngine):
         self._made_dirs: set[Path] = set()
         self.group_cap_hint = 4   # dictionary capacity per workgroup of the partial aggregate (grows on overflow)
         self.merge_cap_hint = 16  # dictionary capacity of the final merge (grows on overflow)
+        self._global_partial: set[int] = set()  # AggregateTask ids (of cached plans) running on the global tier
+        self._global_merge: set[int] = set()
         self.last_stats: dict[str, Any] = {}
         self.dist: Any = None  # torch.distributed once enable_distributed() was called
         self.rank, self.world = 0, 1
@@ -162,8 +164,11 @@ class HipExecutionEngine(ExecutionEngine):
                     stage.job_results.extend(results)
                 return results
             except RetryWithLargerDictionary:
-                # more distinct GROUP BY keys than the dictionaries were sized for: grow and re-run
+                # more distinct GROUP BY keys than the dictionaries were sized for: grow and re-run; past the
+                # on-chip limits the stages switch to the global-memory tier (TierExceeded in _run_stage)
                 self.group_cap_hint *= 2
+                if self.merge_cap_hint >= 4096:
+                    self._merge_overflowed = True
                 self.merge_cap_hint = min(self.merge_cap_hint * 4, 4096)
             except (HipSparkError, DeviceError) as e:
                 raise ExecutionError(str(e)) from e
@@ -203,6 +208,8 @@ class HipExecutionEngine(ExecutionEngine):
 
     # ---- stage execution -------------------------------------------------------------------------------
     def _run_stage(self, stage: Any, outputs: dict[int, Any]) -> list[JobResult]:
+        from .device import TierExceeded  # noqa: PLC0415
+
         producer, consumers, writer = stage.producer, list(stage.consumers), stage.writer
         kind = _cls(producer)
         if kind == "LoadTableBlockTask":
@@ -227,7 +234,14 @@ class HipExecutionEngine(ExecutionEngine):
                 batch = self._project(batch, pending, task)
                 pending = []
             elif tname == "AggregateTask":
-                if task.before_shuffle:
+                if task.before_shuffle and (id(task) in self._global_partial or self.group_cap_hint > 256):
+                    self._global_partial.add(id(task))
+                    if self.dist is not None:
+                        raise NotImplementedError("multi-GPU GROUP BY beyond the on-chip tiers")
+                    batch = self.dev.aggregate_partial_global(batch, pending, task.group_by_column, task.agg_columns,
+                                                              task.inferred_schema)
+                    pending = []
+                elif task.before_shuffle:
                     slab_rows = None
                     if self.dist is not None:
                         from .distributed import max_local_units  # noqa: PLC0415
@@ -235,15 +249,30 @@ class HipExecutionEngine(ExecutionEngine):
                         if batch.total_units is None:
                             raise NotImplementedError("multi-GPU aggregation needs a block-partitioned table scan")
                         slab_rows = max_local_units(batch.total_units, self.world) * self.group_cap_hint
-                    batch = self.dev.aggregate_partial(batch, pending, task.group_by_column, task.agg_columns,
-                                                       task.inferred_schema, self.group_cap_hint, cache_key=id(task),
-                                                       slab_rows=slab_rows)
-                    self.group_cap_hint = max(self.group_cap_hint, getattr(self.dev, "last_group_cap", 4))
+                    try:
+                        batch = self.dev.aggregate_partial(batch, pending, task.group_by_column, task.agg_columns,
+                                                           task.inferred_schema, self.group_cap_hint,
+                                                           cache_key=id(task), slab_rows=slab_rows)
+                    except TierExceeded:
+                        if self.dist is not None:
+                            raise
+                        self._global_partial.add(id(task))
+                        batch = self.dev.aggregate_partial_global(batch, pending, task.group_by_column,
+                                                                  task.agg_columns, task.inferred_schema)
                     pending = []
                 else:
                     batch = self._materialise(batch, pending)
                     pending = []
-                    batch = self.dev.aggregate_merge(batch, task.agg_columns, task.inferred_schema, self.merge_cap_hint)
+                    use_global = id(task) in self._global_merge or getattr(self, "_merge_overflowed", False)
+                    if not use_global:
+                        try:
+                            batch = self.dev.aggregate_merge(batch, task.agg_columns, task.inferred_schema,
+                                                             self.merge_cap_hint)
+                        except TierExceeded:
+                            use_global = True
+                    if use_global:
+                        self._global_merge.add(id(task))
+                        batch = self.dev.aggregate_merge_global(batch, task.agg_columns, task.inferred_schema)
             else:
                 raise NotImplementedError(f"consumer {tname}")
         batch = self._materialise(batch, pending)

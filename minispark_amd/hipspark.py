@@ -127,6 +127,9 @@ SIGNATURES: dict[str, tuple] = {
     "hs_partition_perm": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P]),
     "hs_join_build_ws_bytes": (C.c_size_t, [_I64, _I64]),
     "hs_join_build": (C.c_int, [_P, _COLP, _I64, _I64, _P, _P, _P, _P, _P, _P]),
+    "hs_group_build": (C.c_int, [_P, _COLP, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P]),
+    "hs_group_mask": (C.c_int, [_P, _P, _I64, _P]),
+    "hs_group_fold": (C.c_int, [_P, _COLP, _SPECP, _P, _I64, _P, _P, _P, _P, _I64, _I32, _P, _P, _P]),
     "hs_join_count": (C.c_int, [_P, _COLP, _COLP, _I64, _I64, _P, _P, _P, _P]),
     "hs_join_fill": (C.c_int, [_P, _COLP, _COLP, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),
     "hs_exclusive_scan_i64": (C.c_int, [_P, _P, _I64, _P, _P]),

@@ -100,3 +100,42 @@ def test_result_independent_of_scan_chunking(setup, monkeypatch):
         assert_rows_match(rows, base, max_ulps=1)
     monkeypatch.delenv("HIPSPARK_CHUNK_STEPS")
     engine.dev._partial_prepared.clear()
+
+
+def test_high_cardinality_group_by_uses_global_tier_and_is_exact(tmp_path):
+    """GROUP BY on a key with ~40 000 distinct values per block (far beyond the on-chip tiers): the engine
+    falls over to the HBM dictionary + ordered per-group fold.  One lane folds a group's rows front to back,
+    i.e. in the reference's own order, so the result must equal the Python oracle BIT FOR BIT (0 flips),
+    integers and floats alike."""
+    from minispark_amd import constants
+    from minispark_amd.constants import ColumnType as T
+    from minispark_amd.dataframe import DataFrame
+    from minispark_amd.execution import HipExecutionEngine
+    from minispark_amd.io import BlockFile
+    from minispark_amd.sql import Col, Functions as F
+    from oracle.py_engine import run_query
+
+    constants.SHUFFLE_FOLDER = tmp_path / "shuffle"
+    rng = np.random.default_rng(5)
+    n = 120_000
+    keys = rng.integers(-20_000, 20_000, n).astype(np.int32)
+    qty = rng.integers(1, 50, n).astype(np.int32)
+    price = (rng.integers(100, 100_000, n) / 7.0).astype(np.float32)
+    path = tmp_path / "t.bin"
+    schema = [("k", T.INTEGER), ("q", T.INTEGER), ("p", T.FLOAT)]
+    per = 50_000
+    BlockFile(path).write_raw_blocks(schema, [[keys[i: i + per], qty[i: i + per], price[i: i + per]] for i in range(0, n, per)])
+
+    def build(engine):
+        return (DataFrame(engine).table(str(path)).filter(Col("q") > 3).group_by(Col("k"))
+                .agg(F.sum(Col("q") * Col("p")).alias("rev"), F.count(), F.min(Col("p")).alias("lo"),
+                     F.avg(Col("p")).alias("mean"), F.max(Col("q")).alias("hi")))
+
+    with HipExecutionEngine(0) as engine:
+        rows = build(engine).collect()
+        assert engine._global_partial and engine._global_merge, "the global tier must have been used"
+        again = build(engine).collect()
+    want = run_query(build(object()).task)
+    assert len(rows) == len(want) > 30_000
+    assert_rows_match(rows, want, max_ulps=0)
+    assert_rows_match(again, want, max_ulps=0)
