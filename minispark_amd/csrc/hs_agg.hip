@@ -457,17 +457,52 @@ extern "C" int hs_agg_partial_geom(const int64_t* host_unit_rows, int64_t n_unit
         }
         total += r;
     }
-    // rows per workgroup: a multiple of wg*V.  Long chunks amortise the per-workgroup table init and
-    // reduction (measured on sf=100: 16 steps/lane 3.25 ms, 64: 2.74 ms, 128: 2.70 ms); small inputs get
-    // shorter chunks so that there are still a few thousand workgroups to balance over 256 CUs.
+    // Rows per workgroup = steps_per_chunk * wg * V.  Model from a chunk-size sweep on MI355X:
+    // a workgroup costs ~11 us fixed + ~3.4 us per step, and `wg_slots` workgroups run at once (LDS-limited).
+    // Pick the number of full-chip rounds R that keeps chunks <= 128 steps, then the chunk length that
+    // fills those rounds exactly: few, long chunks without a ragged last round.
     const int64_t step = (int64_t)wg * HS_V;
-    int64_t steps_per_chunk = 128;
-    if (const char* e = getenv("HIPSPARK_CHUNK_STEPS")) {  // tuning knob (power of two)
-        const long v = atol(e);
-        if (v >= 1 && v <= 4096) steps_per_chunk = v;
+    static int n_cus = 0;
+    if (!n_cus) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        n_cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+                 prop.multiProcessorCount > 0)
+                    ? prop.multiProcessorCount
+                    : 256;
+        (void)hipGetLastError();
     }
-    int64_t chunk = step * steps_per_chunk;
-    while (chunk > step && total / chunk < 3072) chunk /= 2;
+    int64_t per_cu = (int64_t)(160 * 1024) / (int64_t)(lds > 1 ? lds : 1);
+    const int64_t by_waves = 32 / (wg / 64);
+    if (per_cu > by_waves) per_cu = by_waves;
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    const int64_t wg_slots = (int64_t)n_cus * per_cu;
+    const int64_t total_steps = (total + step - 1) / step;
+    int64_t steps_per_chunk;
+    if (const char* e = getenv("HIPSPARK_CHUNK_STEPS")) {  // tuning knob
+        steps_per_chunk = atol(e);
+    } else {
+        const int64_t max_steps = 128;
+        int64_t rounds = (total_steps + wg_slots * max_steps - 1) / (wg_slots * max_steps);
+        if (rounds < 1) rounds = 1;
+        steps_per_chunk = (total_steps + wg_slots * rounds - 1) / (wg_slots * rounds);
+        if (steps_per_chunk < 1) steps_per_chunk = 1;
+        // every unit rounds its chunk count up: lengthen the chunks until the grid really fits the rounds
+        // (a handful of workgroups spilling into an extra round would cost a whole round)
+        for (int guard = 0; guard < 64; ++guard) {
+            int64_t n = 0;
+            for (int64_t u = 0; u < n_units; ++u) {
+                const int64_t span = host_unit_rows[u + 1] - (host_unit_rows[u] & ~(int64_t)(HS_V - 1));
+                n += span > 0 ? (span + step * steps_per_chunk - 1) / (step * steps_per_chunk) : 0;
+            }
+            if (n <= wg_slots * rounds) break;
+            ++steps_per_chunk;
+        }
+    }
+    if (steps_per_chunk < 1) steps_per_chunk = 1;
+    if (steps_per_chunk > 4096) steps_per_chunk = 4096;
+    const int64_t chunk = step * steps_per_chunk;
     int64_t n_chunks = 0;
     for (int64_t u = 0; u < n_units; ++u) {
         const int64_t anchor = host_unit_rows[u] & ~(int64_t)(HS_V - 1);

@@ -119,6 +119,50 @@ class DeviceError(RuntimeError):
     pass
 
 
+class Recording:
+    """The device work of one query run as a flat list of calls (library entry points and a few tensor
+    copies), with every buffer they touch kept alive.  Replaying the list re-runs the query without any
+    planning / lowering / allocation on the host.  A run that had to learn a size on the host mid-way
+    (``poisoned``) is data-dependent and is not replayable."""
+
+    def __init__(self) -> None:
+        self.calls: list[tuple[Any, tuple]] = []
+        self.keep: list[Any] = []
+        self.poisoned = False
+        self.finish: Any = None  # () -> (raw columns, nrows, flags)
+        self.result: Any = None  # (schema, stage_id) of the writer
+
+    def replay(self) -> bool:
+        for fn, args in self.calls:
+            rc = fn(*args)
+            if rc:  # library calls return 0 on success; recorded tensor ops return None
+                return False
+        return True
+
+
+def _call_void(fn: Any, *args: Any) -> None:
+    fn(*args)  # tensor ops return the tensor; a replayed call must report "no error"
+
+
+class _RecordingLib:
+    """Stands in for the ctypes library while a run is being recorded."""
+
+    def __init__(self, lib: Any, rec: Recording) -> None:
+        self._lib, self._rec = lib, rec
+
+    def __getattr__(self, name: str) -> Any:
+        fn = getattr(self._lib, name)
+        if fn.restype is not C.c_int or name.endswith("_geom") or name.endswith("_chunks"):
+            return fn  # queries (sizes, error text) and host-side helpers are not device work
+
+        def recorded(*args: Any) -> int:
+            self._rec.calls.append((fn, args))
+            self._rec.keep.append(args)
+            return fn(*args)
+
+        return recorded
+
+
 class Device:
     """One GPU + the loaded operator library."""
 
@@ -134,6 +178,32 @@ class Device:
         torch.cuda.set_device(self.device)
         self.flags = torch.zeros(4, dtype=torch.int32, device=self.device)
         self._partial_prepared: dict[Any, dict] = {}
+        self._raw_lib = self.lib
+        self.rec: Recording | None = None
+
+    # ---- recording ------------------------------------------------------------------------------------
+    def start_recording(self) -> Recording:
+        self.rec = Recording()
+        self.lib = _RecordingLib(self._raw_lib, self.rec)
+        return self.rec
+
+    def stop_recording(self) -> Recording | None:
+        rec, self.rec = self.rec, None
+        self.lib = self._raw_lib
+        return rec
+
+    def op(self, fn: Any, *args: Any) -> None:
+        """Run a small tensor op (fill / copy) now and, when recording, on every replay."""
+        fn(*args)
+        if self.rec is not None:
+            self.rec.calls.append((_call_void, (fn, *args)))
+
+    def host_int(self, t: torch.Tensor) -> int:
+        """A device value the HOST needs to go on (sizes an allocation): synchronises, and makes the current
+        run data-dependent, i.e. not replayable."""
+        if self.rec is not None:
+            self.rec.poisoned = True
+        return int(t.item())
 
     # ---- plumbing ------------------------------------------------------------------------------------
     def time_scan_kernel(self, enable: bool = True) -> None:
@@ -160,7 +230,10 @@ class Device:
     def empty(self, n: int, dtype: torch.dtype) -> torch.Tensor:
         esize = torch.empty((), dtype=dtype).element_size()
         pad = (PAD + esize - 1) // esize
-        return torch.empty(int(n) + pad, dtype=dtype, device=self.device)[: int(n)]
+        t = torch.empty(int(n) + pad, dtype=dtype, device=self.device)[: int(n)]
+        if self.rec is not None:
+            self.rec.keep.append(t)
+        return t
 
     def zeros(self, n: int, dtype: torch.dtype) -> torch.Tensor:
         t = self.empty(n, dtype)
@@ -168,18 +241,25 @@ class Device:
         return t
 
     def workspace(self, nbytes: int) -> torch.Tensor:
-        return torch.empty(max(int(nbytes), 256) + PAD, dtype=torch.uint8, device=self.device)
+        t = torch.empty(max(int(nbytes), 256) + PAD, dtype=torch.uint8, device=self.device)
+        if self.rec is not None:
+            self.rec.keep.append(t)
+        return t
 
     def to_device(self, arr: np.ndarray, dtype: torch.dtype | None = None) -> torch.Tensor:
         src = torch.from_numpy(np.require(arr, requirements=["C", "W"]))  # copies read-only views (np.frombuffer)
         dst = self.empty(src.numel(), dtype or src.dtype)
         dst.copy_(src, non_blocking=False)
+        if self.rec is not None:
+            self.rec.poisoned = True  # host data went into this run: re-running needs the host side again
         return dst
 
     def reset_flags(self) -> None:
         self.flags.zero_()
 
     def read_flags(self) -> int:
+        if self.rec is not None:
+            self.rec.poisoned = True
         return int(self.flags[0].item()) & 0xFFFFFFFF
 
     def raise_for_flags(self, flags: int) -> None:
@@ -207,6 +287,8 @@ class Device:
         ws = self.workspace(self.lib.hs_scan_ws_bytes(n))
         hs.check(self.lib.hs_str_offsets(self.stream, lens.data_ptr(), n, offs.data_ptr(), minmax.data_ptr(),
                                          ws.data_ptr()), "hs_str_offsets")
+        if self.rec is not None:
+            self.rec.poisoned = True
         mn, mx = minmax.tolist()
         fixed = mn if (n > 0 and mn == mx) else (0 if n == 0 else -1)
         return DCol(hs.STR, data, n, lens=lens, offs=None if fixed >= 0 else offs, fixed_len=fixed)
@@ -253,9 +335,19 @@ class Device:
                 add("sdata", c.data, c)
             else:
                 add("col", c.data[: c.n], c)
-        host = torch.cat(parts).cpu().numpy()  # the single synchronising copy
+        def finish() -> tuple[list[Any], int, int]:
+            host = torch.cat(parts).cpu().numpy()  # the single synchronising copy
+            return self._parse_download(host, layout, batch.nrows)
+
+        if self.rec is not None:
+            self.rec.finish = finish
+            self.rec.keep.append(parts)
+        return finish()
+
+    def _parse_download(self, host: np.ndarray, layout: list, nrows_max: int) -> tuple[list[Any], int, int]:
         flags = int(host[0:4].view(np.uint32)[0])
-        n = batch.nrows
+        batch_nrows = nrows_max
+        n = batch_nrows
         for tag, off, size, _ in layout:
             if tag == "nrows":
                 n = min(n, int(host[off: off + size].view(np.int64)[0]))
@@ -318,7 +410,7 @@ class Device:
         ws = self.workspace(self.lib.hs_scan_ws_bytes(n))
         hs.check(self.lib.hs_compact(self.stream, mask.data.data_ptr(), n, sel.data_ptr(), count.data_ptr(),
                                      ws.data_ptr()), "hs_compact")
-        return sel, int(count.item())
+        return sel, self.host_int(count)
 
     # ---- gathers -------------------------------------------------------------------------------------
     def gather_col(self, col: DCol, idx: torch.Tensor, n: int, n_dev: torch.Tensor | None = None,
@@ -332,11 +424,13 @@ class Device:
             hs.check(self.lib.hs_gather_fixed(self.stream, col.data.data_ptr(), width, idx.data_ptr(), n, n_dev_ptr,
                                               data.data_ptr()), "hs_gather_fixed")
             lens = self.empty(n, torch.uint8)
-            lens.fill_(width)
+            self.op(lens.fill_, width)
             return DCol(hs.STR, data, n, lens=lens, offs=None, fixed_len=width)
         if col.kind == hs.STR:
             if n_dev is not None:
-                n = min(n, int(n_dev[0].item()))
+                n = min(n, self.host_int(n_dev[0]))
+            if self.rec is not None:
+                self.rec.poisoned = True  # payload size of variable-length strings is learnt on the host
             src = col.as_hs()
             lens = self.empty(n, torch.uint8)
             hs.check(self.lib.hs_gather_str_lens(self.stream, C.byref(src), idx.data_ptr(), n, lens.data_ptr()),
@@ -364,7 +458,7 @@ class Device:
         """Make a lazily-sized batch exact (one D2H of the row count)."""
         if not batch.lazy:
             return batch
-        n = min(batch.nrows, int(batch.nrows_dev[0].item()))
+        n = min(batch.nrows, self.host_int(batch.nrows_dev[0]))
         cols = []
         for c in batch.cols:
             if c.kind == hs.STR:
@@ -506,8 +600,8 @@ class Device:
             out_cols.append(DCol(p["acc_kinds"][acc], p["acc_bufs"][acc][:n_max], n_max))
         self.last_group_cap = cap
         if p["slab"] is not None:  # header of the exchange slab: status so far + number of rows
-            p["layout"].flags_view(p["slab"]).copy_(self.flags[:1])
-            p["layout"].count_view(p["slab"]).copy_(p["pack_start"][p["n_units"]: p["n_units"] + 1])
+            self.op(p["layout"].flags_view(p["slab"]).copy_, self.flags[:1])
+            self.op(p["layout"].count_view(p["slab"]).copy_, p["pack_start"][p["n_units"]: p["n_units"] + 1])
         return DBatch(list(out_schema), out_cols, n_max, None, n_dev, order=p["out_unit"], slab=p["slab"],
                       slab_layout=p["layout"], total_units=batch.total_units,
                       slab_cols=[0] + [1 + acc for acc in p["agg_to_acc"]])
@@ -666,7 +760,7 @@ class Device:
         ws2 = self.workspace(self.lib.hs_scan_ws_bytes(cap))
         hs.check(self.lib.hs_compact(self.stream, mask.data_ptr(), cap, slot_list.data_ptr(), count.data_ptr(),
                                      ws2.data_ptr()), "hs_compact")
-        return slot_start, positions, slot_list, int(count.item())
+        return slot_start, positions, slot_list, self.host_int(count)
 
     def _group_fold(self, vals: Sequence[DCol], ops: Sequence[int], is_int: Sequence[bool], slot_start, positions,
                     slot_list, n_groups: int, sel: torch.Tensor | None, quantise: bool):

@@ -99,6 +99,10 @@ class HipExecutionEngine(ExecutionEngine):
         self._work_folder = work_folder
         self._tables: dict[str, Any] = {}
         self._plans: dict[Any, Any] = {}
+        self._recordings: dict[Any, Any] = {}  # plan key -> device.Recording of a fully device-resident run
+        self.replay_enabled = os.environ.get("HIPSPARK_REPLAY", "1") != "0"
+        self.replays = 0
+        self._plan_runs: dict[Any, int] = {}
         self._owned_dirs: set[Path] = set()
         self._result_root: Path | None = None
         self._made_dirs: set[Path] = set()
@@ -155,15 +159,33 @@ class HipExecutionEngine(ExecutionEngine):
 
         for _attempt in range(12):
             plan = self._cached_plan(full_task)
+            rec_key = self._recording_key(plan)
+            rec = self._recordings.get(rec_key) if self.replay_enabled else None
+            if rec is not None:
+                replayed = self._replay(rec)
+                if replayed is not None:
+                    return replayed
+                del self._recordings[rec_key]  # something data-dependent changed: take the full path again
             self.dev.reset_flags()
             outputs: dict[int, Any] = {}
             results: list[JobResult] = []
+            # record the second (cache-warm) run of a plan: by then every buffer it needs is prepared
+            want_record = self.replay_enabled and self.dist is None and self._plan_runs.get(rec_key, 0) >= 1
+            recording = self.dev.start_recording() if want_record else None
             try:
                 for stage in plan.stages:
                     results = self._run_stage(stage, outputs)
                     stage.job_results.extend(results)
+                self._plan_runs[rec_key] = self._plan_runs.get(rec_key, 0) + 1
+                if recording is not None:
+                    self.dev.stop_recording()
+                    if not recording.poisoned and recording.finish is not None and recording.result is not None:
+                        if len(self._recordings) >= 8:
+                            self._recordings.pop(next(iter(self._recordings)))
+                        self._recordings[rec_key] = recording
                 return results
             except RetryWithLargerDictionary:
+                self.dev.stop_recording()
                 # more distinct GROUP BY keys than the dictionaries were sized for: grow and re-run; past the
                 # on-chip limits the stages switch to the global-memory tier (TierExceeded in _run_stage)
                 self.group_cap_hint *= 2
@@ -171,8 +193,36 @@ class HipExecutionEngine(ExecutionEngine):
                     self._merge_overflowed = True
                 self.merge_cap_hint = min(self.merge_cap_hint * 4, 4096)
             except (HipSparkError, DeviceError) as e:
+                self.dev.stop_recording()
                 raise ExecutionError(str(e)) from e
+            except BaseException:
+                self.dev.stop_recording()
+                raise
         raise ExecutionError("GROUP BY cardinality exceeds the on-chip aggregation tiers")
+
+    def _recording_key(self, plan: Any) -> Any:
+        """A recorded run is valid for the same plan object over the same device buffers and capacities."""
+        tables = []
+        for stage in plan.stages:
+            if _cls(stage.producer) == "LoadTableBlockTask":
+                t = self._tables.get(str(Path(stage.producer.file_path).resolve()))
+                tables.append((id(t), tuple(sorted((cid, c.data.data_ptr()) for cid, c in t.columns.items()))) if t else None)
+        return (id(plan), tuple(tables), self.group_cap_hint, self.merge_cap_hint, len(self._global_partial),
+                len(self._global_merge))
+
+    def _replay(self, rec: Any) -> list[JobResult] | None:
+        from . import hipspark as hs  # noqa: PLC0415
+
+        self.dev.flags.zero_()
+        if not rec.replay():
+            return None
+        raw, nrows, flags = rec.finish()
+        if flags:
+            return None  # errors and dictionary growth are handled by the full path
+        schema, stage_id = rec.result
+        self.replays += 1
+        _ = hs
+        return [self._emit_result(raw, nrows, schema, stage_id)]
 
     def _cached_plan(self, full_task: Any) -> Any:
         """Planning is pure in (task tree, table headers): keep the physical plan of the last few task
@@ -423,13 +473,18 @@ class HipExecutionEngine(ExecutionEngine):
         from . import hipspark as hs  # noqa: PLC0415
         from .device import RetryWithLargerDictionary  # noqa: PLC0415
 
-        job_id = str(uuid.uuid4())
         quantised = self._quantise_batch(batch, schema)
         raw, nrows, flags = self.dev.download_batch(quantised, schema, self._remote_flags)  # the one host round trip
         self._remote_flags = None
+        if self.dev.rec is not None:
+            self.dev.rec.result = (list(schema), stage_id)
         if flags & hs.FLAG_DICT_FULL:
             raise RetryWithLargerDictionary
         self.dev.raise_for_flags(flags)
+        return self._emit_result(raw, nrows, schema, stage_id)
+
+    def _emit_result(self, raw: list, nrows: int, schema: Schema, stage_id: str) -> JobResult:
+        job_id = str(uuid.uuid4())
         if nrows == 0 or self.rank != 0:
             # empty result: the reference writes no file (tasks.py:405); multi-GPU: rank 0 owns the result
             return JobResult(job_id, f"hip:{self.dev.index}", [])

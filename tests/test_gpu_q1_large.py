@@ -139,3 +139,17 @@ def test_high_cardinality_group_by_uses_global_tier_and_is_exact(tmp_path):
     assert len(rows) == len(want) > 30_000
     assert_rows_match(rows, want, max_ulps=0)
     assert_rows_match(again, want, max_ulps=0)
+
+
+def test_replay_of_recorded_query_is_identical(setup):
+    """The third and later runs of a cached plan replay the recorded device calls: same bits, and a query with
+    other literals (different program constants) must not reuse it."""
+    engine, path, _ = setup
+    frame = _frame(engine, path, "1997-01-01")
+    before = engine.replays
+    runs = [frame.collect() for _ in range(5)]
+    assert all(r == runs[0] for r in runs)
+    assert engine.replays - before >= 2, "later runs must have taken the replay path"
+    other = _frame(engine, path, "1996-01-01").collect()
+    assert other != runs[0]
+    assert sum(r["count_order"] for r in other) < sum(r["count_order"] for r in runs[0])
