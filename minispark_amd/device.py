@@ -178,6 +178,7 @@ class Device:
         torch.cuda.set_device(self.device)
         self.flags = torch.zeros(4, dtype=torch.int32, device=self.device)
         self._partial_prepared: dict[Any, dict] = {}
+        self._const_lens: dict[int, torch.Tensor] = {}
         self._raw_lib = self.lib
         self.rec: Recording | None = None
 
@@ -423,9 +424,7 @@ class Device:
             data = out if out is not None else self.empty(n * width, torch.uint8)
             hs.check(self.lib.hs_gather_fixed(self.stream, col.data.data_ptr(), width, idx.data_ptr(), n, n_dev_ptr,
                                               data.data_ptr()), "hs_gather_fixed")
-            lens = self.empty(n, torch.uint8)
-            self.op(lens.fill_, width)
-            return DCol(hs.STR, data, n, lens=lens, offs=None, fixed_len=width)
+            return DCol(hs.STR, data, n, lens=self.const_lens(width, n), offs=None, fixed_len=width)
         if col.kind == hs.STR:
             if n_dev is not None:
                 n = min(n, self.host_int(n_dev[0]))
@@ -453,6 +452,14 @@ class Device:
         hs.check(self.lib.hs_gather_fixed(self.stream, col.data.data_ptr(), hs.KIND_BYTES[col.kind], idx.data_ptr(), n,
                                           n_dev_ptr, out.data_ptr()), "hs_gather_fixed")
         return DCol(col.kind, out, n)
+
+    def const_lens(self, width: int, n: int) -> torch.Tensor:
+        """Length bytes of a fixed-width string column (all equal): one shared read-only buffer per width."""
+        buf = self._const_lens.get(width)
+        if buf is None or buf.numel() < n:
+            buf = torch.full((max(n, 1024) + PAD,), width, dtype=torch.uint8, device=self.device)
+            self._const_lens[width] = buf
+        return buf[:n]
 
     def resolve(self, batch: DBatch) -> DBatch:
         """Make a lazily-sized batch exact (one D2H of the row count)."""

@@ -406,9 +406,8 @@ class HipExecutionEngine(ExecutionEngine):
         for src, slab_col in zip(batch.cols, batch.slab_cols):
             data = cols[slab_col]
             if src.kind == hs.STR:
-                lens = self.dev.empty(n, data.dtype)
-                lens.fill_(src.fixed_len)
-                out.append(DCol(hs.STR, data, n, lens=lens, offs=None, fixed_len=src.fixed_len))
+                out.append(DCol(hs.STR, data, n, lens=self.dev.const_lens(src.fixed_len, n), offs=None,
+                                fixed_len=src.fixed_len))
             else:
                 out.append(DCol(src.kind, data, n))
         return DBatch(list(batch.schema), out, n, [0, n], None, order=order, total_units=batch.total_units)

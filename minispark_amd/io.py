@@ -341,14 +341,22 @@ class BlockFile:
         self.schema = list(schema)
         self._invalidate()
         starts = []
+        header = encode_schema(schema)
+        pos = len(header)
+        pieces = [header]
         with self.file.open("wb") as f:
-            f.write(encode_schema(schema))
             for cols in blocks:
                 if raw_len(cols[0]) == 0:
                     continue
-                starts.append(f.tell())
-                f.write(encode_block(schema, cols))
-            f.write(encode_footer(starts))
+                block = encode_block(schema, cols)
+                starts.append(pos)
+                pos += len(block)
+                pieces.append(block)
+                if pos > (64 << 20):  # flush large files piecewise, small ones with a single write
+                    f.write(b"".join(pieces))
+                    pieces = []
+            pieces.append(encode_footer(starts))
+            f.write(b"".join(pieces))
         return self
 
     def write_raw(self, schema: Schema, cols: Sequence[RawColumn]) -> "BlockFile":
@@ -439,6 +447,13 @@ class BlockFile:
             yield [dict(zip(names, row, strict=True)) for row in self.read_block_data(block_id)]
 
     def read_data_rows(self) -> Iterator[Row]:
+        try:
+            small = self.file.stat().st_size <= _SMALL_FILE
+        except OSError:
+            small = False
+        if small:  # result files are a few hundred bytes: one read, parse in memory
+            yield from _rows_from_bytes(self.file.read_bytes())
+            return
         for block in self.read_blocks_sequentially():
             yield from block
 
@@ -451,6 +466,33 @@ class BlockFile:
             for block_id in range(len(src.block_starts)):
                 self.append_raw(src.read_block_raw(block_id))
         return self
+
+
+_SMALL_FILE = 1 << 20
+
+
+def _rows_from_bytes(buf: bytes) -> Iterator[Row]:
+    """Whole-file decode of a small BlockFile held in memory (same format walk as the file-based reader)."""
+    schema, _ = decode_schema(buf)
+    names = [n for n, _ in schema]
+    nblocks = int(np.frombuffer(buf, dtype="<u4", count=1, offset=len(buf) - 4)[0])
+    starts = np.frombuffer(buf, dtype="<u8", count=nblocks, offset=len(buf) - 4 - 8 * nblocks)
+    for start in starts.tolist():
+        nrows = int(np.frombuffer(buf, dtype="<u4", count=1, offset=start)[0])
+        pos = start + 4
+        cols = []
+        for _, col_type in schema:
+            nbytes = int(np.frombuffer(buf, dtype="<u8", count=1, offset=pos)[0])
+            pos += 8
+            if col_type == ColumnType.STRING:
+                arr = np.frombuffer(buf, dtype=np.uint8, count=nbytes, offset=pos)
+                cols.append(raw_to_python(StrCol(arr[:nrows], arr[nrows:]), col_type))
+            else:
+                dt = _FIXED_DTYPES[col_type]
+                cols.append(raw_to_python(np.frombuffer(buf, dtype=dt, count=nbytes // dt.itemsize, offset=pos), col_type))
+            pos += nbytes
+        for row in zip(*cols, strict=True):
+            yield dict(zip(names, row, strict=True))
 
 
 def _split_rows(cols: Sequence[RawColumn], rows_per_block: int) -> Iterator[list[RawColumn]]:
