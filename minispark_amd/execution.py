@@ -31,7 +31,7 @@ from typing import Any, Iterable, Iterator, Sequence
 
 from . import constants
 from .constants import ColumnType, Row, Schema
-from .io import BlockFile
+from .io import BlockFile, write_single_block_file
 from .jobs import JobResult, OutputFile
 
 
@@ -203,10 +203,14 @@ class HipExecutionEngine(ExecutionEngine):
     def _recording_key(self, plan: Any) -> Any:
         """A recorded run is valid for the same plan object over the same device buffers and capacities."""
         tables = []
-        for stage in plan.stages:
-            if _cls(stage.producer) == "LoadTableBlockTask":
-                t = self._tables.get(str(Path(stage.producer.file_path).resolve()))
-                tables.append((id(t), tuple(sorted((cid, c.data.data_ptr()) for cid, c in t.columns.items()))) if t else None)
+        scans = getattr(plan, "_hs_scan_keys", None)
+        if scans is None:
+            scans = [str(Path(st.producer.file_path).resolve()) for st in plan.stages
+                     if _cls(st.producer) == "LoadTableBlockTask"]
+            plan._hs_scan_keys = scans
+        for key in scans:
+            t = self._tables.get(key)
+            tables.append((id(t), tuple(sorted((cid, c.data.data_ptr()) for cid, c in t.columns.items()))) if t else None)
         return (id(plan), tuple(tables), self.group_cap_hint, self.merge_cap_hint, len(self._global_partial),
                 len(self._global_merge))
 
@@ -495,5 +499,8 @@ class HipExecutionEngine(ExecutionEngine):
             out_dir.mkdir(parents=True, exist_ok=True)
             self._made_dirs.add(out_dir)
         out_file = out_dir / "result.bin"
-        BlockFile(out_file, list(schema)).write_raw(list(schema), raw)
+        if nrows <= constants.ROWS_PER_BLOCK:
+            write_single_block_file(out_file, schema, raw)
+        else:
+            BlockFile(out_file, list(schema)).write_raw(list(schema), raw)
         return JobResult(job_id, f"hip:{self.dev.index}", [OutputFile(out_file)])

@@ -25,6 +25,7 @@ INTEGER values as i32 (``OverflowError`` when out of range, like ``int.to_bytes(
 from __future__ import annotations
 
 import os
+import struct
 from dataclasses import dataclass, field
 from datetime import datetime
 from pathlib import Path
@@ -43,6 +44,8 @@ _FIXED_DTYPES = {
     ColumnType.FLOAT: np.dtype("<f4"),
     ColumnType.TIMESTAMP: np.dtype("<i8"),
 }
+_U8 = np.dtype(np.uint8)
+_STRUCT_CODE = {ColumnType.INTEGER: ("i", 4), ColumnType.FLOAT: ("f", 4), ColumnType.TIMESTAMP: ("q", 8)}
 
 
 class StrCol(NamedTuple):
@@ -187,7 +190,18 @@ def raw_slice(col: RawColumn, lo: int, hi: int) -> RawColumn:
 # --------------------------------------------------------------------------------------------------
 
 
+_SCHEMA_BYTES: dict[tuple, bytes] = {}
+
+
 def encode_schema(schema: Schema) -> bytes:
+    key = tuple(schema)
+    hit = _SCHEMA_BYTES.get(key)
+    if hit is None:
+        hit = _SCHEMA_BYTES[key] = _encode_schema(schema)
+    return hit
+
+
+def _encode_schema(schema: Schema) -> bytes:
     if not len(schema) < MAX_COLUMNS:
         raise AssertionError("too many columns")
     out = bytearray([len(schema)])
@@ -218,23 +232,29 @@ def _deserialize_schema(f) -> Schema:  # name kept: the reference's tests call i
     return decode_schema(head)[0]
 
 
+def _column_bytes(col: np.ndarray, dtype: np.dtype) -> bytes:
+    if col.dtype == dtype and col.flags.c_contiguous:
+        return col.tobytes()
+    return np.ascontiguousarray(col, dtype=dtype).tobytes()
+
+
 def encode_block(schema: Schema, cols: Sequence[RawColumn]) -> bytes:
     nrows = raw_len(cols[0])
-    parts = [np.uint32(nrows).astype("<u4").tobytes()]
+    parts = [struct.pack("<I", nrows)]
     for (_, col_type), col in zip(schema, cols, strict=True):
         if raw_len(col) != nrows:
             raise ValueError("ragged block: columns differ in length")
         if col_type == ColumnType.STRING:
-            payload = col.lens.astype(np.uint8).tobytes() + col.data.astype(np.uint8).tobytes()
+            payload = _column_bytes(col.lens, _U8) + _column_bytes(col.data, _U8)
         else:
-            payload = np.ascontiguousarray(col, dtype=_FIXED_DTYPES[col_type]).tobytes()
-        parts.append(np.uint64(len(payload)).astype("<u8").tobytes())
+            payload = _column_bytes(col, _FIXED_DTYPES[col_type])
+        parts.append(struct.pack("<Q", len(payload)))
         parts.append(payload)
     return b"".join(parts)
 
 
 def encode_footer(block_starts: Sequence[int]) -> bytes:
-    return np.asarray(block_starts, dtype="<u8").tobytes() + np.uint32(len(block_starts)).astype("<u4").tobytes()
+    return struct.pack(f"<{len(block_starts)}QI", *block_starts, len(block_starts))
 
 
 class BlockLayout(NamedTuple):
@@ -452,7 +472,8 @@ class BlockFile:
         except OSError:
             small = False
         if small:  # result files are a few hundred bytes: one read, parse in memory
-            yield from _rows_from_bytes(self.file.read_bytes())
+            with open(self.file, "rb") as f:
+                yield from _rows_from_bytes(f.read())
             return
         for block in self.read_blocks_sequentially():
             yield from block
@@ -471,25 +492,39 @@ class BlockFile:
 _SMALL_FILE = 1 << 20
 
 
+def write_single_block_file(path: Any, schema: Schema, cols: Sequence[RawColumn]) -> None:
+    """header + one block + footer in a single write (result files: a handful of rows)."""
+    header = encode_schema(schema)
+    with open(path, "wb") as f:
+        f.write(b"".join((header, encode_block(schema, cols), struct.pack("<QI", len(header), 1))))
+
+
 def _rows_from_bytes(buf: bytes) -> Iterator[Row]:
-    """Whole-file decode of a small BlockFile held in memory (same format walk as the file-based reader)."""
+    """Whole-file decode of a small BlockFile held in memory (same format walk as the file-based reader,
+    struct-based: result files hold a handful of rows and numpy's per-call overhead would dominate)."""
     schema, _ = decode_schema(buf)
     names = [n for n, _ in schema]
-    nblocks = int(np.frombuffer(buf, dtype="<u4", count=1, offset=len(buf) - 4)[0])
-    starts = np.frombuffer(buf, dtype="<u8", count=nblocks, offset=len(buf) - 4 - 8 * nblocks)
-    for start in starts.tolist():
-        nrows = int(np.frombuffer(buf, dtype="<u4", count=1, offset=start)[0])
+    (nblocks,) = struct.unpack_from("<I", buf, len(buf) - 4)
+    starts = struct.unpack_from(f"<{nblocks}Q", buf, len(buf) - 4 - 8 * nblocks)
+    for start in starts:
+        (nrows,) = struct.unpack_from("<I", buf, start)
         pos = start + 4
         cols = []
         for _, col_type in schema:
-            nbytes = int(np.frombuffer(buf, dtype="<u8", count=1, offset=pos)[0])
+            (nbytes,) = struct.unpack_from("<Q", buf, pos)
             pos += 8
             if col_type == ColumnType.STRING:
-                arr = np.frombuffer(buf, dtype=np.uint8, count=nbytes, offset=pos)
-                cols.append(raw_to_python(StrCol(arr[:nrows], arr[nrows:]), col_type))
+                lens = buf[pos: pos + nrows]
+                p = pos + nrows
+                vals = []
+                for ln in lens:
+                    vals.append(buf[p: p + ln].decode("utf-8"))
+                    p += ln
+                cols.append(vals)
             else:
-                dt = _FIXED_DTYPES[col_type]
-                cols.append(raw_to_python(np.frombuffer(buf, dtype=dt, count=nbytes // dt.itemsize, offset=pos), col_type))
+                code, size = _STRUCT_CODE[col_type]
+                vals = struct.unpack_from(f"<{nbytes // size}{code}", buf, pos)
+                cols.append([timestamp_to_datetime(v) for v in vals] if col_type == ColumnType.TIMESTAMP else vals)
             pos += nbytes
         for row in zip(*cols, strict=True):
             yield dict(zip(names, row, strict=True))
