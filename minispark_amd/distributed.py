@@ -86,6 +86,28 @@ def all_gather_slabs(dist: Any, slab: torch.Tensor, world: int, group: Any = Non
     return out.view(world, slab.numel())
 
 
+def all_gather_slabs_into(dist: Any, slab: torch.Tensor, out: torch.Tensor, group: Any = None) -> None:
+    """all_gather_slabs writing into a caller-owned buffer ``out`` (uint8, world * slab bytes): the form the
+    engine records and replays."""
+    backend = dist.get_backend(group)
+    if backend == "gloo" and slab.device.type != "cpu":
+        host_out = torch.empty(out.numel(), dtype=torch.uint8)
+        dist.all_gather_into_tensor(host_out, slab.cpu(), group=group)
+        out.copy_(host_out)
+    else:
+        dist.all_gather_into_tensor(out, slab, group=group)
+
+
+def unpack_gathered_into(gathered: torch.Tensor, layout: SlabLayout, flags_out: torch.Tensor, order_out: torch.Tensor,
+                         cols_out: list[torch.Tensor]) -> None:
+    """unpack_gathered into caller-owned tensors (same results)."""
+    flags, order, cols = unpack_gathered(gathered, layout)
+    flags_out.copy_(flags)
+    order_out.copy_(order)
+    for dst, src in zip(cols_out, cols):
+        dst.copy_(src)
+
+
 def unpack_gathered(gathered: torch.Tensor, layout: SlabLayout) -> tuple[torch.Tensor, torch.Tensor, list[torch.Tensor]]:
     """[world, slab_bytes] -> (flags int32[world], order int64[world*M] with -1 on padding rows,
     columns, each contiguous over all world*M rows in rank-major order)."""

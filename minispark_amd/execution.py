@@ -170,7 +170,7 @@ class HipExecutionEngine(ExecutionEngine):
             outputs: dict[int, Any] = {}
             results: list[JobResult] = []
             # record the second (cache-warm) run of a plan: by then every buffer it needs is prepared
-            want_record = self.replay_enabled and self.dist is None and self._plan_runs.get(rec_key, 0) >= 1
+            want_record = self.replay_enabled and self._plan_runs.get(rec_key, 0) >= 1
             recording = self.dev.start_recording() if want_record else None
             try:
                 for stage in plan.stages:
@@ -394,18 +394,35 @@ class HipExecutionEngine(ExecutionEngine):
         return DBatch(list(left.schema) + list(right.schema), cols, n_out, unit_rows)
 
     def _exchange_partials(self, batch: Any) -> Any:
-        """The shuffle between the two aggregation phases on N GPUs: all-gather the fixed-size slabs."""
+        """The shuffle between the two aggregation phases on N GPUs: all-gather the fixed-size slabs, then
+        un-interleave the columns.  Buffers are allocated here once per run and the collective + unpack is one
+        recorded operation, so a replayed query repeats exactly this exchange."""
+        import torch  # noqa: PLC0415
+
         from . import hipspark as hs  # noqa: PLC0415
         from .device import DBatch, DCol  # noqa: PLC0415
-        from .distributed import all_gather_slabs, unpack_gathered  # noqa: PLC0415
+        from .distributed import all_gather_slabs_into, unpack_gathered_into  # noqa: PLC0415
 
         if batch.slab is None:
             raise NotImplementedError("multi-GPU exchange of this stage's output is not built yet")
         layout = batch.slab_layout
-        gathered = all_gather_slabs(self.dist, batch.slab, self.world, self.group)
-        flags, order, cols = unpack_gathered(gathered, layout)
+        world, m = self.world, layout.slab_rows
+        n = world * m
+        device = batch.slab.device
+        gathered = torch.empty(world * layout.nbytes, dtype=torch.uint8, device=device)
+        flags = torch.empty(world, dtype=torch.int32, device=device)
+        order = torch.empty(n, dtype=torch.int64, device=device)
+        cols = [torch.empty(n * c.row_bytes // torch.empty((), dtype=c.dtype).element_size() + 16, dtype=c.dtype,
+                            device=device)[: n * c.row_bytes // torch.empty((), dtype=c.dtype).element_size()]
+                for c in layout.columns]
+        slab, dist, group = batch.slab, self.dist, self.group
+
+        def exchange() -> None:
+            all_gather_slabs_into(dist, slab, gathered, group)
+            unpack_gathered_into(gathered.view(world, layout.nbytes), layout, flags, order, cols)
+
+        self.dev.op(exchange)
         self._remote_flags = flags
-        n = self.world * layout.slab_rows
         out = []
         for src, slab_col in zip(batch.cols, batch.slab_cols):
             data = cols[slab_col]

@@ -38,8 +38,9 @@ def main() -> None:
         api = api_namespace(lambda: DataFrame(engine), Col, Functions, Lit)
         frame = case.build(api, golden["paths"])
         rows = None
-        for _ in range(2):  # second run exercises the plan / launch caches
+        for _ in range(4):  # later runs exercise the plan / launch caches and the recorded replay
             rows = frame.collect()
+        assert engine.replays >= 1, "the recorded replay path must have been exercised"
         if rank == 0:
             enc = [{k: (v.hex() if type(v) is float else v) for k, v in r.items()} for r in rows]
             Path(out_path).write_text(json.dumps(enc))
