@@ -629,7 +629,7 @@ extern "C" size_t hs_partition_ws_bytes(int64_t nrows, int32_t n_parts) {
 }
 extern "C" int hs_partition_perm(void* stream, const uint8_t* part, int64_t nrows, int32_t n_parts, int64_t* perm,
                                  int64_t* part_start, void* ws) {
-    if ((!part && nrows > 0) || !perm || !part_start || !ws || nrows < 0 || n_parts < 1 ||
+    if ((!part && nrows > 0) || (!perm && nrows > 0) || !part_start || !ws || nrows < 0 || n_parts < 1 ||
         n_parts > HS_MAX_PARTS_SORT) {
         hs_set_error("hs_partition_perm: bad arguments (n_parts <= %d)", HS_MAX_PARTS_SORT);
         return HS_E_ARG;

@@ -78,6 +78,7 @@ class DBatch:
     slab: torch.Tensor | None = None      # multi-GPU: the exchange slab the columns live in
     slab_layout: Any = None
     slab_cols: list[int] | None = None    # slab column holding each batch column (aggregates may share one)
+    partitioned: bool = False             # multi-GPU: every rank holds DIFFERENT rows (else replicated)
 
     def __post_init__(self) -> None:
         if self.nrows_dev is None and not self.unit_rows:
@@ -108,6 +109,11 @@ class DBatch:
 
 class TierExceeded(NotImplementedError):
     """The on-chip (LDS) aggregation tier cannot hold this launch: the engine switches to the global tier."""
+
+
+class SlabUnsupported(NotImplementedError):
+    """This partial aggregate cannot be written into a fixed-size exchange slab (variable-length string key):
+    the engine exchanges its rows with the generic all-to-all instead."""
 
 
 class RetryWithLargerDictionary(Exception):
@@ -447,7 +453,7 @@ class Device:
             fixed = mn if (n > 0 and mn == mx) else (0 if n == 0 else -1)
             return DCol(hs.STR, data, n, lens=lens, offs=None if fixed >= 0 else offs, fixed_len=fixed)
         if col.kind == hs.STR and out is not None:
-            raise NotImplementedError("variable-length string keys cannot be written into a fixed-size exchange slab")
+            raise SlabUnsupported("variable-length string keys cannot be written into a fixed-size exchange slab")
         out = out if out is not None else self.empty(n, _TORCH_DTYPE[col.kind])
         hs.check(self.lib.hs_gather_fixed(self.stream, col.data.data_ptr(), hs.KIND_BYTES[col.kind], idx.data_ptr(), n,
                                           n_dev_ptr, out.data_ptr()), "hs_gather_fixed")
@@ -570,6 +576,8 @@ class Device:
         buffers, capacity) - lowered program, geometry, unit tables, output buffers - is prepared once
         and re-used by later runs of the same query (``cache_key``)."""
         batch = self.resolve(batch)  # units are row ranges: the row count must be exact
+        if batch.nrows == 0:  # e.g. a rank that owns no block of a small table
+            return self._empty_partial(batch, filters, group_by, agg_columns, out_schema, slab_rows)
         cap = max(1, int(group_cap_hint))
         key = None
         if cache_key is not None:
@@ -613,6 +621,28 @@ class Device:
                       slab_layout=p["layout"], total_units=batch.total_units,
                       slab_cols=[0] + [1 + acc for acc in p["agg_to_acc"]])
 
+    def _empty_partial(self, batch: DBatch, filters: Sequence[Any], group_by: Any, agg_columns: Sequence[Any],
+                       out_schema: Schema, slab_rows: int | None) -> DBatch:
+        """Partial aggregate of zero rows (a rank that owns no block): no launch, but the same column /
+        slab layout as the other ranks so the exchange stays symmetric."""
+        low = lower_aggregate(batch.schema, batch.kinds, filters, group_by, agg_columns)
+        key_src = batch.cols[low.program.columns[low.key_slot]]
+        acc_kinds = [hs.I32 if is_int else hs.F32 for is_int in low.acc_is_int]
+        if slab_rows is not None and key_src.kind == hs.STR and key_src.fixed_len not in (1, 2, 4, 8):
+            raise SlabUnsupported("variable-length string GROUP BY key")
+        cols = [self.gather_col(key_src, self.empty(0, torch.int64), 0)]
+        cols += [DCol(acc_kinds[acc], self.empty(0, _TORCH_DTYPE[acc_kinds[acc]]), 0) for acc in low.agg_to_acc]
+        out = DBatch(list(out_schema), cols, 0, [0, 0], order=self.empty(0, torch.int64), total_units=batch.total_units)
+        if slab_rows is not None:
+            from .distributed import SlabLayout  # noqa: PLC0415
+
+            key_spec = ((key_src.fixed_len, torch.uint8) if key_src.kind == hs.STR
+                        else (hs.KIND_BYTES[key_src.kind], _TORCH_DTYPE[key_src.kind]))
+            out.slab_layout = SlabLayout.build(slab_rows, [key_spec] + [(4, _TORCH_DTYPE[k]) for k in acc_kinds])
+            out.slab = torch.zeros(out.slab_layout.nbytes, dtype=torch.uint8, device=self.device)  # count = 0
+            out.slab_cols = [0] + [1 + acc for acc in low.agg_to_acc]
+        return out
+
     def _prepare_partial(self, batch: DBatch, filters: Sequence[Any], group_by: Any, agg_columns: Sequence[Any],
                          cap: int, slab_rows: int | None = None) -> dict:
         low = lower_aggregate(batch.schema, batch.kinds, filters, group_by, agg_columns)
@@ -648,7 +678,7 @@ class Device:
             kc = batch.cols[key_idx]
             if kc.kind == hs.STR:
                 if kc.fixed_len not in (1, 2, 4, 8):
-                    raise NotImplementedError("multi-GPU GROUP BY on variable-length string keys")
+                    raise SlabUnsupported("variable-length string GROUP BY key")
                 key_spec = (kc.fixed_len, torch.uint8)
             else:
                 key_spec = (hs.KIND_BYTES[kc.kind], _TORCH_DTYPE[kc.kind])
@@ -846,7 +876,12 @@ class Device:
             return DBatch(list(out_schema), out_cols, 0, unit_rows)
         key_col = self.concat_cols(key_parts)
         accs = [self.concat_cols(parts) for parts in acc_parts]
-        return DBatch(list(out_schema), [key_col] + [accs[a] for a in agg_to_acc], total, unit_rows)
+        order = None
+        if batch.unit_ids is not None:  # multi-GPU: remember which global unit every partial row came from
+            counts = torch.tensor([unit_rows[u + 1] - unit_rows[u] for u in range(batch.n_units)], device=self.device)
+            order = torch.repeat_interleave(torch.tensor(batch.unit_ids, dtype=torch.int64, device=self.device), counts)
+        return DBatch(list(out_schema), [key_col] + [accs[a] for a in agg_to_acc], total, unit_rows, order=order,
+                      total_units=batch.total_units)
 
     def aggregate_merge_global(self, batch: DBatch, agg_columns: Sequence[Any], out_schema: Schema) -> DBatch:
         """Final merge for any number of groups: dictionary over the partial rows' keys, row lists in merge
@@ -884,6 +919,24 @@ class Device:
         hs.check(self.lib.hs_partition_perm(self.stream, part.data_ptr(), n, n_parts, perm.data_ptr(),
                                             part_start.data_ptr(), ws.data_ptr()), "hs_partition_perm")
         return perm, [int(v) for v in part_start.tolist()]
+
+    def partition_by_ids(self, ids: torch.Tensor, n: int, n_parts: int) -> tuple[torch.Tensor, list[int]]:
+        """Stable counting sort of rows by a u8 id per row -> (perm, start)."""
+        perm = self.empty(n, torch.int64)
+        part_start = self.empty(n_parts + 1, torch.int64)
+        ws = self.workspace(self.lib.hs_partition_ws_bytes(n, n_parts))
+        hs.check(self.lib.hs_partition_perm(self.stream, ids.data_ptr(), n, n_parts, perm.data_ptr(),
+                                            part_start.data_ptr(), ws.data_ptr()), "hs_partition_perm")
+        if self.rec is not None:
+            self.rec.poisoned = True
+        return perm, [int(v) for v in part_start.tolist()]
+
+    def partition_ids(self, batch: DBatch, key_index: int, n_parts: int) -> torch.Tensor:
+        part = self.empty(batch.nrows, torch.uint8)
+        key = batch.cols[key_index].as_hs()
+        hs.check(self.lib.hs_partition_ids(self.stream, C.byref(key), None, batch.nrows, n_parts, part.data_ptr()),
+                 "hs_partition_ids")
+        return part
 
     # ---- hash join (A8) --------------------------------------------------------------------------------
     def join_indices(self, left_key: DCol, right_key: DCol) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, int]:

@@ -135,3 +135,47 @@ def local_blocks(n_blocks: int, rank: int, world: int) -> list[int]:
 
 def max_local_units(n_blocks: int, world: int) -> int:
     return (n_blocks + world - 1) // world
+
+
+# ---- generic row exchange: all-to-all-v by destination rank ---------------------------------------------------
+def _a2a(dist: Any, out: torch.Tensor, inp: torch.Tensor, out_splits: list[int], in_splits: list[int],
+         group: Any = None) -> None:
+    """all_to_all_single with split sizes; device tensors are staged through the host under gloo."""
+    backend = dist.get_backend(group)
+    if backend == "gloo" and inp.device.type != "cpu":
+        host_out = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(host_out, inp.cpu(), out_splits, in_splits, group=group)
+        out.copy_(host_out)
+    else:
+        dist.all_to_all_single(out, inp, out_splits, in_splits, group=group)
+
+
+def exchange_counts(dist: Any, send_counts: list[int], device: torch.device, group: Any = None) -> list[int]:
+    """Tell every rank how many items it will receive from each rank (one tiny all-to-all + D2H)."""
+    world = len(send_counts)
+    backend = dist.get_backend(group)
+    dev = torch.device("cpu") if backend == "gloo" else device
+    inp = torch.tensor(send_counts, dtype=torch.int64, device=dev)
+    out = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_to_all_single(out, inp, group=group)
+    return [int(v) for v in out.tolist()]
+
+
+def all_to_all_rows(dist: Any, send: torch.Tensor, send_counts: list[int], recv_counts: list[int], elems_per_row: int = 1,
+                    group: Any = None) -> torch.Tensor:
+    """Rows of ``send`` are grouped by destination rank (send_counts rows each); returns the rows received,
+    grouped by source rank.  RCCL runs this as direct peer-to-peer transfers over the xGMI mesh."""
+    n_out = sum(recv_counts) * elems_per_row
+    out = torch.empty(n_out + 16, dtype=send.dtype, device=send.device)[:n_out]
+    _a2a(dist, out, send[: sum(send_counts) * elems_per_row].contiguous(), [c * elems_per_row for c in recv_counts],
+         [c * elems_per_row for c in send_counts], group)
+    return out
+
+
+def or_flags(dist: Any, flags: int, device: torch.device, group: Any = None) -> int:
+    """Bitwise OR of a status word over all ranks (so every rank takes the same retry / error decision)."""
+    backend = dist.get_backend(group)
+    dev = torch.device("cpu") if backend == "gloo" else device
+    bits = torch.tensor([(flags >> b) & 1 for b in range(8)], dtype=torch.int32, device=dev)
+    dist.all_reduce(bits, op=dist.ReduceOp.MAX, group=group)
+    return sum(int(v) << b for b, v in enumerate(bits.tolist()))

@@ -262,7 +262,7 @@ class HipExecutionEngine(ExecutionEngine):
 
     # ---- stage execution -------------------------------------------------------------------------------
     def _run_stage(self, stage: Any, outputs: dict[int, Any]) -> list[JobResult]:
-        from .device import TierExceeded  # noqa: PLC0415
+        from .device import SlabUnsupported, TierExceeded  # noqa: PLC0415
 
         producer, consumers, writer = stage.producer, list(stage.consumers), stage.writer
         kind = _cls(producer)
@@ -271,10 +271,8 @@ class HipExecutionEngine(ExecutionEngine):
         elif kind == "LoadShuffleFilesTask":
             batch = outputs[id(stage.dependencies[0])]
             if self.dist is not None:
-                batch = self._exchange_partials(batch)
+                batch = self._exchange_partials(batch) if batch.slab is not None else self._exchange_partial_rows(batch)
         elif kind == "BroadcastHashJoinTask":
-            if self.dist is not None:
-                raise NotImplementedError("multi-GPU hash join (all-to-all of both inputs) is not built yet")
             batch = self._join(producer, outputs[id(stage.dependencies[0])], outputs[id(stage.dependencies[1])])
         else:
             raise NotImplementedError(f"Job creation not implemented for {type(producer)}")
@@ -290,10 +288,9 @@ class HipExecutionEngine(ExecutionEngine):
             elif tname == "AggregateTask":
                 if task.before_shuffle and (id(task) in self._global_partial or self.group_cap_hint > 256):
                     self._global_partial.add(id(task))
-                    if self.dist is not None:
-                        raise NotImplementedError("multi-GPU GROUP BY beyond the on-chip tiers")
                     batch = self.dev.aggregate_partial_global(batch, pending, task.group_by_column, task.agg_columns,
                                                               task.inferred_schema)
+                    batch.partitioned = self.dist is not None
                     pending = []
                 elif task.before_shuffle:
                     slab_rows = None
@@ -301,23 +298,29 @@ class HipExecutionEngine(ExecutionEngine):
                         from .distributed import max_local_units  # noqa: PLC0415
 
                         if batch.total_units is None:
-                            raise NotImplementedError("multi-GPU aggregation needs a block-partitioned table scan")
-                        slab_rows = max_local_units(batch.total_units, self.world) * self.group_cap_hint
+                            raise NotImplementedError("multi-GPU aggregation needs a block-partitioned input")
+                        slab_rows = max(batch.n_units, max_local_units(batch.total_units, self.world)) * self.group_cap_hint
                     try:
                         batch = self.dev.aggregate_partial(batch, pending, task.group_by_column, task.agg_columns,
                                                            task.inferred_schema, self.group_cap_hint,
                                                            cache_key=id(task), slab_rows=slab_rows)
+                    except SlabUnsupported:
+                        # e.g. variable-length string keys: partial rows go through the generic all-to-all
+                        batch = self.dev.aggregate_partial(batch, pending, task.group_by_column, task.agg_columns,
+                                                           task.inferred_schema, self.group_cap_hint,
+                                                           cache_key=(id(task), "noslab"))
                     except TierExceeded:
-                        if self.dist is not None:
-                            raise
                         self._global_partial.add(id(task))
                         batch = self.dev.aggregate_partial_global(batch, pending, task.group_by_column,
                                                                   task.agg_columns, task.inferred_schema)
+                    batch.partitioned = self.dist is not None and batch.slab is None
                     pending = []
                 else:
                     batch = self._materialise(batch, pending)
                     pending = []
-                    use_global = id(task) in self._global_merge or getattr(self, "_merge_overflowed", False)
+                    was_partitioned = batch.partitioned
+                    use_global = (id(task) in self._global_merge or getattr(self, "_merge_overflowed", False)
+                                  or (batch.partitioned and batch.order is not None))
                     if not use_global:
                         try:
                             batch = self.dev.aggregate_merge(batch, task.agg_columns, task.inferred_schema,
@@ -325,8 +328,10 @@ class HipExecutionEngine(ExecutionEngine):
                         except TierExceeded:
                             use_global = True
                     if use_global:
-                        self._global_merge.add(id(task))
+                        if not was_partitioned:
+                            self._global_merge.add(id(task))
                         batch = self.dev.aggregate_merge_global(batch, task.agg_columns, task.inferred_schema)
+                    batch.partitioned = was_partitioned
             else:
                 raise NotImplementedError(f"consumer {tname}")
         batch = self._materialise(batch, pending)
@@ -338,6 +343,8 @@ class HipExecutionEngine(ExecutionEngine):
             outputs[id(stage)] = self._quantise_batch(batch, schema)
             return [JobResult(str(uuid.uuid4()), f"hip:{self.dev.index}", [])]
         if wname == "WriteToLocalFileTask":
+            if self.dist is not None and batch.partitioned:
+                batch = self._gather_to_root(batch)
             return [self._write_result(batch, schema, stage.stage_id)]
         raise NotImplementedError(f"writer {wname}")
 
@@ -368,7 +375,9 @@ class HipExecutionEngine(ExecutionEngine):
         if not col_ids:
             col_ids = [0]
         tbl.load_columns(self.dev, table, col_ids)
-        return tbl.table_batch(table, col_ids, producer.alias)
+        batch = tbl.table_batch(table, col_ids, producer.alias)
+        batch.partitioned = self.dist is not None
+        return batch
 
     def _join(self, task: Any, left: Any, right: Any) -> Any:
         """Partitioned inner hash join; output rows grouped by ``hash(key) % SHUFFLE_PARTITIONS`` so
@@ -378,7 +387,13 @@ class HipExecutionEngine(ExecutionEngine):
         left, right = self.dev.resolve(left), self.dev.resolve(right)
         lkey = left.column_index(task.left_key.name)
         rkey = right.column_index(task.right_key.name)
-        perm, part_start = self.dev.partition(right, rkey, constants.SHUFFLE_PARTITIONS)
+        if self.dist is not None:
+            # both inputs travel to the owner of their key's partition (p % world), then a local join
+            left, _ = self._exchange_by_key(left, lkey)
+            right, rpart = self._exchange_by_key(right, rkey)
+            perm, part_start = self.dev.partition_by_ids(rpart, right.nrows, constants.SHUFFLE_PARTITIONS)
+        else:
+            perm, part_start = self.dev.partition(right, rkey, constants.SHUFFLE_PARTITIONS)
         right = self.dev.gather_batch(right, perm, right.nrows, part_start)
         out_left, out_right, out_start, n_out = self.dev.join_indices(left.cols[lkey], right.cols[rkey])
         starts = out_start.tolist() if right.nrows <= 4096 else None
@@ -391,7 +406,12 @@ class HipExecutionEngine(ExecutionEngine):
             unit_rows = [int(starts[p]) for p in part_start]
         cols = [self.dev.gather_col(c, out_left, n_out) for c in left.cols]
         cols += [self.dev.gather_col(c, out_right, n_out) for c in right.cols]
-        return DBatch(list(left.schema) + list(right.schema), cols, n_out, unit_rows)
+        joined = DBatch(list(left.schema) + list(right.schema), cols, n_out, unit_rows)
+        if self.dist is not None:  # units = shuffle partitions, the same ids on every rank
+            joined.unit_ids = list(range(constants.SHUFFLE_PARTITIONS))
+            joined.total_units = constants.SHUFFLE_PARTITIONS
+            joined.partitioned = True
+        return joined
 
     def _exchange_partials(self, batch: Any) -> Any:
         """The shuffle between the two aggregation phases on N GPUs: all-gather the fixed-size slabs, then
@@ -433,6 +453,82 @@ class HipExecutionEngine(ExecutionEngine):
                 out.append(DCol(src.kind, data, n))
         return DBatch(list(batch.schema), out, n, [0, n], None, order=order, total_units=batch.total_units)
 
+    def _exchange_rows(self, batch: Any, dest: Any, extras: Sequence[Any] = ()) -> tuple[Any, list[Any]]:
+        """Generic shuffle (reference tasks.py:347-375 routes every row by hash(key) % 10 through files):
+        row i goes to rank dest[i] with an all-to-all-v per column (RCCL: direct peer-to-peer over the xGMI
+        mesh); `extras` are per-row tensors (u8 / i64) that travel along.  Returns (batch of received rows
+        grouped by source rank, received extras).  Sizes are exchanged first, so this path synchronises."""
+        import torch  # noqa: PLC0415
+
+        from . import hipspark as hs  # noqa: PLC0415
+        from .device import DBatch, DCol  # noqa: PLC0415
+        from .distributed import all_to_all_rows, exchange_counts  # noqa: PLC0415
+
+        dev, world, dist, group = self.dev, self.world, self.dist, self.group
+        batch = dev.resolve(batch)
+        n = batch.nrows
+        self._generic_exchange_used = True
+        perm, start = dev.partition_by_ids(dest, n, world)
+        send = [start[d + 1] - start[d] for d in range(world)]
+        recv = exchange_counts(dist, send, dev.device, group)
+        n_in = sum(recv)
+        out_cols = []
+        for col in batch.cols:
+            g = dev.gather_col(col, perm, n)
+            if g.kind == hs.STR:
+                lens = all_to_all_rows(dist, g.lens, send, recv, 1, group)
+                if g.fixed_len >= 0:
+                    send_b = [c * g.fixed_len for c in send]
+                else:
+                    offs = g.offs[torch.tensor(start, dtype=torch.int64, device=dev.device)].tolist()
+                    send_b = [int(offs[d + 1] - offs[d]) for d in range(world)]
+                recv_b = exchange_counts(dist, send_b, dev.device, group)
+                data = all_to_all_rows(dist, g.data, send_b, recv_b, 1, group)
+                out_cols.append(dev.string_col(lens, data, n_in))
+            else:
+                out_cols.append(DCol(g.kind, all_to_all_rows(dist, g.data, send, recv, 1, group), n_in))
+        out_extras = []
+        for t in extras:
+            kind = hs.U8 if t.dtype == torch.uint8 else hs.I64
+            g = dev.gather_col(DCol(kind, t, n), perm, n)
+            out_extras.append(all_to_all_rows(dist, g.data, send, recv, 1, group))
+        received = DBatch(list(batch.schema), out_cols, n_in, [0, n_in], total_units=batch.total_units)
+        received.partitioned = True
+        return received, out_extras
+
+    def _exchange_by_key(self, batch: Any, key_index: int) -> tuple[Any, Any]:
+        """Route rows to the rank owning hash(key) % SHUFFLE_PARTITIONS (owner = partition % world); the
+        partition id of every row travels along.  -> (received batch, received partition ids)."""
+        batch = self.dev.resolve(batch)
+        part = self.dev.partition_ids(batch, key_index, constants.SHUFFLE_PARTITIONS)
+        dest = part % self.world  # u8 arithmetic on a per-row id: plumbing
+        received, (rpart,) = self._exchange_rows(batch, dest.contiguous(), [part])
+        return received, rpart
+
+    def _exchange_partial_rows(self, batch: Any) -> Any:
+        """Partial-aggregate rows -> the rank owning their key's partition (generic form of the shuffle between
+        the two aggregation phases: any key type, any cardinality).  The global unit id of every row travels
+        along so the final merge keeps the reference's order."""
+        import torch  # noqa: PLC0415
+
+        batch = self.dev.resolve(batch)
+        order = batch.order if batch.order is not None else torch.zeros(batch.nrows, dtype=torch.int64,
+                                                                         device=self.dev.device)
+        part = self.dev.partition_ids(batch, 0, constants.SHUFFLE_PARTITIONS)
+        received, (rorder,) = self._exchange_rows(batch, (part % self.world).contiguous(), [order[: batch.nrows].contiguous()])
+        received.order = rorder
+        return received
+
+    def _gather_to_root(self, batch: Any) -> Any:
+        """Rows that are spread over the ranks travel to rank 0, which writes the result."""
+        import torch  # noqa: PLC0415
+
+        batch = self._materialise(self.dev.resolve(batch), [])
+        dest = torch.zeros(batch.nrows, dtype=torch.uint8, device=self.dev.device)
+        received, _ = self._exchange_rows(batch, dest, [])
+        received.partitioned = False
+        return received
+
     # ---- consumers -------------------------------------------------------------------------------------
     def _materialise(self, batch: Any, pending: Sequence[Any]) -> Any:
         """Apply deferred WHERE conditions: compaction to a row list, then gather every column."""
@@ -440,11 +536,18 @@ class HipExecutionEngine(ExecutionEngine):
             return batch
         import torch  # noqa: PLC0415
 
+        from . import hipspark as hs  # noqa: PLC0415
+        from .device import DCol  # noqa: PLC0415
+
         batch = self.dev.resolve(batch)
         sel, count = self.dev.filter_select(batch, pending)
         bounds = torch.tensor(batch.unit_rows, dtype=torch.int64, device=sel.device)
         unit_rows = [int(v) for v in torch.searchsorted(sel[:count].contiguous(), bounds).tolist()]
-        return self.dev.gather_batch(batch, sel, count, unit_rows)
+        out = self.dev.gather_batch(batch, sel, count, unit_rows)
+        out.unit_ids, out.total_units, out.partitioned = batch.unit_ids, batch.total_units, batch.partitioned
+        if batch.order is not None:
+            out.order = self.dev.gather_col(DCol(hs.I64, batch.order, batch.nrows), sel, count).data
+        return out
 
     def _project(self, batch: Any, pending: Sequence[Any], task: Any) -> Any:
         from . import hipspark as hs  # noqa: PLC0415
@@ -474,7 +577,8 @@ class HipExecutionEngine(ExecutionEngine):
                 out_cols[i] = dcol
         _ = hs
         return DBatch(list(task.inferred_schema), out_cols, n, list(batch.unit_rows) if batch.unit_rows else None,
-                      batch.nrows_dev)
+                      batch.nrows_dev, unit_ids=batch.unit_ids, total_units=batch.total_units, order=batch.order,
+                      partitioned=batch.partitioned)
 
     # ---- writers ---------------------------------------------------------------------------------------
     def _quantise_batch(self, batch: Any, schema: Schema) -> Any:
@@ -498,6 +602,11 @@ class HipExecutionEngine(ExecutionEngine):
         self._remote_flags = None
         if self.dev.rec is not None:
             self.dev.rec.result = (list(schema), stage_id)
+        if self.dist is not None and getattr(self, "_generic_exchange_used", False):
+            from .distributed import or_flags  # noqa: PLC0415
+
+            flags = or_flags(self.dist, flags, self.dev.device, self.group)  # same decision on every rank
+            self._generic_exchange_used = False
         if flags & hs.FLAG_DICT_FULL:
             raise RetryWithLargerDictionary
         self.dev.raise_for_flags(flags)

@@ -26,7 +26,9 @@ def _free_port() -> int:
 
 
 @pytest.mark.parametrize("case_name,world", [("q1_multiblock", 2), ("q1_ragged_blocks", 3), ("q1_selective", 2),
-                                              ("edge_int_key", 2)])
+                                              ("edge_int_key", 2), ("fruit", 2), ("join_group", 2), ("join_group", 3),
+                                              ("concat_like", 2), ("e2e_join_select", 2), ("e2e_join_group_sum", 3),
+                                              ("fruits5_filter", 2), ("e2e_group_avg_float", 2)])
 def test_world_n_matches_reference(tmp_path, case_name, world):
     port = _free_port()
     out = tmp_path / "rows.json"
@@ -37,9 +39,18 @@ def test_world_n_matches_reference(tmp_path, case_name, world):
         procs.append(subprocess.Popen([sys.executable, str(ROOT / "tests" / "dist_worker.py"), case_name, str(out), "gloo"],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = [p.communicate(timeout=300)[0].decode() for p in procs]
-    for rank, (p, log) in enumerate(zip(procs, logs)):
-        assert p.returncode == 0, f"rank {rank} failed:\n{log[-3000:]}"
+    if any(p.returncode != 0 for p in procs):
+        report = "\n".join(f"--- rank {r} (exit {p.returncode}) ---\n{log[-2500:]}" for r, (p, log) in enumerate(zip(procs, logs)))
+        raise AssertionError(report)
     rows = [{k: (float.fromhex(v) if isinstance(v, str) and v.startswith(("0x", "-0x")) else v) for k, v in r.items()}
             for r in json.loads(out.read_text())]
-    flips = assert_rows_match(rows, load_golden(case_name)["rows"], max_ulps=1)
+    from datetime import datetime
+
+    golden = load_golden(case_name)["rows"]
+    for r, g in zip(rows, golden[:1]):  # datetimes travel as ISO strings through the worker's JSON
+        for k, v in g.items():
+            if isinstance(v, datetime):
+                for row in rows:
+                    row[k] = datetime.fromisoformat(row[k])
+    flips = assert_rows_match(rows, golden, max_ulps=1)
     assert flips == 0
