@@ -24,6 +24,11 @@
 
 #define HS_FUSED_COLS 8 /* numeric column slots preloaded per step */
 
+// 16-byte vector types usable with __builtin_nontemporal_load (HIP's float4 & co. are structs)
+typedef float hs_f32x4 __attribute__((ext_vector_type(4)));
+typedef int hs_i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long hs_u64x2 __attribute__((ext_vector_type(2)));
+
 struct AggMainArgs {
     HsCols cols;
     hs_program prog;

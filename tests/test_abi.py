@@ -77,4 +77,4 @@ def test_jit_translates_and_compiles_q1_for_gfx950():
     assert rc == 0, (lib.hs_last_error(), lib.hs_jit_last_log()[:2000])
     assert nbytes.value > 4096
     text = src.value.decode()
-    assert "hs_agg_main_body<JitProg>" in text and text.count("fold_c<6,") == 6 and "float4" in text
+    assert "hs_agg_main_body<JitProg>" in text and text.count("fold_c<6,") == 6 and "hs_f32x4" in text
