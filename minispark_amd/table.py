@@ -15,6 +15,7 @@ from __future__ import annotations
 
 from dataclasses import dataclass, field
 from pathlib import Path
+from typing import Any
 
 import numpy as np
 import torch
@@ -69,8 +70,29 @@ def open_table(path: Path, rank: int = 0, world: int = 1) -> DeviceTable:
                        global_blocks=mine, total_blocks=len(rows))
 
 
+# ---- BlockFile -> HBM ingest ---------------------------------------------------------
+# Column pruning first (only the referenced columns' byte spans are read), then a pipeline: reader threads
+# preadv() every (block, column) span straight into pinned staging slots (the GIL is released during the read),
+# the caller's thread issues the H2D copies asynchronously on a side stream and recycles a slot once its copy's
+# event has fired.  Disk / page cache and PCIe run concurrently; nothing is copied twice on the host.
+import os as _os
+
+INGEST_READERS = int(_os.environ.get("HIPSPARK_INGEST_READERS", "8"))
+INGEST_SLOTS = 2 * INGEST_READERS
+
+
+class _Staging:
+    def __init__(self, nbytes: int) -> None:
+        self.buf = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        self.view = self.buf.numpy()
+        self.event: torch.cuda.Event | None = None
+
+
 def load_columns(dev: Device, table: DeviceTable, col_ids: list[int]) -> None:
     """Read the byte spans of ``col_ids`` block by block and place them in per-column device buffers."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+
     missing = [c for c in col_ids if c not in table.columns]
     if not missing:
         return
@@ -80,37 +102,94 @@ def load_columns(dev: Device, table: DeviceTable, col_ids: list[int]) -> None:
     file_blocks = table.global_blocks if table.global_blocks is not None else list(range(nblocks))
     with table.path.open("rb") as f:
         layouts = [bf.block_layout(b, f) for b in file_blocks]
-        for cid in missing:
-            col_type = table.schema[cid][1]
-            if col_type == ColumnType.STRING:
-                payload = sum(layouts[b].spans[cid][1] - layouts[b].nrows for b in range(nblocks))
-                lens = dev.empty(total_rows, torch.uint8)
-                data = dev.empty(payload, torch.uint8)
-                row, byte = 0, 0
-                for b in range(nblocks):
-                    off, nbytes = layouts[b].spans[cid]
-                    n = layouts[b].nrows
-                    f.seek(off)
-                    buf = np.frombuffer(f.read(nbytes), dtype=np.uint8)
-                    lens[row: row + n].copy_(torch.from_numpy(buf[:n].copy()))
-                    if nbytes > n:
-                        data[byte: byte + nbytes - n].copy_(torch.from_numpy(buf[n:].copy()))
-                    row += n
-                    byte += nbytes - n
-                table.columns[cid] = dev.string_col(lens, data, total_rows)
-            else:
-                out = dev.empty(total_rows, _TORCH[col_type])
-                row = 0
-                for b in range(nblocks):
-                    off, nbytes = layouts[b].spans[cid]
-                    n = layouts[b].nrows
-                    f.seek(off)
-                    buf = np.frombuffer(f.read(nbytes), dtype=_NP_DTYPE[col_type])
-                    if len(buf) != n:
-                        raise ValueError(f"{table.path}: block {b} column {cid} holds {len(buf)} values, expected {n}")
-                    out[row: row + n].copy_(torch.from_numpy(buf.copy()))
-                    row += n
-                table.columns[cid] = DCol(FILE_KIND[col_type], out, total_rows)
+
+    # destination buffers + the list of (file offset, nbytes, destination byte view) pieces
+    pieces: list[tuple[int, int, torch.Tensor]] = []
+    finish: list[tuple[int, torch.Tensor, torch.Tensor | None]] = []
+    for cid in missing:
+        col_type = table.schema[cid][1]
+        if col_type == ColumnType.STRING:
+            payload = sum(layouts[b].spans[cid][1] - layouts[b].nrows for b in range(nblocks))
+            lens = dev.empty(total_rows, torch.uint8)
+            data = dev.empty(payload, torch.uint8)
+            row, byte = 0, 0
+            for b in range(nblocks):
+                off, nbytes = layouts[b].spans[cid]
+                n = layouts[b].nrows
+                if n:
+                    pieces.append((off, n, lens[row: row + n]))
+                if nbytes > n:
+                    pieces.append((off + n, nbytes - n, data[byte: byte + nbytes - n]))
+                row += n
+                byte += nbytes - n
+            finish.append((cid, data, lens))
+        else:
+            out = dev.empty(total_rows, _TORCH[col_type])
+            esize = out.element_size()
+            row = 0
+            for b in range(nblocks):
+                off, nbytes = layouts[b].spans[cid]
+                n = layouts[b].nrows
+                if nbytes != n * esize:
+                    raise ValueError(f"{table.path}: block {b} column {cid} holds {nbytes} bytes, expected {n * esize}")
+                if n:
+                    pieces.append((off, nbytes, out[row: row + n].view(torch.uint8)))
+                row += n
+            finish.append((cid, out, None))
+
+    if pieces:
+        slot_bytes = max(p[1] for p in pieces)
+        cached = getattr(dev, "_ingest_slots", None)  # pinning host memory is slow: keep the slots per device
+        if cached is None or cached[0].buf.numel() < slot_bytes:
+            cached = [_Staging(max(slot_bytes, 16 << 20)) for _ in range(INGEST_SLOTS)]
+            dev._ingest_slots = cached
+        slots = cached[: min(INGEST_SLOTS, len(pieces))]
+        for slot in slots:
+            slot.event = None
+        copy_stream = torch.cuda.Stream(device=dev.device)
+        fd = os.open(table.path, os.O_RDONLY)
+
+        def read_into(slot: _Staging, off: int, nbytes: int) -> None:
+            done = 0
+            while done < nbytes:
+                got = os.preadv(fd, [memoryview(slot.view[done:nbytes])], off + done)
+                if got <= 0:
+                    raise OSError(f"{table.path}: short read at offset {off + done}")
+                done += got
+
+        try:
+            with ThreadPoolExecutor(max_workers=INGEST_READERS) as pool:
+                inflight: list[tuple[Any, _Staging, int, torch.Tensor]] = []
+                free = list(slots)
+                it = iter(pieces)
+                exhausted = False
+                while inflight or not exhausted:
+                    while free and not exhausted:
+                        nxt = next(it, None)
+                        if nxt is None:
+                            exhausted = True
+                            break
+                        slot = free.pop()
+                        if slot.event is not None:
+                            slot.event.synchronize()  # the previous H2D out of this slot has finished
+                        inflight.append((pool.submit(read_into, slot, nxt[0], nxt[1]), slot, nxt[1], nxt[2]))
+                    if inflight:
+                        fut, slot, nbytes, dst = inflight.pop(0)
+                        fut.result()
+                        with torch.cuda.stream(copy_stream):
+                            dst.copy_(slot.buf[:nbytes], non_blocking=True)
+                            slot.event = torch.cuda.Event()
+                            slot.event.record(copy_stream)
+                        free.append(slot)
+            copy_stream.synchronize()
+        finally:
+            os.close(fd)
+
+    for cid, data, lens in finish:
+        if lens is not None:
+            table.columns[cid] = dev.string_col(lens, data, total_rows)
+        else:
+            table.columns[cid] = DCol(FILE_KIND[table.schema[cid][1]], data, total_rows)
 
 
 def table_batch(table: DeviceTable, col_ids: list[int], alias: str = "") -> DBatch:
