@@ -100,7 +100,8 @@ def main() -> None:
         local_rank = int(os.environ["HIPSPARK_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("HIPSPARK_FORCE_DIST") == "1"  # exercise the collective path even at world 1
+    if world > 1 or force_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -116,7 +117,7 @@ def main() -> None:
     constants.SHUFFLE_FOLDER = scratch / "shuffle"
     total_rows = synth.lineitem_rows(args.sf)
     engine = HipExecutionEngine(device=local_rank)
-    if world > 1:
+    if dist is not None:
         engine.enable_distributed(dist)
     table_path = scratch / f"lineitem_sf{args.sf:g}.bin"
     table = synth.make_lineitem(engine.dev, table_path, total_rows, rank=rank, world=world)

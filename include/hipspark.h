@@ -314,6 +314,17 @@ int hs_quantise_many(void* stream, int32_t n_cols, void* const* srcs, const int3
                      const int64_t* n_dev, void* const* dsts, uint32_t* flags);
 
 /* =================================================================================================
+ * Multi-GPU: un-interleave the all-gathered exchange slabs of the partial-aggregate shuffle (the slab
+ * layout is minispark_amd/distributed.py SlabLayout: [flags u32][pad][row count i64][order key i64 x M]
+ * [column 0: M x row_bytes] ...).  gathered = [world][slab_bytes].  Outputs: flags_out[world];
+ * order_out[world * M] (-1 on rows at or beyond a rank's count); every column contiguous over world * M rows
+ * (rank-major) in col_dsts[c].  Replaces the reference's shuffle-file read-back (tasks.py:144-150).
+ * ===============================================================================================*/
+int hs_slab_unpack(void* stream, const uint8_t* gathered, int32_t world, int64_t slab_bytes, int64_t slab_rows,
+                   int64_t order_offset, int32_t n_cols, const int64_t* col_offsets, const int32_t* col_row_bytes,
+                   void* const* col_dsts, int32_t* flags_out, int64_t* order_out);
+
+/* =================================================================================================
  * Run-time specialisation (reference: codegen.py:230-247 compiles every query with `zig build`).
  * hs_agg_partial translates its bytecode to straight-line code inside the hand-written kernel skeleton,
  * compiles it with hiprtc for the running GPU and caches it per program; on any failure it launches the

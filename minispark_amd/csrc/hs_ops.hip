@@ -965,6 +965,73 @@ extern "C" int hs_join_fill(void* stream, const hs_col* left_key, const hs_col* 
     return HS_OK;
 }
 
+// ---- multi-GPU: un-interleave all-gathered exchange slabs (minispark_amd/distributed.py SlabLayout) --------------
+// slab := [flags u32][pad u32][row count i64][order key i64 x M][column 0: M x row_bytes][column 1] ...
+#define HS_MAX_SLAB_COLS 20
+struct SlabUnpackArgs {
+    const uint8_t* gathered;  // [world][slab_bytes]
+    int32_t world;
+    int32_t n_cols;
+    int64_t slab_bytes, slab_rows, order_offset;
+    int64_t col_offset[HS_MAX_SLAB_COLS];
+    int32_t col_row_bytes[HS_MAX_SLAB_COLS];
+    void* col_dst[HS_MAX_SLAB_COLS];  // contiguous over world * slab_rows rows, rank-major
+    int32_t* flags_out;               // [world]
+    int64_t* order_out;               // [world * slab_rows], -1 on padding rows
+};
+__global__ void __launch_bounds__(256) k_slab_unpack(const SlabUnpackArgs A_kernarg) {
+    HS_KERNARG(SlabUnpackArgs, A);
+    const int64_t total = (int64_t)A.world * A.slab_rows;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t rank = i / A.slab_rows, row = i % A.slab_rows;
+        const uint8_t* slab = A.gathered + rank * A.slab_bytes;
+        const int64_t count = *reinterpret_cast<const int64_t*>(slab + 8);
+        A.order_out[i] = row < count ? reinterpret_cast<const int64_t*>(slab + A.order_offset)[row] : -1;
+        if (row == 0) A.flags_out[rank] = *reinterpret_cast<const int32_t*>(slab);
+        for (int c = 0; c < A.n_cols; ++c) {
+            const int rb = A.col_row_bytes[c];
+            const uint8_t* src = slab + A.col_offset[c] + row * rb;
+            uint8_t* dst = (uint8_t*)A.col_dst[c] + i * rb;
+            switch (rb) {
+                case 8: *reinterpret_cast<uint64_t*>(dst) = *reinterpret_cast<const uint64_t*>(src); break;
+                case 4: *reinterpret_cast<uint32_t*>(dst) = *reinterpret_cast<const uint32_t*>(src); break;
+                case 2: *reinterpret_cast<uint16_t*>(dst) = *reinterpret_cast<const uint16_t*>(src); break;
+                default:
+                    for (int b = 0; b < rb; ++b) dst[b] = src[b];
+                    break;
+            }
+        }
+    }
+}
+extern "C" int hs_slab_unpack(void* stream, const uint8_t* gathered, int32_t world, int64_t slab_bytes,
+                              int64_t slab_rows, int64_t order_offset, int32_t n_cols, const int64_t* col_offsets,
+                              const int32_t* col_row_bytes, void* const* col_dsts, int32_t* flags_out,
+                              int64_t* order_out) {
+    if (!gathered || world < 1 || slab_rows < 0 || n_cols < 0 || n_cols > HS_MAX_SLAB_COLS || !flags_out ||
+        (slab_rows > 0 && !order_out) || (n_cols > 0 && (!col_offsets || !col_row_bytes || !col_dsts))) {
+        hs_set_error("hs_slab_unpack: bad arguments");
+        return HS_E_ARG;
+    }
+    SlabUnpackArgs A;
+    A.gathered = gathered;
+    A.world = world;
+    A.n_cols = n_cols;
+    A.slab_bytes = slab_bytes;
+    A.slab_rows = slab_rows;
+    A.order_offset = order_offset;
+    for (int c = 0; c < HS_MAX_SLAB_COLS; ++c) {
+        A.col_offset[c] = c < n_cols ? col_offsets[c] : 0;
+        A.col_row_bytes[c] = c < n_cols ? col_row_bytes[c] : 0;
+        A.col_dst[c] = c < n_cols ? col_dsts[c] : nullptr;
+    }
+    A.flags_out = flags_out;
+    A.order_out = order_out;
+    const int64_t total = (int64_t)world * (slab_rows > 0 ? slab_rows : 1);
+    hipLaunchKernelGGL(k_slab_unpack, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, A);
+    HS_CHECK_LAUNCH("hs_slab_unpack");
+    return HS_OK;
+}
+
 // ---- synthetic TPC-H-shaped lineitem --------------------------------------------------
 // value(row i, column c) = f(splitmix64(seed ^ c*GOLDEN + i)).  oracle/q1_oracle.c holds the CPU twin.
 __host__ __device__ __forceinline__ uint64_t hs_splitmix(uint64_t x) {

@@ -421,7 +421,7 @@ class HipExecutionEngine(ExecutionEngine):
 
         from . import hipspark as hs  # noqa: PLC0415
         from .device import DBatch, DCol  # noqa: PLC0415
-        from .distributed import all_gather_slabs_into, unpack_gathered_into  # noqa: PLC0415
+        from .distributed import all_gather_slabs_into  # noqa: PLC0415
 
         if batch.slab is None:
             raise NotImplementedError("multi-GPU exchange of this stage's output is not built yet")
@@ -436,12 +436,19 @@ class HipExecutionEngine(ExecutionEngine):
                             device=device)[: n * c.row_bytes // torch.empty((), dtype=c.dtype).element_size()]
                 for c in layout.columns]
         slab, dist, group = batch.slab, self.dist, self.group
+        # one collective (recorded as an opaque step) + ONE library launch that un-interleaves the slabs
+        self.dev.op(all_gather_slabs_into, dist, slab, gathered, group)
+        import ctypes as C  # noqa: PLC0415
 
-        def exchange() -> None:
-            all_gather_slabs_into(dist, slab, gathered, group)
-            unpack_gathered_into(gathered.view(world, layout.nbytes), layout, flags, order, cols)
-
-        self.dev.op(exchange)
+        ncols = len(layout.columns)
+        offs = (C.c_int64 * ncols)(*[c.offset for c in layout.columns])
+        rbytes = (C.c_int32 * ncols)(*[c.row_bytes for c in layout.columns])
+        dsts = (C.c_void_p * ncols)(*[t.data_ptr() for t in cols])
+        hs.check(self.dev.lib.hs_slab_unpack(self.dev.stream, gathered.data_ptr(), world, layout.nbytes, m,
+                                             layout.order_offset, ncols, offs, rbytes, dsts, flags.data_ptr(),
+                                             order.data_ptr()), "hs_slab_unpack")
+        if self.dev.rec is not None:
+            self.dev.rec.keep.append((gathered, flags, order, cols))
         self._remote_flags = flags
         out = []
         for src, slab_col in zip(batch.cols, batch.slab_cols):

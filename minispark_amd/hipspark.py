@@ -135,6 +135,8 @@ SIGNATURES: dict[str, tuple] = {
     "hs_exclusive_scan_i64": (C.c_int, [_P, _P, _I64, _P, _P]),
     "hs_quantise": (C.c_int, [_P, _P, _I32, _I64, _P, _P, _P]),
     "hs_quantise_many": (C.c_int, [_P, _I32, C.POINTER(_P), C.POINTER(_I32), _I64, _P, C.POINTER(_P), _P]),
+    "hs_slab_unpack": (C.c_int, [_P, _P, _I32, _I64, _I64, _I64, _I32, C.POINTER(_I64), C.POINTER(_I32),
+                                 C.POINTER(_P), _P, _P]),
     "hs_jit_set_enabled": (None, [C.c_int]),
     "hs_jit_get_enabled": (C.c_int, []),
     "hs_jit_stats": (None, [C.POINTER(_I32)]),
