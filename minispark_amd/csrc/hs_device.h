@@ -69,16 +69,6 @@ __device__ __forceinline__ uint64_t hs_load_cell(const hs_col& c, int64_t row) {
     }
 }
 
-// widen a raw (as stored) 32/64-bit pattern to the in-flight cell of its kind
-__device__ __forceinline__ uint64_t hs_widen(int32_t kind, uint64_t raw) {
-    switch (kind) {
-        case HS_I32: return (uint64_t)(int64_t)(int32_t)(uint32_t)raw;
-        case HS_F32: return hs_d2u((double)__uint_as_float((uint32_t)raw));
-        case HS_U8: return raw & 0xff;
-        default: return raw;
-    }
-}
-
 // ---- strings -------------------------------------------------------------------------------------
 struct HsStr {
     const uint8_t* p;

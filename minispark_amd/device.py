@@ -22,7 +22,7 @@ import torch
 from . import hipspark as hs
 from .constants import ColumnType, Schema
 from .io import StrCol
-from .lowering import AggregateLowering, ProgramBuilder, StringParts, lower_aggregate
+from .lowering import ProgramBuilder, StringParts, lower_aggregate
 
 PAD = 64  # bytes of slack behind every buffer
 
@@ -30,8 +30,6 @@ _TORCH_DTYPE = {hs.I32: torch.int32, hs.F32: torch.float32, hs.I64: torch.int64,
                 hs.U8: torch.uint8}
 FILE_KIND = {ColumnType.INTEGER: hs.I32, ColumnType.FLOAT: hs.F32, ColumnType.TIMESTAMP: hs.I64,
              ColumnType.STRING: hs.STR}
-INFLIGHT_KIND = {ColumnType.INTEGER: hs.I64, ColumnType.FLOAT: hs.F64, ColumnType.TIMESTAMP: hs.I64,
-                 ColumnType.STRING: hs.STR}
 
 
 @dataclass
@@ -240,11 +238,6 @@ class Device:
         t = torch.empty(int(n) + pad, dtype=dtype, device=self.device)[: int(n)]
         if self.rec is not None:
             self.rec.keep.append(t)
-        return t
-
-    def zeros(self, n: int, dtype: torch.dtype) -> torch.Tensor:
-        t = self.empty(n, dtype)
-        t.zero_()
         return t
 
     def workspace(self, nbytes: int) -> torch.Tensor:

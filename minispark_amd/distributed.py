@@ -10,7 +10,8 @@ meet through ONE collective per query:
   global unit id (= file block id) of every row, then the columns, each padded to ``slab_rows`` rows;
   the producing kernels write straight into the slab, there is no packing pass;
 * ``all_gather_into_tensor`` of the slabs (a few KB per rank: latency-bound, one RCCL call);
-* every rank un-interleaves the columns and runs the same final merge, which folds the partials of a key
+* every rank un-interleaves the columns (one launch of hs_slab_unpack; ``unpack_gathered`` below is its torch
+  statement, used by the CPU tests) and runs the same final merge, which folds the partials of a key
   in ascending (block id, row) order - exactly the order in which the reference's single shuffle file
   holds them - so the result does not depend on the number of GPUs.  Rank 0 writes the result file.
 
@@ -98,16 +99,6 @@ def all_gather_slabs_into(dist: Any, slab: torch.Tensor, out: torch.Tensor, grou
         dist.all_gather_into_tensor(out, slab, group=group)
 
 
-def unpack_gathered_into(gathered: torch.Tensor, layout: SlabLayout, flags_out: torch.Tensor, order_out: torch.Tensor,
-                         cols_out: list[torch.Tensor]) -> None:
-    """unpack_gathered into caller-owned tensors (same results)."""
-    flags, order, cols = unpack_gathered(gathered, layout)
-    flags_out.copy_(flags)
-    order_out.copy_(order)
-    for dst, src in zip(cols_out, cols):
-        dst.copy_(src)
-
-
 def unpack_gathered(gathered: torch.Tensor, layout: SlabLayout) -> tuple[torch.Tensor, torch.Tensor, list[torch.Tensor]]:
     """[world, slab_bytes] -> (flags int32[world], order int64[world*M] with -1 on padding rows,
     columns, each contiguous over all world*M rows in rank-major order)."""
@@ -123,10 +114,6 @@ def unpack_gathered(gathered: torch.Tensor, layout: SlabLayout) -> tuple[torch.T
     for c in layout.columns:
         cols.append(gathered[:, c.offset: c.offset + c.row_bytes * m].contiguous().view(c.dtype).reshape(-1))
     return flags, order, cols
-
-
-def owner_of_block(block: int, world: int) -> int:
-    return block % world
 
 
 def local_blocks(n_blocks: int, rank: int, world: int) -> list[int]:

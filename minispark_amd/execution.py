@@ -110,7 +110,6 @@ class HipExecutionEngine(ExecutionEngine):
         self.merge_cap_hint = 16  # dictionary capacity of the final merge (grows on overflow)
         self._global_partial: set[int] = set()  # AggregateTask ids (of cached plans) running on the global tier
         self._global_merge: set[int] = set()
-        self.last_stats: dict[str, Any] = {}
         self.dist: Any = None  # torch.distributed once enable_distributed() was called
         self.rank, self.world = 0, 1
         self._remote_flags: Any = None
@@ -215,8 +214,6 @@ class HipExecutionEngine(ExecutionEngine):
                 len(self._global_merge))
 
     def _replay(self, rec: Any) -> list[JobResult] | None:
-        from . import hipspark as hs  # noqa: PLC0415
-
         self.dev.flags.zero_()
         if not rec.replay():
             return None
@@ -225,7 +222,6 @@ class HipExecutionEngine(ExecutionEngine):
             return None  # errors and dictionary growth are handled by the full path
         schema, stage_id = rec.result
         self.replays += 1
-        _ = hs
         return [self._emit_result(raw, nrows, schema, stage_id)]
 
     def _cached_plan(self, full_task: Any) -> Any:
@@ -582,7 +578,6 @@ class HipExecutionEngine(ExecutionEngine):
                 if tag == "B":
                     raise AssertionError("a comparison cannot be selected as a column (the reference has no BOOL type)")
                 out_cols[i] = dcol
-        _ = hs
         return DBatch(list(task.inferred_schema), out_cols, n, list(batch.unit_rows) if batch.unit_rows else None,
                       batch.nrows_dev, unit_ids=batch.unit_ids, total_units=batch.total_units, order=batch.order,
                       partitioned=batch.partitioned)

@@ -25,7 +25,6 @@ from __future__ import annotations
 
 import operator
 import re
-import uuid
 from datetime import datetime
 from pathlib import Path
 from typing import Any, Callable, Iterable
@@ -307,6 +306,3 @@ def run_query(task: Any, rows_per_block: int | None = None) -> list[dict]:
     plan = PhysicalPlan.generate_physical_plan(task)
     return OracleEngine(rows_per_block).run(plan)
 
-
-def new_id() -> str:
-    return str(uuid.uuid4())
