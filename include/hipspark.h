@@ -48,6 +48,8 @@ extern "C" {
 #define HS_FLAG_FLT_OVERFLOW 0x4u  /* reference: OverflowError in struct.pack('<f'), io.py:94 */
 #define HS_FLAG_DICT_FULL 0x8u     /* more distinct group keys than the launch's capacity: retry larger */
 #define HS_FLAG_BAD_PROGRAM 0x10u  /* interpreter met an op it cannot run in this kernel */
+#define HS_FLAG_TYPE_ASSERT 0x40u   /* a FLOAT MIN/MAX never left its int identity (MAX_INT / MIN_INT): the reference
+                                     * then fails `assert type(val) is float` at the file write, io.py:93 */
 #define HS_FLAG_STR_TOO_LONG 0x20u /* a concatenated string exceeds 255 bytes (BlockFile length byte, io.py:18) */
 
 /* ---- storage kinds of a device column ---- */

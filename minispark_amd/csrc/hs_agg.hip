@@ -32,6 +32,8 @@ struct AggUnitArgs {
     hs_agg_spec spec;
     int32_t group_cap;
     int32_t hashed;
+    int32_t batch;  // chunks staged through LDS per step (<= HS_UNIT_BATCH, sized to the LDS budget)
+    int32_t pad;
     const int64_t* unit_chunk0;
     const uint64_t* part_keys;
     const int64_t* part_rep;
@@ -55,7 +57,8 @@ __global__ void __launch_bounds__(256) k_agg_unit(const AggUnitArgs A_kernarg) {
     int64_t* ureps = (int64_t*)(lds + GC);                  // [GC]
     uint64_t* uacc = lds + 2 * GC;                          // [GC][NA]
     uint64_t* pacc = uacc + GC * NA;                        // [BATCH][GC][NA] staged chunk partials
-    int* inv = (int*)(pacc + (size_t)HS_UNIT_BATCH * GC * NA);  // [BATCH][GC] unit slot -> chunk slot (or -1)
+    const int BATCH = A.batch;
+    int* inv = (int*)(pacc + (size_t)BATCH * GC * NA);  // [BATCH][GC] unit slot -> chunk slot (or -1)
     __shared__ int s_count;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int64_t u = blockIdx.x;
@@ -71,8 +74,8 @@ __global__ void __launch_bounds__(256) k_agg_unit(const AggUnitArgs A_kernarg) {
 
     const uint32_t mask = (uint32_t)GC - 1;
     const int64_t cbeg = A.unit_chunk0[u], cend = A.unit_chunk0[u + 1];
-    for (int64_t b0 = cbeg; b0 < cend; b0 += HS_UNIT_BATCH) {
-        const int nb = (int)((cend - b0) < HS_UNIT_BATCH ? (cend - b0) : HS_UNIT_BATCH);
+    for (int64_t b0 = cbeg; b0 < cend; b0 += BATCH) {
+        const int nb = (int)((cend - b0) < BATCH ? (cend - b0) : BATCH);
         for (int i = tid; i < nb * GC; i += nthr) inv[i] = -1;
         __syncthreads();
         for (int i = tid; i < nb * GC; i += nthr) {
@@ -110,6 +113,8 @@ __global__ void __launch_bounds__(256) k_agg_unit(const AggUnitArgs A_kernarg) {
     }
     for (int i = tid; i < GC * NA; i += nthr) {
         const int a = i % NA;
+        if (ureps[i / NA] >= 0 && hs_float_identity_left(A.spec.op[a], A.spec.is_int[a] != 0, uacc[i]))
+            err |= HS_FLAG_TYPE_ASSERT;
         A.out_acc[u * (int64_t)GC * NA + i] = hs_quantise_cell(A.spec.is_int[a] != 0, uacc[i], err);
     }
     __syncthreads();
@@ -639,12 +644,17 @@ extern "C" int hs_agg_partial(void* stream, const hs_col* cols, int32_t n_cols, 
     U.out_acc = out_acc;
     U.out_ngroups = out_ngroups;
     U.flags = flags;
-    const size_t ulds = (size_t)geom->group_cap * 16 + (size_t)geom->group_cap * spec->n_acc * 8 +
-                        (size_t)HS_UNIT_BATCH * geom->group_cap * spec->n_acc * 8 + (size_t)HS_UNIT_BATCH * geom->group_cap * 4;
+    const size_t ubase = (size_t)geom->group_cap * 16 + (size_t)geom->group_cap * spec->n_acc * 8;
+    const size_t uper = (size_t)geom->group_cap * spec->n_acc * 8 + (size_t)geom->group_cap * 4;  // per staged chunk
+    int ubatch = HS_UNIT_BATCH;
+    while (ubatch > 1 && ubase + (size_t)ubatch * uper > HS_LDS_SOFT) ubatch /= 2;
+    const size_t ulds = ubase + (size_t)ubatch * uper;
     if (ulds > HS_LDS_HARD) {
         hs_set_error("hs_agg_partial: unit combine needs %zu B LDS", ulds);
         return HS_E_LIMIT;
     }
+    U.batch = ubatch;
+    U.pad = 0;
     static bool unit_attr = false;
     if (!unit_attr) {
         allow_big_lds(k_agg_unit);

@@ -491,6 +491,12 @@ __device__ __forceinline__ uint64_t hs_acc_fold(uint32_t op, bool is_int, uint64
     return hs_d2u(b > a ? b : a);
 }
 
+// Python: min(MAX_INT, x) keeps the int MAX_INT unless x < MAX_INT; a FLOAT aggregate that still holds the int
+// identity makes the reference's writer fail its type assertion (io.py:93).  True when `cell` is that case.
+__device__ __forceinline__ bool hs_float_identity_left(uint32_t op, bool is_int, uint64_t cell) {
+    return !is_int && op != HS_AGG_SUM && cell == hs_acc_identity(op, false);
+}
+
 // fp64 -> "what a shuffle/result file holds": f32 rounding (RNE) widened back; finite overflow flagged
 __device__ __forceinline__ uint64_t hs_quantise_cell(bool is_int, uint64_t cell, uint32_t& err) {
     if (is_int) {

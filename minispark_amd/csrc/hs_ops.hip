@@ -290,7 +290,7 @@ extern "C" int hs_gather_str_lens(void* stream, const hs_col* src, const int64_t
 extern "C" int hs_gather_str_bytes(void* stream, const hs_col* src, const int64_t* idx, int64_t n,
                                    const int64_t* out_offs, uint8_t* out_data) {
     if (n == 0) return HS_OK;
-    if (!src || src->kind != HS_STR || !out_offs || !out_data || n < 0) {
+    if (!src || src->kind != HS_STR || !out_offs || n < 0) {  // out_data may be NULL when every string is empty
         hs_set_error("hs_gather_str_bytes: bad arguments");
         return HS_E_ARG;
     }
@@ -836,6 +836,7 @@ __global__ void __launch_bounds__(256) k_group_fold(const GroupFoldArgs A_kernar
             const bool is_int = A.spec.is_int[a] != 0;
             uint64_t v = hs_acc_identity(op, is_int);
             for (int64_t q = b; q < e; ++q) v = hs_acc_fold(op, is_int, v, hs_load_cell(A.vals[a], A.positions[q]));
+            if (hs_float_identity_left(op, is_int, v)) err |= HS_FLAG_TYPE_ASSERT;  // both phases write a file next
             if (A.quantise) v = hs_quantise_cell(is_int, v, err);
             A.out_acc[(int64_t)a * A.n_groups_max + g] = v;
         }

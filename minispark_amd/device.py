@@ -270,6 +270,10 @@ class Device:
             raise OverflowError("int too big to convert")  # io.py:90
         if flags & hs.FLAG_FLT_OVERFLOW:
             raise OverflowError("float too large to pack with f format")  # io.py:94
+        if flags & hs.FLAG_TYPE_ASSERT:
+            # MIN/MAX identities are ints (constants.py:14-15): a FLOAT aggregate that never got below MAX_INT /
+            # above MIN_INT is still an int when the reference writes it (tasks.py:303-310 -> io.py:93)
+            raise AssertionError("FLOAT column holds int")
         if flags & hs.FLAG_STR_TOO_LONG:
             raise ValueError("string longer than 255 bytes cannot be stored in a BlockFile")
         if flags & hs.FLAG_BAD_PROGRAM:

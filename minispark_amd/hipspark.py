@@ -31,6 +31,7 @@ FLAG_FLT_OVERFLOW = 0x4
 FLAG_DICT_FULL = 0x8
 FLAG_BAD_PROGRAM = 0x10
 FLAG_STR_TOO_LONG = 0x20
+FLAG_TYPE_ASSERT = 0x40
 
 AGG_SUM, AGG_MIN, AGG_MAX = 0, 1, 2
 
