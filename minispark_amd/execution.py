@@ -269,7 +269,8 @@ class HipExecutionEngine(ExecutionEngine):
             if self.dist is not None:
                 batch = self._exchange_partials(batch) if batch.slab is not None else self._exchange_partial_rows(batch)
         elif kind == "BroadcastHashJoinTask":
-            batch = self._join(producer, outputs[id(stage.dependencies[0])], outputs[id(stage.dependencies[1])])
+            batch = self._join(producer, outputs[id(stage.dependencies[0])], outputs[id(stage.dependencies[1])],
+                               self._needed_names(consumers))
         else:
             raise NotImplementedError(f"Job creation not implemented for {type(producer)}")
 
@@ -375,7 +376,27 @@ class HipExecutionEngine(ExecutionEngine):
         batch.partitioned = self.dist is not None
         return batch
 
-    def _join(self, task: Any, left: Any, right: Any) -> Any:
+    @staticmethod
+    def _needed_names(consumers: Sequence[Any]) -> set[str] | None:
+        """Column names the consumers of a producer reference before the schema changes (projection /
+        aggregate); None = rows reach the writer as they are, every column is needed."""
+        needed: set[str] = set()
+        for task in consumers:
+            tname = _cls(task)
+            if tname == "FilterTask":
+                needed.update(_plain_names(task.condition))
+            elif tname == "ProjectTask":
+                for col in task.columns:
+                    needed.update(_plain_names(col))
+                return needed
+            elif tname == "AggregateTask":
+                needed.update(_plain_names(task.group_by_column))
+                for agg in task.agg_columns:
+                    needed.update(_plain_names(agg))
+                return needed
+        return None
+
+    def _join(self, task: Any, left: Any, right: Any, needed: set[str] | None = None) -> Any:
         """Partitioned inner hash join; output rows grouped by ``hash(key) % SHUFFLE_PARTITIONS`` so
         that a following partial aggregate sees the reference's JoinJob units (plan.py:99-109)."""
         from .device import DBatch  # noqa: PLC0415
@@ -400,9 +421,18 @@ class HipExecutionEngine(ExecutionEngine):
             unit_rows = [int(v) for v in out_start[idx].tolist()]
         else:
             unit_rows = [int(starts[p]) for p in part_start]
-        cols = [self.dev.gather_col(c, out_left, n_out) for c in left.cols]
-        cols += [self.dev.gather_col(c, out_right, n_out) for c in right.cols]
-        joined = DBatch(list(left.schema) + list(right.schema), cols, n_out, unit_rows)
+        # column pruning: the reference materialises every column of both sides for every matching pair
+        # (tasks.py:229-238); only the columns a downstream operator names are gathered here
+        schema, cols = [], []
+        for side, idx in ((left, out_left), (right, out_right)):
+            for (name, ctype), col in zip(side.schema, side.cols):
+                if needed is None or name in needed:
+                    schema.append((name, ctype))
+                    cols.append(self.dev.gather_col(col, idx, n_out))
+        if not cols:  # e.g. COUNT only: keep one column so the batch has a row count carrier
+            schema.append(right.schema[rkey])
+            cols.append(self.dev.gather_col(right.cols[rkey], out_right, n_out))
+        joined = DBatch(schema, cols, n_out, unit_rows)
         if self.dist is not None:  # units = shuffle partitions, the same ids on every rank
             joined.unit_ids = list(range(constants.SHUFFLE_PARTITIONS))
             joined.total_units = constants.SHUFFLE_PARTITIONS
