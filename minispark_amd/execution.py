@@ -31,8 +31,8 @@ from typing import Any, Iterable, Iterator, Sequence
 
 from . import constants
 from .constants import ColumnType, Row, Schema
-from .io import BlockFile, write_single_block_file
-from .jobs import JobResult, OutputFile
+from .io import BlockFile
+from .jobs import JobResult, OutputFile, ResultFile
 
 
 class ExecutionError(Exception):
@@ -58,7 +58,8 @@ class ExecutionEngine(AbstractContextManager, ABC):
     def collect_results(self, results: list[JobResult], limit: float = math.inf) -> Iterator[Row]:
         output_files = {file for result in results for file in result.output_files}
         for file in output_files:
-            for row in BlockFile(file.file_path).read_data_rows():
+            rows = file.rows() if isinstance(file, ResultFile) else BlockFile(file.file_path).read_data_rows()
+            for row in rows:
                 yield row
                 limit -= 1
                 if limit <= 0:
@@ -96,6 +97,7 @@ class HipExecutionEngine(ExecutionEngine):
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", "0"))
         self.dev = Device(device)
+        self._executor_id = f"hip:{self.dev.index}"
         self._work_folder = work_folder
         self._tables: dict[str, Any] = {}
         self._plans: dict[Any, Any] = {}
@@ -105,7 +107,8 @@ class HipExecutionEngine(ExecutionEngine):
         self._plan_runs: dict[Any, int] = {}
         self._owned_dirs: set[Path] = set()
         self._result_root: Path | None = None
-        self._made_dirs: set[Path] = set()
+        self._result_paths: dict[Any, Path] = {}
+        self._job_prefix, self._job_seq = uuid.uuid4().hex[:12], 0
         self.group_cap_hint = 4   # dictionary capacity per workgroup of the partial aggregate (grows on overflow)
         self.merge_cap_hint = 16  # dictionary capacity of the final merge (grows on overflow)
         self._global_partial: set[int] = set()  # AggregateTask ids (of cached plans) running on the global tier
@@ -119,7 +122,7 @@ class HipExecutionEngine(ExecutionEngine):
         for d in self._owned_dirs:
             shutil.rmtree(d, ignore_errors=True)
         self._owned_dirs.clear()
-        self._made_dirs.clear()
+        self._result_paths.clear()
         self._result_root = None
 
     # ---- multi-GPU -------------------------------------------------------------------------------------
@@ -232,12 +235,12 @@ class HipExecutionEngine(ExecutionEngine):
         node, stack = full_task, []
         while node is not None and _cls(node) != "VoidTask":
             if _cls(node) == "LoadTableBlockTask":
-                p = Path(node.file_path)
+                p = os.fspath(node.file_path)
                 try:
-                    st = p.stat()
-                    stamps.append((str(p), node.alias, st.st_mtime_ns, st.st_size))
+                    st = os.stat(p)
+                    stamps.append((p, node.alias, st.st_mtime_ns, st.st_size))
                 except OSError:
-                    stamps.append((str(p), node.alias, 0, 0))
+                    stamps.append((p, node.alias, 0, 0))
             if _cls(node) == "BroadcastHashJoinTask":
                 stack.append(node.right_side_task)
             node = node.parent_task
@@ -338,7 +341,8 @@ class HipExecutionEngine(ExecutionEngine):
         if wname == "WriteToShufflePartitions":
             # the "shuffle file" stays in HBM; data-dependent errors surface at the query's final read-back
             outputs[id(stage)] = self._quantise_batch(batch, schema)
-            return [JobResult(str(uuid.uuid4()), f"hip:{self.dev.index}", [])]
+            self._job_seq += 1
+            return [JobResult(f"{self._job_prefix}-{self._job_seq}", self._executor_id, [])]
         if wname == "WriteToLocalFileTask":
             if self.dist is not None and batch.partitioned:
                 batch = self._gather_to_root(batch)
@@ -645,20 +649,16 @@ class HipExecutionEngine(ExecutionEngine):
         return self._emit_result(raw, nrows, schema, stage_id)
 
     def _emit_result(self, raw: list, nrows: int, schema: Schema, stage_id: str) -> JobResult:
-        job_id = str(uuid.uuid4())
+        self._job_seq += 1
+        job_id = f"{self._job_prefix}-{self._job_seq}"
         if nrows == 0 or self.rank != 0:
             # empty result: the reference writes no file (tasks.py:405); multi-GPU: rank 0 owns the result
-            return JobResult(job_id, f"hip:{self.dev.index}", [])
+            return JobResult(job_id, self._executor_id, [])
         if self._result_root is None:
             self._result_root = Path(self._work_folder or (constants.SHUFFLE_FOLDER / f"hip-{uuid.uuid4().hex[:12]}"))
             self._owned_dirs.add(self._result_root)
-        out_dir = self._result_root / str(stage_id)
-        if out_dir not in self._made_dirs:
-            out_dir.mkdir(parents=True, exist_ok=True)
-            self._made_dirs.add(out_dir)
-        out_file = out_dir / "result.bin"
-        if nrows <= constants.ROWS_PER_BLOCK:
-            write_single_block_file(out_file, schema, raw)
-        else:
-            BlockFile(out_file, list(schema)).write_raw(list(schema), raw)
-        return JobResult(job_id, f"hip:{self.dev.index}", [OutputFile(out_file)])
+        out_file = self._result_paths.get(stage_id)
+        if out_file is None:
+            out_file = self._result_paths[stage_id] = self._result_root / str(stage_id) / "result.bin"
+        # the rows are already in host memory: hand them over; the BlockFile is written when its path is read
+        return JobResult(job_id, self._executor_id, [ResultFile(out_file, list(schema), raw, nrows)])

@@ -530,6 +530,27 @@ def _rows_from_bytes(buf: bytes) -> Iterator[Row]:
             yield dict(zip(names, row, strict=True))
 
 
+def rows_from_raw(schema: Schema, cols: Sequence[RawColumn]) -> Iterator[Row]:
+    """Rows (dicts of Python values) straight from raw columns: the values a reader of the BlockFile
+    holding these columns would produce (f32 widened to float, TIMESTAMP as datetime, STRING as str)."""
+    names = [n for n, _ in schema]
+    values = []
+    for (_, col_type), c in zip(schema, cols, strict=True):
+        if isinstance(c, StrCol):
+            data = c.data.tobytes()
+            vals, p = [], 0
+            for ln in c.lens.tolist():
+                vals.append(data[p: p + ln].decode("utf-8"))
+                p += ln
+            values.append(vals)
+        elif col_type == ColumnType.TIMESTAMP:
+            values.append([timestamp_to_datetime(v) for v in c.tolist()])
+        else:
+            values.append(c.tolist())
+    for row in zip(*values, strict=True):
+        yield dict(zip(names, row, strict=True))
+
+
 def _split_rows(cols: Sequence[RawColumn], rows_per_block: int) -> Iterator[list[RawColumn]]:
     total = raw_len(cols[0]) if len(cols) else 0
     str_offsets = {i: c.offsets() for i, c in enumerate(cols) if isinstance(c, StrCol)}

@@ -20,6 +20,37 @@ class OutputFile:
     partition: int = 0
 
 
+class ResultFile:
+    """The final result of a query, handed over in host memory: the rows arrived with the query's single
+    device->host copy, so ``collect_results`` serves them directly.  It still stands for the BlockFile the
+    reference's engines write (tasks.py:391-410): reading ``file_path`` writes that file on first use."""
+
+    __slots__ = ("_path", "partition", "schema", "raw", "nrows", "_written")
+
+    def __init__(self, path: Path, schema: list, raw: list, nrows: int, partition: int = 0) -> None:
+        self._path, self.partition, self.schema, self.raw, self.nrows = path, partition, schema, raw, nrows
+        self._written = False
+
+    @property
+    def file_path(self) -> Path:
+        if not self._written:
+            from .constants import ROWS_PER_BLOCK  # noqa: PLC0415
+            from .io import BlockFile, write_single_block_file  # noqa: PLC0415
+
+            self._path.parent.mkdir(parents=True, exist_ok=True)
+            if self.nrows <= ROWS_PER_BLOCK:
+                write_single_block_file(self._path, self.schema, self.raw)
+            else:
+                BlockFile(self._path, list(self.schema)).write_raw(list(self.schema), self.raw)
+            self._written = True
+        return self._path
+
+    def rows(self):  # noqa: ANN201
+        from .io import rows_from_raw  # noqa: PLC0415
+
+        return rows_from_raw(self.schema, self.raw)
+
+
 @dataclass
 class JobResult:
     job_id: str

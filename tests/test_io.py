@@ -106,3 +106,27 @@ def test_quantisation_errors_match_reference():
         BlockFile(Path("/tmp/x"), [("f", ColumnType.FLOAT)])._write_python_columns(([1],), [("f", ColumnType.FLOAT)])
     with pytest.raises(ValueError):
         StrCol.from_strings(["x" * 256])
+
+
+def test_result_file_rows_equal_the_rows_of_the_file_it_writes(tmp_path):
+    """The in-memory result hand-over (jobs.ResultFile.rows) yields exactly what a reader of the BlockFile
+    written for the same result yields - same Python types and values; the file appears on first use."""
+    from minispark_amd.jobs import ResultFile
+
+    schema = [("k", ColumnType.STRING), ("i", ColumnType.INTEGER), ("f", ColumnType.FLOAT), ("t", ColumnType.TIMESTAMP)]
+    words = ["", "a", "héllo", "x" * 200]
+    enc = [w.encode() for w in words]
+    raw = [
+        StrCol(np.array([len(e) for e in enc], dtype=np.uint8), np.frombuffer(b"".join(enc), dtype=np.uint8)),
+        np.array([0, -1, 2**31 - 1, -(2**31)], dtype=np.int32),
+        np.array([0.1, -2.5e30, 1e-40, 3.0], dtype=np.float32),
+        np.array([0, 1, 912_470_400_000_000, 86_400_000_000], dtype=np.int64),
+    ]
+    res = ResultFile(tmp_path / "stage" / "result.bin", schema, raw, 4)
+    assert not (tmp_path / "stage").exists()
+    direct = list(res.rows())
+    from_file = list(BlockFile(res.file_path).read_data_rows())
+    assert (tmp_path / "stage" / "result.bin").exists()
+    assert direct == from_file
+    assert [type(v) for v in direct[1].values()] == [type(v) for v in from_file[1].values()]
+    assert isinstance(direct[0]["t"], datetime) and isinstance(direct[0]["f"], float) and isinstance(direct[0]["i"], int)
