@@ -79,6 +79,7 @@ typedef struct hs_col {
 #define HS_MAX_POOL 256
 #define HS_MAX_COLS 12
 #define HS_MAX_ACC 16
+#define HS_MAX_OUTS 16 /* output columns of one hs_eval / projection program */
 #define HS_MAX_STACK 8
 
 enum hs_op {
@@ -121,6 +122,9 @@ typedef struct hs_agg_spec {
 
 const char* hs_last_error(void);
 int hs_version(void);
+/* sizeof() of ABI structure `which` as compiled: 0 hs_col, 1 hs_program, 2 hs_agg_spec, 3 hs_agg_geom, 4 hs_chunk,
+ * 5 hs_slab_desc, 6 hs_finish_out, 7 hs_finish_spec (0 for anything else) - lets a binding verify its mirror. */
+size_t hs_sizeof(int32_t which);
 
 /* =================================================================================================
  * A1  BlockFile decode helpers (reference io.py:112-153: STRING = nrows length bytes + payload)
@@ -314,6 +318,69 @@ int hs_quantise(void* stream, const void* src, int32_t src_kind, int64_t n, cons
 /* The same for up to 16 columns of one batch in a single launch. */
 int hs_quantise_many(void* stream, int32_t n_cols, void* const* srcs, const int32_t* src_kinds, int64_t n,
                      const int64_t* n_dev, void* const* dsts, uint32_t* flags);
+
+/* =================================================================================================
+ * The short tail: partial rows written straight into the exchange slab, and ONE launch from the
+ * (all-gathered) slabs to the query's result.  For GROUP BY queries whose partial rows fit the LDS tiers
+ * the work after the scan is latency-bound (a few hundred rows); this pair replaces
+ * hs_agg_pack + key gather + [all-gather] + hs_slab_unpack + hs_agg_merge + key gather + hs_eval +
+ * hs_quantise_many + concatenation by two launches around the collective.  Same arithmetic, same order.
+ *
+ * Slab of one rank (hs_slab_desc; host mirror: minispark_amd/distributed.py SlabLayout):
+ *   [flags u32][pad u32][row count i64] | order key i64 x M | key column M x key_bytes | accumulator
+ *   columns M x 4 bytes (HS_F32 / HS_I32 = what the reference's shuffle file holds, io.py:87-94).
+ * Unit u owns rows [u * group_cap, (u + 1) * group_cap): its groups dense from the first row, order key =
+ * the unit's global id; unused rows carry order key -1.
+ * ===============================================================================================*/
+typedef struct hs_slab_desc {
+    int64_t slab_rows;           /* M */
+    int64_t stride;              /* bytes from one rank's slab to the next in the gathered buffer */
+    int64_t order_off, key_off;  /* byte offsets inside a slab */
+    int64_t acc_off[HS_MAX_ACC];
+    int32_t key_kind;            /* HS_I32 / HS_F32 / HS_I64 / HS_F64 / HS_U8, or HS_STR of fixed length key_len */
+    int32_t key_len;             /* HS_STR: 1, 2 or 4 bytes (packs into the 64-bit key word); else ignored */
+    int32_t n_acc, pad;
+    int32_t acc_kind[HS_MAX_ACC]; /* HS_F32 / HS_I32 */
+} hs_slab_desc;
+
+/* hs_agg_partial with the unit combine emitting into `slab` (this rank's slab, device memory, order keys
+ * pre-set to -1, header zero).  unit_ids (device, optional) = global id of every local unit.  Status bits of
+ * the scan and the combine are OR-ed into the slab header as well as into *flags, so they reach every rank. */
+int hs_agg_partial_slab(void* stream, const hs_col* cols, int32_t n_cols, int32_t key_col, const hs_program* prog,
+                        const hs_agg_spec* spec, const hs_chunk* chunks, const int64_t* unit_chunk0, int64_t n_units,
+                        const hs_agg_geom* geom, const int64_t* unit_ids, uint8_t* slab, const hs_slab_desc* desc,
+                        void* ws, uint32_t* flags, void* ev_begin, void* ev_end);
+
+/* One result column of hs_agg_finish. */
+typedef struct hs_finish_out {
+    int32_t src;     /* 0 = the group key, 1 = merged aggregate `index` (fold number), 2 = output `index` of the program */
+    int32_t index;
+    int32_t kind;    /* stored kind: HS_F32 (from an f64 cell, overflow flagged), HS_I32 (from i64, range flagged),
+                        HS_I64 (as is); src 0: ignored - the key element is copied */
+    int32_t pad;
+    int64_t offset;  /* byte offset of the column inside `result` (cap elements) */
+} hs_finish_out;
+#define HS_FINISH_MAX_OUT 24
+typedef struct hs_finish_spec {
+    int32_t n_fold;                   /* merged aggregates: fold j = fold_op[j] over slab accumulator fold_src[j] */
+    int32_t fold_src[HS_MAX_ACC];
+    int32_t fold_op[HS_MAX_ACC];      /* HS_AGG_SUM / MIN / MAX (reference tasks.py:290-292) */
+    int32_t n_out;
+    hs_finish_out outs[HS_FINISH_MAX_OUT];
+    int32_t prog_src[HS_MAX_COLS];    /* program column slot -> -1 = the group key, j = merged aggregate j */
+    int32_t prog_out[HS_MAX_OUTS];    /* program output -> index into outs[] */
+} hs_finish_spec;
+size_t hs_agg_finish_scratch_bytes(int32_t cap, int32_t n_fold);
+/* Final merge of the partial rows of `world` slabs (gathered: world slabs desc->stride bytes apart; world 1 =
+ * the rank's own slab) in ascending (order key, row) order exactly like hs_agg_merge, then the projection
+ * `prog` over the merged rows (NULL / n_ins 0: none), quantisation to the stored kinds and the result image:
+ *   result := [flags u32][pad u32][number of groups i64] + the columns at outs[].offset.
+ * flags = *flags | every slab's header flags | this launch's own bits; *flags and *own_slab_flags (optional)
+ * are reset to 0 for the next run.  n_order: order keys lie in [0, n_order).  HS_E_LIMIT (2) when the rows do
+ * not fit the LDS tier. */
+int hs_agg_finish(void* stream, const uint8_t* gathered, int32_t world, const hs_slab_desc* desc,
+                  const hs_finish_spec* fin, const hs_program* prog, int64_t n_order, int32_t cap, uint8_t* result,
+                  void* scratch, uint32_t* flags, uint32_t* own_slab_flags);
 
 /* =================================================================================================
  * Multi-GPU: un-interleave the all-gathered exchange slabs of the partial-aggregate shuffle (the slab

@@ -15,6 +15,7 @@
 // lane owns a private accumulator table in LDS laid out [slot][acc][lane] (conflict-free ds_read_b64 /
 // ds_write_b64, no atomics), reduced at the end in a fixed order -> bitwise reproducible results.
 #include <stdlib.h>
+#include <string.h>
 
 #include "hs_agg_kernel.h"
 
@@ -42,6 +43,12 @@ struct AggUnitArgs {
     uint64_t* out_acc;     // [n_units][GC][NA] quantised
     int32_t* out_ngroups;  // [n_units]
     uint32_t* flags;
+    // slab emission (hs_agg_partial_slab): rows of unit u dense from slab row u * GC; NULL = the arrays above
+    uint8_t* slab;
+    const int64_t* unit_ids;
+    int64_t order_off, key_off;
+    int64_t acc_off[HS_MAX_ACC];
+    int32_t key_bytes, pad2;
 };
 
 // One workgroup per unit.  Phase 1: every (chunk, slot) entry of the unit is inserted into the unit's
@@ -103,6 +110,52 @@ __global__ void __launch_bounds__(256) k_agg_unit(const AggUnitArgs A_kernarg) {
             uacc[i] = v;
         }
         __syncthreads();
+    }
+    if (A.slab) {
+        // the unit's groups, dense from slab row u * GC, in the stored kinds (what the reference's shuffle file
+        // holds); dense position of a slot = number of occupied slots before it (wave 0, ballot prefix)
+        int* dpos = inv;  // [GC]
+        if (tid < HS_WAVE) {
+            int running = 0;
+            for (int base = 0; base < GC; base += HS_WAVE) {
+                const int sl = base + tid;
+                const bool valid = sl < GC && ureps[sl] >= 0;
+                const unsigned long long m = __ballot(valid);
+                if (valid) dpos[sl] = running + __popcll(m & ((1ull << tid) - 1));
+                running += __popcll(m);
+            }
+            if (tid == 0) s_count = running;
+        }
+        __syncthreads();
+        const int count = s_count;
+        const int64_t row0 = u * GC;
+        int64_t* order = (int64_t*)(A.slab + A.order_off) + row0;
+        const int64_t uid = A.unit_ids ? A.unit_ids[u] : u;
+        for (int i = tid; i < GC; i += nthr) order[i] = i < count ? uid : -1;
+        const int kb = A.key_bytes;
+        for (int sl = tid; sl < GC; sl += nthr) {
+            const int64_t rep = ureps[sl];
+            if (rep < 0) continue;
+            const uint8_t* src = (const uint8_t*)A.key.data + rep * kb;
+            uint8_t* dst = A.slab + A.key_off + (row0 + dpos[sl]) * kb;
+            for (int b = 0; b < kb; ++b) dst[b] = src[b];
+        }
+        for (int i = tid; i < GC * NA; i += nthr) {
+            const int sl = i / NA, a = i % NA;
+            if (ureps[sl] < 0) continue;
+            const bool is_int = A.spec.is_int[a] != 0;
+            if (hs_float_identity_left(A.spec.op[a], is_int, uacc[i])) err |= HS_FLAG_TYPE_ASSERT;
+            const uint64_t v = hs_quantise_cell(is_int, uacc[i], err);
+            uint8_t* col = A.slab + A.acc_off[a];
+            if (is_int) ((int32_t*)col)[row0 + dpos[sl]] = (int32_t)(int64_t)v;
+            else ((float*)col)[row0 + dpos[sl]] = (float)hs_u2d(v);
+        }
+        if (tid == 0) err |= __hip_atomic_load(A.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the scan's status
+        if (err) {
+            atomicOr(A.flags, err);
+            atomicOr((uint32_t*)A.slab, err);  // slab header: reaches every rank with the rows
+        }
+        return;
     }
     for (int sl = tid; sl < GC; sl += nthr) {
         // representative = smallest row index seen for the slot would need a second pass; any row of the
@@ -202,8 +255,67 @@ struct AggMergeArgs {
     uint32_t* flags;
 };
 
+// Row sources of the merge core.  Flat: the columns of a batch.  Slabs: `world` exchange slabs, row r =
+// row r % M of slab r / M (hs_slab_desc).
+struct MergeFlatIn {
+    const AggMergeArgs& A;
+    __device__ __forceinline__ bool has_order() const { return A.order != nullptr; }
+    __device__ __forceinline__ int64_t order(int r) const { return A.order ? A.order[r] : 0; }
+    __device__ __forceinline__ int upsert(uint64_t* dkeys, int64_t* dreps, uint32_t mask, int r) const {
+        const uint64_t k = hs_key_at(A.key, r);
+        return A.hashed ? hs_dict_upsert_rows(dreps, mask, A.key, k, r) : hs_dict_upsert_word(dkeys, dreps, mask, k, r);
+    }
+    __device__ __forceinline__ uint64_t cell(int a, int r) const { return hs_load_cell(A.acc_cols[a], r); }
+};
+
+struct AggFinishArgs {
+    const uint8_t* slabs;
+    hs_slab_desc desc;
+    hs_finish_spec fin;
+    hs_agg_spec spec;  // per fold: op / is_int
+    hs_program prog;
+    HsCols nocols;     // the projection reads merged cells through the sink; string operators never occur
+    int32_t world, cap, n_order, key_bytes;
+    uint8_t* result;
+    int64_t* out_rep;     // scratch [cap]
+    uint64_t* out_acc;    // scratch [n_fold][cap]
+    uint8_t* key_scratch; // scratch [cap][key_bytes]
+    uint32_t* flags;
+    uint32_t* own_slab_flags;
+};
+struct MergeSlabIn {
+    const AggFinishArgs& A;
+    __device__ __forceinline__ const uint8_t* slab_of(int r, int& i) const {
+        const int k = r / (int)A.desc.slab_rows;
+        i = r - k * (int)A.desc.slab_rows;
+        return A.slabs + (int64_t)k * A.desc.stride;
+    }
+    __device__ __forceinline__ bool has_order() const { return true; }
+    __device__ __forceinline__ int64_t order(int r) const {
+        int i;
+        const uint8_t* s = slab_of(r, i);
+        return ((const int64_t*)(s + A.desc.order_off))[i];
+    }
+    __device__ __forceinline__ hs_col key_col(const uint8_t* s) const {
+        return hs_col{A.desc.key_kind, A.desc.key_kind == HS_STR ? A.desc.key_len : -1, s + A.desc.key_off, nullptr, nullptr};
+    }
+    __device__ __forceinline__ int upsert(uint64_t* dkeys, int64_t* dreps, uint32_t mask, int r) const {
+        int i;
+        const uint8_t* s = slab_of(r, i);
+        return hs_dict_upsert_word(dkeys, dreps, mask, hs_key_at(key_col(s), i), r);
+    }
+    __device__ __forceinline__ uint64_t cell(int a, int r) const {
+        int i;
+        const uint8_t* s = slab_of(r, i);
+        const int src = A.fin.fold_src[a];
+        const uint8_t* base = s + A.desc.acc_off[src];
+        if (A.desc.acc_kind[src] == HS_I32) return (uint64_t)(int64_t)((const int32_t*)base)[i];
+        return hs_d2u((double)((const float*)base)[i]);
+    }
+};
+
 // Final merge, everything staged in LDS.  The partials of a group must be folded in the reference's
-// order: ascending (order key, row) - with order == NULL simply ascending row - i.e. block order of the
+// order: ascending (order key, row) - with no order keys simply ascending row - i.e. block order of the
 // shuffle file (0 + p_block0 + p_block1 + ... in fp64).  All steps are O(n):
 //   1. rows -> dictionary slot (parallel);
 //   2. visiting sequence = rows sorted by (order key, row): a counting sort on the order key (block id);
@@ -213,19 +325,12 @@ struct AggMergeArgs {
 //   4. cells are scattered to [group bucket][rank], then one lane per (group, aggregate) folds its
 //      bucket front to back from contiguous LDS.
 // Outputs are dense (groups in ascending dictionary-slot order) and column-major: out_acc[a * cap + i].
-__global__ void __launch_bounds__(1024) k_agg_merge_small(const AggMergeArgs A_kernarg) {
-    HS_KERNARG(AggMergeArgs, A);
-    extern __shared__ __align__(16) uint64_t lds[];
-    const int NA = A.spec.n_acc;
-    const int cap = A.cap;
-    const int64_t nmax = A.n_rows;
-    const int nord = A.n_order;  // order keys lie in [0, n_order)
-    int64_t n64 = nmax;
-    if (A.n_rows_dev) {
-        const int64_t nd = *A.n_rows_dev;
-        n64 = nd < nmax ? nd : nmax;
-    }
-    const int n = (int)n64;
+// One workgroup; returns the number of groups (uniform).
+template <typename In>
+__device__ __forceinline__ int hs_merge_small_core(const In& in, const hs_agg_spec& spec, const int n, const int64_t nmax,
+                                                   const int nord, const int cap, uint64_t* lds, int64_t* out_rep,
+                                                   uint64_t* out_acc, uint32_t& err) {
+    const int NA = spec.n_acc;
     uint64_t* dkeys = lds;                                // [cap]
     int64_t* dreps = (int64_t*)(lds + cap);               // [cap]
     uint64_t* sorted = lds + 2 * cap;                     // [nmax][NA] cells bucketed by group
@@ -241,7 +346,7 @@ __global__ void __launch_bounds__(1024) k_agg_merge_small(const AggMergeArgs A_k
     __shared__ int s_scan[1024];
     __shared__ int s_nvalid;
     const int tid = threadIdx.x, nthr = blockDim.x;
-    uint32_t err = 0;
+    const bool ordered = in.has_order();
 
     for (int i = tid; i < cap; i += nthr) {
         dkeys[i] = HS_EMPTY_KEY;
@@ -258,13 +363,12 @@ __global__ void __launch_bounds__(1024) k_agg_merge_small(const AggMergeArgs A_k
     const uint32_t mask = (uint32_t)cap - 1;
     for (int r = tid; r < n; r += nthr) {  // step 1
         int sl = -1;
-        const int64_t o = A.order ? A.order[r] : 0;
+        const int64_t o = in.order(r);
         if (o >= 0) {
-            const uint64_t k = hs_key_at(A.key, r);
-            sl = A.hashed ? hs_dict_upsert_rows(dreps, mask, A.key, k, r) : hs_dict_upsert_word(dkeys, dreps, mask, k, r);
+            sl = in.upsert(dkeys, dreps, mask, r);
             if (sl < 0) err |= HS_FLAG_DICT_FULL;
             else atomicAdd(&cnt[sl], 1);
-            if (A.order && sl >= 0) {
+            if (ordered && sl >= 0) {
                 if (o >= nord) {
                     err |= HS_FLAG_BAD_PROGRAM;
                     sl = -1;
@@ -311,11 +415,10 @@ __global__ void __launch_bounds__(1024) k_agg_merge_small(const AggMergeArgs A_k
         pos += cnt[sl];
     }
     __syncthreads();
-    if (tid == 0) *A.out_ngroups = ngroups;
 
     // step 2: visiting sequence
     int nseq = n;
-    if (A.order) {
+    if (ordered) {
         const int operth = (nord + nthr - 1) / nthr;
         const int o0 = tid * operth, o1 = (o0 + operth) < nord ? (o0 + operth) : nord;
         int osum = 0;
@@ -339,7 +442,7 @@ __global__ void __launch_bounds__(1024) k_agg_merge_small(const AggMergeArgs A_k
         nseq = s_nvalid;
         for (int r = tid; r < n; r += nthr) {
             if (rslot[r] < 0) continue;
-            const int o = (int)A.order[r];
+            const int o = (int)in.order(r);
             seq[ocnt[o] + (r - ofirst[o])] = r;
         }
         __syncthreads();
@@ -349,7 +452,7 @@ __global__ void __launch_bounds__(1024) k_agg_merge_small(const AggMergeArgs A_k
     if (tid < HS_WAVE) {
         for (int base = 0; base < nseq; base += HS_WAVE) {
             const int i = base + tid;
-            const int r = i < nseq ? (A.order ? seq[i] : i) : -1;
+            const int r = i < nseq ? (ordered ? seq[i] : i) : -1;
             const int sl = r >= 0 ? rslot[r] : -1;
             unsigned long long todo = __ballot(sl >= 0);
             while (todo) {
@@ -369,21 +472,125 @@ __global__ void __launch_bounds__(1024) k_agg_merge_small(const AggMergeArgs A_k
         if (sl < 0) continue;
         const int rk = rrank[r];
         const int at = start[sl] + rk;
-        for (int a = 0; a < NA; ++a) sorted[(int64_t)at * NA + a] = hs_load_cell(A.acc_cols[a], r);
-        if (rk == 0) A.out_rep[dense[sl]] = r;  // first row of the group in merge order: race-independent
+        for (int a = 0; a < NA; ++a) sorted[(int64_t)at * NA + a] = in.cell(a, r);
+        if (rk == 0) out_rep[dense[sl]] = r;  // first row of the group in merge order: race-independent
     }
     __syncthreads();
     for (int i = tid; i < cap * NA; i += nthr) {
         const int sl = i / NA, a = i % NA;
         if (dense[sl] < 0) continue;
-        const uint32_t op = A.spec.op[a];
-        const bool is_int = A.spec.is_int[a] != 0;
+        const uint32_t op = spec.op[a];
+        const bool is_int = spec.is_int[a] != 0;
         uint64_t v = hs_acc_identity(op, is_int);
         const int b = start[sl], e = b + cnt[sl];
         for (int q = b; q < e; ++q) v = hs_acc_fold(op, is_int, v, sorted[(int64_t)q * NA + a]);
-        A.out_acc[(int64_t)a * cap + dense[sl]] = v;
+        out_acc[(int64_t)a * cap + dense[sl]] = v;
+    }
+    return ngroups;
+}
+
+__global__ void __launch_bounds__(1024) k_agg_merge_small(const AggMergeArgs A_kernarg) {
+    HS_KERNARG(AggMergeArgs, A);
+    extern __shared__ __align__(16) uint64_t lds[];
+    int64_t n64 = A.n_rows;
+    if (A.n_rows_dev) {
+        const int64_t nd = *A.n_rows_dev;
+        n64 = nd < A.n_rows ? nd : A.n_rows;
+    }
+    uint32_t err = 0;
+    const MergeFlatIn in{A};
+    const int ngroups = hs_merge_small_core(in, A.spec, (int)n64, A.n_rows, A.n_order, A.cap, lds, A.out_rep, A.out_acc, err);
+    if (threadIdx.x == 0) *A.out_ngroups = ngroups;
+    if (err) atomicOr(A.flags, err);
+}
+
+// --------------------------------------------------------------------------------------------------
+// The short tail, second half: slabs -> merged groups -> projection -> stored kinds -> result image.
+struct FinishSink {
+    const AggFinishArgs& A;
+    int g;
+    uint32_t& err;
+    __device__ __forceinline__ FinishSink(const AggFinishArgs& a, uint32_t& e) : A(a), g(0), err(e) {}
+    __device__ __forceinline__ void store(const hs_finish_out& d, uint64_t cell) {
+        uint8_t* col = A.result + d.offset;
+        switch (d.kind) {
+            case HS_F32: {
+                const double v = hs_u2d(cell);
+                const float f = (float)v;
+                if (isinf(f) && !isinf(v)) err |= HS_FLAG_FLT_OVERFLOW;
+                ((float*)col)[g] = f;
+                break;
+            }
+            case HS_I32: {
+                const int64_t v = (int64_t)cell;
+                if (v > 2147483647ll || v < -2147483648ll) err |= HS_FLAG_INT_OVERFLOW;
+                ((int32_t*)col)[g] = (int32_t)v;
+                break;
+            }
+            default: ((uint64_t*)col)[g] = cell; break;
+        }
+    }
+    __device__ __forceinline__ uint64_t load(uint32_t s, int) const {
+        const int j = A.fin.prog_src[s];
+        if (j >= 0) return A.out_acc[(int64_t)j * A.cap + g];
+        const hs_col kc{A.desc.key_kind, -1, A.key_scratch, nullptr, nullptr};
+        return hs_load_cell(kc, g);
+    }
+    __device__ __forceinline__ bool live(int) const { return true; }
+    __device__ __forceinline__ int64_t row(int) const { return g; }
+    __device__ __forceinline__ void filter(int, bool) {}
+    __device__ __forceinline__ void agg(uint32_t, int, uint64_t) {}
+    __device__ __forceinline__ void key() {}
+    __device__ __forceinline__ void out(uint32_t o, int, uint64_t cell) { store(A.fin.outs[A.fin.prog_out[o]], cell); }
+};
+
+__global__ void __launch_bounds__(1024) k_agg_finish(const AggFinishArgs A_kernarg) {
+    HS_KERNARG(AggFinishArgs, A);
+    extern __shared__ __align__(16) uint64_t lds[];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int n = A.world * (int)A.desc.slab_rows;
+    uint32_t err = 0;
+    const MergeSlabIn in{A};
+    const int ng = hs_merge_small_core(in, A.spec, n, n, A.n_order, A.cap, lds, A.out_rep, A.out_acc, err);
+    __syncthreads();  // out_rep / out_acc are complete (one workgroup: global writes are visible after the barrier)
+    const int kb = A.key_bytes;
+    for (int g = tid; g < ng; g += nthr) {
+        int i;
+        const uint8_t* s = in.slab_of((int)A.out_rep[g], i);
+        const uint8_t* src = s + A.desc.key_off + (int64_t)i * kb;
+        for (int b = 0; b < kb; ++b) A.key_scratch[(int64_t)g * kb + b] = src[b];
+    }
+    __syncthreads();
+    FinishSink sink(A, err);
+    for (int o = 0; o < A.fin.n_out; ++o) {
+        const hs_finish_out& d = A.fin.outs[o];
+        if (d.src == 2) continue;
+        for (int g = tid; g < ng; g += nthr) {
+            if (d.src == 0) {
+                for (int b = 0; b < kb; ++b) A.result[d.offset + (int64_t)g * kb + b] = A.key_scratch[(int64_t)g * kb + b];
+            } else {
+                sink.g = g;
+                sink.store(d, A.out_acc[(int64_t)d.index * A.cap + g]);
+            }
+        }
+    }
+    if (A.prog.n_ins) {
+        for (int g = tid; g < ng; g += nthr) {
+            sink.g = g;
+            hs_run<HS_MAX_STACK, 1>(A.prog, A.nocols, 0, A.prog.n_ins, sink, err);
+        }
     }
     if (err) atomicOr(A.flags, err);
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t f = atomicExch(A.flags, 0u);  // hands the status over and leaves the word clean for the next run
+        for (int k = 0; k < A.world; ++k) f |= *(const uint32_t*)(A.slabs + (int64_t)k * A.desc.stride);
+        ((uint32_t*)A.result)[0] = f;
+        ((uint32_t*)A.result)[1] = 0;
+        ((int64_t*)A.result)[1] = ng;
+        if (A.own_slab_flags) *A.own_slab_flags = 0;
+    }
 }
 
 // ==================================================================================================
@@ -557,15 +764,32 @@ static void allow_big_lds(K kernel) {
     (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HS_LDS_HARD);
 }
 
-extern "C" int hs_agg_partial(void* stream, const hs_col* cols, int32_t n_cols, int32_t key_col,
-                              const hs_program* prog, const hs_agg_spec* spec, const hs_chunk* chunks,
-                              const int64_t* unit_chunk0, int64_t n_units, const hs_agg_geom* geom, int64_t* out_rep,
-                              uint64_t* out_acc, int32_t* out_ngroups, void* ws, uint32_t* flags, void* ev_begin,
-                              void* ev_end) {
-    if (!cols || !prog || !spec || !chunks || !unit_chunk0 || !geom || !out_rep || !out_acc || !out_ngroups ||
-        !ws || !flags || key_col < 0 || key_col >= n_cols) {
+static int agg_partial_impl(void* stream, const hs_col* cols, int32_t n_cols, int32_t key_col, const hs_program* prog,
+                            const hs_agg_spec* spec, const hs_chunk* chunks, const int64_t* unit_chunk0,
+                            int64_t n_units, const hs_agg_geom* geom, int64_t* out_rep, uint64_t* out_acc,
+                            int32_t* out_ngroups, const int64_t* unit_ids, uint8_t* slab, const hs_slab_desc* desc,
+                            void* ws, uint32_t* flags, void* ev_begin, void* ev_end) {
+    if (!cols || !prog || !spec || !chunks || !unit_chunk0 || !geom || !ws || !flags || key_col < 0 ||
+        key_col >= n_cols || (!slab && (!out_rep || !out_acc || !out_ngroups)) || (slab && !desc)) {
         hs_set_error("hs_agg_partial: null or out-of-range argument");
         return HS_E_ARG;
+    }
+    int key_bytes = 0;
+    if (slab) {
+        const hs_col& kc = cols[key_col];
+        if (kc.kind == HS_STR) key_bytes = (kc.fixed_len == 1 || kc.fixed_len == 2 || kc.fixed_len == 4) ? kc.fixed_len : 0;
+        else key_bytes = kc.kind == HS_U8 ? 1 : (kc.kind == HS_I32 || kc.kind == HS_F32) ? 4 : 8;
+        if (!key_bytes || desc->key_kind != kc.kind || (kc.kind == HS_STR && desc->key_len != kc.fixed_len) ||
+            desc->n_acc != spec->n_acc || n_units * (int64_t)geom->group_cap > desc->slab_rows) {
+            hs_set_error("hs_agg_partial_slab: slab description does not match the key column / aggregates / units");
+            return HS_E_ARG;
+        }
+        for (int a = 0; a < spec->n_acc; ++a) {
+            if (desc->acc_kind[a] != (spec->is_int[a] ? HS_I32 : HS_F32)) {
+                hs_set_error("hs_agg_partial_slab: accumulator %d kind mismatch", a);
+                return HS_E_ARG;
+            }
+        }
     }
     if (prog->n_ins > HS_MAX_INS || prog->n_lit > HS_MAX_LIT) {
         hs_set_error("hs_agg_partial: program too long");
@@ -644,6 +868,17 @@ extern "C" int hs_agg_partial(void* stream, const hs_col* cols, int32_t n_cols, 
     U.out_acc = out_acc;
     U.out_ngroups = out_ngroups;
     U.flags = flags;
+    U.slab = slab;
+    U.unit_ids = unit_ids;
+    U.order_off = U.key_off = 0;
+    U.key_bytes = key_bytes;
+    U.pad2 = 0;
+    for (int a = 0; a < HS_MAX_ACC; ++a) U.acc_off[a] = 0;
+    if (slab) {
+        U.order_off = desc->order_off;
+        U.key_off = desc->key_off;
+        for (int a = 0; a < spec->n_acc; ++a) U.acc_off[a] = desc->acc_off[a];
+    }
     const size_t ubase = (size_t)geom->group_cap * 16 + (size_t)geom->group_cap * spec->n_acc * 8;
     const size_t uper = (size_t)geom->group_cap * spec->n_acc * 8 + (size_t)geom->group_cap * 4;  // per staged chunk
     int ubatch = HS_UNIT_BATCH;
@@ -666,6 +901,28 @@ extern "C" int hs_agg_partial(void* stream, const hs_col* cols, int32_t n_cols, 
         return HS_E_LAUNCH;
     }
     return HS_OK;
+}
+
+extern "C" int hs_agg_partial(void* stream, const hs_col* cols, int32_t n_cols, int32_t key_col,
+                              const hs_program* prog, const hs_agg_spec* spec, const hs_chunk* chunks,
+                              const int64_t* unit_chunk0, int64_t n_units, const hs_agg_geom* geom, int64_t* out_rep,
+                              uint64_t* out_acc, int32_t* out_ngroups, void* ws, uint32_t* flags, void* ev_begin,
+                              void* ev_end) {
+    return agg_partial_impl(stream, cols, n_cols, key_col, prog, spec, chunks, unit_chunk0, n_units, geom, out_rep,
+                            out_acc, out_ngroups, nullptr, nullptr, nullptr, ws, flags, ev_begin, ev_end);
+}
+
+extern "C" int hs_agg_partial_slab(void* stream, const hs_col* cols, int32_t n_cols, int32_t key_col,
+                                   const hs_program* prog, const hs_agg_spec* spec, const hs_chunk* chunks,
+                                   const int64_t* unit_chunk0, int64_t n_units, const hs_agg_geom* geom,
+                                   const int64_t* unit_ids, uint8_t* slab, const hs_slab_desc* desc, void* ws,
+                                   uint32_t* flags, void* ev_begin, void* ev_end) {
+    if (!slab || !desc) {
+        hs_set_error("hs_agg_partial_slab: null slab");
+        return HS_E_ARG;
+    }
+    return agg_partial_impl(stream, cols, n_cols, key_col, prog, spec, chunks, unit_chunk0, n_units, geom, nullptr,
+                            nullptr, nullptr, unit_ids, slab, desc, ws, flags, ev_begin, ev_end);
 }
 
 extern "C" int hs_agg_pack(void* stream, const int64_t* rep, const uint64_t* acc, const int32_t* ngroups,
@@ -745,6 +1002,103 @@ extern "C" int hs_agg_merge(void* stream, const hs_col* key, const hs_col* acc_c
     hipLaunchKernelGGL(k_agg_merge_small, dim3(1), dim3(1024), lds, (hipStream_t)stream, A);
     if (hipGetLastError() != hipSuccess) {
         hs_set_error("hs_agg_merge: kernel launch failed");
+        return HS_E_LAUNCH;
+    }
+    return HS_OK;
+}
+
+extern "C" size_t hs_agg_finish_scratch_bytes(int32_t cap, int32_t n_fold) {
+    return (size_t)cap * 8 * (size_t)(n_fold + 2) + 64;  // out_rep + out_acc + key elements (<= 8 bytes each)
+}
+
+extern "C" int hs_agg_finish(void* stream, const uint8_t* gathered, int32_t world, const hs_slab_desc* desc,
+                             const hs_finish_spec* fin, const hs_program* prog, int64_t n_order, int32_t cap,
+                             uint8_t* result, void* scratch, uint32_t* flags, uint32_t* own_slab_flags) {
+    if (!gathered || !desc || !fin || !result || !scratch || !flags || world < 1 || cap < 1 || (cap & (cap - 1)) ||
+        fin->n_fold < 0 || fin->n_fold > HS_MAX_ACC || fin->n_out < 0 || fin->n_out > HS_FINISH_MAX_OUT ||
+        desc->slab_rows < 1 || desc->n_acc < 0 || desc->n_acc > HS_MAX_ACC) {
+        hs_set_error("hs_agg_finish: bad arguments");
+        return HS_E_ARG;
+    }
+    if (n_order < 1 || n_order > 65536) {
+        hs_set_error("hs_agg_finish: n_order=%lld out of range", (long long)n_order);
+        return HS_E_ARG;
+    }
+    int key_bytes;
+    if (desc->key_kind == HS_STR) {
+        if (desc->key_len != 1 && desc->key_len != 2 && desc->key_len != 4) {
+            hs_set_error("hs_agg_finish: string keys must have a fixed length of 1, 2 or 4 bytes");
+            return HS_E_ARG;
+        }
+        key_bytes = desc->key_len;
+    } else {
+        key_bytes = desc->key_kind == HS_U8 ? 1 : (desc->key_kind == HS_I32 || desc->key_kind == HS_F32) ? 4 : 8;
+    }
+    const int64_t n_rows = (int64_t)world * desc->slab_rows;
+    const size_t lds = (size_t)cap * 16 + (size_t)n_rows * fin->n_fold * 8 + (size_t)n_rows * 12 + (size_t)cap * 16 +
+                       (size_t)n_order * 8 + 16;
+    if (n_rows > 0x3fffffff || lds > HS_MERGE_LDS_MAX) {
+        hs_set_error("hs_agg_finish: %lld partial rows x %d aggregates need %zu B LDS (> %zu)", (long long)n_rows,
+                     fin->n_fold, lds, HS_MERGE_LDS_MAX);
+        return HS_E_LIMIT;
+    }
+    AggFinishArgs A;
+    memset(&A, 0, sizeof(A));
+    A.slabs = gathered;
+    A.desc = *desc;
+    A.fin = *fin;
+    A.spec.n_acc = fin->n_fold;
+    for (int j = 0; j < fin->n_fold; ++j) {
+        const int src = fin->fold_src[j];
+        if (src < 0 || src >= desc->n_acc || (fin->fold_op[j] != HS_AGG_SUM && fin->fold_op[j] != HS_AGG_MIN &&
+                                             fin->fold_op[j] != HS_AGG_MAX)) {
+            hs_set_error("hs_agg_finish: fold %d is malformed", j);
+            return HS_E_ARG;
+        }
+        A.spec.op[j] = (uint8_t)fin->fold_op[j];
+        A.spec.is_int[j] = desc->acc_kind[src] == HS_I32 ? 1 : 0;
+    }
+    int n_prog_out = 0;
+    for (int o = 0; o < fin->n_out; ++o) {
+        const hs_finish_out& d = fin->outs[o];
+        const bool ok = d.src == 0 || (d.src == 1 && d.index >= 0 && d.index < fin->n_fold) ||
+                        (d.src == 2 && d.index >= 0 && d.index < HS_MAX_OUTS);
+        if (!ok || d.offset < 16 || (d.src != 0 && d.kind != HS_F32 && d.kind != HS_I32 && d.kind != HS_I64)) {
+            hs_set_error("hs_agg_finish: output %d is malformed", o);
+            return HS_E_ARG;
+        }
+        if (d.src == 2) ++n_prog_out;
+    }
+    if (prog && prog->n_ins) {
+        if (prog->n_ins > HS_MAX_INS || prog->n_lit > HS_MAX_LIT || program_depth(prog) > HS_MAX_STACK) {
+            hs_set_error("hs_agg_finish: program too long or too deep");
+            return HS_E_LIMIT;
+        }
+        A.prog = *prog;
+    } else if (n_prog_out) {
+        hs_set_error("hs_agg_finish: program outputs without a program");
+        return HS_E_ARG;
+    }
+    A.nocols.n = 0;
+    for (int i = 0; i < HS_MAX_COLS; ++i) A.nocols.c[i] = hs_col{HS_U8, -1, nullptr, nullptr, nullptr};
+    A.world = world;
+    A.cap = cap;
+    A.n_order = (int32_t)n_order;
+    A.key_bytes = key_bytes;
+    A.result = result;
+    A.out_rep = (int64_t*)scratch;
+    A.out_acc = (uint64_t*)scratch + cap;
+    A.key_scratch = (uint8_t*)((uint64_t*)scratch + (size_t)cap * (fin->n_fold + 1));
+    A.flags = flags;
+    A.own_slab_flags = own_slab_flags;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)k_agg_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HS_MERGE_LDS_MAX);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_agg_finish, dim3(1), dim3(1024), lds, (hipStream_t)stream, A);
+    if (hipGetLastError() != hipSuccess) {
+        hs_set_error("hs_agg_finish: kernel launch failed");
         return HS_E_LAUNCH;
     }
     return HS_OK;

@@ -21,6 +21,19 @@ void hs_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* hs_last_error(void) { return g_hs_err; }
+extern "C" size_t hs_sizeof(int32_t which) {
+    switch (which) {
+        case 0: return sizeof(hs_col);
+        case 1: return sizeof(hs_program);
+        case 2: return sizeof(hs_agg_spec);
+        case 3: return sizeof(hs_agg_geom);
+        case 4: return sizeof(hs_chunk);
+        case 5: return sizeof(hs_slab_desc);
+        case 6: return sizeof(hs_finish_out);
+        case 7: return sizeof(hs_finish_spec);
+        default: return 0;
+    }
+}
 extern "C" int hs_version(void) { return HS_VERSION; }
 
 #define HS_CHECK_LAUNCH(name)                                \
@@ -375,7 +388,6 @@ extern "C" int hs_concat_bytes(void* stream, const hs_col* parts, int32_t n_part
 }
 
 // ---- A4: expression evaluation, one row per lane (reference tasks.py:32-35, sql.py:262-266) ----------------
-#define HS_MAX_OUTS 16
 struct EvalArgs {
     HsCols cols;
     hs_program prog;

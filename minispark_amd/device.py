@@ -28,6 +28,7 @@ PAD = 64  # bytes of slack behind every buffer
 
 _TORCH_DTYPE = {hs.I32: torch.int32, hs.F32: torch.float32, hs.I64: torch.int64, hs.F64: torch.float64,
                 hs.U8: torch.uint8}
+_NP_DTYPE = {hs.I32: np.int32, hs.F32: np.float32, hs.I64: np.int64, hs.F64: np.float64, hs.U8: np.uint8}
 FILE_KIND = {ColumnType.INTEGER: hs.I32, ColumnType.FLOAT: hs.F32, ColumnType.TIMESTAMP: hs.I64,
              ColumnType.STRING: hs.STR}
 
@@ -77,6 +78,7 @@ class DBatch:
     slab_layout: Any = None
     slab_cols: list[int] | None = None    # slab column holding each batch column (aggregates may share one)
     partitioned: bool = False             # multi-GPU: every rank holds DIFFERENT rows (else replicated)
+    tail: dict | None = None              # partial rows emitted in slab form for aggregate_finish (the short tail)
 
     def __post_init__(self) -> None:
         if self.nrows_dev is None and not self.unit_rows:
@@ -135,6 +137,7 @@ class Recording:
         self.poisoned = False
         self.finish: Any = None  # () -> (raw columns, nrows, flags)
         self.result: Any = None  # (schema, stage_id) of the writer
+        self.self_cleaning = False  # the run's last launch resets the status words itself (no zeroing before a replay)
 
     def replay(self) -> bool:
         for fn, args in self.calls:
@@ -182,6 +185,7 @@ class Device:
         torch.cuda.set_device(self.device)
         self.flags = torch.zeros(4, dtype=torch.int32, device=self.device)
         self._partial_prepared: dict[Any, dict] = {}
+        self._finish_prepared: dict[Any, dict] = {}
         self._const_lens: dict[int, torch.Tensor] = {}
         self._raw_lib = self.lib
         self.rec: Recording | None = None
@@ -256,6 +260,9 @@ class Device:
 
     def reset_flags(self) -> None:
         self.flags.zero_()
+        for prep in self._partial_prepared.values():  # slab headers of a run that did not reach its finish launch
+            if prep.get("tail") is not None:
+                prep["slab"][:4].zero_()
 
     def read_flags(self) -> int:
         if self.rec is not None:
@@ -564,7 +571,7 @@ class Device:
     # ---- partial aggregate (A5/A6) -------------------------------------------------------------------------
     def aggregate_partial(self, batch: DBatch, filters: Sequence[Any], group_by: Any, agg_columns: Sequence[Any],
                           out_schema: Schema, group_cap_hint: int = 4, cache_key: Any = None,
-                          slab_rows: int | None = None) -> DBatch:
+                          slab_rows: int | None = None, tail: bool = False) -> DBatch:
         """Fused scan + WHERE + aggregate arguments + per-unit partial aggregate.
 
         Returns the partial rows exactly as the reference would have written them to its shuffle
@@ -574,20 +581,32 @@ class Device:
         and re-used by later runs of the same query (``cache_key``)."""
         batch = self.resolve(batch)  # units are row ranges: the row count must be exact
         if batch.nrows == 0:  # e.g. a rank that owns no block of a small table
-            return self._empty_partial(batch, filters, group_by, agg_columns, out_schema, slab_rows)
+            return self._empty_partial(batch, filters, group_by, agg_columns, out_schema, slab_rows, tail)
         cap = max(1, int(group_cap_hint))
         key = None
         if cache_key is not None:
             key = (cache_key, cap, batch.nrows, tuple((c.data.data_ptr(), c.n) for c in batch.cols),
-                   len(batch.unit_rows), batch.unit_rows[-1], slab_rows)
+                   len(batch.unit_rows), batch.unit_rows[-1], slab_rows, tail)
         prep = self._partial_prepared.get(key) if key is not None else None
         if prep is None:
-            prep = self._prepare_partial(batch, filters, group_by, agg_columns, cap, slab_rows)
+            prep = self._prepare_partial(batch, filters, group_by, agg_columns, cap, slab_rows, tail, out_schema)
             if key is not None:
                 if len(self._partial_prepared) >= 8:
                     self._partial_prepared.pop(next(iter(self._partial_prepared)))
                 self._partial_prepared[key] = prep
         p = prep
+        if tail:
+            # the unit combine writes the partial rows (stored kinds) straight into the slab: no pack, no gather
+            hs.check(self.lib.hs_agg_partial_slab(
+                self.stream, p["cols"], p["n_cols"], p["key_slot"], C.byref(p["prog"]), C.byref(p["spec"]),
+                p["d_units"].data_ptr(), p["d_chunk0"].data_ptr(), p["n_units"], C.byref(p["geom"]),
+                p["d_unit_ids"].data_ptr() if p["d_unit_ids"] is not None else None, p["slab"].data_ptr(),
+                C.byref(p["desc"]), p["ws"].data_ptr(), self.flags.data_ptr(), self._event_handle(0),
+                self._event_handle(1)), "hs_agg_partial_slab")
+            self.last_scan = p["info"]
+            self.last_group_cap = cap
+            return DBatch(list(out_schema), [], p["slots"], [0, p["slots"]], None, total_units=batch.total_units,
+                          slab=p["slab"], slab_layout=p["layout"], tail=p["tail"])
         hs.check(self.lib.hs_agg_partial(self.stream, p["cols"], p["n_cols"], p["key_slot"], C.byref(p["prog"]),
                                          C.byref(p["spec"]), p["d_units"].data_ptr(), p["d_chunk0"].data_ptr(),
                                          p["n_units"], C.byref(p["geom"]), p["out_rep"].data_ptr(),
@@ -619,12 +638,20 @@ class Device:
                       slab_cols=[0] + [1 + acc for acc in p["agg_to_acc"]])
 
     def _empty_partial(self, batch: DBatch, filters: Sequence[Any], group_by: Any, agg_columns: Sequence[Any],
-                       out_schema: Schema, slab_rows: int | None) -> DBatch:
+                       out_schema: Schema, slab_rows: int | None, tail: bool = False) -> DBatch:
         """Partial aggregate of zero rows (a rank that owns no block): no launch, but the same column /
         slab layout as the other ranks so the exchange stays symmetric."""
         low = lower_aggregate(batch.schema, batch.kinds, filters, group_by, agg_columns)
         key_src = batch.cols[low.program.columns[low.key_slot]]
         acc_kinds = [hs.I32 if is_int else hs.F32 for is_int in low.acc_is_int]
+        if tail:
+            if slab_rows is None:
+                raise SlabUnsupported("an empty single-GPU input takes the general path")
+            layout, slab, desc = self._tail_slab(key_src, out_schema, acc_kinds, slab_rows)
+            info = {"desc": desc, "layout": layout, "slab": slab, "agg_to_acc": list(low.agg_to_acc),
+                    "acc_kinds": acc_kinds, "key_kind": key_src.kind, "key_len": key_src.fixed_len, "n_units": 0}
+            return DBatch(list(out_schema), [], 0, [0, 0], None, total_units=batch.total_units, slab=slab,
+                          slab_layout=layout, tail=info)
         if slab_rows is not None and key_src.kind == hs.STR and key_src.fixed_len not in (1, 2, 4, 8):
             raise SlabUnsupported("variable-length string GROUP BY key")
         cols = [self.gather_col(key_src, self.empty(0, torch.int64), 0)]
@@ -640,8 +667,35 @@ class Device:
             out.slab_cols = [0] + [1 + acc for acc in low.agg_to_acc]
         return out
 
+    def _tail_slab(self, key_col: DCol, out_schema: Schema, acc_kinds: Sequence[int], rows: int):
+        """Slab (order keys -1 = no rows yet) + its description for the short tail.  Keys must be stored
+        kinds that pack into the 64-bit key word."""
+        from .distributed import SlabLayout  # noqa: PLC0415
+
+        if key_col.kind == hs.STR:
+            if key_col.fixed_len not in (1, 2, 4):
+                raise SlabUnsupported("string GROUP BY key without a short fixed length")
+            key_spec = (key_col.fixed_len, torch.uint8)
+        else:
+            if key_col.kind not in (hs.I32, hs.F32, hs.I64) or key_col.kind != FILE_KIND[out_schema[0][1]]:
+                raise SlabUnsupported("GROUP BY key is not in its stored kind")
+            key_spec = (hs.KIND_BYTES[key_col.kind], _TORCH_DTYPE[key_col.kind])
+        layout = SlabLayout.build(rows, [key_spec] + [(4, _TORCH_DTYPE[k]) for k in acc_kinds])
+        slab = torch.zeros(layout.nbytes, dtype=torch.uint8, device=self.device)
+        layout.order_view(slab).fill_(-1)
+        desc = hs.hs_slab_desc()
+        desc.slab_rows, desc.stride, desc.order_off = rows, layout.nbytes, layout.order_offset
+        desc.key_off = layout.columns[0].offset
+        desc.key_kind, desc.key_len = key_col.kind, max(key_col.fixed_len, 0)
+        desc.n_acc = len(acc_kinds)
+        for a, k in enumerate(acc_kinds):
+            desc.acc_off[a] = layout.columns[1 + a].offset
+            desc.acc_kind[a] = k
+        return layout, slab, desc
+
     def _prepare_partial(self, batch: DBatch, filters: Sequence[Any], group_by: Any, agg_columns: Sequence[Any],
-                         cap: int, slab_rows: int | None = None) -> dict:
+                         cap: int, slab_rows: int | None = None, tail: bool = False,
+                         out_schema: Schema | None = None) -> dict:
         low = lower_aggregate(batch.schema, batch.kinds, filters, group_by, agg_columns)
         if low.numeric_slots > hs.HS_FUSED_COLS:
             raise TierExceeded(f"aggregate reads more than {hs.HS_FUSED_COLS} numeric columns")
@@ -666,6 +720,25 @@ class Device:
         acc_kinds = [hs.I32 if is_int else hs.F32 for is_int in low.acc_is_int]
         key_idx = low.program.columns[low.key_slot]
         slab = layout = key_out = out_unit = None
+        if tail:
+            rows = slab_rows if slab_rows is not None else slots
+            if slots > rows:
+                raise DeviceError(f"exchange slab of {rows} rows cannot hold {slots} partial rows")
+            layout, slab, desc = self._tail_slab(batch.cols[key_idx], out_schema, acc_kinds, rows)
+            d_unit_ids = self.to_device(np.asarray(batch.unit_ids, dtype=np.int64)) if batch.unit_ids is not None else None
+            return {
+                "slab": slab, "layout": layout, "desc": desc, "d_unit_ids": d_unit_ids,
+                "cols": self._cols_array(batch, low.program.columns), "n_cols": len(low.program.columns),
+                "key_slot": low.key_slot, "prog": low.program.to_struct(), "spec": low.spec(), "geom": geom,
+                "n_units": n_units, "slots": slots,
+                "d_units": self.to_device(chunks.reshape(-1)), "d_chunk0": self.to_device(chunk0),
+                "ws": self.workspace(geom.ws_bytes),
+                "tail": {"desc": desc, "layout": layout, "slab": slab, "agg_to_acc": list(low.agg_to_acc),
+                         "acc_kinds": acc_kinds, "key_kind": batch.cols[key_idx].kind,
+                         "key_len": batch.cols[key_idx].fixed_len, "n_units": n_units},
+                "info": {"rows": batch.nrows, "chunks": int(geom.n_chunks), "chunk_rows": int(geom.chunk_rows),
+                         "wg_threads": int(geom.wg_threads), "group_cap": cap, "lds_bytes": int(geom.lds_bytes)},
+            }
         if slab_rows is not None:
             # multi-GPU: outputs are written straight into the fixed-size slab that gets all-gathered
             from .distributed import SlabLayout  # noqa: PLC0415
@@ -754,6 +827,140 @@ class Device:
             raw = out_acc[i * cap: i * cap + n_out]
             cols.append(DCol(hs.I64, raw, n_out) if is_int[i] else DCol(hs.F64, raw.view(torch.float64), n_out))
         return DBatch(list(out_schema), cols, n_out, None, ngroups_dev)
+
+    # ---- the short tail: slabs -> result in one launch ------------------------------------------------------
+    def aggregate_finish(self, tail: dict, gathered: torch.Tensor, world: int, agg_columns: Sequence[Any],
+                         merged_schema: Schema, project: Sequence[Any] | None, out_schema: Schema, cap_hint: int,
+                         n_order: int, cache_key: Any = None) -> tuple[list[Any], int, int]:
+        """Final merge (reference tasks.py:290-292) + the projection after it (plan.py:190-203: AVG = sum / count,
+        renames) + rounding to the stored kinds (io.py:87-94) + the result image, as ONE launch over the partial
+        rows of ``world`` slabs; then the query's single device->host copy.  -> (raw columns, nrows, flags)."""
+        cap = 4
+        while cap < cap_hint:
+            cap *= 2
+        key = (cache_key, cap, world, gathered.data_ptr(), n_order, tail["slab"].data_ptr())
+        prep = self._finish_prepared.get(key) if cache_key is not None else None
+        if prep is None:
+            prep = self._prepare_finish(tail, agg_columns, merged_schema, project, out_schema, cap)
+            if cache_key is not None:
+                if len(self._finish_prepared) >= 8:
+                    self._finish_prepared.pop(next(iter(self._finish_prepared)))
+                self._finish_prepared[key] = prep
+        p = prep
+        desc = p["desc"]
+        rc = self.lib.hs_agg_finish(self.stream, gathered.data_ptr(), world, C.byref(desc), C.byref(p["fin"]),
+                                    C.byref(p["prog"]) if p["prog"] is not None else None, n_order, cap,
+                                    p["result"].data_ptr(), p["scratch"].data_ptr(), self.flags.data_ptr(),
+                                    tail["slab"].data_ptr())
+        if rc == 2:
+            raise TierExceeded("final merge exceeds the LDS tier: " + self.lib.hs_last_error().decode())
+        hs.check(rc, "hs_agg_finish")
+        self.last_merge_cap = cap
+        result, columns = p["result"], p["columns"]
+
+        def finish() -> tuple[list[Any], int, int]:
+            host = result.cpu().numpy()  # the single synchronising copy
+            flags = int(host[0:4].view(np.uint32)[0])
+            n = min(int(host[8:16].view(np.int64)[0]), cap)
+            raw: list[Any] = []
+            for off, kind, width in columns:
+                if kind == hs.STR:
+                    raw.append(StrCol(np.full(n, width, dtype=np.uint8), host[off: off + n * width].copy()))
+                else:
+                    raw.append(host[off: off + n * width].view(_NP_DTYPE[kind]).copy())
+            return raw, n, flags
+
+        if self.rec is not None:
+            self.rec.finish = finish
+            self.rec.self_cleaning = True  # the launch hands the status words over and zeroes them
+            self.rec.keep.append((p, tail, gathered))
+        return finish()
+
+    def _prepare_finish(self, tail: dict, agg_columns: Sequence[Any], merged_schema: Schema,
+                        project: Sequence[Any] | None, out_schema: Schema, cap: int) -> dict:
+        from .lowering import unalias  # noqa: PLC0415
+
+        ops = {"sum": hs.AGG_SUM, "min": hs.AGG_MIN, "max": hs.AGG_MAX}
+        fin = hs.hs_finish_spec()
+        folds: dict[tuple[int, int], int] = {}
+        col_fold: list[int] = []  # merged column i + 1 -> fold
+        for i, agg in enumerate(agg_columns):
+            pair = (tail["agg_to_acc"][i], ops[agg.type])
+            if pair not in folds:
+                if len(folds) >= hs.HS_MAX_ACC:
+                    raise TierExceeded("too many aggregates for the fused tail")
+                folds[pair] = len(folds)
+                fin.fold_src[folds[pair]], fin.fold_op[folds[pair]] = pair
+            col_fold.append(folds[pair])
+        fin.n_fold = len(folds)
+        key_kind = tail["key_kind"]
+        key_bytes = tail["key_len"] if key_kind == hs.STR else hs.KIND_BYTES[key_kind]
+        merged_kinds = [key_kind] + [hs.I64 if tail["acc_kinds"][tail["agg_to_acc"][i]] == hs.I32 else hs.F64
+                                     for i in range(len(agg_columns))]
+        if len(merged_schema) != len(merged_kinds):
+            raise AssertionError(f"merge schema {merged_schema} does not match {len(agg_columns)} aggregates")
+
+        def stored(in_kind: int, col_type: ColumnType) -> int:
+            want = FILE_KIND[col_type]
+            if (in_kind, want) in ((hs.F64, hs.F32), (hs.I64, hs.I32), (hs.I64, hs.I64)):
+                return want
+            raise AssertionError(f"column of kind {in_kind} cannot be stored as {col_type}")
+
+        outs: list[tuple[int, int, int]] = []  # (src, index, stored kind)
+        prog = None
+        if project is None:
+            if len(out_schema) != len(merged_kinds):
+                raise AssertionError(f"writer schema {out_schema} does not match merged columns {merged_schema}")
+            outs.append((0, 0, key_kind))
+            for i in range(len(agg_columns)):
+                outs.append((1, col_fold[i], stored(merged_kinds[i + 1], out_schema[i + 1][1])))
+        else:
+            if len(out_schema) != len(project):
+                raise AssertionError(f"writer schema {out_schema} does not match the projection")
+            b = ProgramBuilder(list(merged_schema), merged_kinds)
+            names = [n for n, _ in merged_schema]
+            n_prog = 0
+            for o, col in enumerate(project):
+                bare = unalias(col)
+                if type(bare).__name__ in ("Col", "SchemaCol"):
+                    idx = names.index(bare.name) if bare.name in names else -1
+                    if idx < 0:
+                        raise ValueError(f'Column "{bare.name}" not found in schema {merged_schema}')
+                    if idx == 0:
+                        outs.append((0, 0, key_kind))
+                    else:
+                        outs.append((1, col_fold[idx - 1], stored(merged_kinds[idx], out_schema[o][1])))
+                    continue
+                if b.string_tag(bare):
+                    raise TierExceeded("string expression after the merge")
+                if n_prog >= hs.HS_MAX_OUTS:
+                    raise TierExceeded("too many computed columns for the fused tail")
+                tag = b.emit_out(n_prog, col)
+                if tag == "B":
+                    raise AssertionError("a comparison cannot be selected as a column (the reference has no BOOL type)")
+                fin.prog_out[n_prog] = o
+                outs.append((2, n_prog, stored(hs.F64 if tag == "F" else hs.I64, out_schema[o][1])))
+                n_prog += 1
+            if n_prog:
+                lowered = b.finish()
+                for slot, idx in enumerate(lowered.columns):
+                    if idx == 0 and key_kind == hs.STR:
+                        raise TierExceeded("expression over a string key after the merge")
+                    fin.prog_src[slot] = -1 if idx == 0 else col_fold[idx - 1]
+                prog = lowered.to_struct()
+        if len(outs) > hs.HS_FINISH_MAX_OUT:
+            raise TierExceeded("too many result columns for the fused tail")
+        fin.n_out = len(outs)
+        pos = 16
+        columns: list[tuple[int, int, int]] = []  # (offset, stored kind, bytes per row)
+        for o, (src, index, kind) in enumerate(outs):
+            width = key_bytes if src == 0 else hs.KIND_BYTES[kind]
+            fin.outs[o].src, fin.outs[o].index, fin.outs[o].kind, fin.outs[o].offset = src, index, kind, pos
+            columns.append((pos, kind, width))
+            pos = (pos + cap * width + 15) & ~15
+        result = torch.zeros(pos + PAD, dtype=torch.uint8, device=self.device)
+        scratch = self.workspace(self.lib.hs_agg_finish_scratch_bytes(cap, fin.n_fold))
+        return {"fin": fin, "prog": prog, "desc": tail["desc"], "result": result, "scratch": scratch, "columns": columns}
 
     # ---- global-memory aggregation tier (any cardinality) ---------------------------------------------------
     def concat_cols(self, parts: Sequence[DCol]) -> DCol:

@@ -40,6 +40,10 @@ class ExecutionError(Exception):
         super().__init__(message)
 
 
+class RestartQuery(Exception):
+    """Run the query again from the start (a fused path found at run time that it does not apply)."""
+
+
 class ExecutionEngine(AbstractContextManager, ABC):
     @abstractmethod
     def execute_full_task(self, full_task: Any) -> list[JobResult]: ...
@@ -104,6 +108,9 @@ class HipExecutionEngine(ExecutionEngine):
         self._recordings: dict[Any, Any] = {}  # plan key -> device.Recording of a fully device-resident run
         self.replay_enabled = os.environ.get("HIPSPARK_REPLAY", "1") != "0"
         self.replays = 0
+        self.short_tail_enabled = os.environ.get("HIPSPARK_SHORT_TAIL", "1") != "0"
+        self._no_short_tail: set[Any] = set()  # partial AggregateTask ids that must take the general path
+        self.short_tails = 0  # queries finished by the short tail (first runs and recordings; replays count in `replays`)
         self._plan_runs: dict[Any, int] = {}
         self._owned_dirs: set[Path] = set()
         self._result_root: Path | None = None
@@ -186,6 +193,8 @@ class HipExecutionEngine(ExecutionEngine):
                             self._recordings.pop(next(iter(self._recordings)))
                         self._recordings[rec_key] = recording
                 return results
+            except RestartQuery:
+                self.dev.stop_recording()
             except RetryWithLargerDictionary:
                 self.dev.stop_recording()
                 # more distinct GROUP BY keys than the dictionaries were sized for: grow and re-run; past the
@@ -217,7 +226,8 @@ class HipExecutionEngine(ExecutionEngine):
                 len(self._global_merge))
 
     def _replay(self, rec: Any) -> list[JobResult] | None:
-        self.dev.flags.zero_()
+        if not rec.self_cleaning:
+            self.dev.flags.zero_()
         if not rec.replay():
             return None
         raw, nrows, flags = rec.finish()
@@ -254,10 +264,33 @@ class HipExecutionEngine(ExecutionEngine):
                 stage.job_results.clear()
             return plan
         plan = self.generate_physical_plan(full_task)
+        self._mark_short_tails(plan)
         if len(self._plans) >= 16:
             self._plans.pop(next(iter(self._plans)))
         self._plans[key] = (full_task, plan)
         return plan
+
+    @staticmethod
+    def _mark_short_tails(plan: Any) -> None:
+        """Find [.. -> partial Aggregate -> shuffle write] feeding [shuffle read -> final Aggregate (-> Project)
+        -> result write]: for these the work after the scan kernel can run as the two-launch short tail
+        (Device.aggregate_partial(tail=True) + Device.aggregate_finish)."""
+        for stage in plan.stages:
+            consumers = list(stage.consumers)
+            if _cls(stage.producer) != "LoadShuffleFilesTask" or _cls(stage.writer) != "WriteToLocalFileTask":
+                continue
+            if not consumers or _cls(consumers[0]) != "AggregateTask" or consumers[0].before_shuffle:
+                continue
+            if len(consumers) > 2 or (len(consumers) == 2 and _cls(consumers[1]) != "ProjectTask"):
+                continue
+            if len(stage.dependencies) != 1:
+                continue
+            dep = stage.dependencies[0]
+            dep_consumers = list(dep.consumers)
+            if (_cls(dep.writer) != "WriteToShufflePartitions" or not dep_consumers
+                    or _cls(dep_consumers[-1]) != "AggregateTask" or not dep_consumers[-1].before_shuffle):
+                continue
+            dep_consumers[-1]._hs_short_tail = True
 
     # ---- stage execution -------------------------------------------------------------------------------
     def _run_stage(self, stage: Any, outputs: dict[int, Any]) -> list[JobResult]:
@@ -269,6 +302,8 @@ class HipExecutionEngine(ExecutionEngine):
             batch = self._scan(producer, consumers, writer)
         elif kind == "LoadShuffleFilesTask":
             batch = outputs[id(stage.dependencies[0])]
+            if batch.tail is not None:
+                return [self._finish_short_tail(batch, consumers, writer, stage.stage_id)]
             if self.dist is not None:
                 batch = self._exchange_partials(batch) if batch.slab is not None else self._exchange_partial_rows(batch)
         elif kind == "BroadcastHashJoinTask":
@@ -300,6 +335,17 @@ class HipExecutionEngine(ExecutionEngine):
                         if batch.total_units is None:
                             raise NotImplementedError("multi-GPU aggregation needs a block-partitioned input")
                         slab_rows = max(batch.n_units, max_local_units(batch.total_units, self.world)) * self.group_cap_hint
+                    if (self.short_tail_enabled and getattr(task, "_hs_short_tail", False)
+                            and id(task) not in self._no_short_tail):
+                        try:
+                            batch = self.dev.aggregate_partial(batch, pending, task.group_by_column, task.agg_columns,
+                                                               task.inferred_schema, self.group_cap_hint,
+                                                               cache_key=(id(task), "tail"), slab_rows=slab_rows, tail=True)
+                            batch.tail["task_id"] = id(task)
+                            pending = []
+                            continue
+                        except (SlabUnsupported, TierExceeded):
+                            self._no_short_tail.add(id(task))
                     try:
                         batch = self.dev.aggregate_partial(batch, pending, task.group_by_column, task.agg_columns,
                                                            task.inferred_schema, self.group_cap_hint,
@@ -340,7 +386,7 @@ class HipExecutionEngine(ExecutionEngine):
         schema = writer.inferred_schema
         if wname == "WriteToShufflePartitions":
             # the "shuffle file" stays in HBM; data-dependent errors surface at the query's final read-back
-            outputs[id(stage)] = self._quantise_batch(batch, schema)
+            outputs[id(stage)] = batch if batch.tail is not None else self._quantise_batch(batch, schema)
             self._job_seq += 1
             return [JobResult(f"{self._job_prefix}-{self._job_seq}", self._executor_id, [])]
         if wname == "WriteToLocalFileTask":
@@ -642,6 +688,47 @@ class HipExecutionEngine(ExecutionEngine):
             from .distributed import or_flags  # noqa: PLC0415
 
             flags = or_flags(self.dist, flags, self.dev.device, self.group)  # same decision on every rank
+            self._generic_exchange_used = False
+        if flags & hs.FLAG_DICT_FULL:
+            raise RetryWithLargerDictionary
+        self.dev.raise_for_flags(flags)
+        return self._emit_result(raw, nrows, schema, stage_id)
+
+    def _finish_short_tail(self, batch: Any, consumers: Sequence[Any], writer: Any, stage_id: str) -> JobResult:
+        """[all-gather of the slabs] + ONE launch: final merge, projection, stored kinds, result image."""
+        import torch  # noqa: PLC0415
+
+        from . import hipspark as hs  # noqa: PLC0415
+        from .device import RetryWithLargerDictionary, TierExceeded  # noqa: PLC0415
+
+        tail = batch.tail
+        merge = consumers[0]
+        project = list(consumers[1].columns) if len(consumers) == 2 else None
+        schema = writer.inferred_schema
+        slab = tail["slab"]
+        if self.dist is not None:
+            from .distributed import all_gather_slabs_into  # noqa: PLC0415
+
+            gathered = torch.empty(self.world * tail["layout"].nbytes, dtype=torch.uint8, device=slab.device)
+            self.dev.op(all_gather_slabs_into, self.dist, slab, gathered, self.group)
+            world, n_order = self.world, batch.total_units
+        else:
+            gathered, world, n_order = slab, 1, max(tail["n_units"], 1)
+        try:
+            raw, nrows, flags = self.dev.aggregate_finish(tail, gathered, world, merge.agg_columns, merge.inferred_schema,
+                                                          project, schema, self.merge_cap_hint, n_order,
+                                                          cache_key=id(merge))
+        except TierExceeded:
+            # too many partial rows for one workgroup's LDS: this query takes the general path from now on
+            self._no_short_tail.add(tail.get("task_id"))
+            raise RestartQuery from None
+        self.short_tails += 1
+        if self.dev.rec is not None:
+            self.dev.rec.result = (list(schema), stage_id)
+        if self.dist is not None and getattr(self, "_generic_exchange_used", False):
+            from .distributed import or_flags  # noqa: PLC0415
+
+            flags = or_flags(self.dist, flags, self.dev.device, self.group)
             self._generic_exchange_used = False
         if flags & hs.FLAG_DICT_FULL:
             raise RetryWithLargerDictionary

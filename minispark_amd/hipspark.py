@@ -94,6 +94,40 @@ class hs_agg_geom(C.Structure):
     ]
 
 
+HS_FINISH_MAX_OUT = 24
+
+
+class hs_slab_desc(C.Structure):
+    _fields_ = [
+        ("slab_rows", C.c_int64),
+        ("stride", C.c_int64),
+        ("order_off", C.c_int64),
+        ("key_off", C.c_int64),
+        ("acc_off", C.c_int64 * HS_MAX_ACC),
+        ("key_kind", C.c_int32),
+        ("key_len", C.c_int32),
+        ("n_acc", C.c_int32),
+        ("pad", C.c_int32),
+        ("acc_kind", C.c_int32 * HS_MAX_ACC),
+    ]
+
+
+class hs_finish_out(C.Structure):
+    _fields_ = [("src", C.c_int32), ("index", C.c_int32), ("kind", C.c_int32), ("pad", C.c_int32), ("offset", C.c_int64)]
+
+
+class hs_finish_spec(C.Structure):
+    _fields_ = [
+        ("n_fold", C.c_int32),
+        ("fold_src", C.c_int32 * HS_MAX_ACC),
+        ("fold_op", C.c_int32 * HS_MAX_ACC),
+        ("n_out", C.c_int32),
+        ("outs", hs_finish_out * HS_FINISH_MAX_OUT),
+        ("prog_src", C.c_int32 * HS_MAX_COLS),
+        ("prog_out", C.c_int32 * HS_MAX_OUTS),
+    ]
+
+
 _P = C.c_void_p
 _I64 = C.c_int64
 _I32 = C.c_int32
@@ -106,6 +140,7 @@ _GEOMP = C.POINTER(hs_agg_geom)
 SIGNATURES: dict[str, tuple] = {
     "hs_last_error": (C.c_char_p, []),
     "hs_version": (C.c_int, []),
+    "hs_sizeof": (C.c_size_t, [_I32]),
     "hs_scan_ws_bytes": (C.c_size_t, [_I64]),
     "hs_str_offsets": (C.c_int, [_P, _P, _I64, _P, _P, _P]),
     "hs_eval": (C.c_int, [_P, _COLP, _I32, _PROGP, _P, _I64, _P, C.POINTER(_P), C.POINTER(_I32), _I32, _P]),
@@ -120,6 +155,15 @@ SIGNATURES: dict[str, tuple] = {
     "hs_agg_partial": (
         C.c_int,
         [_P, _COLP, _I32, _I32, _PROGP, _SPECP, _P, _P, _I64, _GEOMP, _P, _P, _P, _P, _P, _P, _P],
+    ),
+    "hs_agg_partial_slab": (
+        C.c_int,
+        [_P, _COLP, _I32, _I32, _PROGP, _SPECP, _P, _P, _I64, _GEOMP, _P, _P, C.POINTER(hs_slab_desc), _P, _P, _P, _P],
+    ),
+    "hs_agg_finish_scratch_bytes": (C.c_size_t, [_I32, _I32]),
+    "hs_agg_finish": (
+        C.c_int,
+        [_P, _P, _I32, C.POINTER(hs_slab_desc), C.POINTER(hs_finish_spec), _PROGP, _I64, _I32, _P, _P, _P, _P],
     ),
     "hs_agg_pack": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _SPECP, _P, _P, C.POINTER(_P), C.POINTER(_I32), _P, _P]),
     "hs_agg_merge": (C.c_int, [_P, _COLP, _COLP, _SPECP, _P, _I64, _I64, _P, _I32, _P, _P, _P, _P]),

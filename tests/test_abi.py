@@ -34,6 +34,13 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(hs.hs_program) == 8 + 8 * hs.HS_MAX_INS + 8 * hs.HS_MAX_LIT + hs.HS_MAX_POOL
     assert C.sizeof(hs.hs_agg_spec) == 4 + 2 * hs.HS_MAX_ACC
     assert C.sizeof(hs.hs_agg_geom) == 40
+    # and the sizes the library was compiled with
+    lib = hs.load_library()
+    mirrors = [hs.hs_col, hs.hs_program, hs.hs_agg_spec, hs.hs_agg_geom, hs.hs_chunk, hs.hs_slab_desc, hs.hs_finish_out,
+               hs.hs_finish_spec]
+    for which, mirror in enumerate(mirrors):
+        assert lib.hs_sizeof(which) == C.sizeof(mirror), mirror.__name__
+    assert lib.hs_sizeof(len(mirrors)) == 0
 
 
 def test_bad_arguments_are_refused_without_a_gpu():

@@ -182,3 +182,9 @@ def test_random_query_matches_oracle(engine, tmp_path, seed):
         return
     got = frame.collect()
     assert_rows_match(got, want, max_ulps=1)
+    # and through the other route after the scan kernel (short tail <-> general operator sequence)
+    engine.short_tail_enabled = not engine.short_tail_enabled
+    try:
+        assert_rows_match(run(engine).collect(), want, max_ulps=1)
+    finally:
+        engine.short_tail_enabled = not engine.short_tail_enabled

@@ -14,11 +14,14 @@ from tests.queries import CASES, api_namespace
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def engine():
+@pytest.fixture(scope="module", params=["short_tail", "general"])
+def engine(request):
+    """Both routes after the scan kernel: the two-launch short tail (where a query qualifies) and the
+    general operator sequence."""
     from minispark_amd.execution import HipExecutionEngine
 
     with HipExecutionEngine() as e:
+        e.short_tail_enabled = request.param == "short_tail"
         yield e
 
 
@@ -38,9 +41,19 @@ def test_golden_case(engine, case):
             frame.collect()
         assert type(info.value).__name__ == golden["error"]
         return
-    rows = frame.collect()
-    flips = assert_rows_match(rows, golden["rows"], max_ulps=1)
-    assert flips == 0, f"{flips} FLOAT values differ from the reference by one f32 ulp"
+    for _run in range(3):  # first run, the recorded run, a replay of the recording
+        rows = frame.collect()
+        flips = assert_rows_match(rows, golden["rows"], max_ulps=1)
+        assert flips == 0, f"{flips} FLOAT values differ from the reference by one f32 ulp"
+
+
+def test_short_tail_ran_where_enabled(engine):
+    """Runs after the golden cases of the module-scoped engine: GROUP BY queries must have taken the
+    two-launch tail in that mode and never in the other."""
+    if engine.short_tail_enabled:
+        assert engine.short_tails >= 10
+    else:
+        assert engine.short_tails == 0
 
 
 def test_library_loaded_is_in_tree():
