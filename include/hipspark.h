@@ -374,13 +374,18 @@ size_t hs_agg_finish_scratch_bytes(int32_t cap, int32_t n_fold);
 /* Final merge of the partial rows of `world` slabs (gathered: world slabs desc->stride bytes apart; world 1 =
  * the rank's own slab) in ascending (order key, row) order exactly like hs_agg_merge, then the projection
  * `prog` over the merged rows (NULL / n_ins 0: none), quantisation to the stored kinds and the result image:
- *   result := [flags u32][pad u32][number of groups i64] + the columns at outs[].offset.
+ *   result := [flags u32][done u32 = 1, written last][number of groups i64] + the columns at outs[].offset.
  * flags = *flags | every slab's header flags | this launch's own bits; *flags and *own_slab_flags (optional)
  * are reset to 0 for the next run.  n_order: order keys lie in [0, n_order).  HS_E_LIMIT (2) when the rows do
  * not fit the LDS tier. */
 int hs_agg_finish(void* stream, const uint8_t* gathered, int32_t world, const hs_slab_desc* desc,
                   const hs_finish_spec* fin, const hs_program* prog, int64_t n_order, int32_t cap, uint8_t* result,
                   void* scratch, uint32_t* flags, uint32_t* own_slab_flags);
+/* `result` may live in pinned host memory mapped into the device (zero-copy hand-over, no device->host copy
+ * in the query): hs_agg_finish stores the image with system-scope visibility and then sets the header's second
+ * word (the pad) to 1, which the host may poll after clearing it.  This returns the device address of such a
+ * host allocation, or an error if the memory is not device-accessible. */
+int hs_host_device_pointer(void* host_ptr, void** device_ptr);
 
 /* =================================================================================================
  * Multi-GPU: un-interleave the all-gathered exchange slabs of the partial-aggregate shuffle (the slab

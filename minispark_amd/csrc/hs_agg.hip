@@ -255,6 +255,29 @@ struct AggMergeArgs {
     uint32_t* flags;
 };
 
+// Inclusive scan of one int per thread over the workgroup (wave shuffles + one LDS hop): 2 barriers instead of
+// the 2 * log2(n) of a Hillis-Steele ladder - the merge below is latency-bound.  s_part: >= 16 ints of LDS.
+__device__ __forceinline__ int hs_block_scan_incl(int v, int* s_part, int& total) {
+    const int tid = threadIdx.x, lane = tid & (HS_WAVE - 1), w = tid / HS_WAVE, nw = (blockDim.x + HS_WAVE - 1) / HS_WAVE;
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < HS_WAVE; d <<= 1) {
+        const int t = __shfl_up(x, d, HS_WAVE);
+        if (lane >= d) x += t;
+    }
+    if (lane == HS_WAVE - 1) s_part[w] = x;
+    __syncthreads();
+    int base = 0, all = 0;
+    for (int k = 0; k < nw; ++k) {
+        const int p = s_part[k];
+        if (k < w) base += p;
+        all += p;
+    }
+    __syncthreads();  // s_part may be reused
+    total = all;
+    return x + base;
+}
+
 // Row sources of the merge core.  Flat: the columns of a batch.  Slabs: `world` exchange slabs, row r =
 // row r % M of slab r / M (hs_slab_desc).
 struct MergeFlatIn {
@@ -343,8 +366,7 @@ __device__ __forceinline__ int hs_merge_small_core(const In& in, const hs_agg_sp
     int32_t* run = start + cap;                           // [cap] running rank per slot (step 3)
     int32_t* ocnt = run + cap;                            // [nord] rows per order key
     int32_t* ofirst = ocnt + nord;                        // [nord] first row of an order key
-    __shared__ int s_scan[1024];
-    __shared__ int s_nvalid;
+    __shared__ int s_part[16];
     const int tid = threadIdx.x, nthr = blockDim.x;
     const bool ordered = in.has_order();
 
@@ -358,7 +380,6 @@ __device__ __forceinline__ int hs_merge_small_core(const In& in, const hs_agg_sp
         ocnt[i] = 0;
         ofirst[i] = 0x7fffffff;
     }
-    if (tid == 0) s_nvalid = 0;
     __syncthreads();
     const uint32_t mask = (uint32_t)cap - 1;
     for (int r = tid; r < n; r += nthr) {  // step 1
@@ -389,27 +410,10 @@ __device__ __forceinline__ int hs_merge_small_core(const In& in, const hs_agg_sp
         mine += cnt[sl] > 0;
         mine_rows += cnt[sl];
     }
-    s_scan[tid] = mine;
-    __syncthreads();
-    for (int d = 1; d < nthr; d <<= 1) {
-        const int t = tid >= d ? s_scan[tid - d] : 0;
-        __syncthreads();
-        s_scan[tid] += t;
-        __syncthreads();
-    }
-    int drun = s_scan[tid] - mine;
-    const int ngroups = s_scan[nthr - 1];
-    __syncthreads();
+    int ngroups, total_rows;
+    int drun = hs_block_scan_incl(mine, s_part, ngroups) - mine;
     for (int sl = s0; sl < s1; ++sl) dense[sl] = cnt[sl] > 0 ? drun++ : -1;
-    s_scan[tid] = mine_rows;
-    __syncthreads();
-    for (int d = 1; d < nthr; d <<= 1) {
-        const int t = tid >= d ? s_scan[tid - d] : 0;
-        __syncthreads();
-        s_scan[tid] += t;
-        __syncthreads();
-    }
-    int pos = s_scan[tid] - mine_rows;
+    int pos = hs_block_scan_incl(mine_rows, s_part, total_rows) - mine_rows;
     for (int sl = s0; sl < s1; ++sl) {
         start[sl] = pos;
         pos += cnt[sl];
@@ -423,23 +427,13 @@ __device__ __forceinline__ int hs_merge_small_core(const In& in, const hs_agg_sp
         const int o0 = tid * operth, o1 = (o0 + operth) < nord ? (o0 + operth) : nord;
         int osum = 0;
         for (int o = o0; o < o1; ++o) osum += ocnt[o];
-        s_scan[tid] = osum;
-        __syncthreads();
-        for (int d = 1; d < nthr; d <<= 1) {
-            const int t = tid >= d ? s_scan[tid - d] : 0;
-            __syncthreads();
-            s_scan[tid] += t;
-            __syncthreads();
-        }
-        int opos = s_scan[tid] - osum;
-        if (tid == nthr - 1) s_nvalid = s_scan[tid];
+        int opos = hs_block_scan_incl(osum, s_part, nseq) - osum;
         for (int o = o0; o < o1; ++o) {  // ocnt becomes the start of the block's run in the sequence
             const int c = ocnt[o];
             ocnt[o] = opos;
             opos += c;
         }
         __syncthreads();
-        nseq = s_nvalid;
         for (int r = tid; r < n; r += nthr) {
             if (rslot[r] < 0) continue;
             const int o = (int)in.order(r);
@@ -581,15 +575,16 @@ __global__ void __launch_bounds__(1024) k_agg_finish(const AggFinishArgs A_kerna
         }
     }
     if (err) atomicOr(A.flags, err);
-    __threadfence();
+    __threadfence_system();  // the image may sit in mapped host memory: every column byte visible before "done"
     __syncthreads();
     if (tid == 0) {
         uint32_t f = atomicExch(A.flags, 0u);  // hands the status over and leaves the word clean for the next run
         for (int k = 0; k < A.world; ++k) f |= *(const uint32_t*)(A.slabs + (int64_t)k * A.desc.stride);
         ((uint32_t*)A.result)[0] = f;
-        ((uint32_t*)A.result)[1] = 0;
         ((int64_t*)A.result)[1] = ng;
         if (A.own_slab_flags) *A.own_slab_flags = 0;
+        __threadfence_system();
+        __hip_atomic_store((uint32_t*)A.result + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -957,6 +952,11 @@ extern "C" int hs_agg_pack(void* stream, const int64_t* rep, const uint64_t* acc
 }
 
 static constexpr size_t HS_MERGE_LDS_MAX = 150 * 1024;
+// threads of the single-workgroup merge: barriers cost per wave, so small inputs get a small workgroup
+static unsigned merge_block(int64_t n_rows, int cap, int n_order) {
+    const int64_t m = n_rows > cap ? (n_rows > n_order ? n_rows : n_order) : (cap > n_order ? cap : n_order);
+    return m <= 256 ? 256u : m <= 512 ? 512u : 1024u;
+}
 
 extern "C" int hs_agg_merge(void* stream, const hs_col* key, const hs_col* acc_cols, const hs_agg_spec* spec,
                             const int64_t* order, int64_t n_order, int64_t n_rows, const int64_t* n_rows_dev,
@@ -999,7 +999,7 @@ extern "C" int hs_agg_merge(void* stream, const hs_col* key, const hs_col* acc_c
                             (int)HS_MERGE_LDS_MAX);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_agg_merge_small, dim3(1), dim3(1024), lds, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(k_agg_merge_small, dim3(1), dim3(merge_block(n_rows, cap, A.n_order)), lds, (hipStream_t)stream, A);
     if (hipGetLastError() != hipSuccess) {
         hs_set_error("hs_agg_merge: kernel launch failed");
         return HS_E_LAUNCH;
@@ -1096,9 +1096,23 @@ extern "C" int hs_agg_finish(void* stream, const uint8_t* gathered, int32_t worl
         hipFuncSetAttribute((const void*)k_agg_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HS_MERGE_LDS_MAX);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_agg_finish, dim3(1), dim3(1024), lds, (hipStream_t)stream, A);
+    hipLaunchKernelGGL(k_agg_finish, dim3(1), dim3(merge_block(n_rows, cap, A.n_order)), lds, (hipStream_t)stream, A);
     if (hipGetLastError() != hipSuccess) {
         hs_set_error("hs_agg_finish: kernel launch failed");
+        return HS_E_LAUNCH;
+    }
+    return HS_OK;
+}
+
+extern "C" int hs_host_device_pointer(void* host_ptr, void** device_ptr) {
+    if (!host_ptr || !device_ptr) {
+        hs_set_error("hs_host_device_pointer: null argument");
+        return HS_E_ARG;
+    }
+    *device_ptr = nullptr;
+    if (hipHostGetDevicePointer(device_ptr, host_ptr, 0) != hipSuccess || !*device_ptr) {
+        (void)hipGetLastError();
+        hs_set_error("hs_host_device_pointer: the allocation is not mapped into the device");
         return HS_E_LAUNCH;
     }
     return HS_OK;

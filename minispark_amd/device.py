@@ -13,6 +13,7 @@ offsets, omitted when every row has the same length - ``fixed_len``).  Buffers a
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import Any, Sequence
 
@@ -186,6 +187,7 @@ class Device:
         self.flags = torch.zeros(4, dtype=torch.int32, device=self.device)
         self._partial_prepared: dict[Any, dict] = {}
         self._finish_prepared: dict[Any, dict] = {}
+        self.zero_copy_results = os.environ.get("HIPSPARK_ZERO_COPY", "1") != "0"
         self._const_lens: dict[int, torch.Tensor] = {}
         self._raw_lib = self.lib
         self.rec: Recording | None = None
@@ -848,18 +850,33 @@ class Device:
                 self._finish_prepared[key] = prep
         p = prep
         desc = p["desc"]
+        if p["host_image"] is not None:
+            self.op(p["host_image"][4:8].fill, 0)  # "done" word: cleared by the host before every launch
         rc = self.lib.hs_agg_finish(self.stream, gathered.data_ptr(), world, C.byref(desc), C.byref(p["fin"]),
                                     C.byref(p["prog"]) if p["prog"] is not None else None, n_order, cap,
-                                    p["result"].data_ptr(), p["scratch"].data_ptr(), self.flags.data_ptr(),
+                                    p["result_ptr"], p["scratch"].data_ptr(), self.flags.data_ptr(),
                                     tail["slab"].data_ptr())
         if rc == 2:
             raise TierExceeded("final merge exceeds the LDS tier: " + self.lib.hs_last_error().decode())
         hs.check(rc, "hs_agg_finish")
         self.last_merge_cap = cap
-        result, columns = p["result"], p["columns"]
+        result, columns, mapped = p["result"], p["columns"], p["host_image"]
+        stream = torch.cuda.current_stream(self.device)
 
         def finish() -> tuple[list[Any], int, int]:
-            host = result.cpu().numpy()  # the single synchronising copy
+            if mapped is not None:
+                # zero-copy hand-over: the launch stored the image into mapped host memory and set "done" last
+                done = mapped[4:8].view(np.uint32)
+                spins = 0
+                while done[0] == 0:
+                    spins += 1
+                    if spins > 200_000:  # a long scan: let the runtime wait instead of this core
+                        stream.synchronize()
+                        if done[0] == 0:
+                            raise DeviceError("hs_agg_finish completed without handing its result over")
+                host = mapped
+            else:
+                host = result.cpu().numpy()  # the single synchronising copy
             flags = int(host[0:4].view(np.uint32)[0])
             n = min(int(host[8:16].view(np.int64)[0]), cap)
             raw: list[Any] = []
@@ -958,9 +975,20 @@ class Device:
             fin.outs[o].src, fin.outs[o].index, fin.outs[o].kind, fin.outs[o].offset = src, index, kind, pos
             columns.append((pos, kind, width))
             pos = (pos + cap * width + 15) & ~15
-        result = torch.zeros(pos + PAD, dtype=torch.uint8, device=self.device)
         scratch = self.workspace(self.lib.hs_agg_finish_scratch_bytes(cap, fin.n_fold))
-        return {"fin": fin, "prog": prog, "desc": tail["desc"], "result": result, "scratch": scratch, "columns": columns}
+        result = host_image = None
+        result_ptr = 0
+        if self.zero_copy_results:
+            # result image in pinned host memory mapped into the device: the launch writes it over PCIe itself
+            pinned = torch.zeros(pos + PAD, dtype=torch.uint8).pin_memory()
+            dev_ptr = C.c_void_p()
+            if self.lib.hs_host_device_pointer(pinned.data_ptr(), C.byref(dev_ptr)) == 0 and dev_ptr.value:
+                result, host_image, result_ptr = pinned, pinned.numpy(), dev_ptr.value
+        if host_image is None:
+            result = torch.zeros(pos + PAD, dtype=torch.uint8, device=self.device)
+            result_ptr = result.data_ptr()
+        return {"fin": fin, "prog": prog, "desc": tail["desc"], "result": result, "result_ptr": result_ptr,
+                "host_image": host_image, "scratch": scratch, "columns": columns}
 
     # ---- global-memory aggregation tier (any cardinality) ---------------------------------------------------
     def concat_cols(self, parts: Sequence[DCol]) -> DCol:

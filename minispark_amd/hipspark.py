@@ -165,6 +165,7 @@ SIGNATURES: dict[str, tuple] = {
         C.c_int,
         [_P, _P, _I32, C.POINTER(hs_slab_desc), C.POINTER(hs_finish_spec), _PROGP, _I64, _I32, _P, _P, _P, _P],
     ),
+    "hs_host_device_pointer": (C.c_int, [_P, C.POINTER(_P)]),
     "hs_agg_pack": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _SPECP, _P, _P, C.POINTER(_P), C.POINTER(_I32), _P, _P]),
     "hs_agg_merge": (C.c_int, [_P, _COLP, _COLP, _SPECP, _P, _I64, _I64, _P, _I32, _P, _P, _P, _P]),
     "hs_partition_ids": (C.c_int, [_P, _COLP, _P, _I64, _I32, _P]),
