@@ -305,13 +305,26 @@ struct AggFinishArgs {
     uint8_t* key_scratch; // scratch [cap][key_bytes]
     uint32_t* flags;
     uint32_t* own_slab_flags;
+    // small inputs keep their whole working set in LDS (every global hop of this one-workgroup kernel is a
+    // serialised ~2 us round trip): byte offsets into the dynamic LDS block, 0 = stay in global memory
+    int64_t lds_slabs, lds_work, lds_image, lds_stack, image_bytes;
+    int64_t* stamps;  // optional [16]: wall_clock64() at the phase boundaries (HIPSPARK_FINISH_STAMPS=1; tools/finish_phases.py)
+};
+// where a launch keeps its working set
+struct FinishView {
+    const uint8_t* slabs;   // world slabs, desc.stride apart
+    int64_t* out_rep;       // [cap]
+    uint64_t* out_acc;      // [n_fold][cap]
+    uint8_t* key_scratch;   // [cap][key_bytes]
+    uint8_t* image;         // the result image (or its LDS staging copy)
 };
 struct MergeSlabIn {
     const AggFinishArgs& A;
+    const FinishView& V;
     __device__ __forceinline__ const uint8_t* slab_of(int r, int& i) const {
         const int k = r / (int)A.desc.slab_rows;
         i = r - k * (int)A.desc.slab_rows;
-        return A.slabs + (int64_t)k * A.desc.stride;
+        return V.slabs + (int64_t)k * A.desc.stride;
     }
     __device__ __forceinline__ bool has_order() const { return true; }
     __device__ __forceinline__ int64_t order(int r) const {
@@ -352,7 +365,8 @@ struct MergeSlabIn {
 template <typename In>
 __device__ __forceinline__ int hs_merge_small_core(const In& in, const hs_agg_spec& spec, const int n, const int64_t nmax,
                                                    const int nord, const int cap, uint64_t* lds, int64_t* out_rep,
-                                                   uint64_t* out_acc, uint32_t& err) {
+                                                   uint64_t* out_acc, uint32_t& err, int64_t* stamps = nullptr) {
+#define HS_STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[i] = (int64_t)wall_clock64(); } while (0)
     const int NA = spec.n_acc;
     uint64_t* dkeys = lds;                                // [cap]
     int64_t* dreps = (int64_t*)(lds + cap);               // [cap]
@@ -402,6 +416,7 @@ __device__ __forceinline__ int hs_merge_small_core(const In& in, const hs_agg_sp
         rslot[r] = sl;
     }
     __syncthreads();
+    HS_STAMP(2);
     // dense group numbering + bucket starts: per-thread slot ranges and two block scans
     const int per = (cap + nthr - 1) / nthr;
     const int s0 = tid * per, s1 = (s0 + per) < cap ? (s0 + per) : cap;
@@ -420,6 +435,7 @@ __device__ __forceinline__ int hs_merge_small_core(const In& in, const hs_agg_sp
     }
     __syncthreads();
 
+    HS_STAMP(3);
     // step 2: visiting sequence
     int nseq = n;
     if (ordered) {
@@ -442,6 +458,7 @@ __device__ __forceinline__ int hs_merge_small_core(const In& in, const hs_agg_sp
         __syncthreads();
     }
 
+    HS_STAMP(4);
     // step 3: stable rank of every row inside its group, one wave, 64 rows of the sequence at a time
     if (tid < HS_WAVE) {
         for (int base = 0; base < nseq; base += HS_WAVE) {
@@ -460,6 +477,7 @@ __device__ __forceinline__ int hs_merge_small_core(const In& in, const hs_agg_sp
         }
     }
     __syncthreads();
+    HS_STAMP(5);
     // step 4: scatter cells into the group buckets, then the ordered fold
     for (int r = tid; r < n; r += nthr) {
         const int sl = rslot[r];
@@ -470,6 +488,7 @@ __device__ __forceinline__ int hs_merge_small_core(const In& in, const hs_agg_sp
         if (rk == 0) out_rep[dense[sl]] = r;  // first row of the group in merge order: race-independent
     }
     __syncthreads();
+    HS_STAMP(6);
     for (int i = tid; i < cap * NA; i += nthr) {
         const int sl = i / NA, a = i % NA;
         if (dense[sl] < 0) continue;
@@ -477,10 +496,21 @@ __device__ __forceinline__ int hs_merge_small_core(const In& in, const hs_agg_sp
         const bool is_int = spec.is_int[a] != 0;
         uint64_t v = hs_acc_identity(op, is_int);
         const int b = start[sl], e = b + cnt[sl];
-        for (int q = b; q < e; ++q) v = hs_acc_fold(op, is_int, v, sorted[(int64_t)q * NA + a]);
+        int q = b;
+        for (; q + 4 <= e; q += 4) {  // four LDS reads in flight; the folds stay in order
+            const uint64_t c0 = sorted[(int64_t)q * NA + a], c1 = sorted[(int64_t)(q + 1) * NA + a],
+                           c2 = sorted[(int64_t)(q + 2) * NA + a], c3 = sorted[(int64_t)(q + 3) * NA + a];
+            v = hs_acc_fold(op, is_int, v, c0);
+            v = hs_acc_fold(op, is_int, v, c1);
+            v = hs_acc_fold(op, is_int, v, c2);
+            v = hs_acc_fold(op, is_int, v, c3);
+        }
+        for (; q < e; ++q) v = hs_acc_fold(op, is_int, v, sorted[(int64_t)q * NA + a]);
         out_acc[(int64_t)a * cap + dense[sl]] = v;
     }
+    HS_STAMP(7);
     return ngroups;
+#undef HS_STAMP
 }
 
 __global__ void __launch_bounds__(1024) k_agg_merge_small(const AggMergeArgs A_kernarg) {
@@ -502,11 +532,12 @@ __global__ void __launch_bounds__(1024) k_agg_merge_small(const AggMergeArgs A_k
 // The short tail, second half: slabs -> merged groups -> projection -> stored kinds -> result image.
 struct FinishSink {
     const AggFinishArgs& A;
+    const FinishView& V;
     int g;
     uint32_t& err;
-    __device__ __forceinline__ FinishSink(const AggFinishArgs& a, uint32_t& e) : A(a), g(0), err(e) {}
+    __device__ __forceinline__ FinishSink(const AggFinishArgs& a, const FinishView& v, uint32_t& e) : A(a), V(v), g(0), err(e) {}
     __device__ __forceinline__ void store(const hs_finish_out& d, uint64_t cell) {
-        uint8_t* col = A.result + d.offset;
+        uint8_t* col = V.image + d.offset;
         switch (d.kind) {
             case HS_F32: {
                 const double v = hs_u2d(cell);
@@ -526,8 +557,8 @@ struct FinishSink {
     }
     __device__ __forceinline__ uint64_t load(uint32_t s, int) const {
         const int j = A.fin.prog_src[s];
-        if (j >= 0) return A.out_acc[(int64_t)j * A.cap + g];
-        const hs_col kc{A.desc.key_kind, -1, A.key_scratch, nullptr, nullptr};
+        if (j >= 0) return V.out_acc[(int64_t)j * A.cap + g];
+        const hs_col kc{A.desc.key_kind, -1, V.key_scratch, nullptr, nullptr};
         return hs_load_cell(kc, g);
     }
     __device__ __forceinline__ bool live(int) const { return true; }
@@ -538,54 +569,102 @@ struct FinishSink {
     __device__ __forceinline__ void out(uint32_t o, int, uint64_t cell) { store(A.fin.outs[A.fin.prog_out[o]], cell); }
 };
 
+// SMALL: the slabs, the merged cells and the result image all live in LDS (every global hop of this
+// one-workgroup kernel is a serialised ~2 us round trip); otherwise they stay in global memory.
+template <bool SMALL>
 __global__ void __launch_bounds__(1024) k_agg_finish(const AggFinishArgs A_kernarg) {
-    HS_KERNARG(AggFinishArgs, A);
+    HS_KERNARG_LDS(AggFinishArgs, A);
     extern __shared__ __align__(16) uint64_t lds[];
+    __shared__ uint32_t s_err, s_flags0;
     const int tid = threadIdx.x, nthr = blockDim.x;
+    int64_t* const stamps = A.stamps;
+#define HS_STAMP(i) do { if (stamps && tid == 0) stamps[i] = (int64_t)wall_clock64(); } while (0)
+    HS_STAMP(0);
     const int n = A.world * (int)A.desc.slab_rows;
+    uint8_t* const lds8 = (uint8_t*)lds;
+    FinishView V;
+    if constexpr (SMALL) {
+        const uint64_t* src = (const uint64_t*)A.slabs;  // one parallel load brings every partial row on chip
+        uint64_t* dst = (uint64_t*)(lds8 + A.lds_slabs);
+        const int64_t words = (int64_t)A.world * A.desc.stride / 8;
+        for (int64_t i = tid; i < words; i += nthr) dst[i] = src[i];
+        V.slabs = lds8 + A.lds_slabs;
+        V.out_rep = (int64_t*)(lds8 + A.lds_work);
+        V.out_acc = (uint64_t*)(lds8 + A.lds_work) + A.cap;
+        V.key_scratch = (uint8_t*)((uint64_t*)(lds8 + A.lds_work) + (int64_t)A.cap * (A.fin.n_fold + 1));
+        V.image = lds8 + A.lds_image;
+    } else {
+        V.slabs = A.slabs;
+        V.out_rep = A.out_rep;
+        V.out_acc = A.out_acc;
+        V.key_scratch = A.key_scratch;
+        V.image = A.result;
+    }
+    if (tid == 0) {
+        // status of everything that ran before this launch (final: the stream is ordered); fetched now so the
+        // end of the kernel does not wait for another global round trip
+        s_flags0 = __hip_atomic_load(A.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_err = 0;
+    }
+    __syncthreads();
+    HS_STAMP(1);
     uint32_t err = 0;
-    const MergeSlabIn in{A};
-    const int ng = hs_merge_small_core(in, A.spec, n, n, A.n_order, A.cap, lds, A.out_rep, A.out_acc, err);
-    __syncthreads();  // out_rep / out_acc are complete (one workgroup: global writes are visible after the barrier)
+    const MergeSlabIn in{A, V};
+    const int ng = hs_merge_small_core(in, A.spec, n, n, A.n_order, A.cap, lds, V.out_rep, V.out_acc, err, stamps);
+    __syncthreads();  // out_rep / out_acc are complete (one workgroup: visible after the barrier wherever they live)
     const int kb = A.key_bytes;
     for (int g = tid; g < ng; g += nthr) {
         int i;
-        const uint8_t* s = in.slab_of((int)A.out_rep[g], i);
+        const uint8_t* s = in.slab_of((int)V.out_rep[g], i);
         const uint8_t* src = s + A.desc.key_off + (int64_t)i * kb;
-        for (int b = 0; b < kb; ++b) A.key_scratch[(int64_t)g * kb + b] = src[b];
+        for (int b = 0; b < kb; ++b) V.key_scratch[(int64_t)g * kb + b] = src[b];
     }
     __syncthreads();
-    FinishSink sink(A, err);
-    for (int o = 0; o < A.fin.n_out; ++o) {
+    HS_STAMP(8);
+    FinishSink sink(A, V, err);
+    for (int t = tid; t < A.fin.n_out * ng; t += nthr) {  // key and merged aggregates that pass through
+        const int o = t / ng, g = t - o * ng;
         const hs_finish_out& d = A.fin.outs[o];
-        if (d.src == 2) continue;
-        for (int g = tid; g < ng; g += nthr) {
-            if (d.src == 0) {
-                for (int b = 0; b < kb; ++b) A.result[d.offset + (int64_t)g * kb + b] = A.key_scratch[(int64_t)g * kb + b];
-            } else {
-                sink.g = g;
-                sink.store(d, A.out_acc[(int64_t)d.index * A.cap + g]);
-            }
-        }
-    }
-    if (A.prog.n_ins) {
-        for (int g = tid; g < ng; g += nthr) {
+        if (d.src == 0) {
+            for (int b = 0; b < kb; ++b) V.image[d.offset + (int64_t)g * kb + b] = V.key_scratch[(int64_t)g * kb + b];
+        } else if (d.src == 1) {
             sink.g = g;
-            hs_run<HS_MAX_STACK, 1>(A.prog, A.nocols, 0, A.prog.n_ins, sink, err);
+            sink.store(d, V.out_acc[(int64_t)d.index * A.cap + g]);
         }
     }
-    if (err) atomicOr(A.flags, err);
-    __threadfence_system();  // the image may sit in mapped host memory: every column byte visible before "done"
+    HS_STAMP(9);
+    if (A.prog.n_ins && tid < HS_WAVE) {  // the projection: one wave, interpreter stack in LDS
+        uint64_t* stack = (uint64_t*)(lds8 + A.lds_stack) + tid;
+        for (int g = tid; g < ng; g += HS_WAVE) {
+            sink.g = g;
+            hs_run_compact(A.prog, A.nocols, sink, err, stack, HS_WAVE);
+        }
+    }
+    HS_STAMP(10);
+    if (err) atomicOr(&s_err, err);
     __syncthreads();
     if (tid == 0) {
-        uint32_t f = atomicExch(A.flags, 0u);  // hands the status over and leaves the word clean for the next run
-        for (int k = 0; k < A.world; ++k) f |= *(const uint32_t*)(A.slabs + (int64_t)k * A.desc.stride);
-        ((uint32_t*)A.result)[0] = f;
-        ((int64_t*)A.result)[1] = ng;
+        uint32_t f = s_flags0 | s_err;
+        for (int k = 0; k < A.world; ++k) f |= *(const uint32_t*)(V.slabs + (int64_t)k * A.desc.stride);
+        ((uint32_t*)V.image)[0] = f;
+        ((int64_t*)V.image)[1] = ng;
+        *A.flags = 0;  // status handed over: the words are clean for the next run
         if (A.own_slab_flags) *A.own_slab_flags = 0;
-        __threadfence_system();
-        __hip_atomic_store((uint32_t*)A.result + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    if constexpr (SMALL) {  // staged image -> result, everything but the "done" word
+        __syncthreads();
+        const uint32_t* src = (const uint32_t*)V.image;
+        uint32_t* dst = (uint32_t*)A.result;
+        for (int64_t i = tid; i < A.image_bytes / 4; i += nthr) {
+            if (i != 1) dst[i] = src[i];
+        }
+    }
+    HS_STAMP(11);
+    __threadfence_system();  // the result may sit in mapped host memory: every byte visible before "done"
+    __syncthreads();
+    HS_STAMP(12);
+    if (tid == 0) __hip_atomic_store((uint32_t*)A.result + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+#undef HS_STAMP
 }
 
 // ==================================================================================================
@@ -951,7 +1030,7 @@ extern "C" int hs_agg_pack(void* stream, const int64_t* rep, const uint64_t* acc
     return HS_OK;
 }
 
-static constexpr size_t HS_MERGE_LDS_MAX = 150 * 1024;
+static constexpr size_t HS_MERGE_LDS_MAX = 150 * 1024;  // dynamic part; the kernels add < 4 KB static
 // threads of the single-workgroup merge: barriers cost per wave, so small inputs get a small workgroup
 static unsigned merge_block(int64_t n_rows, int cap, int n_order) {
     const int64_t m = n_rows > cap ? (n_rows > n_order ? n_rows : n_order) : (cap > n_order ? cap : n_order);
@@ -1008,7 +1087,7 @@ extern "C" int hs_agg_merge(void* stream, const hs_col* key, const hs_col* acc_c
 }
 
 extern "C" size_t hs_agg_finish_scratch_bytes(int32_t cap, int32_t n_fold) {
-    return (size_t)cap * 8 * (size_t)(n_fold + 2) + 64;  // out_rep + out_acc + key elements (<= 8 bytes each)
+    return (size_t)cap * 8 * (size_t)(n_fold + 2) + 64 + 128;  // out_rep + out_acc + key elements (<= 8 bytes each) + stamps
 }
 
 extern "C" int hs_agg_finish(void* stream, const uint8_t* gathered, int32_t world, const hs_slab_desc* desc,
@@ -1091,12 +1170,44 @@ extern "C" int hs_agg_finish(void* stream, const uint8_t* gathered, int32_t worl
     A.key_scratch = (uint8_t*)((uint64_t*)scratch + (size_t)cap * (fin->n_fold + 1));
     A.flags = flags;
     A.own_slab_flags = own_slab_flags;
+    static const bool want_stamps = getenv("HIPSPARK_FINISH_STAMPS") && getenv("HIPSPARK_FINISH_STAMPS")[0] == '1';
+    A.stamps = want_stamps ? (int64_t*)((char*)scratch + (((size_t)cap * 8 * (size_t)(fin->n_fold + 2) + 64 + 7) & ~(size_t)7)) : nullptr;
+    // result image size, and the working set that may move into LDS behind the merge core's block
+    int64_t image_bytes = 16;
+    for (int o = 0; o < fin->n_out; ++o) {
+        const hs_finish_out& d = fin->outs[o];
+        const int width = d.src == 0 ? key_bytes : (d.kind == HS_I64 ? 8 : 4);
+        const int64_t end = d.offset + (int64_t)cap * width;
+        if (end > image_bytes) image_bytes = end;
+    }
+    image_bytes = (image_bytes + 15) & ~(int64_t)15;
+    A.image_bytes = image_bytes;
+    size_t total_lds = (lds + 15) & ~(size_t)15;
+    A.lds_stack = (int64_t)total_lds;  // projection stack: (HS_MAX_STACK + 1) cells x one wave
+    total_lds += (size_t)(HS_MAX_STACK + 1) * HS_WAVE * 8;
+    const size_t slab_bytes = ((size_t)world * (size_t)desc->stride + 15) & ~(size_t)15;
+    const size_t work_bytes = ((size_t)cap * 8 * (size_t)(fin->n_fold + 2) + 15) & ~(size_t)15;
+    const bool small = desc->stride % 8 == 0 && total_lds + slab_bytes + work_bytes + (size_t)image_bytes <= HS_MERGE_LDS_MAX;
+    if (small) {
+        A.lds_slabs = (int64_t)total_lds;
+        A.lds_work = A.lds_slabs + (int64_t)slab_bytes;
+        A.lds_image = A.lds_work + (int64_t)work_bytes;
+        total_lds += slab_bytes + work_bytes + (size_t)image_bytes;
+    }
+    if (total_lds > HS_MERGE_LDS_MAX) {
+        hs_set_error("hs_agg_finish: %lld partial rows x %d aggregates need %zu B LDS (> %zu)", (long long)n_rows,
+                     fin->n_fold, total_lds, HS_MERGE_LDS_MAX);
+        return HS_E_LIMIT;
+    }
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)k_agg_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HS_MERGE_LDS_MAX);
+        hipFuncSetAttribute((const void*)k_agg_finish<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HS_MERGE_LDS_MAX);
+        hipFuncSetAttribute((const void*)k_agg_finish<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HS_MERGE_LDS_MAX);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_agg_finish, dim3(1), dim3(merge_block(n_rows, cap, A.n_order)), lds, (hipStream_t)stream, A);
+    const dim3 block(merge_block(n_rows, cap, A.n_order));
+    if (small) hipLaunchKernelGGL(k_agg_finish<true>, dim3(1), block, total_lds, (hipStream_t)stream, A);
+    else hipLaunchKernelGGL(k_agg_finish<false>, dim3(1), block, total_lds, (hipStream_t)stream, A);
     if (hipGetLastError() != hipSuccess) {
         hs_set_error("hs_agg_finish: kernel launch failed");
         return HS_E_LAUNCH;

@@ -41,6 +41,19 @@ static constexpr uint64_t HS_EMPTY_KEY = 0x8000000000000000ull;
     (void)name##_kernarg;   \
     const T& name = *(const T*)__builtin_amdgcn_kernarg_segment_ptr()
 
+// Latency-bound single-workgroup kernels: every first touch of a kernarg cache line is a serialised miss
+// (a 2.6 KB argument block = 40 of them).  This variant copies the block into LDS with one cooperative
+// vector load at kernel start; afterwards all argument reads are LDS reads.  sizeof(T) % 8 == 0.
+#define HS_KERNARG_LDS(T, name)                                                                        \
+    (void)name##_kernarg;                                                                              \
+    __shared__ __align__(16) uint64_t name##_lds[(sizeof(T) + 7) / 8];                                 \
+    {                                                                                                  \
+        const uint64_t* name##_src = (const uint64_t*)__builtin_amdgcn_kernarg_segment_ptr();          \
+        for (unsigned i_ = threadIdx.x; i_ < (sizeof(T) + 7) / 8; i_ += blockDim.x) name##_lds[i_] = name##_src[i_]; \
+    }                                                                                                  \
+    __syncthreads();                                                                                   \
+    const T& name = *(const T*)name##_lds
+
 struct HsCols {
     int32_t n;
     int32_t pad;
@@ -369,6 +382,55 @@ __device__ __forceinline__ void hs_run(const hs_program& P, const HsCols& C, uin
                 break;
         }
     }
+}
+
+// Compact interpreter, one row: a single op switch over a run-time indexed stack.  A fraction of the code
+// of hs_run (which instantiates every operator per stack depth to keep the stack in registers): for the
+// latency-bound one-workgroup kernels, where each first visit of an instruction-cache line is a serialised
+// miss and throughput is irrelevant.  Same operators (hs_bin<>), same sink concept (j = 0).
+// The stack lives in LDS (a dynamically indexed private array would go to scratch = global memory latency per
+// access): `stack` = this lane's first cell, entries `stride` cells apart, HS_MAX_STACK + 1 of them.
+template <typename Sink>
+__device__ __forceinline__ void hs_run_compact(const hs_program& P, const HsCols& C, Sink& sink, uint32_t& err,
+                                               uint64_t* stack, int stride) {
+#define st(d) stack[(int)(d) * stride]
+    const uint32_t n_ins = P.n_ins;
+    for (uint32_t pc = 0; pc < n_ins; ++pc) {
+        const uint64_t w = P.ins[pc];
+        const uint32_t op = hs_ins_op(w), sp = hs_ins_sp(w), a = hs_ins_a(w);
+        if (sp > HS_MAX_STACK) {
+            err |= HS_FLAG_BAD_PROGRAM;
+            return;
+        }
+        const uint32_t t = sp >= 1 ? sp - 1 : 0, s2 = sp >= 2 ? sp - 2 : 0, nx = sp < HS_MAX_STACK ? sp : HS_MAX_STACK;
+        const uint64_t x = st(s2), y = st(t);
+        const bool live = sink.live(0);
+#define HS_CBIN(OPC) case OPC: st(s2) = hs_bin<OPC>(x, y, live, err); break;
+        switch (op) {
+            case HS_OP_LD: st(nx) = sink.load(a, 0); break;
+            case HS_OP_LIT: st(nx) = P.lit[a]; break;
+            HS_CBIN(HS_OP_ADD_F) HS_CBIN(HS_OP_SUB_F) HS_CBIN(HS_OP_MUL_F) HS_CBIN(HS_OP_DIV_F)
+            HS_CBIN(HS_OP_FLOORDIV_F) HS_CBIN(HS_OP_MOD_F)
+            HS_CBIN(HS_OP_ADD_I) HS_CBIN(HS_OP_SUB_I) HS_CBIN(HS_OP_MUL_I) HS_CBIN(HS_OP_FLOORDIV_I) HS_CBIN(HS_OP_MOD_I)
+            HS_CBIN(HS_OP_LT_F) HS_CBIN(HS_OP_LE_F) HS_CBIN(HS_OP_GT_F) HS_CBIN(HS_OP_GE_F) HS_CBIN(HS_OP_EQ_F) HS_CBIN(HS_OP_NE_F)
+            HS_CBIN(HS_OP_LT_I) HS_CBIN(HS_OP_LE_I) HS_CBIN(HS_OP_GT_I) HS_CBIN(HS_OP_GE_I) HS_CBIN(HS_OP_EQ_I) HS_CBIN(HS_OP_NE_I)
+            HS_CBIN(HS_OP_AND) HS_CBIN(HS_OP_OR)
+            case HS_OP_I2F:
+                if (a == 0) st(t) = hs_d2u((double)(int64_t)y);
+                else st(s2) = hs_d2u((double)(int64_t)x);
+                break;
+            case HS_OP_STRCMP_LIT: st(nx) = live ? hs_strcmp_lit(P, C.c[a], sink.row(0), hs_ins_b(w), hs_ins_c(w)) : 0; break;
+            case HS_OP_STRCMP_COL: st(nx) = live ? hs_strcmp_col(C.c[a], C.c[hs_ins_b(w)], sink.row(0), hs_ins_c(w)) : 0; break;
+            case HS_OP_LIKE: st(nx) = live ? hs_like_lit(P, C.c[a], sink.row(0), hs_ins_b(w)) : 0; break;
+            case HS_OP_FILTER: sink.filter(0, y != 0); break;
+            case HS_OP_AGG: sink.agg(a, 0, y); break;
+            case HS_OP_OUT: sink.out(a, 0, y); break;
+            case HS_OP_KEY: sink.key(); break;
+            default: err |= HS_FLAG_BAD_PROGRAM; break;
+        }
+#undef HS_CBIN
+    }
+#undef st
 }
 
 // ---- group keys ------------------------------------------------------------------------------------
