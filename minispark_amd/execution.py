@@ -70,18 +70,11 @@ class ExecutionEngine(AbstractContextManager, ABC):
                     return
 
     def sql(self, query: str) -> Any:
-        """SQL text -> DataFrame bound to this engine.  The parser is the reference's (parser.py:391-397,
-        needs `parsimonious`): the SQL front-end is outside the accelerated path."""
-        try:
-            from mini_spark.parser import parse_sql  # type: ignore[import-not-found]  # noqa: PLC0415
-        except ImportError as e:
-            raise NotImplementedError(
-                "no SQL front-end available (the reference's mini_spark.parser is not importable); "
-                "build the query with DataFrame"
-            ) from e
-        df = parse_sql(query)
-        df.engine = self
-        return df
+        """SQL text -> DataFrame bound to this engine (reference execution.py:57-62).  Parsed by this package's
+        own parser of the reference's grammar (minispark_amd/parser.py): no third-party dependency."""
+        from .parser import parse_sql  # noqa: PLC0415
+
+        return parse_sql(query, self)
 
 
 def _cls(obj: Any) -> str:
