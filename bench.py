@@ -27,18 +27,41 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s)
-CUTOFF = "1998-12-01"
+CUTOFF = "1998-12-01"  # the reference's query; --cutoff 1998-09-02 keeps ~97 % of the rows (predicate not vacuous)
 
 
-def q1_frame(engine, table_path: str):
+def q1_frame(engine, table_path: str, cutoff: str = CUTOFF):
     from minispark_amd.dataframe import DataFrame
     from minispark_amd.sql import Col, Functions, Lit
     from tests.queries import api_namespace, q1
 
-    return q1(api_namespace(lambda: DataFrame(engine), Col, Functions, Lit), table_path, CUTOFF)
+    return q1(api_namespace(lambda: DataFrame(engine), Col, Functions, Lit), table_path, cutoff)
 
 
-def cpu_baseline(engine, table, sample_blocks: int, gpu_rows_for_sample):
+def python_engine_baseline(scratch: Path, cutoff: str, n: int = 120_000) -> dict:
+    """The row-at-a-time pure-Python restatement of the reference's PythonExecutionEngine (oracle/py_engine.py:
+    BlockFile decode value by value, expression tree per row, dict aggregators) on a small sample, 1 core -
+    the kind of number the reference's own Python engine produces (it cannot run on this box)."""
+    import numpy as np
+
+    from minispark_amd import synth
+    from minispark_amd.io import BlockFile, StrCol
+    from oracle import py_engine, q1_native
+
+    cols = q1_native.gen(synth.SEED, 0, n)
+    schema = [c for c in synth.LINEITEM_SCHEMA if c[0] != "l_orderkey"]
+    raw = [cols["l_quantity"], cols["l_extendedprice"], cols["l_discount"], cols["l_tax"],
+           StrCol(np.ones(n, dtype=np.uint8), cols["l_returnflag"]), cols["l_shipdate"]]
+    path = scratch / "py_sample.bin"
+    BlockFile(path, schema).write_raw(schema, raw)
+    frame = q1_frame(object(), str(path), cutoff)
+    t0 = time.perf_counter()
+    rows = py_engine.run_query(frame.task)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "rows/s", "cores": 1, "rows": n, "groups": len(rows)}
+
+
+def cpu_baseline(engine, table, sample_blocks: int, gpu_rows_for_sample, cutoff: str = CUTOFF):
     """The C port of the reference's algorithm (oracle/q1_oracle.c) timed on the host cores over the
     first ``sample_blocks`` blocks of the same table; also checks the GPU's rows for that sample."""
     import numpy as np
@@ -51,7 +74,7 @@ def cpu_baseline(engine, table, sample_blocks: int, gpu_rows_for_sample):
     n = sum(sizes)
     names = {1: "l_quantity", 2: "l_extendedprice", 3: "l_discount", 4: "l_tax", 5: "l_returnflag", 6: "l_shipdate"}
     cols = {name: table.columns[cid].data[:n].cpu().numpy() for cid, name in names.items()}
-    cutoff_us = bfio.to_us(datetime.fromisoformat(CUTOFF))
+    cutoff_us = bfio.to_us(datetime.fromisoformat(cutoff))
     threads = q1_native.host_threads()
     q1_native.run(cols, sizes, cutoff_us, threads=threads)  # warm-up (page in, build)
     t0 = time.perf_counter()
@@ -85,6 +108,7 @@ def main() -> None:
     ap.add_argument("--sf", type=float, default=100.0)
     ap.add_argument("--sample-blocks", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cutoff", default=CUTOFF, help="WHERE l_shipdate <= CUTOFF")
     args = ap.parse_args()
 
     import torch
@@ -122,7 +146,7 @@ def main() -> None:
     table_path = scratch / f"lineitem_sf{args.sf:g}.bin"
     table = synth.make_lineitem(engine.dev, table_path, total_rows, rank=rank, world=world)
     engine.attach_device_table(table_path, table)
-    frame = q1_frame(engine, str(table_path))
+    frame = q1_frame(engine, str(table_path), args.cutoff)
     engine.dev.time_scan_kernel(True)
 
     def step():
@@ -165,7 +189,7 @@ def main() -> None:
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": f"TPC-H Q1 variant (8 aggregates, WHERE l_shipdate <= '{CUTOFF}', GROUP BY l_returnflag) "
+                "workload": f"TPC-H Q1 variant (8 aggregates, WHERE l_shipdate <= '{args.cutoff}', GROUP BY l_returnflag) "
                             f"on synthetic lineitem sf={args.sf:g}",
                 "rows": total_rows, "blocks": len(synth.block_sizes(total_rows)), "rows_per_block": constants.ROWS_PER_BLOCK,
                 "bytes_per_row": synth.Q1_BYTES_PER_ROW, "groups": len(rows or []), "placement": "block b on rank b % n_gpus",
@@ -177,6 +201,9 @@ def main() -> None:
                 "rows_per_launch": local_rows, "launch": scan,
             },
             "whole_step_GBps_per_gpu": synth.Q1_BYTES_PER_ROW * local_rows / (elapsed / args.steps) / 1e9,
+            # where a step goes: the scan kernel (HIP events) and everything else (unit combine, [collective],
+            # finish launch, hand-over, host)
+            "time_split_ms": {"scan_kernel": kernel_avg_ms, "rest_of_step": ms_per_step - kernel_avg_ms},
         }
         # HBM traffic of the scan kernel per launch from the PMC counters: rocprofv3 cannot run inside this
         # process, so the figure comes from the committed counter passes of this same command (profiles/)
@@ -189,8 +216,9 @@ def main() -> None:
             blocks = min(args.sample_blocks, len(table.block_rows))
             sample = synth.make_lineitem(engine.dev, scratch / "sample.bin", sum(table.block_rows[:blocks]))
             engine.attach_device_table(scratch / "sample.bin", sample)
-            gpu_sample_rows = q1_frame(engine, str(scratch / "sample.bin")).collect()
-            out["cpu_baseline"] = cpu_baseline(engine, table, blocks, gpu_sample_rows)
+            gpu_sample_rows = q1_frame(engine, str(scratch / "sample.bin"), args.cutoff).collect()
+            out["cpu_baseline"] = cpu_baseline(engine, table, blocks, gpu_sample_rows, args.cutoff)
+            out["cpu_baseline"]["python_engine_port"] = python_engine_baseline(scratch, args.cutoff)
         print(json.dumps(out), flush=True)
     engine.__exit__(None, None, None)
     if dist is not None:

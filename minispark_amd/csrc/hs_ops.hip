@@ -49,21 +49,27 @@ static constexpr int SCAN_ITEMS = 8;
 static constexpr int SCAN_TILE = SCAN_WG * SCAN_ITEMS;
 
 // ---- block-level helpers ---------------------------------------------------------------------------
-// exclusive scan of one int64 per thread across a 256-thread workgroup; returns (exclusive, total)
-__device__ __forceinline__ int64_t block_excl_scan(int64_t v, int64_t* s_tmp, int64_t& total) {
-    const int tid = threadIdx.x;
-    s_tmp[tid] = v;
-    __syncthreads();
-    for (int d = 1; d < SCAN_WG; d <<= 1) {
-        const int64_t t = tid >= d ? s_tmp[tid - d] : 0;
-        __syncthreads();
-        s_tmp[tid] += t;
-        __syncthreads();
+__device__ __forceinline__ int64_t wave_incl_scan_i64(int64_t v) {
+    const int lane = threadIdx.x & (HS_WAVE - 1);
+#pragma unroll
+    for (int d = 1; d < HS_WAVE; d <<= 1) {
+        const int64_t t = __shfl_up(v, d, HS_WAVE);
+        if (lane >= d) v += t;
     }
-    total = s_tmp[SCAN_WG - 1];
-    const int64_t excl = s_tmp[tid] - v;
+    return v;
+}
+// exclusive scan of one int64 per thread across a 256-thread workgroup; returns the exclusive prefix and the
+// total: wave shuffles + one LDS hop (2 barriers).  s_tmp: >= 4 cells.
+__device__ __forceinline__ int64_t block_excl_scan(int64_t v, int64_t* s_tmp, int64_t& total) {
+    const int tid = threadIdx.x, w = tid / HS_WAVE;
+    const int64_t incl = wave_incl_scan_i64(v);
+    if ((tid & (HS_WAVE - 1)) == HS_WAVE - 1) s_tmp[w] = incl;
     __syncthreads();
-    return excl;
+    const int64_t p0 = s_tmp[0], p1 = s_tmp[1], p2 = s_tmp[2], p3 = s_tmp[3];
+    __syncthreads();  // s_tmp may be reused by the caller
+    total = p0 + p1 + p2 + p3;
+    const int64_t base = w == 0 ? 0 : w == 1 ? p0 : w == 2 ? p0 + p1 : p0 + p1 + p2;
+    return base + incl - v;
 }
 
 struct InLens {
@@ -144,8 +150,129 @@ __global__ void __launch_bounds__(SCAN_WG) k_scan_down(In in, int64_t n, const i
     if (blockIdx.x == 0 && threadIdx.x == 0 && total_out) *total_out = tile_sums[gridDim.x];
 }
 
+// ---- byte inputs (string lengths, filter masks): 16 rows per lane from one 16-byte load -------------------------
+// Tile = 256 lanes x 16 bytes = 4096 rows.  A lane's rows are consecutive, so its serial prefix needs no
+// exchange; across lanes a wave shuffle scan; results go through LDS so that the stores to HBM are contiguous
+// per wave.  Requires a 16-byte aligned input (the launchers fall back to the generic kernels otherwise).
+static constexpr int VT_U8 = 16;
+static constexpr int TILE_U8 = SCAN_WG * VT_U8;
+
+__device__ __forceinline__ void load_bytes16(const uint8_t* p, int64_t base, int64_t n, uint32_t (&w)[4]) {
+    if (base + VT_U8 <= n) {
+        const uint4 v = *reinterpret_cast<const uint4*>(p + base);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    } else {
+        w[0] = w[1] = w[2] = w[3] = 0;
+        for (int k = 0; k < VT_U8; ++k)
+            if (base + k < n) w[k >> 2] |= (uint32_t)p[base + k] << (8 * (k & 3));
+    }
+}
+__device__ __forceinline__ uint32_t bytes_sum4(uint32_t w) {
+    w = (w & 0x00ff00ffu) + ((w >> 8) & 0x00ff00ffu);
+    return (w & 0xffffu) + (w >> 16);
+}
+__device__ __forceinline__ uint32_t bytes_nonzero4(uint32_t w) {  // 0x80 in every byte that is not zero
+    return (((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u;
+}
+
+// MASK: count of non-zero bytes; otherwise the byte sum (+ min / max of the bytes for fixed-length detection)
+template <bool MASK>
+__global__ void __launch_bounds__(SCAN_WG) k_bytes_reduce(const uint8_t* p, int64_t n, int64_t* tile_sums,
+                                                          int32_t* minmax) {
+    __shared__ int64_t s_tmp[4];
+    const int64_t base = (int64_t)blockIdx.x * TILE_U8 + (int64_t)threadIdx.x * VT_U8;
+    uint32_t w[4];
+    load_bytes16(p, base, n, w);
+    int64_t sum = 0;
+    if constexpr (MASK) {
+        sum = __popc(bytes_nonzero4(w[0])) + __popc(bytes_nonzero4(w[1])) + __popc(bytes_nonzero4(w[2])) +
+              __popc(bytes_nonzero4(w[3]));
+    } else {
+        sum = bytes_sum4(w[0]) + bytes_sum4(w[1]) + bytes_sum4(w[2]) + bytes_sum4(w[3]);
+        if (minmax) {
+            int mn = 256, mx = -1;
+            for (int k = 0; k < VT_U8; ++k) {
+                if (base + k < n) {
+                    const int v = (w[k >> 2] >> (8 * (k & 3))) & 0xff;
+                    mn = v < mn ? v : mn;
+                    mx = v > mx ? v : mx;
+                }
+            }
+            for (int d = HS_WAVE / 2; d >= 1; d >>= 1) {
+                const int omn = __shfl_down(mn, d, HS_WAVE), omx = __shfl_down(mx, d, HS_WAVE);
+                mn = omn < mn ? omn : mn;
+                mx = omx > mx ? omx : mx;
+            }
+            // one address for the whole grid: only waves that improve on the current value touch it
+            if ((threadIdx.x % HS_WAVE) == 0 && mx >= 0) {
+                if (mn < __hip_atomic_load(&minmax[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&minmax[0], mn);
+                if (mx > __hip_atomic_load(&minmax[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&minmax[1], mx);
+            }
+        }
+    }
+    int64_t total;
+    block_excl_scan(sum, s_tmp, total);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+
+// offs[i] = exclusive prefix of the lengths; staged through LDS (padded: lane * 17 + k) for contiguous stores
+__global__ void __launch_bounds__(SCAN_WG) k_lens_offsets(const uint8_t* lens, int64_t n, const int64_t* tile_sums,
+                                                          int64_t* offs, int64_t* total_out) {
+    __shared__ int64_t s_tmp[4];
+    __shared__ int64_t s_out[TILE_U8 + TILE_U8 / VT_U8];
+    const int tid = threadIdx.x;
+    const int64_t tile0 = (int64_t)blockIdx.x * TILE_U8;
+    const int64_t base = tile0 + (int64_t)tid * VT_U8;
+    uint32_t w[4];
+    load_bytes16(lens, base, n, w);
+    const int64_t sum = bytes_sum4(w[0]) + bytes_sum4(w[1]) + bytes_sum4(w[2]) + bytes_sum4(w[3]);
+    int64_t total;
+    int64_t run = tile_sums[blockIdx.x] + block_excl_scan(sum, s_tmp, total);
+#pragma unroll
+    for (int k = 0; k < VT_U8; ++k) {
+        s_out[tid * (VT_U8 + 1) + k] = run;
+        run += (w[k >> 2] >> (8 * (k & 3))) & 0xff;
+    }
+    __syncthreads();
+    const int64_t left = n - tile0;
+    const int count = left < TILE_U8 ? (int)left : TILE_U8;
+    for (int i = tid; i < count; i += SCAN_WG) offs[tile0 + i] = s_out[i + i / VT_U8];
+    if (blockIdx.x == 0 && tid == 0 && total_out) *total_out = tile_sums[gridDim.x];
+}
+
+// sel[prefix] = row for every row whose mask byte is set: wave ballot-free variant of the classic compaction -
+// per-lane popcount, shuffle prefix across the wave, selected rows staged in LDS as 16-bit tile offsets, then
+// contiguous 8-byte stores
+__global__ void __launch_bounds__(SCAN_WG) k_mask_select(const uint8_t* mask, int64_t n, const int64_t* tile_sums,
+                                                         int64_t* sel, int64_t* total_out) {
+    __shared__ int64_t s_tmp[4];
+    __shared__ uint16_t s_sel[TILE_U8];
+    const int tid = threadIdx.x;
+    const int64_t tile0 = (int64_t)blockIdx.x * TILE_U8;
+    const int64_t base = tile0 + (int64_t)tid * VT_U8;
+    uint32_t w[4];
+    load_bytes16(mask, base, n, w);
+    uint32_t bits = 0;  // bit k = row base + k is selected
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t t = bytes_nonzero4(w[q]);
+        bits |= (((t >> 7) & 1u) | ((t >> 14) & 2u) | ((t >> 21) & 4u) | ((t >> 28) & 8u)) << (4 * q);
+    }
+    int64_t total;
+    int pos = (int)block_excl_scan((int64_t)__popc(bits), s_tmp, total);
+    while (bits) {
+        const int k = __ffs((int)bits) - 1;
+        bits &= bits - 1;
+        s_sel[pos++] = (uint16_t)(tid * VT_U8 + k);
+    }
+    __syncthreads();
+    const int64_t out0 = tile_sums[blockIdx.x];
+    for (int i = tid; i < (int)total; i += SCAN_WG) sel[out0 + i] = tile0 + s_sel[i];
+    if (blockIdx.x == 0 && tid == 0 && total_out) *total_out = tile_sums[gridDim.x];
+}
+
 extern "C" size_t hs_scan_ws_bytes(int64_t nrows) {
-    const int64_t ntiles = (nrows + SCAN_TILE - 1) / SCAN_TILE;
+    const int64_t ntiles = (nrows + SCAN_TILE - 1) / SCAN_TILE;  // the smallest tile any scan uses
     return (size_t)(ntiles + 2) * 8;
 }
 
@@ -196,6 +323,28 @@ __global__ void __launch_bounds__(256) k_lens_minmax(const uint8_t* lens, int64_
     }
 }
 
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// reduce -> scan of the tile sums -> down-sweep, byte-input form
+template <bool MASK>
+static int run_bytes_scan(hipStream_t s, const uint8_t* p, int64_t n, int64_t* out, int64_t* total_out, int32_t* minmax,
+                          void* ws, const char* name) {
+    const int64_t ntiles = (n + TILE_U8 - 1) / TILE_U8;
+    int64_t* tiles = (int64_t*)ws;
+    if (ntiles > 0x7fffffffll) {
+        hs_set_error("%s: input too large", name);
+        return HS_E_LIMIT;
+    }
+    hipLaunchKernelGGL((k_bytes_reduce<MASK>), dim3((unsigned)ntiles), dim3(SCAN_WG), 0, s, p, n, tiles, minmax);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_WG), 0, s, tiles, ntiles);
+    if constexpr (MASK)
+        hipLaunchKernelGGL(k_mask_select, dim3((unsigned)ntiles), dim3(SCAN_WG), 0, s, p, n, tiles, out, total_out);
+    else
+        hipLaunchKernelGGL(k_lens_offsets, dim3((unsigned)ntiles), dim3(SCAN_WG), 0, s, p, n, tiles, out, total_out);
+    HS_CHECK_LAUNCH(name);
+    return HS_OK;
+}
+
 extern "C" int hs_str_offsets(void* stream, const uint8_t* lens, int64_t nrows, int64_t* offs, int32_t* minmax,
                               void* ws) {
     if ((!lens && nrows > 0) || !offs || !ws || nrows < 0) {
@@ -203,13 +352,13 @@ extern "C" int hs_str_offsets(void* stream, const uint8_t* lens, int64_t nrows, 
         return HS_E_ARG;
     }
     hipStream_t s = (hipStream_t)stream;
-    if (minmax) {
-        hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(1), 0, s, minmax);
-        if (nrows > 0) {
-            int64_t blocks = (nrows + 256 * 16 - 1) / (256 * 16);
-            if (blocks > 2048) blocks = 2048;
-            hipLaunchKernelGGL(k_lens_minmax, dim3((unsigned)blocks), dim3(256), 0, s, lens, nrows, minmax);
-        }
+    if (minmax) hipLaunchKernelGGL(k_minmax_init, dim3(1), dim3(1), 0, s, minmax);
+    if (nrows > 0 && aligned16(lens))  // min / max ride along with the reduce pass
+        return run_bytes_scan<false>(s, lens, nrows, offs, offs + nrows, minmax, ws, "hs_str_offsets");
+    if (minmax && nrows > 0) {
+        int64_t blocks = (nrows + 256 * 16 - 1) / (256 * 16);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(k_lens_minmax, dim3((unsigned)blocks), dim3(256), 0, s, lens, nrows, minmax);
     }
     return run_scan(s, InLens{lens}, nrows, EmitOffsets{offs}, offs + nrows, ws, "hs_str_offsets");
 }
@@ -228,6 +377,8 @@ extern "C" int hs_compact(void* stream, const uint8_t* mask, int64_t nrows, int6
         hs_set_error("hs_compact: bad arguments");
         return HS_E_ARG;
     }
+    if (nrows > 0 && aligned16(mask))
+        return run_bytes_scan<true>((hipStream_t)stream, mask, nrows, sel, count, nullptr, ws, "hs_compact");
     return run_scan((hipStream_t)stream, InMask{mask}, nrows, EmitSelected{sel}, count, ws, "hs_compact");
 }
 

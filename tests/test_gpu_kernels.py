@@ -42,7 +42,7 @@ def test_synthetic_generator_matches_cpu_twin(dev):
     assert (t["l"].cpu().numpy() == 1).all()
 
 
-@pytest.mark.parametrize("n", [0, 1, 2047, 2048, 2049, 100_003])
+@pytest.mark.parametrize("n", [0, 1, 15, 16, 17, 2047, 2048, 2049, 4095, 4096, 4097, 8193, 100_003])
 def test_string_offsets_and_fixed_len(dev, n):
     import torch
 
@@ -59,7 +59,8 @@ def test_string_offsets_and_fixed_len(dev, n):
         assert col.fixed_len == 0
 
 
-@pytest.mark.parametrize("n,p", [(0, 0.5), (1, 1.0), (4097, 0.0), (4097, 1.0), (250_000, 0.3)])
+@pytest.mark.parametrize("n,p", [(0, 0.5), (1, 1.0), (17, 0.5), (4096, 0.5), (4097, 0.0), (4097, 1.0), (250_000, 0.3),
+                                 (1_000_003, 0.9)])
 def test_compact_is_stable_selection(dev, n, p):
     import torch
 
@@ -73,6 +74,31 @@ def test_compact_is_stable_selection(dev, n, p):
     hs.check(dev.lib.hs_compact(dev.stream, d_mask.data_ptr(), n, sel.data_ptr(), count.data_ptr(), ws.data_ptr()))
     k = int(count.item())
     assert np.array_equal(sel[:k].cpu().numpy(), np.nonzero(mask)[0])
+
+
+@pytest.mark.parametrize("shift", [1, 5, 16])
+def test_scans_accept_unaligned_inputs(dev, shift):
+    """Views that do not start on a 16-byte boundary take the generic kernels: same results."""
+    import torch
+
+    from minispark_amd import hipspark as hs
+
+    n = 20_000
+    raw = _rng(3).integers(0, 200, n + shift).astype(np.uint8)
+    d = dev.to_device(raw, torch.uint8)[shift:]
+    lens = raw[shift:]
+    offs = dev.empty(n + 1, torch.int64)
+    mm = dev.empty(2, torch.int32)
+    ws = dev.workspace(dev.lib.hs_scan_ws_bytes(n))
+    hs.check(dev.lib.hs_str_offsets(dev.stream, d.data_ptr(), n, offs.data_ptr(), mm.data_ptr(), ws.data_ptr()))
+    assert np.array_equal(offs.cpu().numpy(), np.concatenate([[0], np.cumsum(lens.astype(np.int64))]))
+    assert mm.cpu().tolist() == [int(lens.min()), int(lens.max())]
+    sel = dev.empty(n, torch.int64)
+    count = dev.empty(1, torch.int64)
+    mask = (lens % 3 == 0).astype(np.uint8)
+    dm = dev.to_device(np.concatenate([np.zeros(shift, np.uint8), mask]), torch.uint8)[shift:]
+    hs.check(dev.lib.hs_compact(dev.stream, dm.data_ptr(), n, sel.data_ptr(), count.data_ptr(), ws.data_ptr()))
+    assert np.array_equal(sel[: int(count.item())].cpu().numpy(), np.nonzero(mask)[0])
 
 
 @pytest.mark.parametrize("n_parts", [1, 7, 10, 16])
