@@ -350,6 +350,39 @@ struct MergeSlabIn {
     }
 };
 
+// Ordered fold of one group's bucket (cells q = b .. e-1 of aggregate a), specialised on the aggregate so that
+// the loop body is the bare dependent chain (one fp64 add per cell for SUM): the fold runs on a handful of
+// lanes of one wave, where every extra instruction is serialised latency.  Four LDS reads in flight.
+template <uint32_t OP, bool IS_INT>
+__device__ __forceinline__ uint64_t hs_fold_bucket(const uint64_t* sorted, int b, int e, int NA, int a) {
+    constexpr int W = 8;  // cells per batch; the next batch is in flight while this one is folded (LDS latency
+                          // ~130 cycles vs ~8 per dependent fp64 add)
+    uint64_t v = hs_acc_identity(OP, IS_INT);
+    const uint64_t* p = sorted + (int64_t)b * NA + a;
+    int left = e - b;
+    if (left >= W) {
+        uint64_t c[W], nx[W];
+#pragma unroll
+        for (int k = 0; k < W; ++k) c[k] = p[k * NA];
+        p += W * NA;
+        left -= W;
+        while (left >= W) {
+#pragma unroll
+            for (int k = 0; k < W; ++k) nx[k] = p[k * NA];
+            p += W * NA;
+            left -= W;
+#pragma unroll
+            for (int k = 0; k < W; ++k) v = hs_acc_fold(OP, IS_INT, v, c[k]);
+#pragma unroll
+            for (int k = 0; k < W; ++k) c[k] = nx[k];
+        }
+#pragma unroll
+        for (int k = 0; k < W; ++k) v = hs_acc_fold(OP, IS_INT, v, c[k]);
+    }
+    for (; left > 0; --left, p += NA) v = hs_acc_fold(OP, IS_INT, v, *p);
+    return v;
+}
+
 // Final merge, everything staged in LDS.  The partials of a group must be folded in the reference's
 // order: ascending (order key, row) - with no order keys simply ascending row - i.e. block order of the
 // shuffle file (0 + p_block0 + p_block1 + ... in fp64).  All steps are O(n):
@@ -459,8 +492,46 @@ __device__ __forceinline__ int hs_merge_small_core(const In& in, const hs_agg_sp
     }
 
     HS_STAMP(4);
-    // step 3: stable rank of every row inside its group, one wave, 64 rows of the sequence at a time
-    if (tid < HS_WAVE) {
+    // step 3: stable rank of every row inside its group.  The sequence is cut into 64-row segments; a wave ranks
+    // the rows of a segment with a ballot / match-any loop and notes the segment's count per group, a scan over
+    // the segments of each group turns the counts into bases.  (The bucket area is free until step 4; when the
+    // segment table does not fit there, one wave walks the whole sequence instead.)
+    const int nseg = (nseq + HS_WAVE - 1) / HS_WAVE;
+    const int lane = tid & (HS_WAVE - 1), wv = tid / HS_WAVE, nwv = nthr / HS_WAVE;
+    if ((int64_t)nseg * cap <= nmax * NA * 2) {
+        int32_t* segcnt = (int32_t*)sorted;  // [nseg][cap]
+        for (int i = tid; i < nseg * cap; i += nthr) segcnt[i] = 0;
+        __syncthreads();
+        for (int seg = wv; seg < nseg; seg += nwv) {
+            const int i = seg * HS_WAVE + lane;
+            const int r = i < nseq ? (ordered ? seq[i] : i) : -1;
+            const int sl = r >= 0 ? rslot[r] : -1;
+            unsigned long long todo = __ballot(sl >= 0);
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const int g = __shfl(sl, leader, HS_WAVE);
+                const unsigned long long same = __ballot(sl == g);
+                if (sl == g) rrank[r] = __popcll(same & ((1ull << lane) - 1));
+                if (lane == leader) segcnt[seg * cap + g] = __popcll(same);
+                todo &= ~same;
+            }
+        }
+        __syncthreads();
+        for (int sl = tid; sl < cap; sl += nthr) {
+            int running = 0;
+            for (int seg = 0; seg < nseg; ++seg) {
+                const int c = segcnt[seg * cap + sl];
+                segcnt[seg * cap + sl] = running;
+                running += c;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < nseq; i += nthr) {
+            const int r = ordered ? seq[i] : i;
+            const int sl = rslot[r];
+            if (sl >= 0) rrank[r] += segcnt[(i / HS_WAVE) * cap + sl];
+        }
+    } else if (tid < HS_WAVE) {
         for (int base = 0; base < nseq; base += HS_WAVE) {
             const int i = base + tid;
             const int r = i < nseq ? (ordered ? seq[i] : i) : -1;
@@ -494,18 +565,11 @@ __device__ __forceinline__ int hs_merge_small_core(const In& in, const hs_agg_sp
         if (dense[sl] < 0) continue;
         const uint32_t op = spec.op[a];
         const bool is_int = spec.is_int[a] != 0;
-        uint64_t v = hs_acc_identity(op, is_int);
         const int b = start[sl], e = b + cnt[sl];
-        int q = b;
-        for (; q + 4 <= e; q += 4) {  // four LDS reads in flight; the folds stay in order
-            const uint64_t c0 = sorted[(int64_t)q * NA + a], c1 = sorted[(int64_t)(q + 1) * NA + a],
-                           c2 = sorted[(int64_t)(q + 2) * NA + a], c3 = sorted[(int64_t)(q + 3) * NA + a];
-            v = hs_acc_fold(op, is_int, v, c0);
-            v = hs_acc_fold(op, is_int, v, c1);
-            v = hs_acc_fold(op, is_int, v, c2);
-            v = hs_acc_fold(op, is_int, v, c3);
-        }
-        for (; q < e; ++q) v = hs_acc_fold(op, is_int, v, sorted[(int64_t)q * NA + a]);
+        uint64_t v;
+        if (op == HS_AGG_SUM) v = is_int ? hs_fold_bucket<HS_AGG_SUM, true>(sorted, b, e, NA, a) : hs_fold_bucket<HS_AGG_SUM, false>(sorted, b, e, NA, a);
+        else if (op == HS_AGG_MIN) v = is_int ? hs_fold_bucket<HS_AGG_MIN, true>(sorted, b, e, NA, a) : hs_fold_bucket<HS_AGG_MIN, false>(sorted, b, e, NA, a);
+        else v = is_int ? hs_fold_bucket<HS_AGG_MAX, true>(sorted, b, e, NA, a) : hs_fold_bucket<HS_AGG_MAX, false>(sorted, b, e, NA, a);
         out_acc[(int64_t)a * cap + dense[sl]] = v;
     }
     HS_STAMP(7);
