@@ -229,3 +229,91 @@ def test_quantise_flags_overflow(dev):
     dev.quantise_col(DCol(hs.I64, dev.to_device(np.array([2**31], dtype=np.int64), torch.int64), 1), T.INTEGER)
     assert dev.read_flags() & hs.FLAG_INT_OVERFLOW
     dev.reset_flags()
+
+
+@pytest.mark.parametrize("world,units,cap,groups", [(1, 5, 4, 3), (4, 9, 8, 6), (8, 36, 4, 3), (8, 20, 8, 6), (6, 12, 16, 20),
+                                                      (2, 60, 16, 10)])
+def test_finish_launch_merges_slabs_of_many_ranks_in_block_order(dev, world, units, cap, groups):
+    """hs_agg_finish over hand-built slabs of `world` ranks (the 8-GPU shape cannot be launched here): every
+    group's partials must be folded in ascending block id, in fp64 from f32 partials - compared bit for bit with
+    a sequential Python fold; block b lives on rank b % world, units hold each key at most once, unused rows
+    carry order key -1.  The last shape does not fit the all-in-LDS variant and runs from global memory."""
+    import ctypes as C
+
+    import torch
+
+    from minispark_amd import hipspark as hs
+    from minispark_amd.distributed import SlabLayout
+
+    rng = _rng(world * 1000 + units)
+    m = units * cap                                   # rows per slab
+    layout = SlabLayout.build(m, [(4, torch.int32), (4, torch.float32), (4, torch.int32), (4, torch.float32)])
+    slabs = np.zeros((world, layout.nbytes), dtype=np.uint8)
+    keys_all = rng.choice(np.arange(-50, 50), size=groups, replace=False).astype(np.int32)
+    partials: dict[int, list[tuple[int, float, int, float]]] = {int(k): [] for k in keys_all}
+    n_blocks = world * units
+    for b in range(n_blocks):
+        rank, u = b % world, b // world
+        present = keys_all[rng.random(groups) < 0.7][:cap]
+        rng.shuffle(present)
+        view = slabs[rank]
+        order = view[layout.order_offset: layout.order_offset + 8 * m].view(np.int64)
+        cols = [view[c.offset: c.offset + 4 * m] for c in layout.columns]
+        order[u * cap: (u + 1) * cap] = -1
+        for j, k in enumerate(present):
+            row = u * cap + j
+            f, i, mx = np.float32(rng.normal(0, 1e3)), int(rng.integers(-10**6, 10**6)), np.float32(rng.normal(0, 50))
+            order[row] = b
+            cols[0].view(np.int32)[row] = k
+            cols[1].view(np.float32)[row] = f
+            cols[2].view(np.int32)[row] = i
+            cols[3].view(np.float32)[row] = mx
+            partials[int(k)].append((b, float(f), i, float(mx)))
+    slabs[:, 0:4].view(np.uint32)[:] = 0
+    slabs[world - 1, 0:4].view(np.uint32)[0] = hs.FLAG_STR_TOO_LONG  # a remote status bit must reach the header
+
+    desc = hs.hs_slab_desc()
+    desc.slab_rows, desc.stride, desc.order_off, desc.key_off = m, layout.nbytes, layout.order_offset, layout.columns[0].offset
+    desc.key_kind, desc.key_len, desc.n_acc = hs.I32, 0, 3
+    for a, kind in enumerate([hs.F32, hs.I32, hs.F32]):
+        desc.acc_off[a], desc.acc_kind[a] = layout.columns[1 + a].offset, kind
+    fin = hs.hs_finish_spec()
+    fin.n_fold = 3
+    for j, (src, op) in enumerate([(0, hs.AGG_SUM), (1, hs.AGG_SUM), (2, hs.AGG_MAX)]):
+        fin.fold_src[j], fin.fold_op[j] = src, op
+    merge_cap = 4
+    while merge_cap < 2 * groups:
+        merge_cap *= 2
+    outs = [(0, 0, hs.I32, 4), (1, 0, hs.F32, 4), (1, 1, hs.I64, 8), (1, 2, hs.F32, 4)]
+    fin.n_out = len(outs)
+    pos, offsets = 16, []
+    for o, (src, index, kind, width) in enumerate(outs):
+        fin.outs[o].src, fin.outs[o].index, fin.outs[o].kind, fin.outs[o].offset = src, index, kind, pos
+        offsets.append(pos)
+        pos = (pos + merge_cap * width + 15) & ~15
+    gathered = dev.to_device(slabs.reshape(-1), torch.uint8)
+    result = torch.zeros(pos + 64, dtype=torch.uint8, device=dev.device)
+    scratch = dev.workspace(dev.lib.hs_agg_finish_scratch_bytes(merge_cap, 3))
+    dev.flags.zero_()
+    hs.check(dev.lib.hs_agg_finish(dev.stream, gathered.data_ptr(), world, C.byref(desc), C.byref(fin), None, n_blocks,
+                                   merge_cap, result.data_ptr(), scratch.data_ptr(), dev.flags.data_ptr(), None),
+             "hs_agg_finish")
+    host = result.cpu().numpy()
+    assert int(host[0:4].view(np.uint32)[0]) == hs.FLAG_STR_TOO_LONG and int(host[4:8].view(np.uint32)[0]) == 1
+    assert int(dev.flags[0].item()) == 0  # handed over and reset
+    ng = int(host[8:16].view(np.int64)[0])
+    want = {k: v for k, v in partials.items() if v}
+    assert ng == len(want)
+    got_keys = host[offsets[0]: offsets[0] + 4 * ng].view(np.int32)
+    got_f = host[offsets[1]: offsets[1] + 4 * ng].view(np.float32)
+    got_i = host[offsets[2]: offsets[2] + 8 * ng].view(np.int64)
+    got_mx = host[offsets[3]: offsets[3] + 4 * ng].view(np.float32)
+    assert sorted(got_keys.tolist()) == sorted(want)
+    for g in range(ng):
+        rows = sorted(want[int(got_keys[g])])  # ascending block id
+        acc_f, acc_i, acc_mx = 0.0, 0, float(-2**31)
+        for _, f, i, mx in rows:
+            acc_f += f
+            acc_i += i
+            acc_mx = mx if mx > acc_mx else acc_mx
+        assert np.float32(acc_f) == got_f[g] and acc_i == int(got_i[g]) and np.float32(acc_mx) == got_mx[g]
