@@ -36,12 +36,13 @@ extern "C" size_t hs_sizeof(int32_t which) {
 }
 extern "C" int hs_version(void) { return HS_VERSION; }
 
-#define HS_CHECK_LAUNCH(name)                                \
-    do {                                                     \
-        if (hipGetLastError() != hipSuccess) {               \
-            hs_set_error("%s: kernel launch failed", name);  \
-            return HS_E_LAUNCH;                              \
-        }                                                    \
+#define HS_CHECK_LAUNCH(name)                                                              \
+    do {                                                                                   \
+        const hipError_t e_ = hipGetLastError();                                           \
+        if (e_ != hipSuccess) {                                                            \
+            hs_set_error("%s: kernel launch failed (%s)", name, hipGetErrorString(e_));    \
+            return HS_E_LAUNCH;                                                            \
+        }                                                                                  \
     } while (0)
 
 static constexpr int SCAN_WG = 256;

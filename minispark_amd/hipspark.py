@@ -210,6 +210,11 @@ def load_library(build_if_missing: bool = True) -> C.CDLL:
         path = _build.build()
     if not path.exists():
         raise HipSparkError(f"{path} is missing: run `python -m minispark_amd._build` (needs hipcc)")
+    # torch first: it brings its own HIP runtime (libamdhip64) and owns the device / stream state this library
+    # works on.  Loaded the other way round, the library would pull in the system's runtime and the two would not
+    # see the same devices ("no ROCm-capable device is detected" at the first launch).
+    import torch  # noqa: F401, PLC0415
+
     lib = C.CDLL(str(path))
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = the library does not export a declared symbol
