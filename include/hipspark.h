@@ -414,6 +414,11 @@ const char* hs_jit_last_log(void);
 int hs_jit_compile_check(const hs_col* cols, int32_t n_cols, int32_t key_col, const hs_program* prog,
                          const hs_agg_spec* spec, const char* arch, int64_t* code_bytes, char* src_out,
                          int64_t src_cap);
+/* The same for an expression program of hs_eval (the compiled form evaluates four rows per lane with 16-byte
+ * loads and stores; hs_eval uses it when sel == NULL and the numeric buffers are 16-byte aligned, and then reads
+ * up to 3 rows past nrows of every column it loads - buffers carry that slack). */
+int hs_jit_compile_check_eval(const hs_col* cols, int32_t n_cols, const hs_program* prog, const int32_t* out_kinds,
+                              int32_t n_outs, const char* arch, int64_t* code_bytes, char* src_out, int64_t src_cap);
 
 /* =================================================================================================
  * Synthetic TPC-H-shaped data (bench / tests only).  Counter-based: the value of

@@ -388,3 +388,15 @@ __device__ __forceinline__ void hs_agg_main_body(const AggMainArgs& A) {
     }
     if (ctx.err) atomicOr(A.flags, ctx.err);
 }
+
+// ---- arguments of the expression-evaluation kernels (hs_eval: interpreter k_eval and the compiled k_eval_jit) ----
+struct EvalArgs {
+    HsCols cols;
+    hs_program prog;
+    const int64_t* sel;
+    int64_t nrows;
+    const int64_t* nrows_dev;
+    void* outs[HS_MAX_OUTS];
+    int32_t out_kinds[HS_MAX_OUTS];
+    uint32_t* flags;
+};

@@ -9,7 +9,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 
-#include "hs_device.h"
+#include "hs_agg_kernel.h"
 
 thread_local char g_hs_err[256] = {0};
 
@@ -540,16 +540,9 @@ extern "C" int hs_concat_bytes(void* stream, const hs_col* parts, int32_t n_part
 }
 
 // ---- A4: expression evaluation, one row per lane (reference tasks.py:32-35, sql.py:262-266) ----------------
-struct EvalArgs {
-    HsCols cols;
-    hs_program prog;
-    const int64_t* sel;
-    int64_t nrows;
-    const int64_t* nrows_dev;
-    void* outs[HS_MAX_OUTS];
-    int32_t out_kinds[HS_MAX_OUTS];
-    uint32_t* flags;
-};
+// hs_jit.hip: HS_OK = a kernel compiled for this program was launched
+int hs_jit_launch_eval(const EvalArgs* args, unsigned grid, hipStream_t stream);
+
 struct EvalSink {
     const EvalArgs& A;
     int64_t in_row, out_row;
@@ -605,6 +598,14 @@ extern "C" int hs_eval(void* stream, const hs_col* cols, int32_t n_cols, const h
         A.out_kinds[i] = i < n_outs ? out_kinds[i] : HS_F64;
     }
     A.flags = flags;
+    // compiled form: four rows per lane with 16-byte loads / stores; needs whole-column inputs (no row list)
+    // and 16-byte aligned numeric buffers.  Otherwise - or when hiprtc is not there - the interpreter kernel.
+    bool vector_ok = sel == nullptr;
+    for (int i = 0; i < n_cols && vector_ok; ++i)
+        if (cols[i].kind != HS_STR && ((uintptr_t)cols[i].data & 15)) vector_ok = false;
+    for (int i = 0; i < n_outs && vector_ok; ++i)
+        if ((uintptr_t)outs[i] & 15) vector_ok = false;
+    if (vector_ok && hs_jit_launch_eval(&A, grid_for((nrows + 3) / 4, 256), (hipStream_t)stream) == HS_OK) return HS_OK;
     hipLaunchKernelGGL(k_eval, dim3(grid_for(nrows, 256)), dim3(256), 0, (hipStream_t)stream, A);
     HS_CHECK_LAUNCH("hs_eval");
     return HS_OK;

@@ -85,3 +85,33 @@ def test_jit_translates_and_compiles_q1_for_gfx950():
     assert nbytes.value > 4096
     text = src.value.decode()
     assert "hs_agg_main_body<JitProg>" in text and text.count("fold_c<6,") == 6 and "hs_f32x4" in text
+
+
+def test_expression_programs_translate_and_compile_for_gfx950_without_a_gpu():
+    """hs_eval's compiled form: bytecode -> four-rows-per-lane kernel source -> hiprtc for gfx950."""
+    from minispark_amd.constants import ColumnType as T
+    from minispark_amd.lowering import ProgramBuilder
+    from minispark_amd.sql import Col, Lit
+
+    lib = hs.load_library()
+    schema = [("a", T.FLOAT), ("b", T.FLOAT), ("i", T.INTEGER), ("t", T.TIMESTAMP), ("s", T.STRING)]
+    kinds = [hs.F32, hs.F32, hs.I32, hs.I64, hs.STR]
+    b = ProgramBuilder(schema, kinds)
+    exprs = [Col("a") * (Lit(1) - Col("b")), (Col("i") // 7 + Col("i") % 5) * 2, (Col("a") > 0.5) & (Col("t") <= "1998-09-02"),
+             Col("s").like("%AIR%") | (Col("s") == "MAIL")]
+    tags = [b.emit_out(o, e) for o, e in enumerate(exprs)]
+    assert tags == ["F", "I", "B", "B"]
+    prog = b.finish()
+    cols = (hs.hs_col * len(prog.columns))()
+    for slot, idx in enumerate(prog.columns):
+        cols[slot].kind, cols[slot].fixed_len = kinds[idx], -1
+    out_kinds = (C.c_int32 * 4)(hs.F64, hs.I64, hs.U8, hs.U8)
+    pstruct = prog.to_struct()
+    size = C.c_int64(0)
+    src = C.create_string_buffer(1 << 16)
+    rc = lib.hs_jit_compile_check_eval(cols, len(prog.columns), C.byref(pstruct), out_kinds, 4, b"gfx950", C.byref(size),
+                                       src, len(src))
+    assert rc == 0, (lib.hs_last_error(), lib.hs_jit_last_log())
+    text = src.value.decode()
+    assert size.value > 1000 and "k_eval_jit" in text and "hs_f32x4" in text and "hs_like_lit" in text
+    assert "__builtin_nontemporal_store" in text  # f64 / i64 outputs leave with 16-byte stores

@@ -165,9 +165,12 @@ def test_join_on_strings_including_long_ones(dev):
     assert got == want
 
 
-def test_expression_evaluator_against_python_semantics(dev):
+@pytest.mark.parametrize("n,jit", [(4000, True), (4000, False), (4003, True), (1, True), (5, True)])
+def test_expression_evaluator_against_python_semantics(dev, n, jit):
     """hs_eval vs the oracle's row evaluator (Python operators): mixed int/float arithmetic, floor division
-    and modulo with negative operands, comparisons, & / |, LIKE, string comparison."""
+    and modulo with negative operands, comparisons, & / |, LIKE, string comparison - through the compiled
+    four-rows-per-lane kernels (row counts that are not multiples of 4 exercise the guarded tail) and through the
+    interpreter kernel."""
     from datetime import datetime
 
     from minispark_amd.constants import ColumnType as T
@@ -176,7 +179,10 @@ def test_expression_evaluator_against_python_semantics(dev):
     from minispark_amd.sql import Col, Lit
     from oracle.py_engine import compile_expr
 
-    n = 4000
+    stats = (C.c_int32 * 3)()
+    dev.lib.hs_jit_stats(stats)
+    launched_before = stats[1]
+    dev.lib.hs_jit_set_enabled(1 if jit else 0)
     r = _rng(11)
     i = r.integers(-1000, 1000, n).astype(np.int32)
     j = np.where(r.random(n) < 0.5, r.integers(1, 17, n), -r.integers(1, 17, n)).astype(np.int32)
@@ -211,6 +217,9 @@ def test_expression_evaluator_against_python_semantics(dev):
     dev.eval_numeric(batch, [Col("i") / (Col("j") - Col("j"))])
     assert dev.read_flags() & 1, "division by zero must raise the flag"
     dev.reset_flags()
+    dev.lib.hs_jit_stats(stats)
+    dev.lib.hs_jit_set_enabled(1)
+    assert (stats[1] > launched_before) == jit, "the compiled / interpreted route was not the one exercised"
 
 
 def test_quantise_flags_overflow(dev):

@@ -58,7 +58,7 @@ report("   hs_gather_fixed 4 B (random permutation)", ms, N * (8 + 4 + 4), "rand
 # A4 expression evaluation (generic interpreter kernel, one row per lane)
 batch = DBatch([("a", T.FLOAT), ("b", T.FLOAT), ("i", T.INTEGER)], [DCol(hs.F32, f32a, N), DCol(hs.F32, f32b, N), DCol(hs.I32, i32, N)], N)
 ms = timed(lambda: dev.eval_numeric(batch, [Col("a") * (Lit(1) - Col("b"))]))
-report("A4 hs_eval a*(1-b) -> f64 (interpreter)", ms, N * (4 + 4 + 8))
+report("A4 hs_eval a*(1-b) -> f64 (compiled)", ms, N * (4 + 4 + 8))
 ms = timed(lambda: dev.eval_numeric(batch, [(Col("a") > 0.5) & (Col("b") <= 0.25)]))
 report("A4 hs_eval (a>0.5)&(b<=0.25) -> mask", ms, N * (4 + 4 + 1))
 
