@@ -14,14 +14,16 @@ from tests.queries import CASES, api_namespace
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=["short_tail", "general"])
+@pytest.fixture(scope="module", params=["short_tail", "short_tail_copy", "general"])
 def engine(request):
-    """Both routes after the scan kernel: the two-launch short tail (where a query qualifies) and the
-    general operator sequence."""
+    """Both routes after the scan kernel: the two-launch short tail (where a query qualifies; result image
+    written into mapped host memory, or - "copy" - into device memory and copied) and the general operator
+    sequence."""
     from minispark_amd.execution import HipExecutionEngine
 
     with HipExecutionEngine() as e:
-        e.short_tail_enabled = request.param == "short_tail"
+        e.short_tail_enabled = request.param != "general"
+        e.dev.zero_copy_results = request.param == "short_tail"
         yield e
 
 
