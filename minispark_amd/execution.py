@@ -88,7 +88,8 @@ def _plain_names(expr: Any) -> list[str]:
 class HipExecutionEngine(ExecutionEngine):
     """Runs query stages on an MI355X.  Zero-argument constructible like the reference's engines."""
 
-    def __init__(self, device: int | None = None, work_folder: Path | None = None) -> None:
+    def __init__(self, device: int | None = None, work_folder: Path | None = None,
+                 trace_file: str | Path | None = None) -> None:
         from .device import Device  # noqa: PLC0415 - loads libhipspark.so and needs a GPU: fail loudly here
 
         if device is None:
@@ -116,9 +117,20 @@ class HipExecutionEngine(ExecutionEngine):
         self.dist: Any = None  # torch.distributed once enable_distributed() was called
         self.rank, self.world = 0, 1
         self._remote_flags: Any = None
+        # tracing (reference utils.py:83-135): spans per query / stage / replay + the scan kernel on a GPU track
+        self.trace_file = trace_file or os.environ.get("HIPSPARK_TRACE") or None
+        self.tracer: Any = None
+        if self.trace_file:
+            from .tracing import Tracer  # noqa: PLC0415
+
+            self.tracer = Tracer()
+            self._gpu_track = self.tracer.new_track(f"GPU {self.dev.index}")
+            self.dev.time_scan_kernel(True)
 
     # ---- context manager -------------------------------------------------------------------------------
     def __exit__(self, exc_type, exc_value, traceback) -> None:  # noqa: ANN001
+        if self.tracer is not None:
+            self.tracer.save(self.trace_file)
         for d in self._owned_dirs:
             shutil.rmtree(d, ignore_errors=True)
         self._owned_dirs.clear()
@@ -154,6 +166,25 @@ class HipExecutionEngine(ExecutionEngine):
 
     # ---- the plug-in entry point ---------------------------------------------------------------------------
     def execute_full_task(self, full_task: Any) -> list[JobResult]:
+        if self.tracer is None:
+            return self._execute_full_task(full_task)
+        import time  # noqa: PLC0415
+
+        self.tracer.start("query")
+        self.dev.last_scan = None  # set again by a partial aggregate of this query (or by its replayed recording)
+        try:
+            return self._execute_full_task(full_task)
+        finally:
+            self.tracer.end()
+            if getattr(self.dev, "last_scan", None) is not None and self.dev.scan_events is not None:
+                try:
+                    ms = self.dev.scan_kernel_ms()
+                    self.tracer.complete("scan kernel (k_agg_jit / k_agg_main)", time.time_ns() - int(ms * 1e6),
+                                         int(ms * 1e6), self._gpu_track, **self.dev.last_scan)
+                except RuntimeError:
+                    pass  # no aggregate ran in this query: the events were never recorded
+
+    def _execute_full_task(self, full_task: Any) -> list[JobResult]:
         from .device import DeviceError  # noqa: PLC0415
         from .hipspark import HipSparkError  # noqa: PLC0415
 
@@ -164,7 +195,11 @@ class HipExecutionEngine(ExecutionEngine):
             rec_key = self._recording_key(plan)
             rec = self._recordings.get(rec_key) if self.replay_enabled else None
             if rec is not None:
+                if self.tracer is not None:
+                    self.tracer.start("replay of the recorded launch sequence")
                 replayed = self._replay(rec)
+                if self.tracer is not None:
+                    self.tracer.end()
                 if replayed is not None:
                     return replayed
                 del self._recordings[rec_key]  # something data-dependent changed: take the full path again
@@ -176,11 +211,18 @@ class HipExecutionEngine(ExecutionEngine):
             recording = self.dev.start_recording() if want_record else None
             try:
                 for stage in plan.stages:
-                    results = self._run_stage(stage, outputs)
+                    if self.tracer is not None:
+                        self.tracer.start(f"stage {stage.stage_id}: {_cls(stage.producer)} -> {_cls(stage.writer)}")
+                    try:
+                        results = self._run_stage(stage, outputs)
+                    finally:
+                        if self.tracer is not None:
+                            self.tracer.end()
                     stage.job_results.extend(results)
                 self._plan_runs[rec_key] = self._plan_runs.get(rec_key, 0) + 1
                 if recording is not None:
                     self.dev.stop_recording()
+                    recording.scan_info = getattr(self.dev, "last_scan", None)
                     if not recording.poisoned and recording.finish is not None and recording.result is not None:
                         if len(self._recordings) >= 8:
                             self._recordings.pop(next(iter(self._recordings)))
@@ -219,6 +261,7 @@ class HipExecutionEngine(ExecutionEngine):
                 len(self._global_merge))
 
     def _replay(self, rec: Any) -> list[JobResult] | None:
+        self.dev.last_scan = getattr(rec, "scan_info", None)
         if not rec.self_cleaning:
             self.dev.flags.zero_()
         if not rec.replay():

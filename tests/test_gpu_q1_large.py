@@ -153,3 +153,30 @@ def test_replay_of_recorded_query_is_identical(setup):
     other = _frame(engine, path, "1996-01-01").collect()
     assert other != runs[0]
     assert sum(r["count_order"] for r in other) < sum(r["count_order"] for r in runs[0])
+
+
+def test_trace_file_holds_query_stage_replay_and_kernel_slices(tmp_path):
+    """HipExecutionEngine(trace_file=...) writes a Chrome-trace JSON (opens in ui.perfetto.dev): host spans per
+    query / stage / replay and the scan kernel's HIP-event duration on a GPU track."""
+    import json
+
+    from minispark_amd import synth
+    from minispark_amd.dataframe import DataFrame
+    from minispark_amd.execution import HipExecutionEngine
+    from minispark_amd.sql import Col, Functions, Lit
+    from tests.queries import api_namespace, q1
+
+    trace = tmp_path / "trace.json"
+    with HipExecutionEngine(trace_file=trace) as engine:
+        path = tmp_path / "li.bin"
+        table = synth.make_lineitem(engine.dev, path, 300_000, rows_per_block=65_536)
+        engine.attach_device_table(path, table)
+        frame = q1(api_namespace(lambda: DataFrame(engine), Col, Functions, Lit), str(path))
+        for _ in range(4):
+            assert len(frame.collect()) == 3
+    events = json.loads(trace.read_text())["traceEvents"]
+    names = [e["name"] for e in events if e["ph"] == "X"]
+    assert names.count("query") == 4 and any(n.startswith("stage 0: LoadTableBlockTask") for n in names)
+    assert any(n.startswith("replay") for n in names)
+    kernels = [e for e in events if e["ph"] == "X" and e["name"].startswith("scan kernel")]
+    assert len(kernels) == 4 and all(0 < e["dur"] < 1e5 and e["args"]["rows"] == 300_000 for e in kernels)

@@ -40,3 +40,23 @@ def test_header_only_csv_and_refusals(tmp_path):
     bad.write_text("id,price,name,day\n1,1.0,x\n")
     with pytest.raises(ValueError):
         convert_csv_to_block_file(bad, tmp_path / "bad3.bin", SCHEMA)
+
+
+def test_tracer_writes_chrome_trace_json(tmp_path):
+    import json
+
+    from minispark_amd.tracing import Tracer
+
+    t = Tracer()
+    gpu = t.new_track("GPU 0")
+    t.start("query")
+    t.start("stage 0")
+    t.end()
+    t.complete("scan kernel", 1_000_000, 250_000, gpu, rows=42)
+    t.end()
+    t.save(tmp_path / "trace.json")
+    data = json.loads((tmp_path / "trace.json").read_text())
+    slices = [e for e in data["traceEvents"] if e["ph"] == "X"]
+    assert [e["name"] for e in slices] == ["stage 0", "scan kernel", "query"]
+    assert slices[1]["tid"] == gpu and slices[1]["dur"] == 250.0 and slices[1]["args"] == {"rows": 42}
+    assert {e["args"]["name"] for e in data["traceEvents"] if e["ph"] == "M"} == {"Main System", "GPU 0"}
