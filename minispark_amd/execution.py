@@ -110,8 +110,10 @@ class HipExecutionEngine(ExecutionEngine):
         self._result_root: Path | None = None
         self._result_paths: dict[Any, Path] = {}
         self._job_prefix, self._job_seq = uuid.uuid4().hex[:12], 0
-        self.group_cap_hint = 4   # dictionary capacity per workgroup of the partial aggregate (grows on overflow)
-        self.merge_cap_hint = 16  # dictionary capacity of the final merge (grows on overflow)
+        # dictionary capacities (partial aggregate per workgroup / final merge) grow when a run overflows them; they
+        # are remembered per QUERY SHAPE, so a query with many groups does not slow down the next one with few
+        self._caps_by_shape: dict[Any, dict] = {}
+        self._caps: dict = {"group": 4, "merge": 16, "merge_overflowed": False}
         self._global_partial: set[int] = set()  # AggregateTask ids (of cached plans) running on the global tier
         self._global_merge: set[int] = set()
         self.dist: Any = None  # torch.distributed once enable_distributed() was called
@@ -126,6 +128,49 @@ class HipExecutionEngine(ExecutionEngine):
             self.tracer = Tracer()
             self._gpu_track = self.tracer.new_track(f"GPU {self.dev.index}")
             self.dev.time_scan_kernel(True)
+
+    @property
+    def group_cap_hint(self) -> int:
+        return self._caps["group"]
+
+    @group_cap_hint.setter
+    def group_cap_hint(self, value: int) -> None:
+        self._caps["group"] = value
+
+    @property
+    def merge_cap_hint(self) -> int:
+        return self._caps["merge"]
+
+    @merge_cap_hint.setter
+    def merge_cap_hint(self, value: int) -> None:
+        self._caps["merge"] = value
+
+    @property
+    def _merge_overflowed(self) -> bool:
+        return self._caps["merge_overflowed"]
+
+    @_merge_overflowed.setter
+    def _merge_overflowed(self, value: bool) -> None:
+        self._caps["merge_overflowed"] = value
+
+    def _select_caps(self, plan: Any) -> None:
+        """Point the capacity hints at the entry of this plan's query shape (tasks, expressions, table paths)."""
+        shape = getattr(plan, "_hs_shape", None)
+        if shape is None:
+            parts = []
+            for stage in plan.stages:
+                for task in (stage.producer, *stage.consumers, stage.writer):
+                    attrs = [str(getattr(task, name)) for name in ("file_path", "alias", "condition", "columns",
+                                                                   "group_by_column", "agg_columns", "join_condition",
+                                                                   "key_column", "before_shuffle") if hasattr(task, name)]
+                    parts.append((_cls(task), *attrs))
+            shape = plan._hs_shape = tuple(parts)
+        caps = self._caps_by_shape.get(shape)
+        if caps is None:
+            if len(self._caps_by_shape) >= 256:
+                self._caps_by_shape.pop(next(iter(self._caps_by_shape)))
+            caps = self._caps_by_shape[shape] = {"group": 4, "merge": 16, "merge_overflowed": False}
+        self._caps = caps
 
     # ---- context manager -------------------------------------------------------------------------------
     def __exit__(self, exc_type, exc_value, traceback) -> None:  # noqa: ANN001
@@ -192,6 +237,7 @@ class HipExecutionEngine(ExecutionEngine):
 
         for _attempt in range(12):
             plan = self._cached_plan(full_task)
+            self._select_caps(plan)
             rec_key = self._recording_key(plan)
             rec = self._recordings.get(rec_key) if self.replay_enabled else None
             if rec is not None:
@@ -401,7 +447,7 @@ class HipExecutionEngine(ExecutionEngine):
                     batch = self._materialise(batch, pending)
                     pending = []
                     was_partitioned = batch.partitioned
-                    use_global = (id(task) in self._global_merge or getattr(self, "_merge_overflowed", False)
+                    use_global = (id(task) in self._global_merge or self._merge_overflowed
                                   or (batch.partitioned and batch.order is not None))
                     if not use_global:
                         try:

@@ -180,3 +180,26 @@ def test_trace_file_holds_query_stage_replay_and_kernel_slices(tmp_path):
     assert any(n.startswith("replay") for n in names)
     kernels = [e for e in events if e["ph"] == "X" and e["name"].startswith("scan kernel")]
     assert len(kernels) == 4 and all(0 < e["dur"] < 1e5 and e["args"]["rows"] == 300_000 for e in kernels)
+
+
+def test_capacity_hints_are_per_query_shape(tmp_path):
+    """A GROUP BY with many groups grows ITS dictionary capacities; Q1 (3 groups) on the same engine keeps the
+    small, fast geometry (4 slots per workgroup, 256-lane workgroups)."""
+    from minispark_amd import synth
+    from minispark_amd.dataframe import DataFrame
+    from minispark_amd.execution import HipExecutionEngine
+    from minispark_amd.sql import Col, Functions, Lit
+    from tests.queries import api_namespace, q1
+
+    with HipExecutionEngine() as engine:
+        path = tmp_path / "li.bin"
+        table = synth.make_lineitem(engine.dev, path, 400_000, rows_per_block=100_000)
+        engine.attach_device_table(path, table)
+        api = api_namespace(lambda: DataFrame(engine), Col, Functions, Lit)
+        many = DataFrame(engine).table(str(path)).group_by(Col("l_quantity")).agg(Functions.count())
+        assert len(many.collect()) == 50  # l_quantity = 1..50
+        assert engine.dev.last_group_cap >= 64
+        rows = q1(api, str(path)).collect()
+        assert len(rows) == 3
+        assert engine.dev.last_scan["group_cap"] == 4 and engine.dev.last_scan["wg_threads"] == 256
+        assert len(many.collect()) == 50 and engine.dev.last_group_cap >= 64  # and its own hint is remembered
