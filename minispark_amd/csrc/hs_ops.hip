@@ -831,19 +831,34 @@ __global__ void __launch_bounds__(256) k_fill_u64(uint64_t* p, int64_t n, uint64
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
+// Returns the slot of `k`, claiming one if the key is new (`inserted`); -1 when the table is full.  Test, then
+// test-and-set: scattered 64-bit atomics are the scarce resource of the build (the chip sustains ~20 G/s of them),
+// so a key that is already in its slot costs a plain read, not a CAS.
 __device__ __forceinline__ int64_t gdict_upsert(uint64_t* keys, int64_t* reps, uint64_t mask, const hs_col& c,
-                                                bool hashed, uint64_t k, int64_t row) {
+                                                bool hashed, uint64_t k, int64_t row, bool& inserted) {
     uint64_t h = hs_mix64(k) & mask;
+    inserted = false;
     for (uint64_t probe = 0; probe <= mask; ++probe) {
         if (hashed) {
-            long long cur = (long long)atomicCAS((unsigned long long*)&reps[h], (unsigned long long)(-1ll),
-                                                 (unsigned long long)row);
-            if (cur < 0) return (int64_t)h;
+            long long cur = __hip_atomic_load(&reps[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur < 0) {
+                cur = (long long)atomicCAS((unsigned long long*)&reps[h], (unsigned long long)(-1ll), (unsigned long long)row);
+                if (cur < 0) {
+                    inserted = true;
+                    return (int64_t)h;
+                }
+            }
             if (hs_rows_equal(c, (int64_t)cur, row)) return (int64_t)h;
         } else {
-            uint64_t cur = atomicCAS((unsigned long long*)&keys[h], (unsigned long long)HS_EMPTY_KEY,
-                                     (unsigned long long)k);
-            if (cur == HS_EMPTY_KEY || cur == k) return (int64_t)h;
+            uint64_t cur = __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == HS_EMPTY_KEY) {
+                cur = atomicCAS((unsigned long long*)&keys[h], (unsigned long long)HS_EMPTY_KEY, (unsigned long long)k);
+                if (cur == HS_EMPTY_KEY) {
+                    inserted = true;
+                    return (int64_t)h;
+                }
+            }
+            if (cur == k) return (int64_t)h;
         }
         h = (h + 1) & mask;
     }
@@ -872,22 +887,36 @@ __device__ __forceinline__ int64_t gdict_find(const uint64_t* keys, const int64_
 // position i of the build input is row sel[i] (or row0 + i) of the key column
 __global__ void __launch_bounds__(256) k_join_slots(const hs_col key, const int64_t* sel, int64_t row0, int64_t n,
                                                     int64_t cap, uint64_t* tkeys, int64_t* treps, int64_t* slot_of_row,
-                                                    int64_t* slot_count, uint32_t* flags) {
+                                                    int64_t* slot_extra, uint32_t* flags) {
     const bool hashed = !hs_col_packs(key);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = sel ? sel[i] : row0 + i;
-        const int64_t s = gdict_upsert(tkeys, treps, (uint64_t)cap - 1, key, hashed, hs_key_at(key, row), row);
+        bool inserted;
+        const int64_t s = gdict_upsert(tkeys, treps, (uint64_t)cap - 1, key, hashed, hs_key_at(key, row), row, inserted);
         slot_of_row[i] = s;
         if (s < 0) atomicOr(flags, HS_FLAG_DICT_FULL);
-        else atomicAdd((unsigned long long*)&slot_count[s], 1ull);
+        else if (!inserted) atomicAdd((unsigned long long*)&slot_extra[s], 1ull);  // rows beyond a slot's first
     }
 }
+// rows of slot s = 1 for the row that claimed it + slot_extra[s]
+struct InSlotCount {
+    const uint64_t* tkeys;
+    const int64_t* treps;
+    const int64_t* extra;
+    bool hashed;
+    __device__ __forceinline__ int64_t operator()(int64_t s) const {
+        const bool occupied = hashed ? treps[s] >= 0 : tkeys[s] != HS_EMPTY_KEY;
+        return (occupied ? 1 : 0) + extra[s];
+    }
+};
 __global__ void __launch_bounds__(256) k_join_rows(const int64_t* slot_of_row, int64_t n, const int64_t* slot_start,
                                                    int64_t* cursor, int64_t* rows) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t s = slot_of_row[i];
         if (s < 0) continue;
-        const int64_t pos = slot_start[s] + (int64_t)atomicAdd((unsigned long long*)&cursor[s], 1ull);
+        const int64_t b = slot_start[s];
+        // a slot with a single row (unique build keys: the usual join) needs no cursor
+        const int64_t pos = slot_start[s + 1] - b == 1 ? b : b + (int64_t)atomicAdd((unsigned long long*)&cursor[s], 1ull);
         rows[pos] = i;
     }
 }
@@ -951,8 +980,8 @@ static int group_build(void* stream, const hs_col* left_key, const int64_t* sel,
     if (n_left > 0)
         hipLaunchKernelGGL(k_join_slots, dim3(grid_for(n_left, 256)), dim3(256), 0, s, *left_key, sel, row0, n_left,
                            table_cap, table_keys, table_reps, slot_of_row, slot_count, flags);
-    int rc = run_scan(s, InI64{slot_count}, table_cap, EmitOffsets{slot_start}, slot_start + table_cap, scan_ws,
-                      "hs_join_build");
+    int rc = run_scan(s, InSlotCount{table_keys, table_reps, slot_count, !hs_col_packs(*left_key)}, table_cap,
+                      EmitOffsets{slot_start}, slot_start + table_cap, scan_ws, "hs_join_build");
     if (rc) return rc;
     if (n_left > 0) {
         hipLaunchKernelGGL(k_join_rows, dim3(grid_for(n_left, 256)), dim3(256), 0, s, slot_of_row, n_left, slot_start,
