@@ -920,10 +920,20 @@ __global__ void __launch_bounds__(256) k_join_rows(const int64_t* slot_of_row, i
         rows[pos] = i;
     }
 }
-// the fill above lands rows of a slot in arrival order; sort each (short) list ascending
-__global__ void __launch_bounds__(256) k_join_sort(const int64_t* slot_start, int64_t cap, int64_t* rows) {
+// The fill above lands the rows of a slot in arrival order; every list must end up ascending.  Short lists
+// (the usual join: one or a few rows per key) are sorted by one lane - they arrive almost sorted, so insertion
+// sort is near linear; longer ones (GROUP BY through this build: thousands of rows per group) are queued and
+// sorted by a workgroup each - an insertion sort by one lane would cost len^2 dependent global round trips.
+static constexpr int HS_SORT_SHORT = 24;
+static constexpr int HS_SORT_LDS = 16384;  // elements of a list one workgroup sorts in LDS (128 KiB)
+__global__ void __launch_bounds__(256) k_join_sort(const int64_t* slot_start, int64_t cap, int64_t* rows,
+                                                   int64_t* long_list, int64_t* long_count) {
     for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < cap; s += (int64_t)gridDim.x * blockDim.x) {
         const int64_t lo = slot_start[s], hi = slot_start[s + 1];
+        if (hi - lo > HS_SORT_SHORT) {
+            long_list[atomicAdd((unsigned long long*)long_count, 1ull)] = s;
+            continue;
+        }
         for (int64_t i = lo + 1; i < hi; ++i) {
             const int64_t v = rows[i];
             int64_t j = i - 1;
@@ -935,10 +945,59 @@ __global__ void __launch_bounds__(256) k_join_sort(const int64_t* slot_start, in
         }
     }
 }
+// Bitonic sort, the variant whose every compare-exchange is ascending (the first stage of each merge pairs i with
+// its mirror image in the block): positions >= len then act as +infinity without ever being touched.
+template <typename T>
+__device__ __forceinline__ void bitonic_sort_ascending(T* a, int64_t len) {
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    int64_t p2 = 1;
+    while (p2 < len) p2 <<= 1;
+    for (int64_t size = 2; size <= p2; size <<= 1) {
+        const int64_t half = size >> 1;
+        for (int64_t t = tid; t < (p2 >> 1); t += nthr) {
+            const int64_t blk = t / half, off = t - blk * half;
+            const int64_t i = blk * size + off, j = blk * size + size - 1 - off;
+            if (j < len) {
+                const T x = a[i], y = a[j];
+                if (x > y) { a[i] = y; a[j] = x; }
+            }
+        }
+        __syncthreads();
+        for (int64_t stride = size >> 2; stride >= 1; stride >>= 1) {
+            for (int64_t t = tid; t < (p2 >> 1); t += nthr) {
+                const int64_t i = (t / stride) * (stride << 1) + (t % stride), j = i + stride;
+                if (j < len) {
+                    const T x = a[i], y = a[j];
+                    if (x > y) { a[i] = y; a[j] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k_join_sort_long(const int64_t* slot_start, int64_t* rows, const int64_t* long_list,
+                                                        const int64_t* long_count) {
+    extern __shared__ __align__(16) int64_t s_list[];
+    const int64_t n_long = *long_count;
+    for (int64_t w = blockIdx.x; w < n_long; w += gridDim.x) {
+        const int64_t s = long_list[w];
+        const int64_t lo = slot_start[s], len = slot_start[s + 1] - lo;
+        if (len <= HS_SORT_LDS) {
+            for (int64_t i = threadIdx.x; i < len; i += blockDim.x) s_list[i] = rows[lo + i];
+            __syncthreads();
+            bitonic_sort_ascending(s_list, len);
+            for (int64_t i = threadIdx.x; i < len; i += blockDim.x) rows[lo + i] = s_list[i];
+            __syncthreads();
+        } else {
+            bitonic_sort_ascending(rows + lo, len);  // in global memory: rare (one key with > 16 Ki rows)
+        }
+    }
+}
 
 extern "C" size_t hs_join_build_ws_bytes(int64_t n_left, int64_t table_cap) {
-    // slot_of_row[n_left] + slot_count[cap] + cursor[cap] + scan ws
-    return (size_t)(n_left + 2 * table_cap + 2) * 8 + hs_scan_ws_bytes(table_cap) + 64;
+    // slot_of_row[n_left] + slot_count[cap] + cursor[cap] + scan ws + queue of the long row lists (+ its counter)
+    return (size_t)(n_left + 2 * table_cap + 2) * 8 + hs_scan_ws_bytes(table_cap) + 64 +
+           (size_t)(n_left / HS_SORT_SHORT + 8) * 8;
 }
 
 static int group_build(void* stream, const hs_col* left_key, const int64_t* sel, int64_t row0, int64_t n_left,
@@ -986,7 +1045,20 @@ static int group_build(void* stream, const hs_col* left_key, const int64_t* sel,
     if (n_left > 0) {
         hipLaunchKernelGGL(k_join_rows, dim3(grid_for(n_left, 256)), dim3(256), 0, s, slot_of_row, n_left, slot_start,
                            cursor, rows);
-        hipLaunchKernelGGL(k_join_sort, dim3(grid_for(table_cap, 256)), dim3(256), 0, s, slot_start, table_cap, rows);
+        int64_t* long_count = (int64_t*)((char*)scan_ws + ((hs_scan_ws_bytes(table_cap) + 63) & ~(size_t)63));
+        int64_t* long_list = long_count + 1;
+        hipMemsetAsync(long_count, 0, 8, s);
+        hipLaunchKernelGGL(k_join_sort, dim3(grid_for(table_cap, 256)), dim3(256), 0, s, slot_start, table_cap, rows,
+                           long_list, long_count);
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute((const void*)k_join_sort_long, hipFuncAttributeMaxDynamicSharedMemorySize, HS_SORT_LDS * 8);
+            attr_set = true;
+        }
+        int64_t wgs = n_left / HS_SORT_SHORT + 1;  // at most this many long lists; every workgroup exits on the count
+        if (wgs > 1024) wgs = 1024;
+        hipLaunchKernelGGL(k_join_sort_long, dim3((unsigned)wgs), dim3(256), HS_SORT_LDS * 8, s, slot_start, rows, long_list,
+                           long_count);
     }
     HS_CHECK_LAUNCH("hs_join_build");
     return HS_OK;

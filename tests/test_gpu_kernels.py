@@ -326,3 +326,27 @@ def test_finish_launch_merges_slabs_of_many_ranks_in_block_order(dev, world, uni
             acc_i += i
             acc_mx = mx if mx > acc_mx else acc_mx
         assert np.float32(acc_f) == got_f[g] and acc_i == int(got_i[g]) and np.float32(acc_mx) == got_mx[g]
+
+
+@pytest.mark.parametrize("n,groups", [(5000, 5000), (200_000, 90), (200_000, 7), (300_000, 3000)])
+def test_group_build_lists_are_ascending_whatever_their_length(dev, n, groups):
+    """hs_group_build (the join's build): the positions of every key must come out ascending - one lane sorts short
+    lists, a workgroup sorts long ones in LDS (<= 16 Ki rows) or in global memory (beyond)."""
+    import torch
+
+    from minispark_amd import hipspark as hs
+    from minispark_amd.device import DCol
+
+    keys = _rng(n + groups).integers(0, groups, n).astype(np.int32) * 7 - 3
+    col = DCol(hs.I32, dev.to_device(keys, torch.int32), n)
+    slot_start, positions, slot_list, ngr = dev._group_build(col, None, n)
+    assert ngr == len(np.unique(keys))
+    starts, pos, slots = slot_start.cpu().numpy(), positions.cpu().numpy(), slot_list[:ngr].cpu().numpy()
+    seen = 0
+    for s in slots:
+        rows = pos[starts[s]: starts[s + 1]]
+        assert len(rows) > 0 and np.all(np.diff(rows) > 0), "row list not strictly ascending"
+        assert len(np.unique(keys[rows])) == 1
+        seen += len(rows)
+    assert seen == n
+    assert dev.read_flags() == 0
