@@ -222,6 +222,18 @@ int hs_agg_partial(void* stream, const hs_col* cols, int32_t n_cols, int32_t key
                    const hs_agg_geom* geom, int64_t* out_rep, uint64_t* out_acc, int32_t* out_ngroups, void* ws,
                    uint32_t* flags, void* ev_begin, void* ev_end);
 
+/* Shared-dictionary tier of the same operator, for tens to thousands of groups per unit: one
+ * 1024-lane workgroup per chunk keeps ONE table of geom->group_cap slots in LDS and updates it with LDS atomics;
+ * chunk tables are merged into per-unit tables of geom->pad slots with global atomics; cells are then rounded like
+ * hs_agg_partial's.  Outputs as hs_agg_partial with group_cap = geom->pad (feed them to hs_agg_pack with that
+ * capacity): out_rep[n_units * pad], out_acc[n_units * pad * n_acc], out_ngroups[n_units]; ws: geom->ws_bytes.
+ * Additions happen in hardware order: results are not bitwise reproducible run to run (within ~1e-13 relative). */
+int hs_agg_shared_geom(const int64_t* host_unit_rows, int64_t n_units, int32_t n_acc, int32_t group_cap, hs_agg_geom* out);
+int hs_agg_shared(void* stream, const hs_col* cols, int32_t n_cols, int32_t key_col, const hs_program* prog,
+                  const hs_agg_spec* spec, const hs_chunk* chunks, int64_t n_units, const hs_agg_geom* geom,
+                  int64_t* out_rep, uint64_t* out_acc, int32_t* out_ngroups, void* ws, uint32_t* flags, void* ev_begin,
+                  void* ev_end);
+
 /* Dense pack of the slot arrays: rows of unit u go to [pack_start[u], pack_start[u+1]).
  * out_cols[a] receives accumulator a as HS_F32 / HS_I32 storage (acc_kinds[a]) = the reference's
  * shuffle-file column; out_rep the representative rows (gather the key column with them).

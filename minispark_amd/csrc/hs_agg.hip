@@ -27,6 +27,63 @@ __global__ void __launch_bounds__(256) k_agg_main(const AggMainArgs A_kernarg) {
     hs_agg_main_body<InterpProg<HASHED, D>>(A);
 }
 
+// shared-dictionary tier (hs_agg_kernel.h): interpreter instantiations
+template <bool HASHED, int D>
+__global__ void __launch_bounds__(1024) k_agg_shared(const AggMainArgs A_kernarg) {
+    HS_KERNARG(AggMainArgs, A);
+    hs_agg_shared_body<InterpProg<HASHED, D>>(A);
+}
+
+// unit tables of the shared tier: keys EMPTY, representative rows -1, cells = the aggregates' identities
+struct SharedInitArgs {
+    uint64_t* keys;
+    int64_t* reps;
+    uint64_t* acc;
+    int64_t n_slots;  // n_units * unit_cap
+    hs_agg_spec spec;
+};
+__global__ void __launch_bounds__(256) k_agg_shared_init(const SharedInitArgs A) {
+    const int NA = A.spec.n_acc;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.n_slots; i += (int64_t)gridDim.x * blockDim.x) {
+        A.keys[i] = HS_EMPTY_KEY;
+        A.reps[i] = -1;
+        for (int a = 0; a < NA; ++a) A.acc[i * NA + a] = hs_acc_identity(A.spec.op[a], A.spec.is_int[a] != 0);
+    }
+}
+// after the scan: cells -> what the reference's shuffle file holds (f32 / i32 rounding, overflow and type flags),
+// groups per unit.  One workgroup per unit.
+struct SharedFinishArgs {
+    const int64_t* reps;
+    uint64_t* acc;
+    int32_t* ngroups;
+    int32_t unit_cap, pad;
+    hs_agg_spec spec;
+    uint32_t* flags;
+};
+__global__ void __launch_bounds__(256) k_agg_shared_finish(const SharedFinishArgs A) {
+    __shared__ int s_count;
+    const int NA = A.spec.n_acc, UC = A.unit_cap;
+    const int64_t u = blockIdx.x;
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    uint32_t err = 0;
+    int mine = 0;
+    for (int sl = threadIdx.x; sl < UC; sl += blockDim.x) {
+        if (A.reps[u * UC + sl] < 0) continue;
+        ++mine;
+        for (int a = 0; a < NA; ++a) {
+            uint64_t* cell = &A.acc[(u * UC + sl) * NA + a];
+            const bool is_int = A.spec.is_int[a] != 0;
+            if (hs_float_identity_left(A.spec.op[a], is_int, *cell)) err |= HS_FLAG_TYPE_ASSERT;
+            *cell = hs_quantise_cell(is_int, *cell, err);
+        }
+    }
+    if (mine) atomicAdd(&s_count, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) A.ngroups[u] = s_count;
+    if (err) atomicOr(A.flags, err);
+}
+
 // --------------------------------------------------------------------------------------------------
 struct AggUnitArgs {
     hs_col key;
@@ -235,6 +292,74 @@ __global__ void __launch_bounds__(256) k_agg_pack(const AggPackArgs A_kernarg) {
         __syncthreads();
     }
     if (tid == 0) A.pack_start[A.n_units] = s_base;
+}
+
+// Wide units (hundreds of slots, shared tier): scan of the per-unit counts by one workgroup, then one workgroup per
+// unit packs its occupied slots in slot order (ballot prefix per wave + a hop through LDS).
+__global__ void __launch_bounds__(256) k_agg_pack_scan(const int32_t* ngroups, int64_t n_units, int64_t* pack_start) {
+    __shared__ int64_t s_part[4];
+    __shared__ int64_t s_base;
+    const int tid = threadIdx.x, lane = tid & (HS_WAVE - 1), w = tid / HS_WAVE;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int64_t u0 = 0; u0 < n_units; u0 += 256) {
+        const int64_t u = u0 + tid;
+        const int64_t n = u < n_units ? ngroups[u] : 0;
+        int64_t x = n;
+        for (int d = 1; d < HS_WAVE; d <<= 1) {
+            const int64_t t = __shfl_up(x, d, HS_WAVE);
+            if (lane >= d) x += t;
+        }
+        if (lane == HS_WAVE - 1) s_part[w] = x;
+        __syncthreads();
+        int64_t before = 0, all = 0;
+        for (int k = 0; k < 4; ++k) {
+            if (k < w) before += s_part[k];
+            all += s_part[k];
+        }
+        if (u < n_units) pack_start[u] = s_base + before + x - n;
+        __syncthreads();
+        if (tid == 0) s_base += all;
+        __syncthreads();
+    }
+    if (tid == 0) pack_start[n_units] = s_base;
+}
+__global__ void __launch_bounds__(256) k_agg_pack_wide(const AggPackArgs A_kernarg) {
+    HS_KERNARG(AggPackArgs, A);
+    __shared__ int s_wave[4];
+    __shared__ int s_run;
+    const int tid = threadIdx.x, lane = tid & (HS_WAVE - 1), w = tid / HS_WAVE;
+    const int64_t u = blockIdx.x;
+    const int GC = A.group_cap;
+    const int64_t out0 = A.pack_start[u];
+    const int64_t uid = A.unit_ids ? A.unit_ids[u] : u;
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    for (int s0 = 0; s0 < GC; s0 += 256) {
+        const int sl = s0 + tid;
+        const int64_t rep = sl < GC ? A.rep[u * GC + sl] : -1;
+        const unsigned long long m = __ballot(rep >= 0);
+        if (lane == 0) s_wave[w] = __popcll(m);
+        __syncthreads();
+        int before = s_run;
+        for (int k = 0; k < w; ++k) before += s_wave[k];
+        if (rep >= 0) {
+            const int64_t o = out0 + before + __popcll(m & ((1ull << lane) - 1));
+            A.out_rep[o] = rep;
+            if (A.out_unit) A.out_unit[o] = uid;
+            for (int a = 0; a < A.n_acc; ++a) {
+                const uint64_t cell = A.acc[(u * GC + sl) * A.n_acc + a];
+                switch (A.acc_kinds[a]) {
+                    case HS_F32: ((float*)A.out_cols[a])[o] = (float)hs_u2d(cell); break;
+                    case HS_I32: ((int32_t*)A.out_cols[a])[o] = (int32_t)(int64_t)cell; break;
+                    default: ((uint64_t*)A.out_cols[a])[o] = cell; break;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_run += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -1086,7 +1211,12 @@ extern "C" int hs_agg_pack(void* stream, const int64_t* rep, const uint64_t* acc
         A.out_cols[a] = a < spec->n_acc ? out_cols[a] : nullptr;
         A.acc_kinds[a] = a < spec->n_acc ? acc_kinds[a] : HS_F64;
     }
-    hipLaunchKernelGGL(k_agg_pack, dim3(1), dim3(256), 0, (hipStream_t)stream, A);
+    if (group_cap > 64 && n_units > 0) {  // wide units: one workgroup per unit instead of one lane per unit
+        hipLaunchKernelGGL(k_agg_pack_scan, dim3(1), dim3(256), 0, (hipStream_t)stream, ngroups, n_units, pack_start);
+        hipLaunchKernelGGL(k_agg_pack_wide, dim3((unsigned)n_units), dim3(256), 0, (hipStream_t)stream, A);
+    } else {
+        hipLaunchKernelGGL(k_agg_pack, dim3(1), dim3(256), 0, (hipStream_t)stream, A);
+    }
     if (hipGetLastError() != hipSuccess) {
         hs_set_error("hs_agg_pack: kernel launch failed");
         return HS_E_LAUNCH;
@@ -1288,6 +1418,153 @@ extern "C" int hs_host_device_pointer(void* host_ptr, void** device_ptr) {
     if (hipHostGetDevicePointer(device_ptr, host_ptr, 0) != hipSuccess || !*device_ptr) {
         (void)hipGetLastError();
         hs_set_error("hs_host_device_pointer: the allocation is not mapped into the device");
+        return HS_E_LAUNCH;
+    }
+    return HS_OK;
+}
+
+// ---- shared-dictionary tier: geometry and launch ------------------------------------------------------------------
+int hs_jit_launch_agg_shared(const AggMainArgs* args, bool hashed, unsigned grid, unsigned block, size_t lds_bytes,
+                             hipStream_t stream);
+
+static constexpr int HS_SHARED_WG = 1024;
+
+extern "C" int hs_agg_shared_geom(const int64_t* host_unit_rows, int64_t n_units, int32_t n_acc, int32_t group_cap,
+                                  hs_agg_geom* out) {
+    if (!host_unit_rows || !out || n_units < 0 || n_acc < 0 || n_acc > HS_MAX_ACC || group_cap < 1 ||
+        (group_cap & (group_cap - 1))) {
+        hs_set_error("hs_agg_shared_geom: bad arguments");
+        return HS_E_ARG;
+    }
+    const size_t lds = (size_t)group_cap * 16 + (size_t)group_cap * (size_t)n_acc * 8;
+    if (lds > HS_LDS_HARD || group_cap > 8192) {
+        hs_set_error("hs_agg_shared_geom: a table of %d groups x %d aggregates needs %zu B LDS (> %zu)", group_cap, n_acc,
+                     lds, HS_LDS_HARD);
+        return HS_E_LIMIT;
+    }
+    int64_t total = 0;
+    for (int64_t u = 0; u < n_units; ++u) {
+        const int64_t r = host_unit_rows[u + 1] - host_unit_rows[u];
+        if (r < 0) {
+            hs_set_error("hs_agg_shared_geom: unit_rows not ascending at %lld", (long long)u);
+            return HS_E_ARG;
+        }
+        total += r;
+    }
+    // one workgroup per CU (it owns the LDS); two rounds of workgroups even out the tail
+    const int64_t step = (int64_t)HS_SHARED_WG * HS_V;
+    int64_t target = 512;
+    int64_t chunk = ((total + target - 1) / target + step - 1) / step * step;
+    if (chunk < 16 * step) chunk = 16 * step;
+    if (chunk > 0x40000000) chunk = 0x40000000 / step * step;
+    int64_t n_chunks = 0;
+    for (int64_t u = 0; u < n_units; ++u) {
+        const int64_t anchor = host_unit_rows[u] & ~(int64_t)(HS_V - 1);
+        const int64_t span = host_unit_rows[u + 1] - anchor;
+        n_chunks += span > 0 ? (span + chunk - 1) / chunk : 0;
+    }
+    int32_t unit_cap = group_cap * 2;  // a unit sees at least the groups of any of its chunks: half-full at worst
+    out->group_cap = group_cap;
+    out->chunk_rows = (int32_t)chunk;
+    out->wg_threads = HS_SHARED_WG;
+    out->pad = unit_cap;
+    out->n_chunks = n_chunks;
+    out->lds_bytes = lds;
+    out->ws_bytes = (size_t)n_units * (size_t)unit_cap * 8 + 256;  // the unit tables' key words
+    return HS_OK;
+}
+
+extern "C" int hs_agg_shared(void* stream, const hs_col* cols, int32_t n_cols, int32_t key_col, const hs_program* prog,
+                             const hs_agg_spec* spec, const hs_chunk* chunks, int64_t n_units, const hs_agg_geom* geom,
+                             int64_t* out_rep, uint64_t* out_acc, int32_t* out_ngroups, void* ws, uint32_t* flags,
+                             void* ev_begin, void* ev_end) {
+    if (!cols || !prog || !spec || !chunks || !geom || !out_rep || !out_acc || !out_ngroups || !ws || !flags ||
+        key_col < 0 || key_col >= n_cols) {
+        hs_set_error("hs_agg_shared: null or out-of-range argument");
+        return HS_E_ARG;
+    }
+    if (prog->n_ins > HS_MAX_INS || prog->n_lit > HS_MAX_LIT) {
+        hs_set_error("hs_agg_shared: program too long");
+        return HS_E_LIMIT;
+    }
+    if (geom->wg_threads != HS_SHARED_WG || geom->pad < geom->group_cap || (geom->pad & (geom->pad - 1))) {
+        hs_set_error("hs_agg_shared: geometry not made by hs_agg_shared_geom");
+        return HS_E_ARG;
+    }
+    if (n_units == 0 || geom->n_chunks == 0) return HS_OK;
+    AggMainArgs A;
+    int rc = fill_cols(A.cols, cols, n_cols);
+    if (rc) return rc;
+    for (int i = HS_FUSED_COLS; i < n_cols; ++i) {
+        if (cols[i].kind != HS_STR || i == key_col) {
+            hs_set_error("hs_agg_shared: more than %d numeric column slots", HS_FUSED_COLS);
+            return HS_E_LIMIT;
+        }
+    }
+    const int depth = program_depth(prog);
+    if (depth > HS_MAX_STACK) {
+        hs_set_error("hs_agg_shared: expression stack depth %d > %d", depth, HS_MAX_STACK);
+        return HS_E_LIMIT;
+    }
+    if (geom->n_chunks > 0x7fffffffll) {
+        hs_set_error("hs_agg_shared: too many chunks");
+        return HS_E_LIMIT;
+    }
+    A.prog = *prog;
+    A.spec = *spec;
+    A.key_col = key_col;
+    A.group_cap = geom->group_cap;
+    A.chunk_rows = geom->chunk_rows;
+    A.pad = geom->pad;
+    A.chunks = chunks;
+    A.unit_chunk0 = nullptr;
+    A.n_units = n_units;
+    A.part_keys = (uint64_t*)ws;
+    A.part_rep = out_rep;
+    A.part_acc = out_acc;
+    A.flags = flags;
+    hipStream_t s = (hipStream_t)stream;
+    SharedInitArgs I;
+    I.keys = A.part_keys;
+    I.reps = out_rep;
+    I.acc = out_acc;
+    I.n_slots = n_units * (int64_t)geom->pad;
+    I.spec = *spec;
+    int64_t init_blocks = (I.n_slots + 255) / 256;
+    if (init_blocks > 4096) init_blocks = 4096;
+    hipLaunchKernelGGL(k_agg_shared_init, dim3((unsigned)init_blocks), dim3(256), 0, s, I);
+    const bool hashed = !hs_col_packs(cols[key_col]);
+    static bool attrs_set = false;
+    if (!attrs_set) {
+        allow_big_lds(k_agg_shared<true, 8>);
+        allow_big_lds(k_agg_shared<false, 4>);
+        allow_big_lds(k_agg_shared<false, 8>);
+        attrs_set = true;
+    }
+    dim3 grid((unsigned)geom->n_chunks), block((unsigned)HS_SHARED_WG);
+    if (ev_begin) (void)hipEventRecord((hipEvent_t)ev_begin, s);
+    const int jit_rc = hs_jit_launch_agg_shared(&A, hashed, grid.x, block.x, geom->lds_bytes, s);
+    if (jit_rc == HS_OK) {
+        // launched the program compiled for exactly this bytecode
+    } else if (hashed) {
+        hipLaunchKernelGGL((k_agg_shared<true, 8>), grid, block, geom->lds_bytes, s, A);
+    } else if (depth <= 4) {
+        hipLaunchKernelGGL((k_agg_shared<false, 4>), grid, block, geom->lds_bytes, s, A);
+    } else {
+        hipLaunchKernelGGL((k_agg_shared<false, 8>), grid, block, geom->lds_bytes, s, A);
+    }
+    if (ev_end) (void)hipEventRecord((hipEvent_t)ev_end, s);
+    SharedFinishArgs F;
+    F.reps = out_rep;
+    F.acc = out_acc;
+    F.ngroups = out_ngroups;
+    F.unit_cap = geom->pad;
+    F.pad = 0;
+    F.spec = *spec;
+    F.flags = flags;
+    hipLaunchKernelGGL(k_agg_shared_finish, dim3((unsigned)n_units), dim3(256), 0, s, F);
+    if (hipGetLastError() != hipSuccess) {
+        hs_set_error("hs_agg_shared: kernel launch failed");
         return HS_E_LAUNCH;
     }
     return HS_OK;

@@ -195,11 +195,12 @@ struct InterpProg {
         }
     }
 
+    template <class Ctx>
     struct Sink {
         const AggMainArgs& A;
         const Cells& x;
-        AggCtx& ctx;
-        __device__ __forceinline__ Sink(const AggMainArgs& a, const Cells& c, AggCtx& k) : A(a), x(c), ctx(k) {}
+        Ctx& ctx;
+        __device__ __forceinline__ Sink(const AggMainArgs& a, const Cells& c, Ctx& k) : A(a), x(c), ctx(k) {}
         __device__ __forceinline__ void load(uint32_t s, uint64_t (&dst)[HS_V]) const {
             switch (s) {
 #define HS_CASE(K)                                                          \
@@ -240,8 +241,9 @@ struct InterpProg {
         }
     };
 
-    static __device__ __forceinline__ void run(const AggMainArgs& A, const Cells& x, AggCtx& ctx) {
-        Sink sink(A, x, ctx);
+    template <class Ctx>
+    static __device__ __forceinline__ void run(const AggMainArgs& A, const Cells& x, Ctx& ctx) {
+        Sink<Ctx> sink(A, x, ctx);
         const hs_program& P = A.prog;
         uint64_t st[D][HS_V];
 #pragma unroll
@@ -385,6 +387,190 @@ __device__ __forceinline__ void hs_agg_main_body(const AggMainArgs& A) {
     for (int i = tid; i < GC; i += nthr) {
         A.part_keys[chunk * GC + i] = dkeys[i];
         A.part_rep[chunk * GC + i] = dreps[i];
+    }
+    if (ctx.err) atomicOr(A.flags, ctx.err);
+}
+
+// ======================================================================================================
+// Shared-dictionary tier: GROUP BY with tens to thousands of groups per unit.
+//
+// Private per-lane tables (above) stop paying once group_cap x n_acc x 8 bytes per LANE no longer leaves room for
+// enough waves.  Here the workgroup (1024 lanes, one per CU) owns ONE table in LDS - key words, representative
+// rows, n_acc accumulators per slot - and every row updates it with LDS atomics (ds_add_f64 / ds_add_u64 /
+// ds_min / ds_max: the LDS does ~10^4 x the atomic rate of HBM).  At the end of its chunk the workgroup merges
+// the occupied slots into the UNIT's table in global memory (dictionary upsert + one global atomic per cell:
+// chunks x groups of them, negligible next to the rows).  fp64 additions of a group happen in hardware order,
+// so this tier is not bitwise reproducible run to run: results stay within ~1e-13 relative of the reference's
+// sequential sum (north_star: 1e-9) and equal after f32 rounding except at a rounding boundary (<= 1 ulp).
+// ======================================================================================================
+template <int OP, bool IS_INT>
+__device__ __forceinline__ void hs_atomic_fold_lds(uint64_t* cell, uint64_t x) {
+    if constexpr (IS_INT) {
+        if constexpr (OP == HS_AGG_SUM) atomicAdd((unsigned long long*)cell, (unsigned long long)x);
+        else if constexpr (OP == HS_AGG_MIN) atomicMin((long long*)cell, (long long)x);
+        else atomicMax((long long*)cell, (long long)x);
+    } else {
+        if constexpr (OP == HS_AGG_SUM) atomicAdd((double*)cell, hs_u2d(x));
+        else if constexpr (OP == HS_AGG_MIN) atomicMin((double*)cell, hs_u2d(x));
+        else atomicMax((double*)cell, hs_u2d(x));
+    }
+}
+template <int OP, bool IS_INT>
+__device__ __forceinline__ void hs_atomic_fold_global(uint64_t* cell, uint64_t x) {
+    if constexpr (IS_INT) {
+        if constexpr (OP == HS_AGG_SUM) atomicAdd((unsigned long long*)cell, (unsigned long long)x);
+        else if constexpr (OP == HS_AGG_MIN) atomicMin((long long*)cell, (long long)x);
+        else atomicMax((long long*)cell, (long long)x);
+    } else {
+        if constexpr (OP == HS_AGG_SUM) unsafeAtomicAdd((double*)cell, hs_u2d(x));
+        else if constexpr (OP == HS_AGG_MIN) unsafeAtomicMin((double*)cell, hs_u2d(x));
+        else unsafeAtomicMax((double*)cell, hs_u2d(x));
+    }
+}
+#define HS_DISPATCH_FOLD(FN, op, is_int, cell, x)                                                         \
+    do {                                                                                                  \
+        if (is_int) {                                                                                     \
+            if ((op) == HS_AGG_SUM) FN<HS_AGG_SUM, true>(cell, x);                                        \
+            else if ((op) == HS_AGG_MIN) FN<HS_AGG_MIN, true>(cell, x);                                   \
+            else FN<HS_AGG_MAX, true>(cell, x);                                                           \
+        } else {                                                                                          \
+            if ((op) == HS_AGG_SUM) FN<HS_AGG_SUM, false>(cell, x);                                       \
+            else if ((op) == HS_AGG_MIN) FN<HS_AGG_MIN, false>(cell, x);                                  \
+            else FN<HS_AGG_MAX, false>(cell, x);                                                          \
+        }                                                                                                 \
+    } while (0)
+
+struct SharedCtx {
+    int64_t row0;
+    bool alive[HS_V];
+    int slot[HS_V];
+    uint64_t* dkeys;
+    int64_t* dreps;
+    uint64_t* acc;  // [slot][n_acc]
+    uint32_t mask;
+    int32_t n_acc;
+    uint32_t err;
+
+    template <bool HASHED>
+    __device__ __forceinline__ int find(const hs_col& key_col, uint64_t k, int64_t row, bool& live) {
+        int s = 0;
+        if (live) {
+            if constexpr (HASHED) s = hs_dict_upsert_rows(dreps, mask, key_col, k, row);
+            else s = hs_dict_upsert_word(dkeys, dreps, mask, k, row);
+            if (s < 0) {
+                err |= HS_FLAG_DICT_FULL;
+                live = false;
+                s = 0;
+            }
+        }
+        return s;
+    }
+    __device__ __forceinline__ void fold(const hs_agg_spec& spec, uint32_t a, int s, bool live, uint64_t x) {
+        if (live) HS_DISPATCH_FOLD(hs_atomic_fold_lds, spec.op[a], spec.is_int[a] != 0, &acc[(uint32_t)s * (uint32_t)n_acc + a], x);
+    }
+    template <int NA, int A, int OP, bool IS_INT>
+    __device__ __forceinline__ void fold_c(int s, bool live, uint64_t x) {
+        if (live) hs_atomic_fold_lds<OP, IS_INT>(&acc[(uint32_t)s * (uint32_t)NA + (uint32_t)A], x);
+    }
+};
+
+// the unit's table in global memory: same open addressing as the LDS dictionaries, claimed with global CAS
+__device__ __forceinline__ int64_t hs_unit_upsert(uint64_t* keys, int64_t* reps, uint32_t mask, bool hashed,
+                                                  const hs_col& key_col, uint64_t k, int64_t row) {
+    uint32_t h = hs_slot_hash(k) & mask;
+    for (uint32_t probe = 0; probe <= mask; ++probe) {
+        if (hashed) {
+            long long cur = __hip_atomic_load(&reps[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur < 0) {
+                cur = (long long)atomicCAS((unsigned long long*)&reps[h], (unsigned long long)(-1ll), (unsigned long long)row);
+                if (cur < 0) return (int64_t)h;
+            }
+            if (hs_rows_equal(key_col, (int64_t)cur, row)) return (int64_t)h;
+        } else {
+            uint64_t cur = __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == HS_EMPTY_KEY) {
+                cur = atomicCAS((unsigned long long*)&keys[h], (unsigned long long)HS_EMPTY_KEY, (unsigned long long)k);
+                if (cur == HS_EMPTY_KEY) {
+                    reps[h] = row;  // read only after the kernel
+                    return (int64_t)h;
+                }
+            }
+            if (cur == k) return (int64_t)h;
+        }
+        h = (h + 1) & mask;
+    }
+    return -1;
+}
+
+// AggMainArgs as used by this tier: group_cap = slots of the LDS table, pad = slots of a unit's global table,
+// part_keys / part_rep / part_acc = the unit tables [n_units][pad] (keys EMPTY, reps -1, cells = identities)
+template <class Prog>
+__device__ __forceinline__ void hs_agg_shared_body(const AggMainArgs& A) {
+    extern __shared__ __align__(16) uint64_t hs_lds[];
+    const uint32_t tid = threadIdx.x, nthr = blockDim.x;
+    const int GC = A.group_cap;
+    const int NA = A.spec.n_acc;
+    uint64_t* dkeys = hs_lds;
+    int64_t* dreps = (int64_t*)(hs_lds + GC);
+    uint64_t* acc = hs_lds + 2 * GC;
+
+    const hs_chunk desc = A.chunks[blockIdx.x];
+    const int64_t us = desc.unit_begin, c0 = desc.row_begin, c1 = desc.row_end;
+    // a run that has already overflowed a dictionary is going to be repeated with larger tables: stop early
+    if (__hip_atomic_load(A.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & HS_FLAG_DICT_FULL) return;
+
+    const int64_t stride = (int64_t)nthr * HS_V;
+    int64_t base = c0 + (int64_t)tid * HS_V;
+    typename Prog::Cells cur, nxt;
+    if (base < c1) Prog::load(A, base, nxt);
+    for (int i = tid; i < GC; i += nthr) {
+        dkeys[i] = HS_EMPTY_KEY;
+        dreps[i] = -1;
+    }
+    for (int i = tid; i < GC * NA; i += nthr) acc[i] = hs_acc_identity(A.spec.op[i % NA], A.spec.is_int[i % NA] != 0);
+    __syncthreads();
+
+    SharedCtx ctx;
+    ctx.dkeys = dkeys;
+    ctx.dreps = dreps;
+    ctx.acc = acc;
+    ctx.mask = (uint32_t)GC - 1;
+    ctx.n_acc = NA;
+    ctx.err = 0;
+    while (base < c1) {
+        cur = nxt;
+        const int64_t next_base = base + stride;
+        if (next_base < c1) Prog::load(A, next_base, nxt);
+        ctx.row0 = base;
+#pragma unroll
+        for (int j = 0; j < HS_V; ++j) {
+            const int64_t r = base + j;
+            ctx.alive[j] = (r >= us) && (r < c1);
+            ctx.slot[j] = 0;
+        }
+        Prog::run(A, cur, ctx);
+        base = next_base;
+    }
+    __syncthreads();
+
+    // merge this chunk's groups into the unit's table
+    const int64_t unit = desc.unit;
+    const int UC = A.pad;
+    uint64_t* ukeys = A.part_keys + unit * UC;
+    int64_t* ureps = A.part_rep + unit * UC;
+    uint64_t* uacc = A.part_acc + unit * (int64_t)UC * NA;
+    const hs_col& kc = A.cols.c[A.key_col];
+    for (int sl = tid; sl < GC; sl += nthr) {
+        const int64_t rep = dreps[sl];
+        if (rep < 0) continue;
+        const uint64_t k = Prog::HASHED ? hs_key_at(kc, rep) : dkeys[sl];
+        const int64_t u = hs_unit_upsert(ukeys, ureps, (uint32_t)UC - 1, Prog::HASHED, kc, k, rep);
+        if (u < 0) {
+            ctx.err |= HS_FLAG_DICT_FULL;
+            continue;
+        }
+        for (int a = 0; a < NA; ++a)
+            HS_DISPATCH_FOLD(hs_atomic_fold_global, A.spec.op[a], A.spec.is_int[a] != 0, &uacc[u * NA + a], acc[sl * NA + a]);
     }
     if (ctx.err) atomicOr(A.flags, ctx.err);
 }

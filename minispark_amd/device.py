@@ -573,7 +573,7 @@ class Device:
     # ---- partial aggregate (A5/A6) -------------------------------------------------------------------------
     def aggregate_partial(self, batch: DBatch, filters: Sequence[Any], group_by: Any, agg_columns: Sequence[Any],
                           out_schema: Schema, group_cap_hint: int = 4, cache_key: Any = None,
-                          slab_rows: int | None = None, tail: bool = False) -> DBatch:
+                          slab_rows: int | None = None, tail: bool = False, shared: bool = False) -> DBatch:
         """Fused scan + WHERE + aggregate arguments + per-unit partial aggregate.
 
         Returns the partial rows exactly as the reference would have written them to its shuffle
@@ -588,10 +588,10 @@ class Device:
         key = None
         if cache_key is not None:
             key = (cache_key, cap, batch.nrows, tuple((c.data.data_ptr(), c.n) for c in batch.cols),
-                   len(batch.unit_rows), batch.unit_rows[-1], slab_rows, tail)
+                   len(batch.unit_rows), batch.unit_rows[-1], slab_rows, tail, shared)
         prep = self._partial_prepared.get(key) if key is not None else None
         if prep is None:
-            prep = self._prepare_partial(batch, filters, group_by, agg_columns, cap, slab_rows, tail, out_schema)
+            prep = self._prepare_partial(batch, filters, group_by, agg_columns, cap, slab_rows, tail, out_schema, shared)
             if key is not None:
                 if len(self._partial_prepared) >= 8:
                     self._partial_prepared.pop(next(iter(self._partial_prepared)))
@@ -609,15 +609,23 @@ class Device:
             self.last_group_cap = cap
             return DBatch(list(out_schema), [], p["slots"], [0, p["slots"]], None, total_units=batch.total_units,
                           slab=p["slab"], slab_layout=p["layout"], tail=p["tail"])
-        hs.check(self.lib.hs_agg_partial(self.stream, p["cols"], p["n_cols"], p["key_slot"], C.byref(p["prog"]),
-                                         C.byref(p["spec"]), p["d_units"].data_ptr(), p["d_chunk0"].data_ptr(),
-                                         p["n_units"], C.byref(p["geom"]), p["out_rep"].data_ptr(),
-                                         p["out_acc"].data_ptr(), p["ngroups"].data_ptr(), p["ws"].data_ptr(),
-                                         self.flags.data_ptr(), self._event_handle(0), self._event_handle(1)),
-                 "hs_agg_partial")
+        if shared:
+            # tens to thousands of groups per unit: one LDS table per workgroup, LDS atomics
+            hs.check(self.lib.hs_agg_shared(self.stream, p["cols"], p["n_cols"], p["key_slot"], C.byref(p["prog"]),
+                                            C.byref(p["spec"]), p["d_units"].data_ptr(), p["n_units"], C.byref(p["geom"]),
+                                            p["out_rep"].data_ptr(), p["out_acc"].data_ptr(), p["ngroups"].data_ptr(),
+                                            p["ws"].data_ptr(), self.flags.data_ptr(), self._event_handle(0),
+                                            self._event_handle(1)), "hs_agg_shared")
+        else:
+            hs.check(self.lib.hs_agg_partial(self.stream, p["cols"], p["n_cols"], p["key_slot"], C.byref(p["prog"]),
+                                             C.byref(p["spec"]), p["d_units"].data_ptr(), p["d_chunk0"].data_ptr(),
+                                             p["n_units"], C.byref(p["geom"]), p["out_rep"].data_ptr(),
+                                             p["out_acc"].data_ptr(), p["ngroups"].data_ptr(), p["ws"].data_ptr(),
+                                             self.flags.data_ptr(), self._event_handle(0), self._event_handle(1)),
+                     "hs_agg_partial")
         self.last_scan = p["info"]
         hs.check(self.lib.hs_agg_pack(self.stream, p["out_rep"].data_ptr(), p["out_acc"].data_ptr(),
-                                      p["ngroups"].data_ptr(), p["n_units"], cap, C.byref(p["spec"]),
+                                      p["ngroups"].data_ptr(), p["n_units"], p["unit_cap"], C.byref(p["spec"]),
                                       p["pack_start"].data_ptr(), p["dense_rep"].data_ptr(), p["out_ptrs"],
                                       p["kinds_arr"], p["d_unit_ids"].data_ptr() if p["d_unit_ids"] is not None else None,
                                       p["out_unit"].data_ptr() if p["out_unit"] is not None else None), "hs_agg_pack")
@@ -697,7 +705,7 @@ class Device:
 
     def _prepare_partial(self, batch: DBatch, filters: Sequence[Any], group_by: Any, agg_columns: Sequence[Any],
                          cap: int, slab_rows: int | None = None, tail: bool = False,
-                         out_schema: Schema | None = None) -> dict:
+                         out_schema: Schema | None = None, shared: bool = False) -> dict:
         low = lower_aggregate(batch.schema, batch.kinds, filters, group_by, agg_columns)
         if low.numeric_slots > hs.HS_FUSED_COLS:
             raise TierExceeded(f"aggregate reads more than {hs.HS_FUSED_COLS} numeric columns")
@@ -705,7 +713,10 @@ class Device:
         n_acc = len(low.acc_ops)
         host_units = (C.c_int64 * (n_units + 1))(*batch.unit_rows)
         geom = hs.hs_agg_geom()
-        rc = self.lib.hs_agg_partial_geom(host_units, n_units, n_acc, cap, C.byref(geom))
+        if shared:
+            rc = self.lib.hs_agg_shared_geom(host_units, n_units, n_acc, cap, C.byref(geom))
+        else:
+            rc = self.lib.hs_agg_partial_geom(host_units, n_units, n_acc, cap, C.byref(geom))
         if rc == 2:
             raise TierExceeded(
                 f"GROUP BY with more than {cap // 2} groups per workgroup x {n_acc} aggregates exceeds the LDS tier: "
@@ -718,7 +729,8 @@ class Device:
         hs.check(self.lib.hs_agg_partial_chunks(host_units, n_units, C.byref(geom),
                                                 chunks.ctypes.data_as(C.POINTER(hs.hs_chunk)),
                                                 chunk0.ctypes.data_as(C.POINTER(C.c_int64))), "hs_agg_partial_chunks")
-        slots = n_units * cap
+        unit_cap = int(geom.pad) if shared else cap  # slots per unit of the kernels' output arrays
+        slots = n_units * unit_cap
         acc_kinds = [hs.I32 if is_int else hs.F32 for is_int in low.acc_is_int]
         key_idx = low.program.columns[low.key_slot]
         slab = layout = key_out = out_unit = None
@@ -770,7 +782,8 @@ class Device:
             "slab": slab, "layout": layout, "key_out": key_out, "out_unit": out_unit, "d_unit_ids": d_unit_ids,
             "cols": self._cols_array(batch, low.program.columns), "n_cols": len(low.program.columns),
             "key_slot": low.key_slot, "key_idx": key_idx, "prog": low.program.to_struct(),
-            "spec": low.spec(), "geom": geom, "n_units": n_units, "slots": slots, "agg_to_acc": low.agg_to_acc,
+            "spec": low.spec(), "geom": geom, "n_units": n_units, "slots": slots, "unit_cap": unit_cap,
+            "agg_to_acc": low.agg_to_acc,
             "d_units": self.to_device(chunks.reshape(-1)), "d_chunk0": self.to_device(chunk0),
             "out_rep": self.empty(slots, torch.int64), "out_acc": self.empty(max(slots * n_acc, 1), torch.int64),
             "ngroups": self.empty(max(n_units, 1), torch.int32), "ws": self.workspace(geom.ws_bytes),
@@ -779,7 +792,8 @@ class Device:
             "out_ptrs": (C.c_void_p * max(n_acc, 1))(*[t.data_ptr() for t in acc_bufs]),
             "kinds_arr": (C.c_int32 * max(n_acc, 1))(*acc_kinds),
             "info": {"rows": batch.nrows, "chunks": int(geom.n_chunks), "chunk_rows": int(geom.chunk_rows),
-                     "wg_threads": int(geom.wg_threads), "group_cap": cap, "lds_bytes": int(geom.lds_bytes)},
+                     "wg_threads": int(geom.wg_threads), "group_cap": cap, "lds_bytes": int(geom.lds_bytes),
+                     "tier": "shared" if shared else "private"},
         }
 
     # ---- final merge (A7) ------------------------------------------------------------------------------

@@ -40,6 +40,10 @@ class ExecutionError(Exception):
         super().__init__(message)
 
 
+PRIVATE_TIER_MAX = 16    # dictionary slots per workgroup up to which every lane keeps private accumulators
+SHARED_TIER_MAX = 4096   # ... and up to which one LDS dictionary per workgroup is used; beyond: the HBM tier
+
+
 class RestartQuery(Exception):
     """Run the query again from the start (a fused path found at run time that it does not apply)."""
 
@@ -103,6 +107,7 @@ class HipExecutionEngine(ExecutionEngine):
         self.replay_enabled = os.environ.get("HIPSPARK_REPLAY", "1") != "0"
         self.replays = 0
         self.short_tail_enabled = os.environ.get("HIPSPARK_SHORT_TAIL", "1") != "0"
+        self.shared_tier_enabled = os.environ.get("HIPSPARK_SHARED_TIER", "1") != "0"
         self._no_short_tail: set[Any] = set()  # partial AggregateTask ids that must take the general path
         self.short_tails = 0  # queries finished by the short tail (first runs and recordings; replays count in `replays`)
         self._plan_runs: dict[Any, int] = {}
@@ -280,7 +285,8 @@ class HipExecutionEngine(ExecutionEngine):
                 self.dev.stop_recording()
                 # more distinct GROUP BY keys than the dictionaries were sized for: grow and re-run; past the
                 # on-chip limits the stages switch to the global-memory tier (TierExceeded in _run_stage)
-                self.group_cap_hint *= 2
+                # x2 while the private-table tier applies, x4 beyond (every step re-runs the scan)
+                self.group_cap_hint *= 2 if self.group_cap_hint < PRIVATE_TIER_MAX else 4
                 if self.merge_cap_hint >= 4096:
                     self._merge_overflowed = True
                 self.merge_cap_hint = min(self.merge_cap_hint * 4, 4096)
@@ -403,10 +409,22 @@ class HipExecutionEngine(ExecutionEngine):
                 batch = self._project(batch, pending, task)
                 pending = []
             elif tname == "AggregateTask":
-                if task.before_shuffle and (id(task) in self._global_partial or self.group_cap_hint > 256):
+                if task.before_shuffle and (id(task) in self._global_partial or self.group_cap_hint > SHARED_TIER_MAX):
                     self._global_partial.add(id(task))
                     batch = self.dev.aggregate_partial_global(batch, pending, task.group_by_column, task.agg_columns,
                                                               task.inferred_schema)
+                    batch.partitioned = self.dist is not None
+                    pending = []
+                elif task.before_shuffle and self.shared_tier_enabled and self.group_cap_hint > PRIVATE_TIER_MAX:
+                    # tens to thousands of groups per unit: one LDS dictionary per workgroup, LDS atomics
+                    try:
+                        batch = self.dev.aggregate_partial(batch, pending, task.group_by_column, task.agg_columns,
+                                                           task.inferred_schema, self.group_cap_hint,
+                                                           cache_key=(id(task), "shared"), shared=True)
+                    except TierExceeded:
+                        self._global_partial.add(id(task))
+                        batch = self.dev.aggregate_partial_global(batch, pending, task.group_by_column,
+                                                                  task.agg_columns, task.inferred_schema)
                     batch.partitioned = self.dist is not None
                     pending = []
                 elif task.before_shuffle:
@@ -438,9 +456,16 @@ class HipExecutionEngine(ExecutionEngine):
                                                            task.inferred_schema, self.group_cap_hint,
                                                            cache_key=(id(task), "noslab"))
                     except TierExceeded:
-                        self._global_partial.add(id(task))
-                        batch = self.dev.aggregate_partial_global(batch, pending, task.group_by_column,
-                                                                  task.agg_columns, task.inferred_schema)
+                        try:  # private tables do not fit (many aggregates): the shared dictionary may
+                            if not self.shared_tier_enabled:
+                                raise
+                            batch = self.dev.aggregate_partial(batch, pending, task.group_by_column, task.agg_columns,
+                                                               task.inferred_schema, max(self.group_cap_hint, 16),
+                                                               cache_key=(id(task), "shared"), shared=True)
+                        except TierExceeded:
+                            self._global_partial.add(id(task))
+                            batch = self.dev.aggregate_partial_global(batch, pending, task.group_by_column,
+                                                                      task.agg_columns, task.inferred_schema)
                     batch.partitioned = self.dist is not None and batch.slab is None
                     pending = []
                 else:

@@ -156,6 +156,8 @@ SIGNATURES: dict[str, tuple] = {
         C.c_int,
         [_P, _COLP, _I32, _I32, _PROGP, _SPECP, _P, _P, _I64, _GEOMP, _P, _P, _P, _P, _P, _P, _P],
     ),
+    "hs_agg_shared_geom": (C.c_int, [C.POINTER(_I64), _I64, _I32, _I32, _GEOMP]),
+    "hs_agg_shared": (C.c_int, [_P, _COLP, _I32, _I32, _PROGP, _SPECP, _P, _I64, _GEOMP, _P, _P, _P, _P, _P, _P, _P]),
     "hs_agg_partial_slab": (
         C.c_int,
         [_P, _COLP, _I32, _I32, _PROGP, _SPECP, _P, _P, _I64, _GEOMP, _P, _P, C.POINTER(hs_slab_desc), _P, _P, _P, _P],

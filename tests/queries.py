@@ -207,6 +207,17 @@ def _edge_divzero(api, t):
     return api.DataFrame().table(t["edge"]).group_by(C("g")).agg(F.sum(C("f") / C("i")).alias("s"))
 
 
+def _many_groups(api, t):
+    """Several hundred groups (computed INTEGER key): beyond the per-lane private tables -> the shared-dictionary
+    tier."""
+    C, F, Lit = api.Col, api.F, api.Lit
+    return (api.DataFrame().table(t["lineitem"]).filter(C("l_shipdate") > "1992-03-01")
+            .select((C("l_orderkey") % 331 - 100).alias("bucket"), C("l_extendedprice"), C("l_tax"), C("l_orderkey"))
+            .group_by(C("bucket"))
+            .agg(F.sum(C("l_extendedprice") * (Lit(1) + C("l_tax"))).alias("gross"), F.avg(C("l_tax")).alias("avg_tax"),
+                 F.min(C("l_orderkey")).alias("first_order"), F.max(C("l_extendedprice")).alias("max_price"), F.count()))
+
+
 def _fruits5_count(api, t):
     return api.DataFrame().table(t["fruits5"]).group_by(api.Col("fruit")).agg(api.F.count())
 
@@ -240,6 +251,7 @@ CASES: list[Case] = [
     Case("join_group", [TableSpec("orders", lambda: orders_rows(300, 11), 128),
                         TableSpec("lineitem", lambda: lineitem_rows(1200, 12), 500)], _join_group),
     Case("concat_like", [TableSpec("lineitem", lambda: lineitem_rows(3000, 5), 700)], _concat_like),
+    Case("many_groups", [TableSpec("lineitem", lambda: lineitem_rows(5000, 21), 1300)], _many_groups, tags=("many",)),
     Case("edge_minmax", [TableSpec("edge", edge_rows, 3)], _edge_minmax),
     Case("edge_int_key", [TableSpec("edge", edge_rows, 3)], _edge_int_key),
     Case("edge_overflow", [TableSpec("edge", edge_rows, 3)], _edge_overflow, expect_error="OverflowError"),
