@@ -308,6 +308,15 @@ __device__ __forceinline__ void hs_agg_main_body(const AggMainArgs& A) {
     const int64_t chunk = blockIdx.x;
     const hs_chunk desc = A.chunks[chunk];
     const int64_t us = desc.unit_begin, c0 = desc.row_begin, c1 = desc.row_end;
+    // a run that has already overflowed a dictionary is going to be repeated with larger tables: later rounds of
+    // workgroups only mark their chunk empty and leave
+    if (__hip_atomic_load(A.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & HS_FLAG_DICT_FULL) {
+        for (int i = threadIdx.x; i < A.group_cap; i += blockDim.x) {
+            A.part_keys[chunk * A.group_cap + i] = HS_EMPTY_KEY;
+            A.part_rep[chunk * A.group_cap + i] = -1;
+        }
+        return;
+    }
 
     // the first quad's loads go out before the LDS tables are initialised: their latency hides the init
     const int64_t stride = (int64_t)nthr * HS_V;
