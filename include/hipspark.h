@@ -157,14 +157,16 @@ int hs_eval(void* stream, const hs_col* cols, int32_t n_cols, const hs_program* 
  * ws: hs_scan_ws_bytes(nrows). count is a device int64. */
 int hs_compact(void* stream, const uint8_t* mask, int64_t nrows, int64_t* sel, int64_t* count, void* ws);
 
-/* out[i] = src[idx[i]] for a fixed-width column (elem_bytes in {1,4,8}). */
-int hs_gather_fixed(void* stream, const void* src, int32_t elem_bytes, const int64_t* idx, int64_t n,
-                    const int64_t* n_dev, void* dst);
+/* out[i] = src[idx[i]] for a fixed-width column of src_rows rows (elem_bytes in {1,2,4,8}).  Indices come from other
+ * kernels; one outside [0, src_rows) reads as zero and raises HS_FLAG_BAD_PROGRAM in *flags instead of faulting. */
+int hs_gather_fixed(void* stream, const void* src, int32_t elem_bytes, int64_t src_rows, const int64_t* idx, int64_t n,
+                    const int64_t* n_dev, void* dst, uint32_t* flags);
 /* STRING gather, two steps around an offsets scan: lengths first ... */
-int hs_gather_str_lens(void* stream, const hs_col* src, const int64_t* idx, int64_t n, uint8_t* out_lens);
-/* ... then payload bytes to out_data at out_offs (from hs_str_offsets over out_lens). */
-int hs_gather_str_bytes(void* stream, const hs_col* src, const int64_t* idx, int64_t n, const int64_t* out_offs,
-                        uint8_t* out_data);
+int hs_gather_str_lens(void* stream, const hs_col* src, int64_t src_rows, const int64_t* idx, int64_t n, uint8_t* out_lens,
+                       uint32_t* flags);
+/* (second pass, after hs_str_offsets over out_lens gave out_offs; rows refused by the first pass are skipped) */
+int hs_gather_str_bytes(void* stream, const hs_col* src, int64_t src_rows, const int64_t* idx, int64_t n,
+                        const int64_t* out_offs, uint8_t* out_data);
 
 /* STRING '+' (reference sql.py:262-266 with operator.add on str; zig utils.zig:118-131).
  * parts: n_parts columns (HS_STR) or literals (kind = -1, data = host-copied into the launch: the

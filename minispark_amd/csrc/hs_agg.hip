@@ -547,6 +547,8 @@ __device__ __forceinline__ int hs_merge_small_core(const In& in, const hs_agg_sp
         dreps[i] = -1;
         cnt[i] = 0;
         run[i] = 0;
+        out_rep[i] = -1;  // a group that never gets its first row shows up as an invalid row index downstream
+                          // (checked gathers raise HS_FLAG_BAD_PROGRAM) instead of as stale memory
     }
     for (int i = tid; i < nord; i += nthr) {
         ocnt[i] = 0;
@@ -1083,6 +1085,8 @@ static int agg_partial_impl(void* stream, const hs_col* cols, int32_t n_cols, in
     A.part_rep = (int64_t*)((char*)ws + slots * 8);
     A.part_acc = (uint64_t*)((char*)ws + slots * 16);
     A.flags = flags;
+    A.replicas = 0;
+    A.pad2 = 0;
     const bool hashed = !hs_col_packs(cols[key_col]);
     const int depth = program_depth(prog);
     if (depth > HS_MAX_STACK) {
@@ -1436,12 +1440,23 @@ extern "C" int hs_agg_shared_geom(const int64_t* host_unit_rows, int64_t n_units
         hs_set_error("hs_agg_shared_geom: bad arguments");
         return HS_E_ARG;
     }
-    const size_t lds = (size_t)group_cap * 16 + (size_t)group_cap * (size_t)n_acc * 8;
+    // LDS table: up to 4x the requested capacity (a quarter-full open-addressing table answers in ~1 probe; at 80 %
+    // the same kernel ran 3x slower), as far as 128 KiB allow; then accumulator replicas per slot (a lane uses
+    // replica lane % R) with what is left, at most one per lane of a wave - with few groups the lanes of a wave
+    // would otherwise serialise on the same LDS words
+    const size_t cell_bytes = (size_t)(n_acc > 0 ? n_acc : 1) * 8;
+    int slots = group_cap;
+    while (slots < 4 * group_cap && (size_t)(slots * 2) * (16 + cell_bytes) <= 128 * 1024 && slots < 8192) slots *= 2;
+    int replicas = 1;
+    while (replicas < HS_WAVE && (size_t)slots * 16 + (size_t)slots * cell_bytes * (size_t)(replicas * 2) <= 128 * 1024)
+        replicas *= 2;
+    const size_t lds = (size_t)slots * 16 + (size_t)slots * cell_bytes * (size_t)replicas;
     if (lds > HS_LDS_HARD || group_cap > 8192) {
         hs_set_error("hs_agg_shared_geom: a table of %d groups x %d aggregates needs %zu B LDS (> %zu)", group_cap, n_acc,
                      lds, HS_LDS_HARD);
         return HS_E_LIMIT;
     }
+    group_cap = slots;
     int64_t total = 0;
     for (int64_t u = 0; u < n_units; ++u) {
         const int64_t r = host_unit_rows[u + 1] - host_unit_rows[u];
@@ -1523,6 +1538,16 @@ extern "C" int hs_agg_shared(void* stream, const hs_col* cols, int32_t n_cols, i
     A.part_rep = out_rep;
     A.part_acc = out_acc;
     A.flags = flags;
+    {  // the replica count the geometry sized the LDS block for
+        const size_t per_replica = (size_t)geom->group_cap * (size_t)(spec->n_acc > 0 ? spec->n_acc : 1) * 8;
+        const size_t r = (geom->lds_bytes - (size_t)geom->group_cap * 16) / per_replica;
+        if (r < 1 || r > HS_WAVE || (r & (r - 1)) || (size_t)geom->group_cap * 16 + per_replica * r != geom->lds_bytes) {
+            hs_set_error("hs_agg_shared: geometry not made by hs_agg_shared_geom");
+            return HS_E_ARG;
+        }
+        A.replicas = (int32_t)r;
+        A.pad2 = 0;
+    }
     hipStream_t s = (hipStream_t)stream;
     SharedInitArgs I;
     I.keys = A.part_keys;

@@ -44,6 +44,8 @@ struct AggMainArgs {
     int64_t* part_rep;    // [n_chunks][GC]
     uint64_t* part_acc;   // [n_chunks][GC][n_acc]
     uint32_t* flags;
+    int32_t replicas;     // shared-dictionary tier: accumulator copies per slot (power of two <= 64), else 0
+    int32_t pad2;
 };
 
 // 64-bit wave shuffle-down
@@ -310,7 +312,12 @@ __device__ __forceinline__ void hs_agg_main_body(const AggMainArgs& A) {
     const int64_t us = desc.unit_begin, c0 = desc.row_begin, c1 = desc.row_end;
     // a run that has already overflowed a dictionary is going to be repeated with larger tables: later rounds of
     // workgroups only mark their chunk empty and leave
-    if (__hip_atomic_load(A.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & HS_FLAG_DICT_FULL) {
+    // (the decision must be the SAME for every lane of the workgroup - one lane reads the flag, LDS hands it round:
+    // lanes leaving on their own would let the others run on half-initialised tables and emit garbage row ids)
+    __shared__ uint32_t s_overflowed;
+    if (threadIdx.x == 0) s_overflowed = __hip_atomic_load(A.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & HS_FLAG_DICT_FULL;
+    __syncthreads();
+    if (s_overflowed) {
         for (int i = threadIdx.x; i < A.group_cap; i += blockDim.x) {
             A.part_keys[chunk * A.group_cap + i] = HS_EMPTY_KEY;
             A.part_rep[chunk * A.group_cap + i] = -1;
@@ -455,7 +462,10 @@ struct SharedCtx {
     int slot[HS_V];
     uint64_t* dkeys;
     int64_t* dreps;
-    uint64_t* acc;  // [slot][n_acc]
+    uint64_t* acc;  // [slot][replica][n_acc]; a lane uses replica lane % replicas: with few groups the lanes of a
+                    // wave would otherwise queue up on the same LDS words
+    uint32_t rep, nrep;
+    volatile int* full;  // LDS: set once the table has overflowed - a probe of a full table walks every slot
     uint32_t mask;
     int32_t n_acc;
     uint32_t err;
@@ -464,8 +474,13 @@ struct SharedCtx {
     __device__ __forceinline__ int find(const hs_col& key_col, uint64_t k, int64_t row, bool& live) {
         int s = 0;
         if (live) {
-            if constexpr (HASHED) s = hs_dict_upsert_rows(dreps, mask, key_col, k, row);
-            else s = hs_dict_upsert_word(dkeys, dreps, mask, k, row);
+            if (*full) {
+                s = -1;
+            } else {
+                if constexpr (HASHED) s = hs_dict_upsert_rows_at(dreps, mask, key_col, k, row, hs_slot_hash_strong(k));
+                else s = hs_dict_upsert_word_at(dkeys, dreps, mask, k, row, hs_slot_hash_strong(k));
+                if (s < 0) *full = 1;
+            }
             if (s < 0) {
                 err |= HS_FLAG_DICT_FULL;
                 live = false;
@@ -475,18 +490,20 @@ struct SharedCtx {
         return s;
     }
     __device__ __forceinline__ void fold(const hs_agg_spec& spec, uint32_t a, int s, bool live, uint64_t x) {
-        if (live) HS_DISPATCH_FOLD(hs_atomic_fold_lds, spec.op[a], spec.is_int[a] != 0, &acc[(uint32_t)s * (uint32_t)n_acc + a], x);
+        if (live)
+            HS_DISPATCH_FOLD(hs_atomic_fold_lds, spec.op[a], spec.is_int[a] != 0,
+                             &acc[((uint32_t)s * nrep + rep) * (uint32_t)n_acc + a], x);
     }
     template <int NA, int A, int OP, bool IS_INT>
     __device__ __forceinline__ void fold_c(int s, bool live, uint64_t x) {
-        if (live) hs_atomic_fold_lds<OP, IS_INT>(&acc[(uint32_t)s * (uint32_t)NA + (uint32_t)A], x);
+        if (live) hs_atomic_fold_lds<OP, IS_INT>(&acc[((uint32_t)s * nrep + rep) * (uint32_t)NA + (uint32_t)A], x);
     }
 };
 
 // the unit's table in global memory: same open addressing as the LDS dictionaries, claimed with global CAS
 __device__ __forceinline__ int64_t hs_unit_upsert(uint64_t* keys, int64_t* reps, uint32_t mask, bool hashed,
                                                   const hs_col& key_col, uint64_t k, int64_t row) {
-    uint32_t h = hs_slot_hash(k) & mask;
+    uint32_t h = hs_slot_hash_strong(k) & mask;
     for (uint32_t probe = 0; probe <= mask; ++probe) {
         if (hashed) {
             long long cur = __hip_atomic_load(&reps[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -526,7 +543,11 @@ __device__ __forceinline__ void hs_agg_shared_body(const AggMainArgs& A) {
     const hs_chunk desc = A.chunks[blockIdx.x];
     const int64_t us = desc.unit_begin, c0 = desc.row_begin, c1 = desc.row_end;
     // a run that has already overflowed a dictionary is going to be repeated with larger tables: stop early
-    if (__hip_atomic_load(A.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & HS_FLAG_DICT_FULL) return;
+    // (one lane reads the flag and LDS hands it round: the decision must be uniform across the workgroup)
+    __shared__ uint32_t s_overflowed;
+    if (threadIdx.x == 0) s_overflowed = __hip_atomic_load(A.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & HS_FLAG_DICT_FULL;
+    __syncthreads();
+    if (s_overflowed) return;
 
     const int64_t stride = (int64_t)nthr * HS_V;
     int64_t base = c0 + (int64_t)tid * HS_V;
@@ -536,13 +557,19 @@ __device__ __forceinline__ void hs_agg_shared_body(const AggMainArgs& A) {
         dkeys[i] = HS_EMPTY_KEY;
         dreps[i] = -1;
     }
-    for (int i = tid; i < GC * NA; i += nthr) acc[i] = hs_acc_identity(A.spec.op[i % NA], A.spec.is_int[i % NA] != 0);
+    const int R = A.replicas > 0 ? A.replicas : 1;
+    for (int i = tid; i < GC * R * NA; i += nthr) acc[i] = hs_acc_identity(A.spec.op[i % NA], A.spec.is_int[i % NA] != 0);
+    __shared__ int s_full;
+    if (tid == 0) s_full = 0;
     __syncthreads();
 
     SharedCtx ctx;
     ctx.dkeys = dkeys;
     ctx.dreps = dreps;
     ctx.acc = acc;
+    ctx.rep = tid & (uint32_t)(R - 1);
+    ctx.nrep = (uint32_t)R;
+    ctx.full = &s_full;
     ctx.mask = (uint32_t)GC - 1;
     ctx.n_acc = NA;
     ctx.err = 0;
@@ -559,8 +586,13 @@ __device__ __forceinline__ void hs_agg_shared_body(const AggMainArgs& A) {
         }
         Prog::run(A, cur, ctx);
         base = next_base;
+        if (s_full) break;  // overflowed: the run is repeated with a larger table
     }
     __syncthreads();
+    if (s_full) {
+        if (tid == 0) atomicOr(A.flags, HS_FLAG_DICT_FULL);
+        return;
+    }
 
     // merge this chunk's groups into the unit's table
     const int64_t unit = desc.unit;
@@ -578,8 +610,13 @@ __device__ __forceinline__ void hs_agg_shared_body(const AggMainArgs& A) {
             ctx.err |= HS_FLAG_DICT_FULL;
             continue;
         }
-        for (int a = 0; a < NA; ++a)
-            HS_DISPATCH_FOLD(hs_atomic_fold_global, A.spec.op[a], A.spec.is_int[a] != 0, &uacc[u * NA + a], acc[sl * NA + a]);
+        for (int a = 0; a < NA; ++a) {
+            const uint32_t op = A.spec.op[a];
+            const bool is_int = A.spec.is_int[a] != 0;
+            uint64_t v = acc[(sl * R) * NA + a];
+            for (int r = 1; r < R; ++r) v = hs_acc_fold(op, is_int, v, acc[(sl * R + r) * NA + a]);  // replicas, in order
+            HS_DISPATCH_FOLD(hs_atomic_fold_global, op, is_int, &uacc[u * NA + a], v);
+        }
     }
     if (ctx.err) atomicOr(A.flags, ctx.err);
 }

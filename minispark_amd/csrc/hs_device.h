@@ -494,12 +494,16 @@ __device__ __forceinline__ bool hs_rows_equal(const hs_col& c, int64_t r0, int64
 __device__ __forceinline__ uint32_t hs_slot_hash(uint64_t k) {
     return ((uint32_t)k ^ (uint32_t)(k >> 32)) * 0x9E3779B1u >> 12;
 }
+// the same for dictionaries with hundreds of slots (shared-dictionary tier): key words often carry their
+// information in few bits (the fp64 patterns of 1.0 .. 50.0 differ only in bits 48-62) and a single multiply
+// clusters them - with ~25 probes per lookup the kernel ran 8x slower; here the full 64-bit mixer
+__device__ __forceinline__ uint32_t hs_slot_hash_strong(uint64_t k) { return (uint32_t)(hs_mix64(k) >> 20); }
 
 // LDS dictionary, exact-word mode.  keys[] initialised to HS_EMPTY_KEY, reps[] to -1.
 // Returns the slot of `k`, inserting it if absent; -1 when the table is full.
-__device__ __forceinline__ int hs_dict_upsert_word(uint64_t* keys, int64_t* reps, uint32_t mask, uint64_t k,
-                                                   int64_t row) {
-    uint32_t h = hs_slot_hash(k) & mask;
+__device__ __forceinline__ int hs_dict_upsert_word_at(uint64_t* keys, int64_t* reps, uint32_t mask, uint64_t k,
+                                                      int64_t row, uint32_t h) {
+    h &= mask;
     for (uint32_t probe = 0; probe <= mask; ++probe) {
         uint64_t cur = *(volatile uint64_t*)&keys[h];
         if (cur == HS_EMPTY_KEY) {
@@ -515,11 +519,17 @@ __device__ __forceinline__ int hs_dict_upsert_word(uint64_t* keys, int64_t* reps
     return -1;
 }
 
+__device__ __forceinline__ int hs_dict_upsert_word(uint64_t* keys, int64_t* reps, uint32_t mask, uint64_t k,
+                                                   int64_t row) {
+    return hs_dict_upsert_word_at(keys, reps, mask, k, row, hs_slot_hash(k));
+}
+
 // LDS dictionary, hashed mode: the slot is claimed by CAS on its representative row; equality is a
 // byte compare against that row (immutable global memory, so no ordering hazard).
-__device__ __forceinline__ int hs_dict_upsert_rows(int64_t* reps, uint32_t mask, const hs_col& c, uint64_t k,
-                                                   int64_t row) {
-    uint32_t h = hs_slot_hash(k) & mask;
+__device__ __forceinline__ int hs_dict_upsert_rows_at(int64_t* reps, uint32_t mask, const hs_col& c, uint64_t k,
+                                                      int64_t row, uint32_t h) {
+    (void)k;
+    h &= mask;
     for (uint32_t probe = 0; probe <= mask; ++probe) {
         long long cur = *(volatile long long*)&reps[h];
         if (cur < 0) {
@@ -531,6 +541,10 @@ __device__ __forceinline__ int hs_dict_upsert_rows(int64_t* reps, uint32_t mask,
         h = (h + 1) & mask;
     }
     return -1;
+}
+__device__ __forceinline__ int hs_dict_upsert_rows(int64_t* reps, uint32_t mask, const hs_col& c, uint64_t k,
+                                                   int64_t row) {
+    return hs_dict_upsert_rows_at(reps, mask, c, k, row, hs_slot_hash(k));
 }
 
 // ---- accumulator folding -----------------------------------------------------------------------------

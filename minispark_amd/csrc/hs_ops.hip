@@ -390,12 +390,24 @@ __device__ __forceinline__ int64_t capped(int64_t n, const int64_t* n_dev) {
     return d < n ? d : n;
 }
 
+// Row indices come out of other kernels (compaction, dictionaries, joins): an index outside the source is a bug
+// upstream, and an unchecked read of it can fault the whole GPU - so it is checked: the row reads as zero and
+// HS_FLAG_BAD_PROGRAM is raised (one compare per element, nothing next to the random read it guards).
 template <typename T>
-__global__ void __launch_bounds__(256) k_gather_fixed(const T* src, const int64_t* idx, int64_t n, const int64_t* n_dev,
-                                                      T* dst) {
+__global__ void __launch_bounds__(256) k_gather_fixed(const T* src, int64_t src_rows, const int64_t* idx, int64_t n,
+                                                      const int64_t* n_dev, T* dst, uint32_t* flags) {
     n = capped(n, n_dev);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        dst[i] = src[idx[i]];
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx[i];
+        if (r < 0 || r >= src_rows) {
+            bad = true;
+            dst[i] = T(0);
+        } else {
+            dst[i] = src[r];
+        }
+    }
+    if (bad) atomicOr(flags, HS_FLAG_BAD_PROGRAM);
 }
 
 static unsigned grid_for(int64_t n, int per_block) {
@@ -405,61 +417,73 @@ static unsigned grid_for(int64_t n, int per_block) {
     return (unsigned)b;
 }
 
-extern "C" int hs_gather_fixed(void* stream, const void* src, int32_t elem_bytes, const int64_t* idx, int64_t n,
-                               const int64_t* n_dev, void* dst) {
+extern "C" int hs_gather_fixed(void* stream, const void* src, int32_t elem_bytes, int64_t src_rows, const int64_t* idx,
+                               int64_t n, const int64_t* n_dev, void* dst, uint32_t* flags) {
     if (n == 0) return HS_OK;
-    if (!src || !idx || !dst || n < 0) {
+    if (!src || !idx || !dst || !flags || n < 0 || src_rows < 0) {
         hs_set_error("hs_gather_fixed: bad arguments");
         return HS_E_ARG;
     }
     hipStream_t s = (hipStream_t)stream;
     const dim3 g(grid_for(n, 256)), b(256);
     switch (elem_bytes) {
-        case 1: hipLaunchKernelGGL(k_gather_fixed<uint8_t>, g, b, 0, s, (const uint8_t*)src, idx, n, n_dev, (uint8_t*)dst); break;
-        case 2: hipLaunchKernelGGL(k_gather_fixed<uint16_t>, g, b, 0, s, (const uint16_t*)src, idx, n, n_dev, (uint16_t*)dst); break;
-        case 4: hipLaunchKernelGGL(k_gather_fixed<uint32_t>, g, b, 0, s, (const uint32_t*)src, idx, n, n_dev, (uint32_t*)dst); break;
-        case 8: hipLaunchKernelGGL(k_gather_fixed<uint64_t>, g, b, 0, s, (const uint64_t*)src, idx, n, n_dev, (uint64_t*)dst); break;
+        case 1: hipLaunchKernelGGL(k_gather_fixed<uint8_t>, g, b, 0, s, (const uint8_t*)src, src_rows, idx, n, n_dev, (uint8_t*)dst, flags); break;
+        case 2: hipLaunchKernelGGL(k_gather_fixed<uint16_t>, g, b, 0, s, (const uint16_t*)src, src_rows, idx, n, n_dev, (uint16_t*)dst, flags); break;
+        case 4: hipLaunchKernelGGL(k_gather_fixed<uint32_t>, g, b, 0, s, (const uint32_t*)src, src_rows, idx, n, n_dev, (uint32_t*)dst, flags); break;
+        case 8: hipLaunchKernelGGL(k_gather_fixed<uint64_t>, g, b, 0, s, (const uint64_t*)src, src_rows, idx, n, n_dev, (uint64_t*)dst, flags); break;
         default: hs_set_error("hs_gather_fixed: elem_bytes=%d", elem_bytes); return HS_E_ARG;
     }
     HS_CHECK_LAUNCH("hs_gather_fixed");
     return HS_OK;
 }
 
-__global__ void __launch_bounds__(256) k_gather_str_lens(const hs_col src, const int64_t* idx, int64_t n,
-                                                         uint8_t* out_lens) {
+// (row indices are checked like in k_gather_fixed: one outside [0, src_rows) gathers the empty string and raises
+// HS_FLAG_BAD_PROGRAM)
+__global__ void __launch_bounds__(256) k_gather_str_lens(const hs_col src, int64_t src_rows, const int64_t* idx, int64_t n,
+                                                         uint8_t* out_lens, uint32_t* flags) {
+    bool bad = false;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = idx ? idx[i] : i;
-        out_lens[i] = src.fixed_len >= 0 ? (uint8_t)src.fixed_len : src.lens[r];
+        if (r < 0 || r >= src_rows) {
+            bad = true;
+            out_lens[i] = 0;
+        } else {
+            out_lens[i] = src.fixed_len >= 0 ? (uint8_t)src.fixed_len : src.lens[r];
+        }
     }
+    if (bad) atomicOr(flags, HS_FLAG_BAD_PROGRAM);
 }
-__global__ void __launch_bounds__(256) k_gather_str_bytes(const hs_col src, const int64_t* idx, int64_t n,
+__global__ void __launch_bounds__(256) k_gather_str_bytes(const hs_col src, int64_t src_rows, const int64_t* idx, int64_t n,
                                                           const int64_t* out_offs, uint8_t* out_data) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const HsStr s = hs_str_at(src, idx ? idx[i] : i);
+        const int64_t r = idx ? idx[i] : i;
+        if (r < 0 || r >= src_rows) continue;  // flagged (and given length 0) by k_gather_str_lens
+        const HsStr s = hs_str_at(src, r);
         uint8_t* d = out_data + out_offs[i];
         for (uint32_t k = 0; k < s.len; ++k) d[k] = s.p[k];
     }
 }
 
-extern "C" int hs_gather_str_lens(void* stream, const hs_col* src, const int64_t* idx, int64_t n, uint8_t* out_lens) {
+extern "C" int hs_gather_str_lens(void* stream, const hs_col* src, int64_t src_rows, const int64_t* idx, int64_t n,
+                                  uint8_t* out_lens, uint32_t* flags) {
     if (n == 0) return HS_OK;
-    if (!src || src->kind != HS_STR || !out_lens || n < 0) {
+    if (!src || src->kind != HS_STR || !out_lens || !flags || n < 0 || src_rows < 0) {
         hs_set_error("hs_gather_str_lens: bad arguments");
         return HS_E_ARG;
     }
-    hipLaunchKernelGGL(k_gather_str_lens, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, *src, idx, n,
-                       out_lens);
+    hipLaunchKernelGGL(k_gather_str_lens, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, *src, src_rows, idx, n,
+                       out_lens, flags);
     HS_CHECK_LAUNCH("hs_gather_str_lens");
     return HS_OK;
 }
-extern "C" int hs_gather_str_bytes(void* stream, const hs_col* src, const int64_t* idx, int64_t n,
+extern "C" int hs_gather_str_bytes(void* stream, const hs_col* src, int64_t src_rows, const int64_t* idx, int64_t n,
                                    const int64_t* out_offs, uint8_t* out_data) {
     if (n == 0) return HS_OK;
-    if (!src || src->kind != HS_STR || !out_offs || n < 0) {  // out_data may be NULL when every string is empty
+    if (!src || src->kind != HS_STR || !out_offs || n < 0 || src_rows < 0) {  // out_data may be NULL when every string is empty
         hs_set_error("hs_gather_str_bytes: bad arguments");
         return HS_E_ARG;
     }
-    hipLaunchKernelGGL(k_gather_str_bytes, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, *src, idx, n,
+    hipLaunchKernelGGL(k_gather_str_bytes, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, *src, src_rows, idx, n,
                        out_offs, out_data);
     HS_CHECK_LAUNCH("hs_gather_str_bytes");
     return HS_OK;

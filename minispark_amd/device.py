@@ -434,8 +434,8 @@ class Device:
         if col.kind == hs.STR and col.fixed_len in (1, 2, 4, 8):
             width = col.fixed_len
             data = out if out is not None else self.empty(n * width, torch.uint8)
-            hs.check(self.lib.hs_gather_fixed(self.stream, col.data.data_ptr(), width, idx.data_ptr(), n, n_dev_ptr,
-                                              data.data_ptr()), "hs_gather_fixed")
+            hs.check(self.lib.hs_gather_fixed(self.stream, col.data.data_ptr(), width, col.n, idx.data_ptr(), n, n_dev_ptr,
+                                              data.data_ptr(), self.flags.data_ptr()), "hs_gather_fixed")
             return DCol(hs.STR, data, n, lens=self.const_lens(width, n), offs=None, fixed_len=width)
         if col.kind == hs.STR:
             if n_dev is not None:
@@ -444,8 +444,8 @@ class Device:
                 self.rec.poisoned = True  # payload size of variable-length strings is learnt on the host
             src = col.as_hs()
             lens = self.empty(n, torch.uint8)
-            hs.check(self.lib.hs_gather_str_lens(self.stream, C.byref(src), idx.data_ptr(), n, lens.data_ptr()),
-                     "hs_gather_str_lens")
+            hs.check(self.lib.hs_gather_str_lens(self.stream, C.byref(src), col.n, idx.data_ptr(), n, lens.data_ptr(),
+                                                 self.flags.data_ptr()), "hs_gather_str_lens")
             offs = self.empty(n + 1, torch.int64)
             minmax = self.empty(2, torch.int32)
             ws = self.workspace(self.lib.hs_scan_ws_bytes(n))
@@ -454,15 +454,15 @@ class Device:
             total = int(offs[n].item()) if n > 0 else 0
             mn, mx = minmax.tolist()
             data = self.empty(total, torch.uint8)
-            hs.check(self.lib.hs_gather_str_bytes(self.stream, C.byref(src), idx.data_ptr(), n, offs.data_ptr(),
+            hs.check(self.lib.hs_gather_str_bytes(self.stream, C.byref(src), col.n, idx.data_ptr(), n, offs.data_ptr(),
                                                   data.data_ptr()), "hs_gather_str_bytes")
             fixed = mn if (n > 0 and mn == mx) else (0 if n == 0 else -1)
             return DCol(hs.STR, data, n, lens=lens, offs=None if fixed >= 0 else offs, fixed_len=fixed)
         if col.kind == hs.STR and out is not None:
             raise SlabUnsupported("variable-length string keys cannot be written into a fixed-size exchange slab")
         out = out if out is not None else self.empty(n, _TORCH_DTYPE[col.kind])
-        hs.check(self.lib.hs_gather_fixed(self.stream, col.data.data_ptr(), hs.KIND_BYTES[col.kind], idx.data_ptr(), n,
-                                          n_dev_ptr, out.data_ptr()), "hs_gather_fixed")
+        hs.check(self.lib.hs_gather_fixed(self.stream, col.data.data_ptr(), hs.KIND_BYTES[col.kind], col.n, idx.data_ptr(),
+                                          n, n_dev_ptr, out.data_ptr(), self.flags.data_ptr()), "hs_gather_fixed")
         return DCol(col.kind, out, n)
 
     def const_lens(self, width: int, n: int) -> torch.Tensor:
@@ -597,6 +597,9 @@ class Device:
                     self._partial_prepared.pop(next(iter(self._partial_prepared)))
                 self._partial_prepared[key] = prep
         p = prep
+        if self.rec is not None:
+            # a recording replays raw pointers into this entry's buffers: it must outlive the cache's eviction
+            self.rec.keep.append(p)
         if tail:
             # the unit combine writes the partial rows (stored kinds) straight into the slab: no pack, no gather
             hs.check(self.lib.hs_agg_partial_slab(

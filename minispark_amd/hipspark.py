@@ -145,9 +145,9 @@ SIGNATURES: dict[str, tuple] = {
     "hs_str_offsets": (C.c_int, [_P, _P, _I64, _P, _P, _P]),
     "hs_eval": (C.c_int, [_P, _COLP, _I32, _PROGP, _P, _I64, _P, C.POINTER(_P), C.POINTER(_I32), _I32, _P]),
     "hs_compact": (C.c_int, [_P, _P, _I64, _P, _P, _P]),
-    "hs_gather_fixed": (C.c_int, [_P, _P, _I32, _P, _I64, _P, _P]),
-    "hs_gather_str_lens": (C.c_int, [_P, _COLP, _P, _I64, _P]),
-    "hs_gather_str_bytes": (C.c_int, [_P, _COLP, _P, _I64, _P, _P]),
+    "hs_gather_fixed": (C.c_int, [_P, _P, _I32, _I64, _P, _I64, _P, _P, _P]),
+    "hs_gather_str_lens": (C.c_int, [_P, _COLP, _I64, _P, _I64, _P, _P]),
+    "hs_gather_str_bytes": (C.c_int, [_P, _COLP, _I64, _P, _I64, _P, _P]),
     "hs_concat_lens": (C.c_int, [_P, _COLP, _I32, _I64, _P, _P]),
     "hs_concat_bytes": (C.c_int, [_P, _COLP, _I32, _I64, _P, _P]),
     "hs_agg_partial_geom": (C.c_int, [C.POINTER(_I64), _I64, _I32, _I32, _GEOMP]),

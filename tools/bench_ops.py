@@ -49,10 +49,10 @@ ms = timed(lambda: lib.hs_compact(dev.stream, mask.data_ptr(), N, sel.data_ptr()
 k = int(cnt.item())
 report("A3 hs_compact (50% selectivity)", ms, 2 * N + 8 * k, "reads mask twice, writes 8 B per kept row")
 out4 = dev.empty(N, torch.int32)
-ms = timed(lambda: lib.hs_gather_fixed(dev.stream, i32.data_ptr(), 4, sel.data_ptr(), k, None, out4.data_ptr()))
+ms = timed(lambda: lib.hs_gather_fixed(dev.stream, i32.data_ptr(), 4, N, sel.data_ptr(), k, None, out4.data_ptr(), dev.flags.data_ptr()))
 report("A3 hs_gather_fixed 4 B (ascending index list)", ms, k * (8 + 4 + 4))
 perm = torch.randperm(N, device="cuda", generator=g)
-ms = timed(lambda: lib.hs_gather_fixed(dev.stream, i32.data_ptr(), 4, perm.data_ptr(), N, None, out4.data_ptr()))
+ms = timed(lambda: lib.hs_gather_fixed(dev.stream, i32.data_ptr(), 4, N, perm.data_ptr(), N, None, out4.data_ptr(), dev.flags.data_ptr()))
 report("   hs_gather_fixed 4 B (random permutation)", ms, N * (8 + 4 + 4), "random 4 B reads: sector-bound")
 
 # A4 expression evaluation (generic interpreter kernel, one row per lane)
