@@ -610,10 +610,25 @@ __device__ __forceinline__ int hs_merge_small_core(const In& in, const hs_agg_sp
             opos += c;
         }
         __syncthreads();
+        // Position of a row inside its block = number of VALID rows of the block before it.  The rows of a block
+        // are contiguous in the input but not all valid (a row whose key did not fit a full dictionary, an unused
+        // slab row): r - first_row would leave holes and push later rows out of the block's range.  Exclusive
+        // count of valid rows before every row (kept in rrank[], which step 3 overwrites): thread ranges + one scan.
+        const int rper = (n + nthr - 1) / nthr;
+        const int r0 = tid * rper < n ? tid * rper : n, r1 = (r0 + rper) < n ? (r0 + rper) : n;
+        int vmine = 0;
+        for (int r = r0; r < r1; ++r) vmine += rslot[r] >= 0;
+        int vtotal;
+        int vrun = hs_block_scan_incl(vmine, s_part, vtotal) - vmine;
+        for (int r = r0; r < r1; ++r) {
+            rrank[r] = vrun;
+            vrun += rslot[r] >= 0;
+        }
+        __syncthreads();
         for (int r = tid; r < n; r += nthr) {
             if (rslot[r] < 0) continue;
             const int o = (int)in.order(r);
-            seq[ocnt[o] + (r - ofirst[o])] = r;
+            seq[ocnt[o] + (rrank[r] - rrank[ofirst[o]])] = r;
         }
         __syncthreads();
     }

@@ -350,3 +350,53 @@ def test_group_build_lists_are_ascending_whatever_their_length(dev, n, groups):
         seen += len(rows)
     assert seen == n
     assert dev.read_flags() == 0
+
+
+@pytest.mark.parametrize("cap,holes", [(16, False), (16, True), (64, True), (256, False)])
+def test_ordered_merge_survives_invalid_rows_and_full_dictionaries(dev, cap, holes):
+    """hs_agg_merge with order keys (block ids): rows that are padding (order -1) or whose key did not fit a full
+    dictionary leave holes inside a block's row range.  The visiting sequence must still be a permutation of the
+    valid rows (it once assumed position = row - first row of the block: with holes the representatives of some
+    groups were never written and stale indices reached the gathers).  With a dictionary large enough the result
+    equals a sequential fold in (block, row) order; with a small one only HS_FLAG_DICT_FULL may be raised."""
+    import torch
+
+    from minispark_amd import hipspark as hs
+    from minispark_amd.constants import ColumnType as T
+    from minispark_amd.device import DBatch, DCol
+    from minispark_amd.sql import AggCol, Col
+
+    rng = _rng(cap + holes)
+    blocks, per_block, groups = 7, 24, 50
+    n = blocks * per_block
+    keys = rng.integers(0, groups, n).astype(np.int32)
+    for b in range(blocks):  # a key occurs at most once per block (like partial rows of a unit)
+        keys[b * per_block: (b + 1) * per_block] = rng.permutation(groups)[:per_block]
+    vals = rng.normal(0, 100, n).astype(np.float32)
+    order = np.repeat(rng.permutation(blocks), per_block).astype(np.int64)  # blocks not in id order
+    if holes:
+        order[rng.random(n) < 0.3] = -1
+    batch = DBatch([("k", T.INTEGER), ("v", T.FLOAT)], [DCol(hs.I32, dev.to_device(keys, torch.int32), n),
+                                                        DCol(hs.F32, dev.to_device(vals, torch.float32), n)], n,
+                   order=dev.to_device(order, torch.int64), total_units=blocks)
+    dev.reset_flags()
+    out = dev.aggregate_merge(batch, [AggCol("sum", Col("v"))], [("k", T.INTEGER), ("v", T.FLOAT)], cap)
+    torch.cuda.synchronize()
+    flags = dev.read_flags()
+    valid = order >= 0
+    n_groups = len(np.unique(keys[valid]))
+    assert not flags & hs.FLAG_BAD_PROGRAM, "a group was left without its representative row"
+    ng = int(out.nrows_dev[0].item())
+    got_keys = out.cols[0].data[:ng].cpu().numpy()
+    if n_groups > cap:
+        assert flags & hs.FLAG_DICT_FULL and ng <= cap and set(got_keys.tolist()) <= set(keys[valid].tolist())
+        dev.reset_flags()
+        return
+    assert flags == 0 and ng == n_groups
+    got = dict(zip(got_keys.tolist(), out.cols[1].data[:ng].cpu().numpy().tolist()))
+    for key in np.unique(keys[valid]):
+        rows = [r for r in np.argsort(order, kind="stable") if valid[r] and keys[r] == key]  # (block id, row) order
+        acc = 0.0
+        for r in rows:
+            acc += float(vals[r])
+        assert got[int(key)] == acc, key
