@@ -81,6 +81,23 @@ class ExecutionEngine(AbstractContextManager, ABC):
         return parse_sql(query, self)
 
 
+_UID = iter(range(1, 1 << 62))
+
+
+def _uid(obj: Any) -> int:
+    """Identity token for cache keys.  id() is NOT one: plans, tasks and tables are freed when they fall out of the
+    engine's caches and a later object can get the same id - together with recycled device addresses that made a
+    recorded run of one query answer another (fuzz seed 467).  The token lives on the object and is never reused."""
+    token = getattr(obj, "_hs_uid", None)
+    if token is None:
+        token = next(_UID)
+        try:
+            obj._hs_uid = token
+        except AttributeError:  # an object without a __dict__: fall back to its id (kept alive by its cache entry)
+            return id(obj)
+    return token
+
+
 def _cls(obj: Any) -> str:
     return type(obj).__name__
 
@@ -167,7 +184,7 @@ class HipExecutionEngine(ExecutionEngine):
         cap = self.group_cap_hint
         if cap > PRIVATE_TIER_MAX:
             return False
-        n_acc = self._distinct_accs.get(id(task))
+        n_acc = self._distinct_accs.get(_uid(task))
         if n_acc is None:
             from .lowering import lower_aggregate  # noqa: PLC0415
 
@@ -175,7 +192,7 @@ class HipExecutionEngine(ExecutionEngine):
                 n_acc = len(lower_aggregate(batch.schema, batch.kinds, pending, task.group_by_column, task.agg_columns).acc_ops)
             except Exception:  # noqa: BLE001 - whatever lowering objects to is reported by the tier that runs it
                 n_acc = len(task.agg_columns)
-            self._distinct_accs[id(task)] = n_acc
+            self._distinct_accs[_uid(task)] = n_acc
         return cap * 16 + cap * max(n_acc, 1) * 256 * 8 <= 64 * 1024
 
     def _select_caps(self, plan: Any) -> None:
@@ -328,8 +345,8 @@ class HipExecutionEngine(ExecutionEngine):
             plan._hs_scan_keys = scans
         for key in scans:
             t = self._tables.get(key)
-            tables.append((id(t), tuple(sorted((cid, c.data.data_ptr()) for cid, c in t.columns.items()))) if t else None)
-        return (id(plan), tuple(tables), self.group_cap_hint, self.merge_cap_hint, len(self._global_partial),
+            tables.append((_uid(t), tuple(sorted((cid, c.data.data_ptr()) for cid, c in t.columns.items()))) if t else None)
+        return (_uid(plan), tuple(tables), self.group_cap_hint, self.merge_cap_hint, len(self._global_partial),
                 len(self._global_merge))
 
     def _replay(self, rec: Any) -> list[JobResult] | None:
@@ -364,7 +381,7 @@ class HipExecutionEngine(ExecutionEngine):
             node = node.parent_task
             if (node is None or _cls(node) == "VoidTask") and stack:
                 node = stack.pop()
-        key = (id(full_task), tuple(stamps))
+        key = (_uid(full_task), tuple(stamps))
         hit = self._plans.get(key)
         if hit is not None and hit[0] is full_task:
             plan = hit[1]
@@ -429,8 +446,8 @@ class HipExecutionEngine(ExecutionEngine):
                 batch = self._project(batch, pending, task)
                 pending = []
             elif tname == "AggregateTask":
-                if task.before_shuffle and (id(task) in self._global_partial or self.group_cap_hint > SHARED_TIER_MAX):
-                    self._global_partial.add(id(task))
+                if task.before_shuffle and (_uid(task) in self._global_partial or self.group_cap_hint > SHARED_TIER_MAX):
+                    self._global_partial.add(_uid(task))
                     batch = self.dev.aggregate_partial_global(batch, pending, task.group_by_column, task.agg_columns,
                                                               task.inferred_schema)
                     batch.partitioned = self.dist is not None
@@ -440,9 +457,9 @@ class HipExecutionEngine(ExecutionEngine):
                     try:
                         batch = self.dev.aggregate_partial(batch, pending, task.group_by_column, task.agg_columns,
                                                            task.inferred_schema, self.group_cap_hint,
-                                                           cache_key=(id(task), "shared"), shared=True)
+                                                           cache_key=(_uid(task), "shared"), shared=True)
                     except TierExceeded:
-                        self._global_partial.add(id(task))
+                        self._global_partial.add(_uid(task))
                         batch = self.dev.aggregate_partial_global(batch, pending, task.group_by_column,
                                                                   task.agg_columns, task.inferred_schema)
                     batch.partitioned = self.dist is not None
@@ -456,34 +473,34 @@ class HipExecutionEngine(ExecutionEngine):
                             raise NotImplementedError("multi-GPU aggregation needs a block-partitioned input")
                         slab_rows = max(batch.n_units, max_local_units(batch.total_units, self.world)) * self.group_cap_hint
                     if (self.short_tail_enabled and getattr(task, "_hs_short_tail", False)
-                            and id(task) not in self._no_short_tail):
+                            and _uid(task) not in self._no_short_tail):
                         try:
                             batch = self.dev.aggregate_partial(batch, pending, task.group_by_column, task.agg_columns,
                                                                task.inferred_schema, self.group_cap_hint,
-                                                               cache_key=(id(task), "tail"), slab_rows=slab_rows, tail=True)
-                            batch.tail["task_id"] = id(task)
+                                                               cache_key=(_uid(task), "tail"), slab_rows=slab_rows, tail=True)
+                            batch.tail["task_id"] = _uid(task)
                             pending = []
                             continue
                         except (SlabUnsupported, TierExceeded):
-                            self._no_short_tail.add(id(task))
+                            self._no_short_tail.add(_uid(task))
                     try:
                         batch = self.dev.aggregate_partial(batch, pending, task.group_by_column, task.agg_columns,
                                                            task.inferred_schema, self.group_cap_hint,
-                                                           cache_key=id(task), slab_rows=slab_rows)
+                                                           cache_key=_uid(task), slab_rows=slab_rows)
                     except SlabUnsupported:
                         # e.g. variable-length string keys: partial rows go through the generic all-to-all
                         batch = self.dev.aggregate_partial(batch, pending, task.group_by_column, task.agg_columns,
                                                            task.inferred_schema, self.group_cap_hint,
-                                                           cache_key=(id(task), "noslab"))
+                                                           cache_key=(_uid(task), "noslab"))
                     except TierExceeded:
                         try:  # private tables do not fit (many aggregates): the shared dictionary may
                             if not self.shared_tier_enabled:
                                 raise
                             batch = self.dev.aggregate_partial(batch, pending, task.group_by_column, task.agg_columns,
                                                                task.inferred_schema, max(self.group_cap_hint, 16),
-                                                               cache_key=(id(task), "shared"), shared=True)
+                                                               cache_key=(_uid(task), "shared"), shared=True)
                         except TierExceeded:
-                            self._global_partial.add(id(task))
+                            self._global_partial.add(_uid(task))
                             batch = self.dev.aggregate_partial_global(batch, pending, task.group_by_column,
                                                                       task.agg_columns, task.inferred_schema)
                     batch.partitioned = self.dist is not None and batch.slab is None
@@ -492,7 +509,7 @@ class HipExecutionEngine(ExecutionEngine):
                     batch = self._materialise(batch, pending)
                     pending = []
                     was_partitioned = batch.partitioned
-                    use_global = (id(task) in self._global_merge or self._merge_overflowed
+                    use_global = (_uid(task) in self._global_merge or self._merge_overflowed
                                   or (batch.partitioned and batch.order is not None))
                     if not use_global:
                         try:
@@ -502,7 +519,7 @@ class HipExecutionEngine(ExecutionEngine):
                             use_global = True
                     if use_global:
                         if not was_partitioned:
-                            self._global_merge.add(id(task))
+                            self._global_merge.add(_uid(task))
                         batch = self.dev.aggregate_merge_global(batch, task.agg_columns, task.inferred_schema)
                     batch.partitioned = was_partitioned
             else:
@@ -844,7 +861,7 @@ class HipExecutionEngine(ExecutionEngine):
         try:
             raw, nrows, flags = self.dev.aggregate_finish(tail, gathered, world, merge.agg_columns, merge.inferred_schema,
                                                           project, schema, self.merge_cap_hint, n_order,
-                                                          cache_key=id(merge))
+                                                          cache_key=_uid(merge))
         except TierExceeded:
             # too many partial rows for one workgroup's LDS: this query takes the general path from now on
             self._no_short_tail.add(tail.get("task_id"))
