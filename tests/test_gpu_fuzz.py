@@ -152,7 +152,10 @@ def engine():
         yield e
 
 
-@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("HIPSPARK_FUZZ_SEEDS", "48")))))
+_FIRST = int(__import__("os").environ.get("HIPSPARK_FUZZ_FIRST", "0"))
+
+
+@pytest.mark.parametrize("seed", list(range(_FIRST, _FIRST + int(__import__("os").environ.get("HIPSPARK_FUZZ_SEEDS", "48")))))
 def test_random_query_matches_oracle(engine, tmp_path, seed):
     from minispark_amd.dataframe import DataFrame
     from minispark_amd.sql import Col, Functions, Lit
@@ -188,3 +191,36 @@ def test_random_query_matches_oracle(engine, tmp_path, seed):
         assert_rows_match(run(engine).collect(), want, max_ulps=1)
     finally:
         engine.short_tail_enabled = not engine.short_tail_enabled
+
+
+@pytest.mark.parametrize("seed", [3, 11, 19, 27, 40, 41, 52, 77])
+def test_random_query_matches_oracle_on_bigger_tables(engine, tmp_path, seed):
+    """The same random queries over 40 000-row tables in 6 blocks: several chunks per unit, dictionaries that grow
+    through retries, the shared-dictionary tier, multi-block joins."""
+    from minispark_amd.dataframe import DataFrame
+    from minispark_amd.sql import Col, Functions, Lit
+    from oracle.py_engine import run_query
+    from tests.queries import api_namespace
+
+    rng = random.Random(5000 + seed)
+    t1, t2 = tmp_path / "a.bin", tmp_path / "b.bin"
+    make_table(t1, rng, 40_000, blocks=6)
+    make_table(t2, rng, 300, blocks=2)
+
+    def run(build_engine):
+        api = api_namespace(lambda: DataFrame(build_engine), Col, Functions, Lit)
+        return random_query(random.Random(seed), api, str(t1), str(t2))
+
+    try:
+        want = run_query(run(object()).task)
+        want_err = None
+    except Exception as e:  # noqa: BLE001
+        want, want_err = None, type(e).__name__
+    frame = run(engine)
+    if want_err is not None:
+        with pytest.raises(Exception) as info:
+            frame.collect()
+        assert type(info.value).__name__ == want_err
+        return
+    for _ in range(2):
+        assert_rows_match(frame.collect(), want, max_ulps=1)
