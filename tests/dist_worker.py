@@ -31,12 +31,23 @@ def main() -> None:
     from tests.queries import api_namespace, case_by_name
 
     constants.SHUFFLE_FOLDER = Path(out_path).parent / f"shuffle_r{rank}"
-    golden = load_golden(case_name)
-    case = case_by_name(case_name)
+    if case_name.startswith("fuzz:"):
+        # a random query of tests/test_gpu_fuzz.py over tables the parent test wrote next to out_path
+        import random
+
+        from tests.test_gpu_fuzz import random_query
+
+        seed = int(case_name.split(":")[1])
+        t1, t2 = Path(out_path).parent / "a.bin", Path(out_path).parent / "b.bin"
+        build = lambda api: random_query(random.Random(seed), api, str(t1), str(t2))  # noqa: E731
+    else:
+        golden = load_golden(case_name)
+        case = case_by_name(case_name)
+        build = lambda api: case.build(api, golden["paths"])  # noqa: E731
     with HipExecutionEngine(device=int(os.environ.get("LOCAL_RANK", "0"))) as engine:
         engine.enable_distributed(dist)
         api = api_namespace(lambda: DataFrame(engine), Col, Functions, Lit)
-        frame = case.build(api, golden["paths"])
+        frame = build(api)
         rows = None
         for _ in range(4):  # later runs exercise the plan / launch caches and the recorded replay
             rows = frame.collect()

@@ -54,3 +54,47 @@ def test_world_n_matches_reference(tmp_path, case_name, world):
                     row[k] = datetime.fromisoformat(row[k])
     flips = assert_rows_match(rows, golden, max_ulps=1)
     assert flips <= (2 if case_name == "many_groups" else 0)  # shared tier: hardware-order additions
+
+
+@pytest.mark.parametrize("seed,world", [(1, 2), (4, 2), (9, 3), (13, 2), (21, 2), (30, 3), (34, 2), (45, 2)])
+def test_random_queries_on_n_ranks_match_the_oracle(tmp_path, seed, world):
+    """Random queries of the fuzz generator (joins, filters, projections, GROUP BY on int / string / computed keys)
+    over 5-block tables, N ranks over gloo on the one GPU: every exchange form against the CPU oracle."""
+    import random
+
+    from minispark_amd.dataframe import DataFrame
+    from minispark_amd.sql import Col, Functions, Lit
+    from oracle.py_engine import run_query
+    from tests.queries import api_namespace
+    from tests.test_gpu_fuzz import make_table, random_query
+
+    rng = random.Random(7000 + seed)
+    make_table(tmp_path / "a.bin", rng, 4000, blocks=5)
+    make_table(tmp_path / "b.bin", rng, 200, blocks=3)
+    api = api_namespace(lambda: DataFrame(object()), Col, Functions, Lit)
+    try:
+        want = run_query(random_query(random.Random(seed), api, str(tmp_path / "a.bin"), str(tmp_path / "b.bin")).task)
+    except Exception:  # noqa: BLE001 - queries that must raise are the single-process fuzz test's business
+        pytest.skip("the oracle raises for this seed")
+    port = _free_port()
+    out = tmp_path / "rows.json"
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(ROOT / "tests" / "dist_worker.py"), f"fuzz:{seed}", str(out), "gloo"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    if any(p.returncode != 0 for p in procs):
+        report = "\n".join(f"--- rank {r} (exit {p.returncode}) ---\n{log[-2500:]}" for r, (p, log) in enumerate(zip(procs, logs)))
+        raise AssertionError(report)
+    from datetime import datetime
+
+    rows = json.loads(out.read_text())
+    for row in rows:
+        for k, v in row.items():
+            if isinstance(v, str) and v.startswith(("0x", "-0x")):
+                row[k] = float.fromhex(v)
+            elif want and isinstance(want[0].get(k), datetime):
+                row[k] = datetime.fromisoformat(v)
+    assert_rows_match(rows, want, max_ulps=1)
