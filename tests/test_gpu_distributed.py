@@ -56,7 +56,13 @@ def test_world_n_matches_reference(tmp_path, case_name, world):
     assert flips <= (2 if case_name == "many_groups" else 0)  # shared tier: hardware-order additions
 
 
-@pytest.mark.parametrize("seed,world", [(1, 2), (4, 2), (9, 3), (13, 2), (21, 2), (30, 3), (34, 2), (45, 2)])
+_DIST_FUZZ = [(1, 2), (4, 2), (9, 3), (13, 2), (21, 2), (30, 3), (34, 2), (45, 2)]
+if os.environ.get("HIPSPARK_DIST_FUZZ"):  # "first:last" - a wider hunt than the default sample
+    _lo, _hi = (int(v) for v in os.environ["HIPSPARK_DIST_FUZZ"].split(":"))
+    _DIST_FUZZ = [(s, 2 + s % 2) for s in range(_lo, _hi)]
+
+
+@pytest.mark.parametrize("seed,world", _DIST_FUZZ)
 def test_random_queries_on_n_ranks_match_the_oracle(tmp_path, seed, world):
     """Random queries of the fuzz generator (joins, filters, projections, GROUP BY on int / string / computed keys)
     over 5-block tables, N ranks over gloo on the one GPU: every exchange form against the CPU oracle."""
