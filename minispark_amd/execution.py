@@ -27,12 +27,12 @@ import uuid
 from abc import ABC, abstractmethod
 from contextlib import AbstractContextManager
 from pathlib import Path
-from typing import Any, Iterable, Iterator, Sequence
+from typing import Any, Iterator, Sequence
 
 from . import constants
-from .constants import ColumnType, Row, Schema
+from .constants import Row, Schema
 from .io import BlockFile
-from .jobs import JobResult, OutputFile, ResultFile
+from .jobs import JobResult, ResultFile
 
 
 class ExecutionError(Exception):

@@ -20,7 +20,6 @@ from typing import Any
 import numpy as np
 import torch
 
-from . import hipspark as hs
 from .constants import ColumnType, Schema
 from .device import FILE_KIND, DBatch, DCol, Device
 from .io import BlockFile
