@@ -111,3 +111,64 @@ def test_counts_and_integer_sums_are_exact_at_scale(engine, tmp_path):
         sel = v[k == key]
         r = rows[key]
         assert (r["count"], r["s"], r["mn"], r["mx"]) == (int(cnt[key]), int(sums[key]), int(sel.min()), int(sel.max()))
+
+
+def _wide_table(path, n, blocks, seed):
+    from minispark_amd.constants import ColumnType as T
+    from minispark_amd.io import BlockFile, StrCol
+
+    rng = np.random.default_rng(seed)
+    cols = {
+        "h": rng.integers(0, int(rng.choice([40, 300, 3000, 9000])), n).astype(np.int32),
+        "u": [WORDS[i] for i in rng.integers(0, int(rng.choice([30, 400])), n)],
+        "f": rng.normal(0, 1e3, n).astype(np.float32),
+        "g": rng.uniform(0, 1, n).astype(np.float32),
+        "i": rng.integers(-10**5, 10**5, n).astype(np.int32),
+    }
+    schema = [("h", T.INTEGER), ("u", T.STRING), ("f", T.FLOAT), ("g", T.FLOAT), ("i", T.INTEGER)]
+    bounds = sorted({0, n, *rng.integers(1, n, blocks - 1).tolist()})
+    out = []
+    for lo, hi in zip(bounds, bounds[1:]):
+        out.append([cols["h"][lo:hi], StrCol.from_strings(cols["u"][lo:hi]), cols["f"][lo:hi], cols["g"][lo:hi], cols["i"][lo:hi]])
+    BlockFile(path).write_raw_blocks(schema, out)
+
+
+def _wide_query(rng: random.Random, api, path):
+    C, F, Lit = api.Col, api.F, api.Lit
+    df = api.DataFrame().table(path)
+    if rng.random() < 0.5:
+        df = df.filter(rng.choice([C("g") > 0.3, C("i") % 3 != 0, (C("f") < 500.0) & (C("g") <= 0.9), C("u") >= "key-0100"]))
+    key = rng.choice(["h", "u", "m", "hu"])
+    if key == "m":
+        df = df.select((C("h") % rng.choice([17, 97, 1013])).alias("m"), C("f"), C("g"), C("i"))
+    elif key == "hu":
+        df = df.select((C("u") + "/" + C("u")).alias("hu"), C("f"), C("g"), C("i"))
+    pool = [lambda: F.sum(C("f")), lambda: F.sum(C("i")), lambda: F.min(C("f")), lambda: F.max(C("i")), lambda: F.avg(C("g")),
+            lambda: F.sum(C("f") * (Lit(1) - C("g"))), lambda: F.min(C("i")), lambda: F.max(C("g"))]
+    aggs = [fn().alias(f"a{n}") for n, fn in enumerate(rng.sample(pool, rng.randint(1, 4)))]
+    if rng.random() < 0.7:
+        aggs.append(F.count())
+    return df.group_by(C(key)).agg(*aggs)
+
+
+_WIDE_FIRST = int(__import__("os").environ.get("HIPSPARK_WIDE_FIRST", "0"))
+
+
+@pytest.mark.parametrize("seed", list(range(_WIDE_FIRST, _WIDE_FIRST + int(__import__("os").environ.get("HIPSPARK_WIDE_SEEDS", "12")))))
+def test_random_many_group_queries_match_the_oracle(engine, tmp_path, seed):
+    """Random GROUP BY queries whose keys have tens to thousands of values (int, long strings, computed int and
+    computed string keys), random filters and aggregates, ragged blocks: private tables, the shared dictionary and
+    the HBM tier, whichever the capacities end up choosing, against the oracle."""
+    from minispark_amd.dataframe import DataFrame
+    from minispark_amd.sql import Col, Functions, Lit
+    from oracle.py_engine import run_query
+    from tests.queries import api_namespace
+
+    rng = random.Random(900 + seed)
+    path = tmp_path / "w.bin"
+    _wide_table(path, rng.choice([5_000, 20_000, 50_000]), rng.choice([1, 3, 7]), seed)
+    want = run_query(_wide_query(random.Random(seed), api_namespace(lambda: DataFrame(object()), Col, Functions, Lit), str(path)).task)
+    frame = _wide_query(random.Random(seed), api_namespace(lambda: DataFrame(engine), Col, Functions, Lit), str(path))
+    for _ in range(2):
+        flips = assert_rows_match(frame.collect(), want, max_ulps=1)
+        assert flips <= 3
