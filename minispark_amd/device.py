@@ -587,7 +587,11 @@ class Device:
         cap = max(1, int(group_cap_hint))
         key = None
         if cache_key is not None:
-            key = (cache_key, cap, batch.nrows, tuple((c.data.data_ptr(), c.n) for c in batch.cols),
+            # every pointer the prepared column table holds: a computed string column is rebuilt per run and the
+            # allocator may hand back the same data block with different lens / offs blocks
+            key = (cache_key, cap, batch.nrows,
+                   tuple((c.kind, c.fixed_len, c.data.data_ptr(), c.n, c.lens.data_ptr() if c.lens is not None else 0,
+                          c.offs.data_ptr() if c.offs is not None else 0) for c in batch.cols),
                    len(batch.unit_rows), batch.unit_rows[-1], slab_rows, tail, shared)
         prep = self._partial_prepared.get(key) if key is not None else None
         if prep is None:
