@@ -861,7 +861,8 @@ class Device:
         cap = 4
         while cap < cap_hint:
             cap *= 2
-        key = (cache_key, cap, world, gathered.data_ptr(), n_order, tail["slab"].data_ptr())
+        key = (cache_key, cap, world, gathered.data_ptr(), n_order, tail["slab"].data_ptr(),
+               tail["desc"].slab_rows, tail["desc"].stride)
         prep = self._finish_prepared.get(key) if cache_key is not None else None
         if prep is None:
             prep = self._prepare_finish(tail, agg_columns, merged_schema, project, out_schema, cap)

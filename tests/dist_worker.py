@@ -40,6 +40,14 @@ def main() -> None:
         seed = int(case_name.split(":")[1])
         t1, t2 = Path(out_path).parent / "a.bin", Path(out_path).parent / "b.bin"
         build = lambda api: random_query(random.Random(seed), api, str(t1), str(t2))  # noqa: E731
+    elif case_name.startswith("wide:"):
+        # a random many-group GROUP BY of tests/test_gpu_shared_tier.py over the table the parent test wrote
+        import random
+
+        from tests.test_gpu_shared_tier import _wide_query
+
+        seed = int(case_name.split(":")[1])
+        build = lambda api: _wide_query(random.Random(seed), api, str(Path(out_path).parent / "w.bin"))  # noqa: E731
     else:
         golden = load_golden(case_name)
         case = case_by_name(case_name)

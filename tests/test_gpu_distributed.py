@@ -84,11 +84,15 @@ def test_random_queries_on_n_ranks_match_the_oracle(tmp_path, seed, world):
         pytest.skip("the oracle raises for this seed")
     port = _free_port()
     out = tmp_path / "rows.json"
+    assert_rows_match(_run_ranks(f"fuzz:{seed}", world, out, port, want), want, max_ulps=1)
+
+
+def _run_ranks(case: str, world: int, out, port: int, want: list) -> list:
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, str(ROOT / "tests" / "dist_worker.py"), f"fuzz:{seed}", str(out), "gloo"],
+        procs.append(subprocess.Popen([sys.executable, str(ROOT / "tests" / "dist_worker.py"), case, str(out), "gloo"],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = [p.communicate(timeout=300)[0].decode() for p in procs]
     if any(p.returncode != 0 for p in procs):
@@ -103,4 +107,30 @@ def test_random_queries_on_n_ranks_match_the_oracle(tmp_path, seed, world):
                 row[k] = float.fromhex(v)
             elif want and isinstance(want[0].get(k), datetime):
                 row[k] = datetime.fromisoformat(v)
-    assert_rows_match(rows, want, max_ulps=1)
+    return rows
+
+
+_DIST_WIDE = [(0, 2), (3, 3), (5, 2), (8, 2)]
+if os.environ.get("HIPSPARK_DIST_WIDE"):
+    _lo, _hi = (int(v) for v in os.environ["HIPSPARK_DIST_WIDE"].split(":"))
+    _DIST_WIDE = [(s, 2 + s % 2) for s in range(_lo, _hi)]
+
+
+@pytest.mark.parametrize("seed,world", _DIST_WIDE)
+def test_random_many_group_queries_on_n_ranks_match_the_oracle(tmp_path, seed, world):
+    """Random GROUP BY queries with tens to thousands of groups (tests/test_gpu_shared_tier.py's generator) on N ranks
+    over gloo: shared-dictionary and HBM-tier partials through the all-to-all exchange against the CPU oracle."""
+    import random
+
+    from minispark_amd.dataframe import DataFrame
+    from minispark_amd.sql import Col, Functions, Lit
+    from oracle.py_engine import run_query
+    from tests.queries import api_namespace
+    from tests.test_gpu_shared_tier import _wide_query, _wide_table
+
+    rng = random.Random(900 + seed)
+    _wide_table(tmp_path / "w.bin", rng.choice([5_000, 20_000]), rng.choice([3, 5, 7]), seed)
+    api = api_namespace(lambda: DataFrame(object()), Col, Functions, Lit)
+    want = run_query(_wide_query(random.Random(seed), api, str(tmp_path / "w.bin")).task)
+    rows = _run_ranks(f"wide:{seed}", world, tmp_path / "rows.json", _free_port(), want)
+    assert assert_rows_match(rows, want, max_ulps=1) <= 3
