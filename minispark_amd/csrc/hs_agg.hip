@@ -1481,17 +1481,25 @@ extern "C" int hs_agg_shared_geom(const int64_t* host_unit_rows, int64_t n_units
         }
         total += r;
     }
-    // one workgroup per CU (it owns the LDS); two rounds of workgroups even out the tail
+    // Two rounds of workgroups even out the tail - but never one workgroup more than the rounds hold: the chunks
+    // are equally long, so 515 of them on 256 CUs (one resident workgroup each) take three rounds, not two
+    // (measured: 1.13 ms instead of 0.76).  Chunks do not span units, hence the re-count per candidate length.
     const int64_t step = (int64_t)HS_SHARED_WG * HS_V;
-    int64_t target = 512;
+    const int64_t resident = lds * 2 + 2048 <= 160 * 1024 ? 2 : 1;  // 1024-lane workgroups: at most two per CU
+    const int64_t target = 256 * resident * 2;
     int64_t chunk = ((total + target - 1) / target + step - 1) / step * step;
     if (chunk < 16 * step) chunk = 16 * step;
     if (chunk > 0x40000000) chunk = 0x40000000 / step * step;
     int64_t n_chunks = 0;
-    for (int64_t u = 0; u < n_units; ++u) {
-        const int64_t anchor = host_unit_rows[u] & ~(int64_t)(HS_V - 1);
-        const int64_t span = host_unit_rows[u + 1] - anchor;
-        n_chunks += span > 0 ? (span + chunk - 1) / chunk : 0;
+    for (int attempt = 0; attempt < 64; ++attempt) {
+        n_chunks = 0;
+        for (int64_t u = 0; u < n_units; ++u) {
+            const int64_t anchor = host_unit_rows[u] & ~(int64_t)(HS_V - 1);
+            const int64_t span = host_unit_rows[u + 1] - anchor;
+            n_chunks += span > 0 ? (span + chunk - 1) / chunk : 0;
+        }
+        if (n_chunks <= target || n_units >= target || chunk >= 0x40000000 / step * step) break;
+        chunk += step * (1 + chunk / step / 32);
     }
     int32_t unit_cap = group_cap * 2;  // a unit sees at least the groups of any of its chunks: half-full at worst
     out->group_cap = group_cap;
@@ -1561,7 +1569,11 @@ extern "C" int hs_agg_shared(void* stream, const hs_col* cols, int32_t n_cols, i
             return HS_E_ARG;
         }
         A.replicas = (int32_t)r;
-        A.pad2 = 0;
+        // the table counts as overflowed once it is half full (lockstep probing: see SharedCtx) - unless it is the
+        // largest one LDS holds: past that only the HBM tier is left, and a crowded LDS table still beats it
+        const size_t slot_bytes = 16 + (size_t)(spec->n_acc > 0 ? spec->n_acc : 1) * 8;
+        const bool can_grow = (size_t)geom->group_cap * 2 * slot_bytes <= 128 * 1024 && geom->group_cap * 2 <= 8192;
+        A.pad2 = can_grow ? geom->group_cap / 2 : geom->group_cap;
     }
     hipStream_t s = (hipStream_t)stream;
     SharedInitArgs I;

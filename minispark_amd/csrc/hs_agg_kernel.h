@@ -465,7 +465,12 @@ struct SharedCtx {
     uint64_t* acc;  // [slot][replica][n_acc]; a lane uses replica lane % replicas: with few groups the lanes of a
                     // wave would otherwise queue up on the same LDS words
     uint32_t rep, nrep;
-    volatile int* full;  // LDS: set once the table has overflowed - a probe of a full table walks every slot
+    int* full;  // LDS: set once the table has overflowed - a probe of a full table walks every slot (read and
+                // written with relaxed atomics: a volatile access would leave the LDS address space, see hs_device.h)
+    int* count;  // LDS: keys in the table so far; past `limit` the table counts as overflowed, so that the run is
+                 // repeated with a larger one: the lanes of a wave probe in lockstep, i.e. every lookup costs the
+                 // LONGEST probe sequence among 64 (at 78 % load: ~17 probes per row; at 25 %: ~2)
+    int32_t limit;
     uint32_t mask;
     int32_t n_acc;
     uint32_t err;
@@ -474,12 +479,20 @@ struct SharedCtx {
     __device__ __forceinline__ int find(const hs_col& key_col, uint64_t k, int64_t row, bool& live) {
         int s = 0;
         if (live) {
-            if (*full) {
+            if (__hip_atomic_load(full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
                 s = -1;
             } else {
-                if constexpr (HASHED) s = hs_dict_upsert_rows_at(dreps, mask, key_col, k, row, hs_slot_hash_strong(k));
-                else s = hs_dict_upsert_word_at(dkeys, dreps, mask, k, row, hs_slot_hash_strong(k));
-                if (s < 0) *full = 1;
+                bool inserted;
+                // double hashing: the probe stride comes from other hash bits than the start slot, so a crowded
+                // table has no clusters for one unlucky lane to walk while the other 63 wait
+                const uint32_t h = hs_slot_hash_strong(k);
+                const uint32_t stride = (h >> 16) | 1u;
+                if constexpr (HASHED) s = hs_dict_upsert_rows_at(dreps, mask, key_col, k, row, h, inserted, stride);
+                else s = hs_dict_upsert_word_at(dkeys, dreps, mask, k, row, h, inserted, stride);
+                if (s < 0 || (inserted && atomicAdd(count, 1) >= limit)) {
+                    __hip_atomic_store(full, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    s = -1;
+                }
             }
             if (s < 0) {
                 err |= HS_FLAG_DICT_FULL;
@@ -559,8 +572,11 @@ __device__ __forceinline__ void hs_agg_shared_body(const AggMainArgs& A) {
     }
     const int R = A.replicas > 0 ? A.replicas : 1;
     for (int i = tid; i < GC * R * NA; i += nthr) acc[i] = hs_acc_identity(A.spec.op[i % NA], A.spec.is_int[i % NA] != 0);
-    __shared__ int s_full;
-    if (tid == 0) s_full = 0;
+    __shared__ int s_full, s_count;
+    if (tid == 0) {
+        s_full = 0;
+        s_count = 0;
+    }
     __syncthreads();
 
     SharedCtx ctx;
@@ -570,6 +586,8 @@ __device__ __forceinline__ void hs_agg_shared_body(const AggMainArgs& A) {
     ctx.rep = tid & (uint32_t)(R - 1);
     ctx.nrep = (uint32_t)R;
     ctx.full = &s_full;
+    ctx.count = &s_count;
+    ctx.limit = A.pad2 > 0 ? A.pad2 : GC;
     ctx.mask = (uint32_t)GC - 1;
     ctx.n_acc = NA;
     ctx.err = 0;
@@ -586,7 +604,7 @@ __device__ __forceinline__ void hs_agg_shared_body(const AggMainArgs& A) {
         }
         Prog::run(A, cur, ctx);
         base = next_base;
-        if (s_full) break;  // overflowed: the run is repeated with a larger table
+        if (__hip_atomic_load(&s_full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;  // overflowed: the run is repeated with a larger table
     }
     __syncthreads();
     if (s_full) {

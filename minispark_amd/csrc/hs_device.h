@@ -502,21 +502,31 @@ __device__ __forceinline__ uint32_t hs_slot_hash_strong(uint64_t k) { return (ui
 // LDS dictionary, exact-word mode.  keys[] initialised to HS_EMPTY_KEY, reps[] to -1.
 // Returns the slot of `k`, inserting it if absent; -1 when the table is full.
 __device__ __forceinline__ int hs_dict_upsert_word_at(uint64_t* keys, int64_t* reps, uint32_t mask, uint64_t k,
-                                                      int64_t row, uint32_t h) {
+                                                      int64_t row, uint32_t h, bool& inserted,
+                                                      uint32_t step = 1) {
     h &= mask;
+    inserted = false;
     for (uint32_t probe = 0; probe <= mask; ++probe) {
-        uint64_t cur = *(volatile uint64_t*)&keys[h];
+        // relaxed atomic load, NOT a volatile read: hipcc leaves volatile accesses on the generic address space
+        // (flat_load + s_waitcnt vmcnt(0), which also drains the prefetched column loads); this one becomes ds_read_b64
+        uint64_t cur = __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (cur == HS_EMPTY_KEY) {
             cur = atomicCAS((unsigned long long*)&keys[h], (unsigned long long)HS_EMPTY_KEY, (unsigned long long)k);
             if (cur == HS_EMPTY_KEY) {
                 reps[h] = row;
+                inserted = true;
                 return (int)h;
             }
         }
         if (cur == k) return (int)h;
-        h = (h + 1) & mask;
+        h = (h + step) & mask;  // step odd: every slot of the power-of-two table is visited
     }
     return -1;
+}
+__device__ __forceinline__ int hs_dict_upsert_word_at(uint64_t* keys, int64_t* reps, uint32_t mask, uint64_t k,
+                                                      int64_t row, uint32_t h) {
+    bool inserted;
+    return hs_dict_upsert_word_at(keys, reps, mask, k, row, h, inserted);
 }
 
 __device__ __forceinline__ int hs_dict_upsert_word(uint64_t* keys, int64_t* reps, uint32_t mask, uint64_t k,
@@ -527,20 +537,30 @@ __device__ __forceinline__ int hs_dict_upsert_word(uint64_t* keys, int64_t* reps
 // LDS dictionary, hashed mode: the slot is claimed by CAS on its representative row; equality is a
 // byte compare against that row (immutable global memory, so no ordering hazard).
 __device__ __forceinline__ int hs_dict_upsert_rows_at(int64_t* reps, uint32_t mask, const hs_col& c, uint64_t k,
-                                                      int64_t row, uint32_t h) {
+                                                      int64_t row, uint32_t h, bool& inserted,
+                                                      uint32_t step = 1) {
     (void)k;
     h &= mask;
+    inserted = false;
     for (uint32_t probe = 0; probe <= mask; ++probe) {
-        long long cur = *(volatile long long*)&reps[h];
+        long long cur = __hip_atomic_load(&reps[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (cur < 0) {
             cur = (long long)atomicCAS((unsigned long long*)&reps[h], (unsigned long long)(-1ll),
                                        (unsigned long long)row);
-            if (cur < 0) return (int)h;
+            if (cur < 0) {
+                inserted = true;
+                return (int)h;
+            }
         }
         if (hs_rows_equal(c, (int64_t)cur, row)) return (int)h;
-        h = (h + 1) & mask;
+        h = (h + step) & mask;
     }
     return -1;
+}
+__device__ __forceinline__ int hs_dict_upsert_rows_at(int64_t* reps, uint32_t mask, const hs_col& c, uint64_t k,
+                                                      int64_t row, uint32_t h) {
+    bool inserted;
+    return hs_dict_upsert_rows_at(reps, mask, c, k, row, h, inserted);
 }
 __device__ __forceinline__ int hs_dict_upsert_rows(int64_t* reps, uint32_t mask, const hs_col& c, uint64_t k,
                                                    int64_t row) {
