@@ -84,7 +84,9 @@ def test_jit_translates_and_compiles_q1_for_gfx950():
     assert rc == 0, (lib.hs_last_error(), lib.hs_jit_last_log()[:2000])
     assert nbytes.value > 4096
     text = src.value.decode()
-    assert "hs_agg_main_body<JitProg>" in text and text.count("fold_c<6,") == 6 and "hs_f32x4" in text
+    # six distinct accumulators, read - folded - written back together per row (one base address, constant offsets)
+    assert "hs_agg_main_body<JitProg>" in text and text.count("= hs_acc_fold(") == 6 and "hs_f32x4" in text
+    assert "cell[1280] = a5;" in text and "const unsigned long long k" in text  # 256-lane workgroup; hoisted literals
 
 
 def test_expression_programs_translate_and_compile_for_gfx950_without_a_gpu():
