@@ -140,9 +140,33 @@ struct AggCtx {
     uint64_t* dkeys;
     int64_t* dreps;
     uint64_t* tbl;
+    uint8_t* dmap;  // LDS [256]: slot of a one-byte key, 0xff = not seen yet by this workgroup
     uint32_t tid, nthr, mask;
     int32_t n_acc;
     uint32_t err;
+
+    // One-byte string keys (TPC-H flags): the byte indexes a 256-entry LDS map straight to its slot - one
+    // ds_read_u8 instead of hash + probe loop; the dictionary is only walked the first time a lane meets a byte.
+    // Lanes racing on dmap[b] all store the slot the dictionary gave that key, so any order is fine.
+    __device__ __forceinline__ int find_byte(const hs_col& key_col, uint64_t k, int64_t row, bool& live) {
+        if (mask >= 255u) return find<false>(key_col, k, row, live);  // slots would not fit the map's byte
+        int s = 0;
+        if (live) {
+            const uint32_t b = (uint32_t)k & 0xffu;
+            s = dmap[b];
+            if (s == 0xff) {
+                s = hs_dict_upsert_word(dkeys, dreps, mask, k, row);
+                if (s < 0) {
+                    err |= HS_FLAG_DICT_FULL;
+                    live = false;
+                    s = 0;
+                } else {
+                    dmap[b] = (uint8_t)s;
+                }
+            }
+        }
+        return s;
+    }
 
     // slot of key word `k` held by `row`; marks the row dead and flags overflow when the table is full
     template <bool HASHED>
@@ -235,7 +259,8 @@ struct InterpProg {
                     if (kc.kind == HS_STR) k = pre ? kcell[j] : hs_key_at(kc, ctx.row0 + j);
                     else k = hs_key_from_cell(kc.kind, kcell[j]);
                 }
-                ctx.slot[j] = ctx.template find<HASHED>(kc, k, ctx.row0 + j, ctx.alive[j]);
+                if (!HASHED && kc.kind == HS_STR && kc.fixed_len == 1) ctx.slot[j] = ctx.find_byte(kc, k, ctx.row0 + j, ctx.alive[j]);
+                else ctx.slot[j] = ctx.template find<HASHED>(kc, k, ctx.row0 + j, ctx.alive[j]);
             }
         }
         __device__ __forceinline__ void agg(uint32_t a, int j, uint64_t v) {
@@ -335,6 +360,8 @@ __device__ __forceinline__ void hs_agg_main_body(const AggMainArgs& A) {
         dkeys[i] = HS_EMPTY_KEY;
         dreps[i] = -1;
     }
+    __shared__ uint8_t s_dmap[256];
+    for (int i = tid; i < 256; i += nthr) s_dmap[i] = 0xff;
     for (int cellid = 0; cellid < GC * NA; ++cellid)
         tbl[(uint32_t)cellid * nthr + tid] = hs_acc_identity(A.spec.op[cellid % NA], A.spec.is_int[cellid % NA] != 0);
     __syncthreads();
@@ -343,6 +370,7 @@ __device__ __forceinline__ void hs_agg_main_body(const AggMainArgs& A) {
     ctx.dkeys = dkeys;
     ctx.dreps = dreps;
     ctx.tbl = tbl;
+    ctx.dmap = s_dmap;
     ctx.tid = tid;
     ctx.nthr = nthr;
     ctx.mask = (uint32_t)GC - 1;
@@ -501,6 +529,9 @@ struct SharedCtx {
             }
         }
         return s;
+    }
+    __device__ __forceinline__ int find_byte(const hs_col& key_col, uint64_t k, int64_t row, bool& live) {
+        return find<false>(key_col, k, row, live);
     }
     __device__ __forceinline__ void fold(const hs_agg_spec& spec, uint32_t a, int s, bool live, uint64_t x) {
         if (live)
