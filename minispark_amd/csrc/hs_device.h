@@ -475,17 +475,58 @@ __host__ __device__ __forceinline__ bool hs_col_packs(const hs_col& c) {
     return c.kind != HS_STR || (c.fixed_len >= 0 && c.fixed_len <= 7);
 }
 
+// The first `len` (<= 16) bytes at p as two little-endian words, zero-padded.  Only ALIGNED 8-byte words that hold at
+// least one byte of the string are loaded: such a word lies inside the buffer's allocation (whose start and size are
+// multiples of 8), so this touches nothing a byte loop would not be entitled to at word granularity - and replaces up
+// to 16 single-byte loads by at most three loads and a funnel shift.
+__device__ __forceinline__ void hs_str_words16(const uint8_t* p, uint32_t len, uint64_t& w0, uint64_t& w1) {
+    const unsigned long long a = (unsigned long long)p;
+    const uint64_t* q = (const uint64_t*)(a & ~7ull);
+    const uint32_t lead = (uint32_t)(a & 7ull);
+    const uint32_t span = lead + len;  // bytes from q to the end of the string
+    const uint64_t x0 = len ? q[0] : 0ull;
+    const uint64_t x1 = span > 8 ? q[1] : 0ull;
+    const uint64_t x2 = span > 16 ? q[2] : 0ull;
+    const uint32_t sh = lead * 8;
+    w0 = sh ? (x0 >> sh) | (x1 << (64 - sh)) : x0;
+    w1 = sh ? (x1 >> sh) | (x2 << (64 - sh)) : x1;
+    if (len < 8) {
+        w0 = len ? w0 & (~0ull >> (64 - 8 * len)) : 0ull;
+        w1 = 0ull;
+    } else if (len < 16) {
+        w1 = len > 8 ? w1 & (~0ull >> (64 - 8 * (len - 8))) : 0ull;
+    }
+}
+
 __device__ __forceinline__ uint64_t hs_key_at(const hs_col& c, int64_t row) {
     if (c.kind == HS_STR) {
         HsStr s = hs_str_at(c, row);
         if (s.len <= 7) return hs_pack_str(s.p, s.len);
-        return (hs_fnv1a(s.p, s.len) & 0x3fffffffffffffffull) | 0x4000000000000000ull;
+        uint64_t h;
+        if (s.len <= 16) {
+            uint64_t w0, w1;
+            hs_str_words16(s.p, s.len, w0, w1);
+            h = hs_mix64(w0 ^ hs_mix64(w1 + s.len));
+        } else {
+            h = hs_fnv1a(s.p, s.len);
+        }
+        return (h & 0x3fffffffffffffffull) | 0x4000000000000000ull;
     }
     return hs_key_from_cell(c.kind, hs_load_cell(c, row));
 }
 
 __device__ __forceinline__ bool hs_rows_equal(const hs_col& c, int64_t r0, int64_t r1) {
-    if (c.kind == HS_STR) return hs_str_cmp(hs_str_at(c, r0), hs_str_at(c, r1)) == 0;
+    if (c.kind == HS_STR) {
+        const HsStr a = hs_str_at(c, r0), b = hs_str_at(c, r1);
+        if (a.len != b.len) return false;
+        if (a.len <= 16) {
+            uint64_t a0, a1, b0, b1;
+            hs_str_words16(a.p, a.len, a0, a1);
+            hs_str_words16(b.p, b.len, b0, b1);
+            return a0 == b0 && a1 == b1;
+        }
+        return hs_str_cmp(a, b) == 0;
+    }
     return hs_key_at(c, r0) == hs_key_at(c, r1);
 }
 
