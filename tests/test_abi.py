@@ -55,6 +55,25 @@ def test_bad_arguments_are_refused_without_a_gpu():
     assert geom.lds_bytes == 4 * 16 + 4 * 6 * 256 * 8
 
 
+def test_shared_tier_geometry_fits_its_rounds_of_workgroups():
+    """The shared-dictionary tier runs equally long chunks, one 1024-lane workgroup each: a chunk more than the
+    rounds of resident workgroups hold costs a whole extra round (29 blocks of 2 Mi rows once made 515 chunks
+    for 512 places).  Chunks never span units and stay multiples of the 4096-row step."""
+    lib = hs.load_library()
+    geom = hs.hs_agg_geom()
+    for n_units, rows in [(29, 2_097_152), (287, 2_097_152), (7, 1_000_003), (1, 50_000), (3, 12_345_678)]:
+        bounds = [i * rows for i in range(n_units + 1)]
+        units = (C.c_int64 * (n_units + 1))(*bounds)
+        for n_acc, cap in [(2, 16), (2, 64), (2, 1024), (8, 256)]:
+            assert lib.hs_agg_shared_geom(units, n_units, n_acc, cap, C.byref(geom)) == 0, lib.hs_last_error()
+            resident = 2 if geom.lds_bytes * 2 + 2048 <= 160 * 1024 else 1
+            assert geom.chunk_rows % 4096 == 0 and geom.wg_threads == 1024
+            assert geom.n_chunks == sum(-(-(bounds[u + 1] - (bounds[u] & ~3)) // geom.chunk_rows) for u in range(n_units))
+            if n_units < 512 * resident:
+                assert geom.n_chunks <= 512 * resident, (n_units, rows, n_acc, cap, geom.n_chunks)
+            assert geom.group_cap >= cap and geom.pad == 2 * geom.group_cap
+
+
 def test_jit_translates_and_compiles_q1_for_gfx950():
     from minispark_amd.constants import ColumnType as T
     from minispark_amd.dataframe import DataFrame
