@@ -89,11 +89,13 @@ struct InI64 {
 template <typename In>
 __global__ void __launch_bounds__(SCAN_WG) k_scan_reduce(In in, int64_t n, int64_t* tile_sums) {
     __shared__ int64_t s_tmp[SCAN_WG];
-    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    // a tile's SUM does not care which lane adds which element: consecutive lanes take consecutive elements
+    // (k_scan_down needs a lane's elements to be consecutive; this pass does not)
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x;
     int64_t sum = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k)
-        if (base + k < n) sum += in(base + k);
+        if (base + (int64_t)k * SCAN_WG < n) sum += in(base + (int64_t)k * SCAN_WG);
     int64_t total;
     block_excl_scan(sum, s_tmp, total);
     if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;

@@ -5,6 +5,7 @@ from __future__ import annotations
 
 import json
 import os
+import math
 import struct
 import sys
 import time
@@ -74,10 +75,14 @@ def assert_rows_match(got: list[dict], want: list[dict], *, max_ulps: int = 0) -
     an f32 rounding boundary).  Returns the number of values that differed by an ulp."""
     assert len(got) == len(want), f"row count {len(got)} != {len(want)}\n got={got}\nwant={want}"
     flips = 0
-    # sort on the non-float columns first so a 1-ulp difference cannot reorder rows
+    # sort on the non-float columns first, then on the floats rounded (so a 1-ulp difference cannot reorder rows),
+    # then on their exact values and signs: rows that tie on everything coarser (say -0.0 and 7.7e-05 next to equal
+    # strings and ints) must still pair up the same way in both lists, whatever order the engines emitted them in
     def stable_key(r):
-        return tuple((type(v).__name__, v) for v in r.values() if type(v) is not float) + tuple(
-            (round(v, 3),) for v in r.values() if type(v) is float)
+        floats = [v for v in r.values() if type(v) is float]
+        return (tuple((type(v).__name__, v) for v in r.values() if type(v) is not float)
+                + tuple((round(v, 3),) for v in floats)
+                + tuple((v, math.copysign(1.0, v)) if v == v else (math.inf, 0.0) for v in floats))
     for g, w in zip(sorted(got, key=stable_key), sorted(want, key=stable_key)):
         assert list(g.keys()) == list(w.keys()), f"columns {list(g.keys())} != {list(w.keys())}"
         for k in g:

@@ -85,3 +85,15 @@ def test_c_generator_is_deterministic_and_blockwise():
     assert set(np.unique(whole["l_returnflag"]).tolist()) <= {ord("A"), ord("N"), ord("R")}
     assert whole["l_quantity"].min() >= 1 and whole["l_quantity"].max() <= 50
     assert whole["l_shipdate"].max() <= 912470400 * 1_000_000  # 1998-12-01
+
+
+def test_row_comparison_pairs_tied_rows_consistently():
+    """Rows that agree on every non-float column and whose floats round alike (-0.0 next to 7.7e-05) must pair up the
+    same way whatever order the two engines emitted them in; genuinely different multisets must still fail."""
+    from tests.conftest import assert_rows_match
+
+    a = [{"s": "x", "k": 1, "e": 7.739576540188864e-05}, {"s": "x", "k": 1, "e": -0.0}, {"s": "x", "k": 1, "e": 0.0}]
+    assert assert_rows_match(a, list(reversed(a))) == 0
+    assert assert_rows_match(a, [a[1], a[2], a[0]], max_ulps=1) == 0
+    with pytest.raises(AssertionError):
+        assert_rows_match(a, [a[0], a[0], a[1]])
