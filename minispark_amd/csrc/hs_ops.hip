@@ -135,12 +135,24 @@ template <typename In, typename Emit>
 __global__ void __launch_bounds__(SCAN_WG) k_scan_down(In in, int64_t n, const int64_t* tile_sums, Emit emit,
                                                        int64_t* total_out) {
     __shared__ int64_t s_tmp[SCAN_WG];
-    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    // a lane scans SCAN_ITEMS consecutive elements, but the tile is READ with consecutive lanes on consecutive
+    // elements and handed over through LDS (one pad word per lane segment keeps the strided read-back at two lanes
+    // per bank): inputs that gather from two arrays per element (the join's slot counts) ran at a quarter of the
+    // single-array rate when every lane walked its own 64-byte line
+    __shared__ int64_t s_vals[SCAN_TILE + SCAN_WG];
+    const int64_t tile0 = (int64_t)blockIdx.x * SCAN_TILE;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const int e = k * SCAN_WG + (int)threadIdx.x;
+        s_vals[e + e / SCAN_ITEMS] = tile0 + e < n ? in(tile0 + e) : 0;
+    }
+    __syncthreads();
+    const int64_t base = tile0 + (int64_t)threadIdx.x * SCAN_ITEMS;
     int64_t vals[SCAN_ITEMS];
     int64_t sum = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
-        vals[k] = base + k < n ? in(base + k) : 0;
+        vals[k] = s_vals[(int)threadIdx.x * (SCAN_ITEMS + 1) + k];
         sum += vals[k];
     }
     int64_t total;
