@@ -101,6 +101,29 @@ __device__ __forceinline__ HsStr hs_str_at(const hs_col& c, int64_t row) {
 }
 
 // memcmp-style three-way compare (Python str ordering == byte ordering for ASCII)
+// The first `len` (<= 16) bytes at p as two little-endian words, zero-padded.  Only ALIGNED 8-byte words that hold at
+// least one byte of the string are loaded: such a word lies inside the buffer's allocation (whose start and size are
+// multiples of 8), so this touches nothing a byte loop would not be entitled to at word granularity - and replaces up
+// to 16 single-byte loads by at most three loads and a funnel shift.
+__device__ __forceinline__ void hs_str_words16(const uint8_t* p, uint32_t len, uint64_t& w0, uint64_t& w1) {
+    const unsigned long long a = (unsigned long long)p;
+    const uint64_t* q = (const uint64_t*)(a & ~7ull);
+    const uint32_t lead = (uint32_t)(a & 7ull);
+    const uint32_t span = lead + len;  // bytes from q to the end of the string
+    const uint64_t x0 = len ? q[0] : 0ull;
+    const uint64_t x1 = span > 8 ? q[1] : 0ull;
+    const uint64_t x2 = span > 16 ? q[2] : 0ull;
+    const uint32_t sh = lead * 8;
+    w0 = sh ? (x0 >> sh) | (x1 << (64 - sh)) : x0;
+    w1 = sh ? (x1 >> sh) | (x2 << (64 - sh)) : x1;
+    if (len < 8) {
+        w0 = len ? w0 & (~0ull >> (64 - 8 * len)) : 0ull;
+        w1 = 0ull;
+    } else if (len < 16) {
+        w1 = len > 8 ? w1 & (~0ull >> (64 - 8 * (len - 8))) : 0ull;
+    }
+}
+
 __device__ __forceinline__ int hs_str_cmp(HsStr a, HsStr b) {
     uint32_t n = a.len < b.len ? a.len : b.len;
     for (uint32_t i = 0; i < n; ++i) {
@@ -124,18 +147,29 @@ __device__ __forceinline__ bool hs_cmp_result(int d, uint32_t cmp) {
 // SQL LIKE with % (any run) and _ (any one byte), anchored both ends; iterative with one
 // backtrack point (classic wildcard matcher).  Reference: re.match("^...$") on the translated
 // pattern, sql.py:178-179,192-194.  '.' does not match '\n' in the reference's regex.
-__device__ __forceinline__ bool hs_like(HsStr s, const uint8_t* pat, uint32_t plen) {
+struct HsBytesMem {  // the string's bytes where they lie
+    const uint8_t* p;
+    __device__ __forceinline__ uint8_t operator[](uint32_t i) const { return p[i]; }
+};
+struct HsBytesReg {  // a string of <= 16 bytes held in two registers (hs_str_words16)
+    uint64_t w0, w1;
+    __device__ __forceinline__ uint8_t operator[](uint32_t i) const {
+        return (uint8_t)(i < 8 ? w0 >> (8 * i) : w1 >> (8 * (i - 8)));
+    }
+};
+template <class Bytes>
+__device__ __forceinline__ bool hs_like_impl(const Bytes& b, uint32_t slen, const uint8_t* pat, uint32_t plen) {
     uint32_t si = 0, pi = 0;
     int64_t star_p = -1;
     uint32_t star_s = 0;
-    while (si < s.len) {
+    while (si < slen) {
         if (pi < plen && pat[pi] == '%') {
             star_p = pi++;
             star_s = si;
-        } else if (pi < plen && ((pat[pi] == '_' && s.p[si] != '\n') || (pat[pi] != '_' && pat[pi] == s.p[si]))) {
+        } else if (pi < plen && ((pat[pi] == '_' && b[si] != '\n') || (pat[pi] != '_' && pat[pi] == b[si]))) {
             ++pi;
             ++si;
-        } else if (star_p >= 0 && s.p[star_s] != '\n') {
+        } else if (star_p >= 0 && b[star_s] != '\n') {
             pi = (uint32_t)star_p + 1;
             si = ++star_s;
         } else {
@@ -144,6 +178,14 @@ __device__ __forceinline__ bool hs_like(HsStr s, const uint8_t* pat, uint32_t pl
     }
     while (pi < plen && pat[pi] == '%') ++pi;
     return pi == plen;
+}
+__device__ __forceinline__ bool hs_like(HsStr s, const uint8_t* pat, uint32_t plen) {
+    if (s.len <= 16) {  // the matcher re-reads bytes while backtracking: keep short strings in registers
+        HsBytesReg r;
+        hs_str_words16(s.p, s.len, r.w0, r.w1);
+        return hs_like_impl(r, s.len, pat, plen);
+    }
+    return hs_like_impl(HsBytesMem{s.p}, s.len, pat, plen);
 }
 
 // ---- Python arithmetic -----------------------------------------------------------------------------
@@ -473,29 +515,6 @@ __device__ __forceinline__ uint64_t hs_pack_str(const uint8_t* p, uint32_t len) 
 // true when every string of the column packs exactly (<= 7 bytes)
 __host__ __device__ __forceinline__ bool hs_col_packs(const hs_col& c) {
     return c.kind != HS_STR || (c.fixed_len >= 0 && c.fixed_len <= 7);
-}
-
-// The first `len` (<= 16) bytes at p as two little-endian words, zero-padded.  Only ALIGNED 8-byte words that hold at
-// least one byte of the string are loaded: such a word lies inside the buffer's allocation (whose start and size are
-// multiples of 8), so this touches nothing a byte loop would not be entitled to at word granularity - and replaces up
-// to 16 single-byte loads by at most three loads and a funnel shift.
-__device__ __forceinline__ void hs_str_words16(const uint8_t* p, uint32_t len, uint64_t& w0, uint64_t& w1) {
-    const unsigned long long a = (unsigned long long)p;
-    const uint64_t* q = (const uint64_t*)(a & ~7ull);
-    const uint32_t lead = (uint32_t)(a & 7ull);
-    const uint32_t span = lead + len;  // bytes from q to the end of the string
-    const uint64_t x0 = len ? q[0] : 0ull;
-    const uint64_t x1 = span > 8 ? q[1] : 0ull;
-    const uint64_t x2 = span > 16 ? q[2] : 0ull;
-    const uint32_t sh = lead * 8;
-    w0 = sh ? (x0 >> sh) | (x1 << (64 - sh)) : x0;
-    w1 = sh ? (x1 >> sh) | (x2 << (64 - sh)) : x1;
-    if (len < 8) {
-        w0 = len ? w0 & (~0ull >> (64 - 8 * len)) : 0ull;
-        w1 = 0ull;
-    } else if (len < 16) {
-        w1 = len > 8 ? w1 & (~0ull >> (64 - 8 * (len - 8))) : 0ull;
-    }
 }
 
 __device__ __forceinline__ uint64_t hs_key_at(const hs_col& c, int64_t row) {
