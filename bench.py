@@ -1,18 +1,21 @@
-"""bench.py - TPC-H Q1 (the reference's benchmark query, README.md:141-158) on synthetic lineitem through
-HipExecutionEngine, N GPUs of one node.
+"""bench.py - the BASELINE.json workloads through HipExecutionEngine on N GPUs of one node.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--sf SF]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config q1|join|strkey] [--sf SF]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the hot path: ``DataFrame.collect()`` of Q1 with the referenced columns already
-resident in HBM (block b on rank b % N) -> result rows on the host of rank 0.  Strong scaling: the
-table (default sf=100 = 600 037 902 rows, 287 blocks) is fixed and split across the ranks.
-Rank 0 prints ONE JSON line (see DESIGN.md section 6 for every field).
+Default = the metric's own configuration: TPC-H Q1 (the reference's benchmark query, README.md:141-158) on synthetic
+lineitem sf=100.  A "step" is one pass of the hot path: ``DataFrame.collect()`` with the referenced columns already
+resident in HBM (block b on rank b % N) -> result rows on the host of rank 0.  Strong scaling: the table is fixed and
+split across the ranks.  Rank 0 prints ONE JSON line (DESIGN.md section 6 explains every field).
+
+``--config join`` / ``--config strkey`` run BASELINE configs 4 and 5 (sf=10 by default) with the same JSON shape, their
+own byte accounting and their own C oracle ports (oracle/q45_oracle.c).
 """
 
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -28,14 +31,38 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s)
 CUTOFF = "1998-12-01"  # the reference's query; --cutoff 1998-09-02 keeps ~97 % of the rows (predicate not vacuous)
+Q1_MOVED_BYTES_PER_ROW = 25  # the length bytes of the fixed-width l_returnflag are never read
 
 
 def q1_frame(engine, table_path: str, cutoff: str = CUTOFF):
-    from minispark_amd.dataframe import DataFrame
-    from minispark_amd.sql import Col, Functions, Lit
-    from tests.queries import api_namespace, q1
+    from minispark_amd import workloads
 
-    return q1(api_namespace(lambda: DataFrame(engine), Col, Functions, Lit), table_path, cutoff)
+    return workloads.q1(workloads.engine_api(engine), table_path, cutoff)
+
+
+def kernel_sources_sha() -> str:
+    """Identity of the device code: PMC traffic figures under profiles/ are only quoted while it is unchanged."""
+    h = hashlib.sha256()
+    for p in sorted([*(ROOT / "minispark_amd" / "csrc").glob("*.h"), *(ROOT / "minispark_amd" / "csrc").glob("*.hip"),
+                     ROOT / "include" / "hipspark.h"]):
+        h.update(p.name.encode())
+        h.update(p.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(name: str) -> dict:
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 counter passes of THIS command
+    (profiles/<name>; rocprofv3 cannot run inside the process) - refused when the kernels changed since."""
+    path = ROOT / "profiles" / name
+    if not path.exists():
+        return {"traffic": None, "traffic_source": f"profiles/{name} not collected yet"}
+    t = json.loads(path.read_text())
+    if t.get("kernel_sources_sha") != kernel_sources_sha():
+        return {"traffic": None, "traffic_source": f"profiles/{name} is stale: measured at kernel sources "
+                                                   f"{t.get('kernel_sources_sha')}, now {kernel_sources_sha()}"}
+    return {"traffic": t["hbm_read_bytes_per_launch (FETCH_SIZE*1024*2)"] + t["hbm_write_bytes_per_launch"],
+            "traffic_source": f"profiles/{name} (separate --pmc FETCH_SIZE / WRITE_SIZE passes at kernel sources "
+                              f"{t['kernel_sources_sha']}, commit {t.get('commit', '?')})"}
 
 
 def python_engine_baseline(scratch: Path, cutoff: str, n: int = 120_000) -> dict:
@@ -61,14 +88,12 @@ def python_engine_baseline(scratch: Path, cutoff: str, n: int = 120_000) -> dict
     return {"value": n / dt, "unit": "rows/s", "cores": 1, "rows": n, "groups": len(rows)}
 
 
-def cpu_baseline(engine, table, sample_blocks: int, gpu_rows_for_sample, cutoff: str = CUTOFF):
+def q1_cpu_baseline(table, sample_blocks: int, gpu_rows_for_sample, cutoff: str = CUTOFF):
     """The C port of the reference's algorithm (oracle/q1_oracle.c) timed on the host cores over the
     first ``sample_blocks`` blocks of the same table; also checks the GPU's rows for that sample."""
-    import numpy as np
-
     from oracle import blockfile as bfio
     from oracle import q1_native
-    from tests.conftest import assert_rows_match
+    from oracle.compare import assert_rows_match
 
     sizes = table.block_rows[:sample_blocks]
     n = sum(sizes)
@@ -100,16 +125,46 @@ def cpu_baseline(engine, table, sample_blocks: int, gpu_rows_for_sample, cutoff:
     }
 
 
+def q1_full_check(rows, total_rows: int, cutoff: str) -> dict:
+    """The TIMED result against the C oracle over the WHOLE table: the oracle regenerates the synthetic table block
+    by block with the generator's CPU twin (nothing of the 15.6 GB is resident) and runs the reference's algorithm -
+    per-block fp64 partials, f32 / i32 shuffle write, block-ordered merge (oracle/q1_oracle.c q1_run_synth)."""
+    from minispark_amd import constants, synth
+    from oracle import blockfile as bfio
+    from oracle import q1_native
+    from oracle.compare import assert_rows_match
+
+    threads = q1_native.host_threads()
+    t0 = time.perf_counter()
+    want = q1_native.run_synth(synth.SEED, total_rows, constants.ROWS_PER_BLOCK,
+                               bfio.to_us(datetime.fromisoformat(cutoff)), threads=threads)
+    dt = time.perf_counter() - t0
+    try:
+        flips = assert_rows_match(rows, want, max_ulps=1)
+        ok, why = True, None
+    except AssertionError as e:
+        flips, ok, why = None, False, str(e)[:400]
+    out = {"gpu_matches_oracle_full": ok, "f32_ulp_flips_full": flips, "rows_checked": total_rows,
+           "oracle": f"oracle/q1_oracle.c q1_run_synth on {threads} host threads, {dt:.1f} s (generation included)"}
+    if why:
+        out["mismatch"] = why
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--sf", type=float, default=100.0)
+    ap.add_argument("--config", choices=["q1", "join", "strkey"], default="q1")
+    ap.add_argument("--sf", type=float, default=None, help="scale factor (default: 100 for q1, 10 for join / strkey)")
     ap.add_argument("--sample-blocks", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cutoff", default=CUTOFF, help="WHERE l_shipdate <= CUTOFF")
+    ap.add_argument("--no-full-check", action="store_true", help="skip the whole-table oracle check of the timed result")
+    ap.add_argument("--cutoff", default=CUTOFF, help="q1: WHERE l_shipdate <= CUTOFF")
     args = ap.parse_args()
+    if args.sf is None:
+        args.sf = 100.0 if args.config == "q1" else 10.0
 
     import torch
 
@@ -134,20 +189,24 @@ def main() -> None:
         else:
             dist.init_process_group(backend)
 
-    from minispark_amd import constants, synth
+    from minispark_amd import constants
     from minispark_amd.execution import HipExecutionEngine
 
     scratch = Path(tempfile.mkdtemp(prefix=f"hipspark_bench_r{rank}_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None))
     constants.SHUFFLE_FOLDER = scratch / "shuffle"
-    total_rows = synth.lineitem_rows(args.sf)
     engine = HipExecutionEngine(device=local_rank)
     if dist is not None:
         engine.enable_distributed(dist)
-    table_path = scratch / f"lineitem_sf{args.sf:g}.bin"
-    table = synth.make_lineitem(engine.dev, table_path, total_rows, rank=rank, world=world)
-    engine.attach_device_table(table_path, table)
-    frame = q1_frame(engine, str(table_path), args.cutoff)
+    if args.config == "q1":
+        wl = Q1Workload(engine, scratch, args, rank, world)
+    else:
+        from tools.bench_configs import JoinWorkload, StrKeyWorkload  # noqa: PLC0415
+
+        wl = (JoinWorkload if args.config == "join" else StrKeyWorkload)(engine, scratch, args, rank, world)
+    frame = wl.frame
     engine.dev.time_scan_kernel(True)
+    if dist is not None:
+        engine.dev.time_exchange(True)
 
     def step():
         return frame.collect()
@@ -166,63 +225,42 @@ def main() -> None:
     for _ in range(args.warmup):
         rows = step()
     fence()
-    kernel_ms = []
+    kernel_ms, exchange_ms = [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         rows = step()
-        kernel_ms.append(engine.dev.scan_kernel_ms())  # the step ended with a D2H sync: events are complete
+        kernel_ms.append(wl.dominant_kernel_ms())  # the step ended with the result on the host: events are complete
+        if dist is not None:
+            exchange_ms.append(wl.exchange_ms())
     fence()
     elapsed = time.perf_counter() - t0
+    kernel_avg_ms = sum(kernel_ms) / len(kernel_ms)
+    exchange_avg_ms = sum(exchange_ms) / len(exchange_ms) if exchange_ms else 0.0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, kernel_avg_ms, exchange_avg_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        k = torch.tensor([sum(kernel_ms) / len(kernel_ms)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(k, op=dist.ReduceOp.MAX)
-        kernel_avg_ms = float(k.item())
-    else:
-        kernel_avg_ms = sum(kernel_ms) / len(kernel_ms)
+        elapsed, kernel_avg_ms, exchange_avg_ms = (float(v) for v in t.tolist())
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        local_rows = table.nrows
-        scan = engine.dev.last_scan
-        achieved = synth.Q1_BYTES_PER_ROW * local_rows / (kernel_avg_ms * 1e-3) / 1e9
         out = {
-            "metric": "TPC-H Q1 lineitem rows/sec", "value": total_rows / (elapsed / args.steps), "unit": "rows/s",
+            "metric": wl.metric, "value": wl.total_units / (elapsed / args.steps), "unit": "rows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {
-                "workload": f"TPC-H Q1 variant (8 aggregates, WHERE l_shipdate <= '{args.cutoff}', GROUP BY l_returnflag) "
-                            f"on synthetic lineitem sf={args.sf:g}",
-                "rows": total_rows, "blocks": len(synth.block_sizes(total_rows)), "rows_per_block": constants.ROWS_PER_BLOCK,
-                "bytes_per_row": synth.Q1_BYTES_PER_ROW, "groups": len(rows or []), "placement": "block b on rank b % n_gpus",
-                "exchange": "none" if world == 1 else f"one all_gather of partial-row slabs per query ({backend})",
-            },
-            "roofline": {
-                "bound": "hbm", "kernel": "k_agg_jit (k_agg_main body)", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel_ms": kernel_avg_ms,
-                "rows_per_launch": local_rows, "launch": scan,
-            },
-            "whole_step_GBps_per_gpu": synth.Q1_BYTES_PER_ROW * local_rows / (elapsed / args.steps) / 1e9,
-            # where a step goes: the scan kernel (HIP events) and everything else (unit combine, [collective],
-            # finish launch, hand-over, host)
-            "time_split_ms": {"scan_kernel": kernel_avg_ms, "rest_of_step": ms_per_step - kernel_avg_ms},
+            "config": dict(wl.config(rows), placement="block b on rank b % n_gpus",
+                           exchange="none" if dist is None else wl.exchange_text(backend)),
+            "roofline": wl.roofline(kernel_avg_ms),
+            # where a step goes (SURVEY.md 8d "Scaling report"): scan + partial aggregate (the dominant kernel with the
+            # per-unit combine fused into its epilogue; HIP events), the exchange collective (events around it on the
+            # launch stream; 0 without ranks), and the final merge + projection + hand-over + host time (the rest)
+            "time_split_ms": {"scan_partial": kernel_avg_ms, "exchange": exchange_avg_ms,
+                              "final": ms_per_step - kernel_avg_ms - exchange_avg_ms},
+            "whole_step_GBps_per_gpu": wl.algorithmic_bytes_per_launch() / (elapsed / args.steps) / 1e9,
         }
-        # HBM traffic of the scan kernel per launch from the PMC counters: rocprofv3 cannot run inside this
-        # process, so the figure comes from the committed counter passes of this same command (profiles/)
-        pmc = ROOT / "profiles" / "r01_pmc_hbm_traffic_q1_sf100.json"
-        if world == 1 and pmc.exists() and total_rows == 600_037_902:
-            t = json.loads(pmc.read_text())
-            out["roofline"]["traffic"] = t["hbm_read_bytes_per_launch (FETCH_SIZE*1024*2)"] + t["hbm_write_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = "profiles/r01_pmc_hbm_traffic_q1_sf100.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes)"
-        if world == 1 and not args.no_cpu_baseline:
-            blocks = min(args.sample_blocks, len(table.block_rows))
-            sample = synth.make_lineitem(engine.dev, scratch / "sample.bin", sum(table.block_rows[:blocks]))
-            engine.attach_device_table(scratch / "sample.bin", sample)
-            gpu_sample_rows = q1_frame(engine, str(scratch / "sample.bin"), args.cutoff).collect()
-            out["cpu_baseline"] = cpu_baseline(engine, table, blocks, gpu_sample_rows, args.cutoff)
-            out["cpu_baseline"]["python_engine_port"] = python_engine_baseline(scratch, args.cutoff)
+        if not args.no_full_check:
+            out["full_check"] = wl.full_check(rows)
+        if world == 1 and dist is None and not args.no_cpu_baseline:
+            out["cpu_baseline"] = wl.cpu_baseline()
         print(json.dumps(out), flush=True)
     engine.__exit__(None, None, None)
     if dist is not None:
@@ -231,6 +269,84 @@ def main() -> None:
     import shutil
 
     shutil.rmtree(scratch, ignore_errors=True)
+
+
+class Q1Workload:
+    """BASELINE configs 2 / 3: Q1 on synthetic lineitem generated in HBM (counter-based, block b on rank b % world)."""
+
+    metric = "TPC-H Q1 lineitem rows/sec"
+
+    def __init__(self, engine, scratch: Path, args, rank: int, world: int) -> None:
+        from minispark_amd import synth
+
+        self.engine, self.scratch, self.args, self.world = engine, scratch, args, world
+        self.total_units = synth.lineitem_rows(args.sf)
+        self.table_path = scratch / f"lineitem_sf{args.sf:g}.bin"
+        self.table = synth.make_lineitem(engine.dev, self.table_path, self.total_units, rank=rank, world=world)
+        engine.attach_device_table(self.table_path, self.table)
+        self.frame = q1_frame(engine, str(self.table_path), args.cutoff)
+
+    def dominant_kernel_ms(self) -> float:
+        return self.engine.dev.scan_kernel_ms()
+
+    def exchange_ms(self) -> float:
+        return self.engine.dev.exchange_ms()
+
+    def exchange_text(self, backend: str) -> str:
+        return f"one all_gather of partial-row slabs per query ({backend})"
+
+    def algorithmic_bytes_per_launch(self) -> float:
+        from minispark_amd import synth
+
+        return synth.Q1_BYTES_PER_ROW * self.table.nrows
+
+    def config(self, rows) -> dict:
+        from minispark_amd import constants, synth
+
+        a = self.args
+        return {
+            "workload": f"TPC-H Q1 variant (8 aggregates, WHERE l_shipdate <= '{a.cutoff}', GROUP BY l_returnflag) "
+                        f"on synthetic lineitem sf={a.sf:g}",
+            "rows": self.total_units, "blocks": len(synth.block_sizes(self.total_units)),
+            "rows_per_block": constants.ROWS_PER_BLOCK, "bytes_per_row": synth.Q1_BYTES_PER_ROW,
+            "groups": len(rows or []),
+        }
+
+    def roofline(self, kernel_avg_ms: float) -> dict:
+        from minispark_amd import synth
+
+        local_rows = self.table.nrows
+        achieved = synth.Q1_BYTES_PER_ROW * local_rows / (kernel_avg_ms * 1e-3) / 1e9
+        out = {
+            "bound": "hbm", "kernel": "k_agg_jit (k_agg_main body; unit combine fused into its epilogue)",
+            "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": None, "kernel_ms": kernel_avg_ms, "rows_per_launch": local_rows,
+            # `achieved` prices the ALGORITHMIC 26 B/row (SURVEY 8d); the kernel moves 25 (fixed-width key: length
+            # bytes are not read), so the rate at which bytes really leave HBM is the lower figure below
+            "algorithmic_bytes_per_row": synth.Q1_BYTES_PER_ROW, "moved_bytes_per_row": Q1_MOVED_BYTES_PER_ROW,
+            "moved_GBps": Q1_MOVED_BYTES_PER_ROW * local_rows / (kernel_avg_ms * 1e-3) / 1e9,
+            "launch": self.engine.dev.last_scan,
+        }
+        if self.world == 1 and self.total_units == 600_037_902:
+            out.update(pmc_traffic("r02_pmc_hbm_traffic_q1_sf100.json"))
+            if out["traffic"]:
+                out["hbm_frac"] = out["traffic"] / (kernel_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
+        return out
+
+    def full_check(self, rows) -> dict:
+        return q1_full_check(rows, self.total_units, self.args.cutoff)
+
+    def cpu_baseline(self) -> dict:
+        from minispark_amd import synth
+
+        a = self.args
+        blocks = min(a.sample_blocks, len(self.table.block_rows))
+        sample = synth.make_lineitem(self.engine.dev, self.scratch / "sample.bin", sum(self.table.block_rows[:blocks]))
+        self.engine.attach_device_table(self.scratch / "sample.bin", sample)
+        gpu_sample_rows = q1_frame(self.engine, str(self.scratch / "sample.bin"), a.cutoff).collect()
+        out = q1_cpu_baseline(self.table, blocks, gpu_sample_rows, a.cutoff)
+        out["python_engine_port"] = python_engine_baseline(self.scratch, a.cutoff)
+        return out
 
 
 if __name__ == "__main__":

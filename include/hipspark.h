@@ -186,7 +186,7 @@ typedef struct hs_agg_geom {
     int32_t group_cap;   /* per-workgroup / per-unit dictionary capacity (power of two) */
     int32_t chunk_rows;  /* rows per workgroup */
     int32_t wg_threads;  /* lanes per workgroup: 256, 128 or 64 (each lane owns a private LDS table) */
-    int32_t pad;
+    int32_t pad;         /* set by the *_geom helpers (shared tier: slots of a unit's table); pass it on unchanged */
     int64_t n_chunks;    /* grid size */
     size_t lds_bytes;    /* dynamic LDS of the main kernel */
     size_t ws_bytes;     /* workspace bytes */
@@ -218,6 +218,10 @@ int hs_agg_partial_chunks(const int64_t* host_unit_rows, int64_t n_units, const 
  *   out_ngroups[n_units] : occupied slots per unit
  * ev_begin / ev_end: optional hipEvent_t recorded on `stream` immediately before / after the main
  * scan kernel (NULL = none) - how bench.py measures the kernel's duration live.
+ * ws: geom->ws_bytes bytes, ZERO-FILLED BEFORE THE FIRST LAUNCH that uses it (it ends in one arrival counter per
+ * unit: the workgroup that finishes a unit's last chunk combines the unit inside the scan kernel and leaves the
+ * counter at zero again, so later launches re-use the buffer as it is).  HIPSPARK_FUSE_UNIT=0, or a unit without
+ * rows, selects the separate combine launch (k_agg_unit) instead.
  */
 int hs_agg_partial(void* stream, const hs_col* cols, int32_t n_cols, int32_t key_col, const hs_program* prog,
                    const hs_agg_spec* spec, const hs_chunk* chunks, const int64_t* unit_chunk0, int64_t n_units,

@@ -85,151 +85,12 @@ __global__ void __launch_bounds__(256) k_agg_shared_finish(const SharedFinishArg
 }
 
 // --------------------------------------------------------------------------------------------------
-struct AggUnitArgs {
-    hs_col key;
-    hs_agg_spec spec;
-    int32_t group_cap;
-    int32_t hashed;
-    int32_t batch;  // chunks staged through LDS per step (<= HS_UNIT_BATCH, sized to the LDS budget)
-    int32_t pad;
-    const int64_t* unit_chunk0;
-    const uint64_t* part_keys;
-    const int64_t* part_rep;
-    const uint64_t* part_acc;
-    int64_t* out_rep;      // [n_units][GC]
-    uint64_t* out_acc;     // [n_units][GC][NA] quantised
-    int32_t* out_ngroups;  // [n_units]
-    uint32_t* flags;
-    // slab emission (hs_agg_partial_slab): rows of unit u dense from slab row u * GC; NULL = the arrays above
-    uint8_t* slab;
-    const int64_t* unit_ids;
-    int64_t order_off, key_off;
-    int64_t acc_off[HS_MAX_ACC];
-    int32_t key_bytes, pad2;
-};
-
-// One workgroup per unit.  Phase 1: every (chunk, slot) entry of the unit is inserted into the unit's
-// dictionary in parallel (the SET of keys does not depend on insertion races) and remembers its unit
-// slot.  Phase 2: one lane per (unit slot, accumulator) folds that key's chunk partials in ascending
-// chunk order = row order, without barriers.  Chunks are staged through LDS in batches.
-#define HS_UNIT_BATCH 64 /* chunks per LDS batch */
+// One workgroup per unit: the stand-alone form of the unit combine (body: hs_agg_kernel.h).  Used when the combine is
+// not fused into the scan kernel's epilogue (HIPSPARK_FUSE_UNIT=0, a unit without rows, tables too small to stage it).
 __global__ void __launch_bounds__(256) k_agg_unit(const AggUnitArgs A_kernarg) {
     HS_KERNARG(AggUnitArgs, A);
     extern __shared__ __align__(16) uint64_t lds[];
-    const int GC = A.group_cap, NA = A.spec.n_acc;
-    uint64_t* ukeys = lds;                                  // [GC]
-    int64_t* ureps = (int64_t*)(lds + GC);                  // [GC]
-    uint64_t* uacc = lds + 2 * GC;                          // [GC][NA]
-    uint64_t* pacc = uacc + GC * NA;                        // [BATCH][GC][NA] staged chunk partials
-    const int BATCH = A.batch;
-    int* inv = (int*)(pacc + (size_t)BATCH * GC * NA);  // [BATCH][GC] unit slot -> chunk slot (or -1)
-    __shared__ int s_count;
-    const int tid = threadIdx.x, nthr = blockDim.x;
-    const int64_t u = blockIdx.x;
-    uint32_t err = 0;
-
-    for (int i = tid; i < GC; i += nthr) {
-        ukeys[i] = HS_EMPTY_KEY;
-        ureps[i] = -1;
-    }
-    for (int i = tid; i < GC * NA; i += nthr) uacc[i] = hs_acc_identity(A.spec.op[i % NA], A.spec.is_int[i % NA] != 0);
-    if (tid == 0) s_count = 0;
-    __syncthreads();
-
-    const uint32_t mask = (uint32_t)GC - 1;
-    const int64_t cbeg = A.unit_chunk0[u], cend = A.unit_chunk0[u + 1];
-    for (int64_t b0 = cbeg; b0 < cend; b0 += BATCH) {
-        const int nb = (int)((cend - b0) < BATCH ? (cend - b0) : BATCH);
-        for (int i = tid; i < nb * GC; i += nthr) inv[i] = -1;
-        __syncthreads();
-        for (int i = tid; i < nb * GC; i += nthr) {
-            const int64_t c = b0 + i / GC;
-            const int sl = i % GC;
-            const int64_t rep = A.part_rep[c * GC + sl];
-            if (rep >= 0) {
-                const int m = A.hashed ? hs_dict_upsert_rows(ureps, mask, A.key, hs_key_at(A.key, rep), rep)
-                                       : hs_dict_upsert_word(ukeys, ureps, mask, A.part_keys[c * GC + sl], rep);
-                if (m < 0) err |= HS_FLAG_DICT_FULL;
-                else inv[(i / GC) * GC + m] = sl;  // keys are distinct within a chunk: one writer per cell
-            }
-        }
-        for (int i = tid; i < nb * GC * NA; i += nthr) pacc[i] = A.part_acc[b0 * GC * NA + i];
-        __syncthreads();
-        for (int i = tid; i < GC * NA; i += nthr) {
-            const int us = i / NA, a = i % NA;
-            const uint32_t op = A.spec.op[a];
-            const bool is_int = A.spec.is_int[a] != 0;
-            uint64_t v = uacc[i];
-            for (int c = 0; c < nb; ++c) {  // ascending chunk order = row order
-                const int sl = inv[c * GC + us];
-                if (sl >= 0) v = hs_acc_fold(op, is_int, v, pacc[(c * GC + sl) * NA + a]);
-            }
-            uacc[i] = v;
-        }
-        __syncthreads();
-    }
-    if (A.slab) {
-        // the unit's groups, dense from slab row u * GC, in the stored kinds (what the reference's shuffle file
-        // holds); dense position of a slot = number of occupied slots before it (wave 0, ballot prefix)
-        int* dpos = inv;  // [GC]
-        if (tid < HS_WAVE) {
-            int running = 0;
-            for (int base = 0; base < GC; base += HS_WAVE) {
-                const int sl = base + tid;
-                const bool valid = sl < GC && ureps[sl] >= 0;
-                const unsigned long long m = __ballot(valid);
-                if (valid) dpos[sl] = running + __popcll(m & ((1ull << tid) - 1));
-                running += __popcll(m);
-            }
-            if (tid == 0) s_count = running;
-        }
-        __syncthreads();
-        const int count = s_count;
-        const int64_t row0 = u * GC;
-        int64_t* order = (int64_t*)(A.slab + A.order_off) + row0;
-        const int64_t uid = A.unit_ids ? A.unit_ids[u] : u;
-        for (int i = tid; i < GC; i += nthr) order[i] = i < count ? uid : -1;
-        const int kb = A.key_bytes;
-        for (int sl = tid; sl < GC; sl += nthr) {
-            const int64_t rep = ureps[sl];
-            if (rep < 0) continue;
-            const uint8_t* src = (const uint8_t*)A.key.data + rep * kb;
-            uint8_t* dst = A.slab + A.key_off + (row0 + dpos[sl]) * kb;
-            for (int b = 0; b < kb; ++b) dst[b] = src[b];
-        }
-        for (int i = tid; i < GC * NA; i += nthr) {
-            const int sl = i / NA, a = i % NA;
-            if (ureps[sl] < 0) continue;
-            const bool is_int = A.spec.is_int[a] != 0;
-            if (hs_float_identity_left(A.spec.op[a], is_int, uacc[i])) err |= HS_FLAG_TYPE_ASSERT;
-            const uint64_t v = hs_quantise_cell(is_int, uacc[i], err);
-            uint8_t* col = A.slab + A.acc_off[a];
-            if (is_int) ((int32_t*)col)[row0 + dpos[sl]] = (int32_t)(int64_t)v;
-            else ((float*)col)[row0 + dpos[sl]] = (float)hs_u2d(v);
-        }
-        if (tid == 0) err |= __hip_atomic_load(A.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the scan's status
-        if (err) {
-            atomicOr(A.flags, err);
-            atomicOr((uint32_t*)A.slab, err);  // slab header: reaches every rank with the rows
-        }
-        return;
-    }
-    for (int sl = tid; sl < GC; sl += nthr) {
-        // representative = smallest row index seen for the slot would need a second pass; any row of the
-        // key is equivalent (same key bytes), so keep the one that won the insert
-        const int64_t rep = ureps[sl];
-        A.out_rep[u * GC + sl] = rep;
-        if (rep >= 0) atomicAdd(&s_count, 1);
-    }
-    for (int i = tid; i < GC * NA; i += nthr) {
-        const int a = i % NA;
-        if (ureps[i / NA] >= 0 && hs_float_identity_left(A.spec.op[a], A.spec.is_int[a] != 0, uacc[i]))
-            err |= HS_FLAG_TYPE_ASSERT;
-        A.out_acc[u * (int64_t)GC * NA + i] = hs_quantise_cell(A.spec.is_int[a] != 0, uacc[i], err);
-    }
-    __syncthreads();
-    if (tid == 0) A.out_ngroups[u] = s_count;
-    if (err) atomicOr(A.flags, err);
+    hs_agg_unit_body<false>(A, (int64_t)blockIdx.x, lds);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -911,6 +772,13 @@ static int program_depth(const hs_program* p) {
 static constexpr size_t HS_LDS_SOFT = 64 * 1024;   // keeps >= 2 workgroups per CU resident
 static constexpr size_t HS_LDS_HARD = 144 * 1024;  // one workgroup per CU (gfx950: 160 KiB per CU)
 
+// hs_agg_geom.pad of the private-table tier: set when every unit owns at least one chunk (fused unit combine allowed)
+static constexpr int32_t HS_GEOM_FUSABLE = 0x46555345;  // "FUSE"
+static size_t hs_agg_partials_bytes(int64_t n_chunks, int32_t group_cap, int32_t n_acc) {
+    const size_t slots = (size_t)n_chunks * (size_t)group_cap;
+    return (slots * 16 + slots * (size_t)n_acc * 8 + 256 + 15) & ~(size_t)15;
+}
+
 static size_t agg_main_lds(int32_t group_cap, int32_t n_acc, int wg) {
     return (size_t)group_cap * 16 + (size_t)group_cap * (size_t)n_acc * (size_t)wg * 8;
 }
@@ -1001,14 +869,18 @@ extern "C" int hs_agg_partial_geom(const int64_t* host_unit_rows, int64_t n_unit
         const int64_t span = host_unit_rows[u + 1] - anchor;
         n_chunks += span > 0 ? (span + chunk - 1) / chunk : 0;
     }
+    bool every_unit_has_rows = n_units > 0;
+    for (int64_t u = 0; u < n_units; ++u) every_unit_has_rows = every_unit_has_rows && host_unit_rows[u + 1] > host_unit_rows[u];
     out->group_cap = group_cap;
     out->chunk_rows = (int32_t)chunk;
     out->wg_threads = wg;
-    out->pad = 0;
+    // a unit without rows owns no chunk, so no workgroup would ever combine it: such launches keep the separate
+    // combine kernel (which writes the empty unit's outputs)
+    out->pad = every_unit_has_rows ? HS_GEOM_FUSABLE : 0;
     out->n_chunks = n_chunks;
     out->lds_bytes = lds;
-    const size_t slots = (size_t)n_chunks * group_cap;
-    out->ws_bytes = slots * 16 + slots * (size_t)n_acc * 8 + 256;
+    // chunk partials + 256 spare bytes + one arrival counter per unit (fused combine)
+    out->ws_bytes = hs_agg_partials_bytes(n_chunks, group_cap, n_acc) + (size_t)n_units * 4 + 64;
     return HS_OK;
 }
 
@@ -1114,29 +986,17 @@ static int agg_partial_impl(void* stream, const hs_col* cols, int32_t n_cols, in
         return HS_E_ARG;
     }
     dim3 grid((unsigned)geom->n_chunks), block((unsigned)geom->wg_threads);
-    static bool attrs_set = false;
-    if (!attrs_set) {
+    static unsigned long long attrs_set = 0;
+    if (hs_first_on_device(attrs_set)) {
         allow_big_lds(k_agg_main<true, 8>);
         allow_big_lds(k_agg_main<false, 4>);
         allow_big_lds(k_agg_main<false, 8>);
-        attrs_set = true;
     }
     if (geom->n_chunks > 0x7fffffffll) {
         hs_set_error("hs_agg_partial: too many chunks");
         return HS_E_LIMIT;
     }
-    if (ev_begin) (void)hipEventRecord((hipEvent_t)ev_begin, s);
-    const int jit_rc = hs_jit_launch_agg_main(&A, hashed, grid.x, block.x, geom->lds_bytes, s);
-    if (jit_rc == HS_OK) {
-        // launched the program compiled for exactly this bytecode
-    } else if (hashed) {
-        hipLaunchKernelGGL((k_agg_main<true, 8>), grid, block, geom->lds_bytes, s, A);
-    } else if (depth <= 4) {
-        hipLaunchKernelGGL((k_agg_main<false, 4>), grid, block, geom->lds_bytes, s, A);
-    } else {
-        hipLaunchKernelGGL((k_agg_main<false, 8>), grid, block, geom->lds_bytes, s, A);
-    }
-    if (ev_end) (void)hipEventRecord((hipEvent_t)ev_end, s);
+    // ---- the unit combine: arguments first, then decide whether it rides in the scan kernel's epilogue ----
     AggUnitArgs U;
     U.key = cols[key_col];
     U.spec = *spec;
@@ -1172,12 +1032,40 @@ static int agg_partial_impl(void* stream, const hs_col* cols, int32_t n_cols, in
     }
     U.batch = ubatch;
     U.pad = 0;
-    static bool unit_attr = false;
-    if (!unit_attr) {
-        allow_big_lds(k_agg_unit);
-        unit_attr = true;
+    // Fused form: the workgroup that finishes a unit's last chunk combines the unit inside the scan
+    // kernel, staging through the kernel's own LDS block.  Needs: the arrival counters (tail of `ws`, zero before the
+    // first launch, left zero by every launch), every unit owning at least one chunk (the caller says so by passing
+    // fused_ok), a staging batch that fits that block.
+    A.unit_arrivals = nullptr;
+    A.unit = U;
+    static const bool fuse_env = !(getenv("HIPSPARK_FUSE_UNIT") && getenv("HIPSPARK_FUSE_UNIT")[0] == '0');
+    bool fused = false;
+    if (fuse_env && geom->pad == HS_GEOM_FUSABLE && spec->n_acc > 0) {
+        int fbatch = ubatch;
+        while (fbatch > 1 && ubase + (size_t)fbatch * uper > geom->lds_bytes) fbatch /= 2;
+        if (ubase + (size_t)fbatch * uper <= geom->lds_bytes) {
+            A.unit.batch = fbatch;
+            A.unit_arrivals = (uint32_t*)((char*)ws + hs_agg_partials_bytes(geom->n_chunks, geom->group_cap, spec->n_acc));
+            fused = true;
+        }
     }
-    hipLaunchKernelGGL(k_agg_unit, dim3((unsigned)n_units), dim3(256), ulds, s, U);
+    if (ev_begin) (void)hipEventRecord((hipEvent_t)ev_begin, s);
+    const int jit_rc = hs_jit_launch_agg_main(&A, hashed, grid.x, block.x, geom->lds_bytes, s);
+    if (jit_rc == HS_OK) {
+        // launched the program compiled for exactly this bytecode
+    } else if (hashed) {
+        hipLaunchKernelGGL((k_agg_main<true, 8>), grid, block, geom->lds_bytes, s, A);
+    } else if (depth <= 4) {
+        hipLaunchKernelGGL((k_agg_main<false, 4>), grid, block, geom->lds_bytes, s, A);
+    } else {
+        hipLaunchKernelGGL((k_agg_main<false, 8>), grid, block, geom->lds_bytes, s, A);
+    }
+    if (ev_end) (void)hipEventRecord((hipEvent_t)ev_end, s);
+    if (!fused) {
+        static unsigned long long unit_attr = 0;
+        if (hs_first_on_device(unit_attr)) allow_big_lds(k_agg_unit);
+        hipLaunchKernelGGL(k_agg_unit, dim3((unsigned)n_units), dim3(256), ulds, s, U);
+    }
     if (hipGetLastError() != hipSuccess) {
         hs_set_error("hs_agg_partial: kernel launch failed");
         return HS_E_LAUNCH;
@@ -1285,11 +1173,10 @@ extern "C" int hs_agg_merge(void* stream, const hs_col* key, const hs_col* acc_c
     A.out_acc = out_acc;
     A.out_ngroups = out_ngroups;
     A.flags = flags;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;
+    if (hs_first_on_device(attr_set)) {
         hipFuncSetAttribute((const void*)k_agg_merge_small, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)HS_MERGE_LDS_MAX);
-        attr_set = true;
     }
     hipLaunchKernelGGL(k_agg_merge_small, dim3(1), dim3(merge_block(n_rows, cap, A.n_order)), lds, (hipStream_t)stream, A);
     if (hipGetLastError() != hipSuccess) {
@@ -1412,11 +1299,10 @@ extern "C" int hs_agg_finish(void* stream, const uint8_t* gathered, int32_t worl
                      fin->n_fold, total_lds, HS_MERGE_LDS_MAX);
         return HS_E_LIMIT;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0;
+    if (hs_first_on_device(attr_set)) {
         hipFuncSetAttribute((const void*)k_agg_finish<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HS_MERGE_LDS_MAX);
         hipFuncSetAttribute((const void*)k_agg_finish<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HS_MERGE_LDS_MAX);
-        attr_set = true;
     }
     const dim3 block(merge_block(n_rows, cap, A.n_order));
     if (small) hipLaunchKernelGGL(k_agg_finish<true>, dim3(1), block, total_lds, (hipStream_t)stream, A);
@@ -1561,6 +1447,8 @@ extern "C" int hs_agg_shared(void* stream, const hs_col* cols, int32_t n_cols, i
     A.part_rep = out_rep;
     A.part_acc = out_acc;
     A.flags = flags;
+    A.unit_arrivals = nullptr;  // this tier merges chunk tables with global atomics, there is no unit combine
+    memset(&A.unit, 0, sizeof(A.unit));
     {  // the replica count the geometry sized the LDS block for
         const size_t per_replica = (size_t)geom->group_cap * (size_t)(spec->n_acc > 0 ? spec->n_acc : 1) * 8;
         const size_t r = (geom->lds_bytes - (size_t)geom->group_cap * 16) / per_replica;
@@ -1586,12 +1474,11 @@ extern "C" int hs_agg_shared(void* stream, const hs_col* cols, int32_t n_cols, i
     if (init_blocks > 4096) init_blocks = 4096;
     hipLaunchKernelGGL(k_agg_shared_init, dim3((unsigned)init_blocks), dim3(256), 0, s, I);
     const bool hashed = !hs_col_packs(cols[key_col]);
-    static bool attrs_set = false;
-    if (!attrs_set) {
+    static unsigned long long attrs_set = 0;
+    if (hs_first_on_device(attrs_set)) {
         allow_big_lds(k_agg_shared<true, 8>);
         allow_big_lds(k_agg_shared<false, 4>);
         allow_big_lds(k_agg_shared<false, 8>);
-        attrs_set = true;
     }
     dim3 grid((unsigned)geom->n_chunks), block((unsigned)HS_SHARED_WG);
     if (ev_begin) (void)hipEventRecord((hipEvent_t)ev_begin, s);

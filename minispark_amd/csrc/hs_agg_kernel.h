@@ -29,6 +29,171 @@ typedef float hs_f32x4 __attribute__((ext_vector_type(4)));
 typedef int hs_i32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long hs_u64x2 __attribute__((ext_vector_type(2)));
 
+// ---- unit combine (fixed-order fold of a unit's workgroup partials + quantisation to the shuffle-file kinds) ----------
+// Reference: is_last emission tasks.py:272-278 -> WriteToShufflePartitions.write tasks.py:373 -> io.py:87-94.
+// Runs either as its own launch (k_agg_unit, one workgroup per unit) or as the EPILOGUE of the scan kernel: the
+// workgroup that finishes a unit's last chunk combines the unit (hs_agg_main_body), so the combine of every unit but
+// the last overlaps the scan and the query's tail loses a launch.
+struct AggUnitArgs {
+    hs_col key;
+    hs_agg_spec spec;
+    int32_t group_cap;
+    int32_t hashed;
+    int32_t batch;  // chunks staged through LDS per step (<= HS_UNIT_BATCH, sized to the LDS budget)
+    int32_t pad;
+    const int64_t* unit_chunk0;
+    const uint64_t* part_keys;
+    const int64_t* part_rep;
+    const uint64_t* part_acc;
+    int64_t* out_rep;      // [n_units][GC]
+    uint64_t* out_acc;     // [n_units][GC][NA] quantised
+    int32_t* out_ngroups;  // [n_units]
+    uint32_t* flags;
+    // slab emission (hs_agg_partial_slab): rows of unit u dense from slab row u * GC; NULL = the arrays above
+    uint8_t* slab;
+    const int64_t* unit_ids;
+    int64_t order_off, key_off;
+    int64_t acc_off[HS_MAX_ACC];
+    int32_t key_bytes, pad2;
+};
+#define HS_UNIT_BATCH 64 /* chunks per LDS batch */
+
+// Chunk partials handed from one workgroup to another INSIDE a launch (fused combine): per-XCD L2s are not coherent
+// and a CU's L1 is never refreshed by other CUs' stores, so both sides use agent-scope (sc1, write-through / L1-
+// bypassing) accesses for exactly these words (cdna_hip_programming.md section 6 G16, R1 with a counter).  Across a
+// launch boundary (HANDOFF false) plain accesses do.
+template <bool HANDOFF, typename T>
+__device__ __forceinline__ T hs_ld_part(const T* p) {
+    if constexpr (HANDOFF) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <typename T>
+__device__ __forceinline__ void hs_st_part(T* p, T v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Phase 1: every (chunk, slot) entry of the unit is inserted into the unit's dictionary in parallel (the SET of keys
+// does not depend on insertion races) and remembers its unit slot.  Phase 2: one lane per (unit slot, accumulator)
+// folds that key's chunk partials in ascending chunk order = row order, without barriers.  Chunks are staged through
+// LDS in batches.  `lds`: GC * 16 + GC * NA * 8 + batch * (GC * NA * 8 + GC * 4) bytes.  All lanes of the workgroup.
+template <bool HANDOFF>
+__device__ __forceinline__ void hs_agg_unit_body(const AggUnitArgs& A, const int64_t u, uint64_t* lds) {
+    const int GC = A.group_cap, NA = A.spec.n_acc;
+    uint64_t* ukeys = lds;                                  // [GC]
+    int64_t* ureps = (int64_t*)(lds + GC);                  // [GC]
+    uint64_t* uacc = lds + 2 * GC;                          // [GC][NA]
+    uint64_t* pacc = uacc + GC * NA;                        // [BATCH][GC][NA] staged chunk partials
+    const int BATCH = A.batch;
+    int* inv = (int*)(pacc + (size_t)BATCH * GC * NA);  // [BATCH][GC] unit slot -> chunk slot (or -1)
+    __shared__ int s_count;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    uint32_t err = 0;
+
+    for (int i = tid; i < GC; i += nthr) {
+        ukeys[i] = HS_EMPTY_KEY;
+        ureps[i] = -1;
+    }
+    for (int i = tid; i < GC * NA; i += nthr) uacc[i] = hs_acc_identity(A.spec.op[i % NA], A.spec.is_int[i % NA] != 0);
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+
+    const uint32_t mask = (uint32_t)GC - 1;
+    const int64_t cbeg = A.unit_chunk0[u], cend = A.unit_chunk0[u + 1];
+    for (int64_t b0 = cbeg; b0 < cend; b0 += BATCH) {
+        const int nb = (int)((cend - b0) < BATCH ? (cend - b0) : BATCH);
+        for (int i = tid; i < nb * GC; i += nthr) inv[i] = -1;
+        __syncthreads();
+        for (int i = tid; i < nb * GC; i += nthr) {
+            const int64_t c = b0 + i / GC;
+            const int sl = i % GC;
+            const int64_t rep = hs_ld_part<HANDOFF>(&A.part_rep[c * GC + sl]);
+            if (rep >= 0) {
+                const int m = A.hashed ? hs_dict_upsert_rows(ureps, mask, A.key, hs_key_at(A.key, rep), rep)
+                                       : hs_dict_upsert_word(ukeys, ureps, mask, hs_ld_part<HANDOFF>(&A.part_keys[c * GC + sl]), rep);
+                if (m < 0) err |= HS_FLAG_DICT_FULL;
+                else inv[(i / GC) * GC + m] = sl;  // keys are distinct within a chunk: one writer per cell
+            }
+        }
+        for (int i = tid; i < nb * GC * NA; i += nthr) pacc[i] = hs_ld_part<HANDOFF>(&A.part_acc[b0 * GC * NA + i]);
+        __syncthreads();
+        for (int i = tid; i < GC * NA; i += nthr) {
+            const int us = i / NA, a = i % NA;
+            const uint32_t op = A.spec.op[a];
+            const bool is_int = A.spec.is_int[a] != 0;
+            uint64_t v = uacc[i];
+            for (int c = 0; c < nb; ++c) {  // ascending chunk order = row order
+                const int sl = inv[c * GC + us];
+                if (sl >= 0) v = hs_acc_fold(op, is_int, v, pacc[(c * GC + sl) * NA + a]);
+            }
+            uacc[i] = v;
+        }
+        __syncthreads();
+    }
+    if (A.slab) {
+        // the unit's groups, dense from slab row u * GC, in the stored kinds (what the reference's shuffle file
+        // holds); dense position of a slot = number of occupied slots before it (wave 0, ballot prefix)
+        int* dpos = inv;  // [GC]
+        if (tid < HS_WAVE) {
+            int running = 0;
+            for (int base = 0; base < GC; base += HS_WAVE) {
+                const int sl = base + tid;
+                const bool valid = sl < GC && ureps[sl] >= 0;
+                const unsigned long long m = __ballot(valid);
+                if (valid) dpos[sl] = running + __popcll(m & ((1ull << tid) - 1));
+                running += __popcll(m);
+            }
+            if (tid == 0) s_count = running;
+        }
+        __syncthreads();
+        const int count = s_count;
+        const int64_t row0 = u * GC;
+        int64_t* order = (int64_t*)(A.slab + A.order_off) + row0;
+        const int64_t uid = A.unit_ids ? A.unit_ids[u] : u;
+        for (int i = tid; i < GC; i += nthr) order[i] = i < count ? uid : -1;
+        const int kb = A.key_bytes;
+        for (int sl = tid; sl < GC; sl += nthr) {
+            const int64_t rep = ureps[sl];
+            if (rep < 0) continue;
+            const uint8_t* src = (const uint8_t*)A.key.data + rep * kb;
+            uint8_t* dst = A.slab + A.key_off + (row0 + dpos[sl]) * kb;
+            for (int b = 0; b < kb; ++b) dst[b] = src[b];
+        }
+        for (int i = tid; i < GC * NA; i += nthr) {
+            const int sl = i / NA, a = i % NA;
+            if (ureps[sl] < 0) continue;
+            const bool is_int = A.spec.is_int[a] != 0;
+            if (hs_float_identity_left(A.spec.op[a], is_int, uacc[i])) err |= HS_FLAG_TYPE_ASSERT;
+            const uint64_t v = hs_quantise_cell(is_int, uacc[i], err);
+            uint8_t* col = A.slab + A.acc_off[a];
+            if (is_int) ((int32_t*)col)[row0 + dpos[sl]] = (int32_t)(int64_t)v;
+            else ((float*)col)[row0 + dpos[sl]] = (float)hs_u2d(v);
+        }
+        // the scan's status so far (fused: at least every chunk of THIS unit has OR-ed its bits in before arriving)
+        if (tid == 0) err |= __hip_atomic_load(A.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (err) {
+            atomicOr(A.flags, err);
+            atomicOr((uint32_t*)A.slab, err);  // slab header: reaches every rank with the rows
+        }
+        return;
+    }
+    for (int sl = tid; sl < GC; sl += nthr) {
+        // representative = smallest row index seen for the slot would need a second pass; any row of the
+        // key is equivalent (same key bytes), so keep the one that won the insert
+        const int64_t rep = ureps[sl];
+        A.out_rep[u * GC + sl] = rep;
+        if (rep >= 0) atomicAdd(&s_count, 1);
+    }
+    for (int i = tid; i < GC * NA; i += nthr) {
+        const int a = i % NA;
+        if (ureps[i / NA] >= 0 && hs_float_identity_left(A.spec.op[a], A.spec.is_int[a] != 0, uacc[i]))
+            err |= HS_FLAG_TYPE_ASSERT;
+        A.out_acc[u * (int64_t)GC * NA + i] = hs_quantise_cell(A.spec.is_int[a] != 0, uacc[i], err);
+    }
+    __syncthreads();
+    if (tid == 0) A.out_ngroups[u] = s_count;
+    if (err) atomicOr(A.flags, err);
+}
+
 struct AggMainArgs {
     HsCols cols;
     hs_program prog;
@@ -46,6 +211,10 @@ struct AggMainArgs {
     uint32_t* flags;
     int32_t replicas;     // shared-dictionary tier: accumulator copies per slot (power of two <= 64), else 0
     int32_t pad2;
+    // fused unit combine (private-table tier): arrivals[u] counts the finished chunks of unit u (zero before the first
+    // launch; the last arriver zeroes it again); NULL = the combine is a separate launch (k_agg_unit)
+    uint32_t* unit_arrivals;
+    AggUnitArgs unit;
 };
 
 // 64-bit wave shuffle-down
@@ -320,6 +489,25 @@ struct InterpProg {
     }
 };
 
+// End of a chunk: its partials (agent-scope stores above) are drained, then ONE lane counts the arrival; the workgroup
+// that brings a unit's count to its number of chunks combines the unit right here (all its lanes; `lds` = the kernel's
+// dynamic LDS block, free again at this point).  Every workgroup arrives - also one that left early - so the counters
+// are back at zero when the launch ends.
+__device__ __forceinline__ void hs_agg_main_arrive(const AggMainArgs& A, const int64_t unit, uint64_t* lds) {
+    if (!A.unit_arrivals) return;  // wave-uniform (kernel argument)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave, before the barrier
+    __syncthreads();                                  // ... which also frees the LDS tables for the combine
+    __shared__ int s_last;
+    if (threadIdx.x == 0) {
+        const uint32_t need = (uint32_t)(A.unit_chunk0[unit + 1] - A.unit_chunk0[unit]);
+        const uint32_t prev = __hip_atomic_fetch_add(&A.unit_arrivals[unit], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = prev + 1 == need;
+        if (s_last) __hip_atomic_store(&A.unit_arrivals[unit], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (s_last) hs_agg_unit_body<true>(A.unit, unit, lds);
+}
+
 // ---- the kernel body ---------------------------------------------------------------------------------
 template <class Prog>
 __device__ __forceinline__ void hs_agg_main_body(const AggMainArgs& A) {
@@ -344,9 +532,10 @@ __device__ __forceinline__ void hs_agg_main_body(const AggMainArgs& A) {
     __syncthreads();
     if (s_overflowed) {
         for (int i = threadIdx.x; i < A.group_cap; i += blockDim.x) {
-            A.part_keys[chunk * A.group_cap + i] = HS_EMPTY_KEY;
-            A.part_rep[chunk * A.group_cap + i] = -1;
+            hs_st_part(&A.part_keys[chunk * A.group_cap + i], HS_EMPTY_KEY);
+            hs_st_part(&A.part_rep[chunk * A.group_cap + i], (int64_t)-1);
         }
+        hs_agg_main_arrive(A, desc.unit, hs_lds);
         return;
     }
 
@@ -424,15 +613,16 @@ __device__ __forceinline__ void hs_agg_main_body(const AggMainArgs& A) {
 #pragma unroll
             for (int k = 0; k < HS_RED; ++k) {
                 const uint32_t cellid = c0id + (uint32_t)k * nwaves;
-                if (on[k]) A.part_acc[((int64_t)chunk * GC + cellid / NA) * NA + cellid % NA] = v[k];
+                if (on[k]) hs_st_part(&A.part_acc[((int64_t)chunk * GC + cellid / NA) * NA + cellid % NA], v[k]);
             }
         }
     }
     for (int i = tid; i < GC; i += nthr) {
-        A.part_keys[chunk * GC + i] = dkeys[i];
-        A.part_rep[chunk * GC + i] = dreps[i];
+        hs_st_part(&A.part_keys[chunk * GC + i], dkeys[i]);
+        hs_st_part(&A.part_rep[chunk * GC + i], dreps[i]);
     }
     if (ctx.err) atomicOr(A.flags, ctx.err);
+    hs_agg_main_arrive(A, desc.unit, hs_lds);
 }
 
 // ======================================================================================================

@@ -54,6 +54,19 @@ static constexpr uint64_t HS_EMPTY_KEY = 0x8000000000000000ull;
     __syncthreads();                                                                                   \
     const T& name = *(const T*)name##_lds
 
+#ifndef HS_JIT_BUILD
+// Host side: one-time per-DEVICE set-up (function attributes live per device; a process may drive several GPUs).
+// `seen` = a static bit set owned by the call site; true the first time the current device comes by.
+static inline bool hs_first_on_device(unsigned long long& seen) {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    const unsigned long long bit = 1ull << (d & 63);
+    if (seen & bit) return false;
+    seen |= bit;
+    return true;
+}
+#endif
+
 struct HsCols {
     int32_t n;
     int32_t pad;

@@ -1100,10 +1100,9 @@ static int group_build(void* stream, const hs_col* left_key, const int64_t* sel,
         hipMemsetAsync(long_count, 0, 8, s);
         hipLaunchKernelGGL(k_join_sort, dim3(grid_for(table_cap, 256)), dim3(256), 0, s, slot_start, table_cap, rows,
                            long_list, long_count);
-        static bool attr_set = false;
-        if (!attr_set) {
+        static unsigned long long attr_set = 0;
+        if (hs_first_on_device(attr_set)) {
             hipFuncSetAttribute((const void*)k_join_sort_long, hipFuncAttributeMaxDynamicSharedMemorySize, HS_SORT_LDS * 8);
-            attr_set = true;
         }
         int64_t wgs = n_left / HS_SORT_SHORT + 1;  // at most this many long lists; every workgroup exits on the count
         if (wgs > 1024) wgs = 1024;

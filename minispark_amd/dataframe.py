@@ -1,105 +1,111 @@
-"""Fluent query builder over :mod:`minispark_amd.tasks` (reference: src/mini_spark/dataframe.py:28-86).
+"""Query builder with the reference's public surface (API to match: src/mini_spark/dataframe.py:28-86).
 
-Only the subset the hot path's harness needs: ``table / alias / select / filter / group_by().agg /
-join / collect / show / explain``, same method names and argument meaning as the reference.  The
-default engine is the HIP engine - there is no interpreted CPU engine in this package.
+A ``DataFrame`` is a cursor over a growing chain of :mod:`minispark_amd.tasks` nodes; every builder call wraps the
+current chain in one more node and hands the same object back, so calls chain.  What each call appends is declared
+in ``_APPENDERS`` (method name -> node class + how the call's arguments map to the node's fields) and the methods
+are generated from that table; only the calls that do more than append (``alias``, ``join``, running the query)
+are written out.  Without an explicit engine the frame binds to the HIP engine on first use - this package has no
+interpreted CPU engine.
 """
 
 from __future__ import annotations
 
-from copy import deepcopy
+import copy
 from pathlib import Path
-from typing import TYPE_CHECKING
+from typing import Any, Callable
 
+from . import tasks as _t
 from .plan import PhysicalPlan
-from .tasks import (
-    AggregateTask,
-    BroadcastHashJoinTask,
-    FilterTask,
-    JoinType,
-    LoadTableBlockTask,
-    ProjectTask,
-    Task,
-    VoidTask,
-)
 
-if TYPE_CHECKING:
-    from .constants import Row, Schema
-    from .execution import ExecutionEngine
-    from .sql import AggCol, Col
+# builder call -> (task class, arguments -> keyword fields of that class)
+_APPENDERS: dict[str, tuple[type, Callable[..., dict[str, Any]]]] = {
+    "table": (_t.LoadTableBlockTask, lambda file_path: {"file_path": Path(file_path)}),
+    "select": (_t.ProjectTask, lambda *columns: {"columns": list(columns)}),
+    "filter": (_t.FilterTask, lambda column: {"condition": column}),
+}
 
 
 class GroupedData:
-    def __init__(self, df: "DataFrame", column: "Col") -> None:
-        self.df = df
-        self.group_column = column
+    """``df.group_by(col)``: waits for ``agg(...)`` to become an aggregate node over ``df``'s chain."""
 
-    def agg(self, *agg_columns: "AggCol") -> "DataFrame":
-        self.df.task = AggregateTask(self.df.task, group_by_column=self.group_column, agg_columns=list(agg_columns))
-        return self.df
+    def __init__(self, df: "DataFrame", column: Any) -> None:
+        self.df, self.group_column = df, column
+
+    def agg(self, *agg_columns: Any) -> "DataFrame":
+        return self.df._append(_t.AggregateTask, group_by_column=self.group_column, agg_columns=list(agg_columns))
 
 
 class DataFrame:
-    def __init__(self, engine: "ExecutionEngine | None" = None) -> None:
+    def __init__(self, engine: Any = None) -> None:
         self._engine = engine
-        self.task: Task = VoidTask()
+        self.task: _t.Task = _t.VoidTask()
 
+    # ---- chain construction ------------------------------------------------------------------------------
+    def _append(self, node_class: type, **fields: Any) -> "DataFrame":
+        self.task = node_class(self.task, **fields)
+        return self
+
+    def alias(self, alias_name: str) -> "DataFrame":
+        if type(self.task) is not _t.LoadTableBlockTask:
+            raise AssertionError("Alias can only be applied to table")
+        self.task.alias = alias_name
+        return self
+
+    def group_by(self, column: Any) -> GroupedData:
+        return GroupedData(self, column)
+
+    def join(self, other_df: "DataFrame", on: Any, how: _t.JoinType) -> "DataFrame":
+        return self._append(_t.BroadcastHashJoinTask, right_side_task=other_df.task, join_condition=on, how=how)
+
+    # ---- binding + execution ---------------------------------------------------------------------------------
     @property
-    def engine(self) -> "ExecutionEngine":
+    def engine(self) -> Any:
         if self._engine is None:
-            from .execution import HipExecutionEngine  # noqa: PLC0415 - loads the HIP library on first use
+            from .execution import HipExecutionEngine  # noqa: PLC0415 - loads libhipspark.so, needs a GPU
 
             self._engine = HipExecutionEngine()
         return self._engine
 
     @engine.setter
-    def engine(self, engine: "ExecutionEngine") -> None:
+    def engine(self, engine: Any) -> None:
         self._engine = engine
 
     @property
-    def schema(self) -> "Schema":
+    def schema(self) -> Any:
         return self.task.validate_schema()
 
-    def table(self, file_path: str) -> "DataFrame":
-        self.task = LoadTableBlockTask(self.task, file_path=Path(file_path))
-        return self
+    def _rows(self, limit: float | None = None) -> list:
+        engine = self.engine
+        results = engine.execute_full_task(self.task)
+        rows = engine.collect_results(results) if limit is None else engine.collect_results(results, limit=limit)
+        return list(rows)
 
-    def alias(self, alias_name: str) -> "DataFrame":
-        if type(self.task) is not LoadTableBlockTask:
-            raise AssertionError("Alias can only be applied to table")
-        self.task.alias = alias_name
-        return self
-
-    def select(self, *columns: "Col") -> "DataFrame":
-        self.task = ProjectTask(self.task, columns=list(columns))
-        return self
-
-    def filter(self, column: "Col") -> "DataFrame":
-        self.task = FilterTask(self.task, condition=column)
-        return self
-
-    def group_by(self, column: "Col") -> GroupedData:
-        return GroupedData(self, column)
-
-    def join(self, other_df: "DataFrame", on: "Col", how: JoinType) -> "DataFrame":
-        self.task = BroadcastHashJoinTask(self.task, right_side_task=other_df.task, join_condition=on, how=how)
-        return self
-
-    def collect(self) -> "list[Row]":
-        job_results = self.engine.execute_full_task(self.task)
-        return list(self.engine.collect_results(job_results))
+    def collect(self) -> list:
+        return self._rows()
 
     def show(self, n: int = 10) -> int:
-        from tabulate import tabulate  # noqa: PLC0415
+        import tabulate  # noqa: PLC0415
 
-        results = self.engine.execute_full_task(self.task)
-        rows = list(self.engine.collect_results(results, limit=n))
-        print(tabulate(rows, tablefmt="rounded_outline", headers="keys"))  # noqa: T201
+        rows = self._rows(limit=n)
+        print(tabulate.tabulate(rows, headers="keys", tablefmt="rounded_outline"))  # noqa: T201
         return len(rows)
 
     def explain(self, *, full: bool = False) -> None:
-        task = deepcopy(self.task)
+        snapshot = copy.deepcopy(self.task)  # planning annotates the nodes it is given
         print("Logical Plan")  # noqa: T201
-        task.explain()
+        snapshot.explain()
         if full:
-            PhysicalPlan.generate_physical_plan(task).explain()
+            PhysicalPlan.generate_physical_plan(snapshot).explain()
+
+
+def _make_appender(name: str, node_class: type, to_fields: Callable[..., dict[str, Any]]) -> Callable[..., DataFrame]:
+    def method(self: DataFrame, *args: Any, **kwargs: Any) -> DataFrame:
+        return self._append(node_class, **to_fields(*args, **kwargs))
+
+    method.__name__ = method.__qualname__ = name
+    method.__doc__ = f"Wrap the chain in a {node_class.__name__}."
+    return method
+
+
+for _name, (_cls, _to_fields) in _APPENDERS.items():
+    setattr(DataFrame, _name, _make_appender(_name, _cls, _to_fields))

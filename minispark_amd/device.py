@@ -191,6 +191,8 @@ class Device:
         self._const_lens: dict[int, torch.Tensor] = {}
         self._raw_lib = self.lib
         self.rec: Recording | None = None
+        self.scan_events = None
+        self.exchange_events = None
 
     # ---- recording ------------------------------------------------------------------------------------
     def start_recording(self) -> Recording:
@@ -226,6 +228,19 @@ class Device:
                 ev.record()  # creates the underlying hipEvent_t
         else:
             self.scan_events = None
+
+    def time_exchange(self, enable: bool = True) -> None:
+        """Bracket the exchange collective of every following query with events on the launch stream (bench.py's
+        time split); read with exchange_ms() after a synchronise."""
+        if enable:
+            self.exchange_events = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+            for ev in self.exchange_events:
+                ev.record()
+        else:
+            self.exchange_events = None
+
+    def exchange_ms(self) -> float:
+        return self.exchange_events[0].elapsed_time(self.exchange_events[1])
 
     def _event_handle(self, i: int):
         ev = getattr(self, "scan_events", None)
@@ -473,6 +488,25 @@ class Device:
             self._const_lens[width] = buf
         return buf[:n]
 
+    def with_string_width(self, col: DCol, width: int) -> DCol:
+        """The same STRING column described with the width agreed over all ranks (distributed.agree_string_width):
+        an empty local column adopts the peers' fixed width; a locally fixed-width column whose peers hold other
+        lengths gets its offsets materialised (``fixed_len`` -1) so every rank runs the same code path."""
+        if col.kind != hs.STR or col.fixed_len == width:
+            return col
+        if width >= 0:
+            if col.n != 0:
+                raise DeviceError(f"ranks disagree: local strings are not {width} bytes long")
+            return DCol(hs.STR, col.data, 0, lens=self.const_lens(width, 0), offs=None, fixed_len=width)
+        n = col.n
+        lens = col.lens if col.lens is not None else self.const_lens(max(col.fixed_len, 0), n)
+        offs = self.empty(n + 1, torch.int64)
+        minmax = self.empty(2, torch.int32)
+        ws = self.workspace(self.lib.hs_scan_ws_bytes(n))
+        hs.check(self.lib.hs_str_offsets(self.stream, lens.data_ptr(), n, offs.data_ptr(), minmax.data_ptr(),
+                                         ws.data_ptr()), "hs_str_offsets")
+        return DCol(hs.STR, col.data, n, lens=lens, offs=offs, fixed_len=-1)
+
     def resolve(self, batch: DBatch) -> DBatch:
         """Make a lazily-sized batch exact (one D2H of the row count)."""
         if not batch.lazy:
@@ -592,7 +626,8 @@ class Device:
             key = (cache_key, cap, batch.nrows,
                    tuple((c.kind, c.fixed_len, c.data.data_ptr(), c.n, c.lens.data_ptr() if c.lens is not None else 0,
                           c.offs.data_ptr() if c.offs is not None else 0) for c in batch.cols),
-                   len(batch.unit_rows), batch.unit_rows[-1], slab_rows, tail, shared)
+                   tuple(batch.unit_rows), tuple(batch.unit_ids) if batch.unit_ids is not None else None, slab_rows,
+                   tail, shared)
         prep = self._partial_prepared.get(key) if key is not None else None
         if prep is None:
             prep = self._prepare_partial(batch, filters, group_by, agg_columns, cap, slab_rows, tail, out_schema, shared)
@@ -753,7 +788,7 @@ class Device:
                 "key_slot": low.key_slot, "prog": low.program.to_struct(), "spec": low.spec(), "geom": geom,
                 "n_units": n_units, "slots": slots,
                 "d_units": self.to_device(chunks.reshape(-1)), "d_chunk0": self.to_device(chunk0),
-                "ws": self.workspace(geom.ws_bytes),
+                "ws": self.workspace(geom.ws_bytes).zero_(),
                 "tail": {"desc": desc, "layout": layout, "slab": slab, "agg_to_acc": list(low.agg_to_acc),
                          "acc_kinds": acc_kinds, "key_kind": batch.cols[key_idx].kind,
                          "key_len": batch.cols[key_idx].fixed_len, "n_units": n_units},
@@ -793,7 +828,7 @@ class Device:
             "agg_to_acc": low.agg_to_acc,
             "d_units": self.to_device(chunks.reshape(-1)), "d_chunk0": self.to_device(chunk0),
             "out_rep": self.empty(slots, torch.int64), "out_acc": self.empty(max(slots * n_acc, 1), torch.int64),
-            "ngroups": self.empty(max(n_units, 1), torch.int32), "ws": self.workspace(geom.ws_bytes),
+            "ngroups": self.empty(max(n_units, 1), torch.int32), "ws": self.workspace(geom.ws_bytes).zero_(),
             "pack_start": self.empty(n_units + 1, torch.int64), "dense_rep": self.empty(max(slots, 1), torch.int64),
             "acc_kinds": acc_kinds, "acc_bufs": acc_bufs,
             "out_ptrs": (C.c_void_p * max(n_acc, 1))(*[t.data_ptr() for t in acc_bufs]),
@@ -1172,6 +1207,8 @@ class Device:
         ws = self.workspace(self.lib.hs_partition_ws_bytes(n, n_parts))
         hs.check(self.lib.hs_partition_perm(self.stream, part.data_ptr(), n, n_parts, perm.data_ptr(),
                                             part_start.data_ptr(), ws.data_ptr()), "hs_partition_perm")
+        if self.rec is not None:
+            self.rec.poisoned = True  # partition sizes reach the host
         return perm, [int(v) for v in part_start.tolist()]
 
     def partition_by_ids(self, ids: torch.Tensor, n: int, n_parts: int) -> tuple[torch.Tensor, list[int]]:
@@ -1216,7 +1253,7 @@ class Device:
         ws2 = self.workspace(self.lib.hs_scan_ws_bytes(n_right))
         hs.check(self.lib.hs_exclusive_scan_i64(self.stream, counts.data_ptr(), n_right, out_start.data_ptr(),
                                                 ws2.data_ptr()), "hs_exclusive_scan_i64")
-        n_out = int(out_start[n_right].item())
+        n_out = self.host_int(out_start[n_right])  # sizes the pair lists: the run is data-dependent (not replayable)
         out_left = self.empty(max(n_out, 1), torch.int64)
         out_right = self.empty(max(n_out, 1), torch.int64)
         hs.check(self.lib.hs_join_fill(self.stream, C.byref(lk), C.byref(rk), n_right, cap, tkeys.data_ptr(),

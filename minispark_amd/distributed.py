@@ -159,6 +159,28 @@ def all_to_all_rows(dist: Any, send: torch.Tensor, send_counts: list[int], recv_
     return out
 
 
+def agree_string_width(dist: Any, fixed_len: int, nrows: int, device: torch.device, group: Any = None) -> int:
+    """The byte length shared by the strings of a column over ALL ranks, or -1 (variable).  A rank's own view
+    (``fixed_len`` from the min / max of its local rows, 0 rows -> no opinion) must not decide between exchange
+    forms: a rank that owns no block, or whose blocks happen to hold equal-length keys while another's do not, would
+    pick another collective than its peers and the job would hang.  One tiny all-reduce; every rank gets the same
+    answer."""
+    if nrows == 0:
+        lo, hi = 1 << 20, -1      # no opinion
+    elif fixed_len >= 0:
+        lo = hi = int(fixed_len)
+    else:
+        lo, hi = 0, 1 << 20       # lengths differ already on this rank
+    backend = dist.get_backend(group)
+    dev = torch.device("cpu") if backend == "gloo" else device
+    t = torch.tensor([-lo, hi], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    neg_lo, hi = (int(v) for v in t.tolist())
+    if hi < 0:
+        return 0  # the column is empty everywhere
+    return -neg_lo if -neg_lo == hi else -1
+
+
 def or_flags(dist: Any, flags: int, device: torch.device, group: Any = None) -> int:
     """Bitwise OR of a status word over all ranks (so every rank takes the same retry / error decision)."""
     backend = dist.get_backend(group)

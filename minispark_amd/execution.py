@@ -247,7 +247,7 @@ class HipExecutionEngine(ExecutionEngine):
         cached = self._tables.get(key)
         if cached is not None and (cached.stamp == () or cached.stamp == tbl.file_stamp(Path(path))):
             return cached
-        opened = tbl.open_table(Path(path), self.rank, self.world)
+        opened = tbl.open_table(Path(path), self.rank, self.world, distributed=self.dist is not None)
         self._tables[key] = opened
         return opened
 
@@ -389,6 +389,11 @@ class HipExecutionEngine(ExecutionEngine):
                 stage.job_results.clear()
             return plan
         plan = self.generate_physical_plan(full_task)
+        # the planner deep-copies the task tree: copies must not inherit the identity tokens of the originals
+        # (a re-plan of the same DataFrame would otherwise reuse cache entries made for other file contents)
+        for stage in plan.stages:
+            for task in (stage.producer, *stage.consumers, stage.writer):
+                getattr(task, "__dict__", {}).pop("_hs_uid", None)
         self._mark_short_tails(plan)
         if len(self._plans) >= 16:
             self._plans.pop(next(iter(self._plans)))
@@ -446,6 +451,8 @@ class HipExecutionEngine(ExecutionEngine):
                 batch = self._project(batch, pending, task)
                 pending = []
             elif tname == "AggregateTask":
+                if task.before_shuffle and self.dist is not None:
+                    batch = self._agree_key_width(batch, task)  # the exchange form must not depend on local rows
                 if task.before_shuffle and (_uid(task) in self._global_partial or self.group_cap_hint > SHARED_TIER_MAX):
                     self._global_partial.add(_uid(task))
                     batch = self.dev.aggregate_partial_global(batch, pending, task.group_by_column, task.agg_columns,
@@ -566,9 +573,26 @@ class HipExecutionEngine(ExecutionEngine):
         if not col_ids:
             col_ids = [0]
         tbl.load_columns(self.dev, table, col_ids)
+        if self.dist is not None:
+            self._agree_table_widths(table, col_ids)
         batch = tbl.table_batch(table, col_ids, producer.alias)
         batch.partitioned = self.dist is not None
         return batch
+
+    def _agree_table_widths(self, table: Any, col_ids: Sequence[int]) -> None:
+        """fixed_len of a stored STRING column becomes a FILE-global property (once per table and column): see
+        _agree_key_width.  Every rank scans the same tables with the same column lists, so the collectives match."""
+        from . import hipspark as hs  # noqa: PLC0415
+        from .distributed import agree_string_width  # noqa: PLC0415
+
+        agreed = table.__dict__.setdefault("_hs_widths_agreed", set())
+        for cid in col_ids:
+            col = table.columns[cid]
+            if col.kind != hs.STR or cid in agreed:
+                continue
+            width = agree_string_width(self.dist, col.fixed_len, col.n, self.dev.device, self.group)
+            table.columns[cid] = self.dev.with_string_width(col, width)
+            agreed.add(cid)
 
     @staticmethod
     def _needed_names(consumers: Sequence[Any]) -> set[str] | None:
@@ -607,6 +631,8 @@ class HipExecutionEngine(ExecutionEngine):
             perm, part_start = self.dev.partition(right, rkey, constants.SHUFFLE_PARTITIONS)
         right = self.dev.gather_batch(right, perm, right.nrows, part_start)
         out_left, out_right, out_start, n_out = self.dev.join_indices(left.cols[lkey], right.cols[rkey])
+        if self.dev.rec is not None:
+            self.dev.rec.poisoned = True  # unit boundaries of the joined rows are learnt on the host below
         starts = out_start.tolist() if right.nrows <= 4096 else None
         if starts is None:
             import torch  # noqa: PLC0415
@@ -632,6 +658,34 @@ class HipExecutionEngine(ExecutionEngine):
             joined.total_units = constants.SHUFFLE_PARTITIONS
             joined.partitioned = True
         return joined
+
+    def _agree_key_width(self, batch: Any, task: Any) -> Any:
+        """Multi-GPU: which exchange a partial aggregate uses (slab all-gather / short tail vs the generic
+        all-to-all) depends on whether its STRING key has a fixed width.  ``fixed_len`` of a column comes from the
+        LOCAL rows (0 on a rank that owns no block), so the ranks agree on the global width first and describe
+        their key column with it: every rank then raises SlabUnsupported - or none does."""
+        import dataclasses  # noqa: PLC0415
+
+        from . import hipspark as hs  # noqa: PLC0415
+        from .distributed import agree_string_width  # noqa: PLC0415
+        from .lowering import unalias  # noqa: PLC0415
+
+        try:
+            idx = batch.column_index(unalias(task.group_by_column).name)
+        except (ValueError, AttributeError):
+            return batch  # reported by the lowering with the reference's error
+        col = batch.cols[idx]
+        if col.kind != hs.STR:
+            return batch
+        if batch.lazy:
+            batch = self.dev.resolve(batch)
+            col = batch.cols[idx]
+        width = agree_string_width(self.dist, col.fixed_len, col.n, self.dev.device, self.group)
+        if width == col.fixed_len:
+            return batch
+        cols = list(batch.cols)
+        cols[idx] = self.dev.with_string_width(col, width)
+        return dataclasses.replace(batch, cols=cols)
 
     def _exchange_partials(self, batch: Any) -> Any:
         """The shuffle between the two aggregation phases on N GPUs: all-gather the fixed-size slabs, then
@@ -854,7 +908,12 @@ class HipExecutionEngine(ExecutionEngine):
             from .distributed import all_gather_slabs_into  # noqa: PLC0415
 
             gathered = torch.empty(self.world * tail["layout"].nbytes, dtype=torch.uint8, device=slab.device)
+            timed = self.dev.exchange_events
+            if timed is not None:
+                self.dev.op(timed[0].record)
             self.dev.op(all_gather_slabs_into, self.dist, slab, gathered, self.group)
+            if timed is not None:
+                self.dev.op(timed[1].record)
             world, n_order = self.world, batch.total_units
         else:
             gathered, world, n_order = slab, 1, max(tail["n_units"], 1)
@@ -886,7 +945,10 @@ class HipExecutionEngine(ExecutionEngine):
             # empty result: the reference writes no file (tasks.py:405); multi-GPU: rank 0 owns the result
             return JobResult(job_id, self._executor_id, [])
         if self._result_root is None:
-            self._result_root = Path(self._work_folder or (constants.SHUFFLE_FOLDER / f"hip-{uuid.uuid4().hex[:12]}"))
+            # always a fresh sub-folder: __exit__ removes only what this engine created, never a directory the
+            # caller handed in (which may hold other files - e.g. the input tables)
+            base = Path(self._work_folder) if self._work_folder else constants.SHUFFLE_FOLDER
+            self._result_root = base / f"hip-{uuid.uuid4().hex[:12]}"
             self._owned_dirs.add(self._result_root)
         out_file = self._result_paths.get(stage_id)
         if out_file is None:

@@ -58,11 +58,12 @@ def file_stamp(path: Path) -> tuple:
     return (st.st_mtime_ns, st.st_size)
 
 
-def open_table(path: Path, rank: int = 0, world: int = 1) -> DeviceTable:
-    """Open a BlockFile; with world > 1 this rank owns the blocks b with b % world == rank."""
+def open_table(path: Path, rank: int = 0, world: int = 1, distributed: bool = False) -> DeviceTable:
+    """Open a BlockFile; a distributed engine's rank owns the blocks b with b % world == rank (also at world 1:
+    the multi-rank path then runs with one rank, which is how the RCCL collectives are tested on a one-GPU box)."""
     bf = BlockFile(path)
     rows = bf.block_rows()
-    if world == 1:
+    if world == 1 and not distributed:
         return DeviceTable(Path(path), list(bf.file_schema), rows, {}, file_stamp(Path(path)))
     mine = [b for b in range(len(rows)) if b % world == rank]
     return DeviceTable(Path(path), list(bf.file_schema), [rows[b] for b in mine], {}, file_stamp(Path(path)),

@@ -88,6 +88,10 @@ def run(cols: dict[str, np.ndarray], block_rows: list[int], cutoff_us: int, thre
                              C.c_int32(threads), rows)
     if n < 0:
         raise OverflowError("int too big to convert")
+    return _rows_out(rows, n, raw)
+
+
+def _rows_out(rows, n: int, raw: bool = False) -> list[dict]:
     out = []
     for i in range(n):
         r = rows[i]
@@ -97,6 +101,19 @@ def run(cols: dict[str, np.ndarray], block_rows: list[int], cutoff_us: int, thre
         row["count_order"] = int(r.count_order)
         out.append(row)
     return out
+
+
+def run_synth(seed: int, total_rows: int, rows_per_block: int, cutoff_us: int, threads: int = 1) -> list[dict]:
+    """Q1 over the synthetic lineitem of ``total_rows`` rows, generated block by block inside the C oracle."""
+    rows = (q1_row * 256)()
+    lib().q1_run_synth.restype = C.c_int
+    n = lib().q1_run_synth(C.c_uint64(seed), C.c_int64(total_rows), C.c_int64(rows_per_block), C.c_int64(cutoff_us),
+                           C.c_int32(threads), rows)
+    if n == -1:
+        raise OverflowError("int too big to convert")
+    if n < 0:
+        raise ValueError("q1_run_synth: bad arguments")
+    return _rows_out(rows, n)
 
 
 def host_threads() -> int:

@@ -107,21 +107,8 @@ static void q1_block(const float* q, const float* p, const float* d, const float
     }
 }
 
-/* returns the number of groups written to out (ascending key byte), or -1 on an i32 overflow at a
- * quantisation point (the reference raises OverflowError, io.py:90) */
-int q1_run_threads(const float* q, const float* p, const float* d, const float* t, const int64_t* ship,
-                   const uint8_t* flag, const int64_t* block_rows, int32_t nblocks, int64_t cutoff_us,
-                   int32_t nthreads, q1_row* out) {
-    block_partial* parts = (block_partial*)malloc(sizeof(block_partial) * (size_t)(nblocks > 0 ? nblocks : 1));
-    int64_t* starts = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nblocks + 1));
-    starts[0] = 0;
-    for (int b = 0; b < nblocks; ++b) starts[b + 1] = starts[b] + block_rows[b];
-    /* stage 0: one job per block; jobs are independent (the reference runs them one after another) */
-#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads) if (nthreads > 1)
-    for (int b = 0; b < nblocks; ++b) {
-        const int64_t s = starts[b];
-        q1_block(q + s, p + s, d + s, t + s, ship + s, flag + s, block_rows[b], cutoff_us, &parts[b]);
-    }
+/* shuffle write + final stage over the per-block partials (see the header): returns the number of groups or -1 */
+static int q1_merge(const block_partial* parts, int32_t nblocks, q1_row* out) {
     /* shuffle write: FLOAT -> f32, INTEGER -> i32; final stage: fp64 merge in block order */
     double fsum[Q1_MAX_GROUPS][7];
     int64_t csum[Q1_MAX_GROUPS][4];
@@ -163,12 +150,65 @@ int q1_run_threads(const float* q, const float* p, const float* d, const float* 
         r->avg_price = (double)(float)r->raw[5];
         r->avg_disc = (double)(float)r->raw[6];
     }
+    return overflow ? -1 : n;
+}
+
+/* returns the number of groups written to out (ascending key byte), or -1 on an i32 overflow at a
+ * quantisation point (the reference raises OverflowError, io.py:90) */
+int q1_run_threads(const float* q, const float* p, const float* d, const float* t, const int64_t* ship,
+                   const uint8_t* flag, const int64_t* block_rows, int32_t nblocks, int64_t cutoff_us,
+                   int32_t nthreads, q1_row* out) {
+    block_partial* parts = (block_partial*)malloc(sizeof(block_partial) * (size_t)(nblocks > 0 ? nblocks : 1));
+    int64_t* starts = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nblocks + 1));
+    starts[0] = 0;
+    for (int b = 0; b < nblocks; ++b) starts[b + 1] = starts[b] + block_rows[b];
+    /* stage 0: one job per block; jobs are independent (the reference runs them one after another) */
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads) if (nthreads > 1)
+    for (int b = 0; b < nblocks; ++b) {
+        const int64_t s = starts[b];
+        q1_block(q + s, p + s, d + s, t + s, ship + s, flag + s, block_rows[b], cutoff_us, &parts[b]);
+    }
+    const int n = q1_merge(parts, nblocks, out);
     free(parts);
     free(starts);
-    return overflow ? -1 : n;
+    return n;
 }
 
 int q1_run(const float* q, const float* p, const float* d, const float* t, const int64_t* ship, const uint8_t* flag,
            const int64_t* block_rows, int32_t nblocks, int64_t cutoff_us, q1_row* out) {
     return q1_run_threads(q, p, d, t, ship, flag, block_rows, nblocks, cutoff_us, 1, out);
+}
+
+/* The same query over the SYNTHETIC table itself: block b = rows [b * rows_per_block, ...) of the counter-based
+ * generator above, produced block by block into per-thread buffers (nothing of the 15.6 GB sf=100 table is ever
+ * resident), one ScanJob per block, then the same merge.  bench.py checks the timed GPU result of the FULL table
+ * against this; block ownership on N GPUs does not change it (the merge runs in block order). */
+int q1_run_synth(uint64_t seed, int64_t total_rows, int64_t rows_per_block, int64_t cutoff_us, int32_t nthreads,
+                 q1_row* out) {
+    if (total_rows < 0 || rows_per_block < 1) return -2;
+    const int64_t nb64 = (total_rows + rows_per_block - 1) / rows_per_block;
+    if (nb64 > 1 << 24) return -2;
+    const int32_t nblocks = (int32_t)nb64;
+    block_partial* parts = (block_partial*)malloc(sizeof(block_partial) * (size_t)(nblocks > 0 ? nblocks : 1));
+#pragma omp parallel num_threads(nthreads) if (nthreads > 1)
+    {
+        const size_t cap = (size_t)rows_per_block;
+        float* q = (float*)malloc(cap * 4);
+        float* p = (float*)malloc(cap * 4);
+        float* d = (float*)malloc(cap * 4);
+        float* t = (float*)malloc(cap * 4);
+        int64_t* ship = (int64_t*)malloc(cap * 8);
+        uint8_t* flag = (uint8_t*)malloc(cap);
+#pragma omp for schedule(dynamic, 1)
+        for (int b = 0; b < nblocks; ++b) {
+            const int64_t row0 = (int64_t)b * rows_per_block;
+            const int64_t n = total_rows - row0 < rows_per_block ? total_rows - row0 : rows_per_block;
+            q1_gen(seed, row0, n, q, p, d, t, ship, flag, NULL, NULL);
+            q1_block(q, p, d, t, ship, flag, n, cutoff_us, &parts[b]);
+        }
+        free(q); free(p); free(d); free(t); free(ship); free(flag);
+    }
+    const int n = q1_merge(parts, nblocks, out);
+    free(parts);
+    return n;
 }

@@ -22,13 +22,19 @@ def main() -> None:
 
     rank = int(os.environ["RANK"])
     world = int(os.environ["WORLD_SIZE"])
-    dist.init_process_group(backend, rank=rank, world_size=world)
+    if backend == "nccl":  # RCCL: one rank per device, communicator bound to it eagerly
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     from minispark_amd import constants
     from minispark_amd.dataframe import DataFrame
     from minispark_amd.execution import HipExecutionEngine
     from minispark_amd.sql import Col, Functions, Lit
     from tests.conftest import load_golden
-    from tests.queries import api_namespace, case_by_name
+    from minispark_amd.workloads import api_namespace
+    from tests.queries import case_by_name
 
     constants.SHUFFLE_FOLDER = Path(out_path).parent / f"shuffle_r{rank}"
     if case_name.startswith("fuzz:"):
@@ -48,6 +54,11 @@ def main() -> None:
 
         seed = int(case_name.split(":")[1])
         build = lambda api: _wide_query(random.Random(seed), api, str(Path(out_path).parent / "w.bin"))  # noqa: E731
+    elif case_name.startswith("width:"):
+        # GROUP BY a string key whose fixed width the ranks see differently (tests/test_gpu_distributed.py)
+        from tests.test_gpu_distributed import width_query
+
+        build = lambda api: width_query(api, str(Path(out_path).parent / "w.bin"))  # noqa: E731
     else:
         golden = load_golden(case_name)
         case = case_by_name(case_name)

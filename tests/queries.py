@@ -61,13 +61,8 @@ ORDERS = [
     for r in _ORDERS
 ]
 
-SHIPMODES = ["REG AIR", "AIR", "RAIL", "SHIP", "TRUCK", "MAIL", "FOB"]
-PRIORITIES = ["1-URGENT", "2-HIGH", "3-MEDIUM", "4-NOT SPECIFIED", "5-LOW"]
-
-
-def order_key(o: int) -> int:
-    """Sparse TPC-H-like order keys: 8 used of every 32."""
-    return 32 * (o // 8) + (o % 8) + 1
+from minispark_amd.workloads import PRIORITIES, SHIPMODES, api_namespace, order_key, q1  # noqa: E402,F401
+from minispark_amd import workloads as _wl  # noqa: E402
 
 
 def lineitem_rows(n: int, seed: int) -> list[dict]:
@@ -139,48 +134,12 @@ def _fruit(api, t):
         api.F.sum(api.Col("quantity") * api.Col("price")).alias("total_price"))
 
 
-def q1(api, path, cutoff="1998-12-01"):
-    """The reference's benchmark query (README.md:141-158, examples/benchmark.py:51-68)."""
-    C, F, Lit = api.Col, api.F, api.Lit
-    disc_price = C("l_extendedprice") * (Lit(1) - C("l_discount"))
-    return (
-        api.DataFrame().table(path)
-        .filter(C("l_shipdate") <= cutoff)
-        .group_by(C("l_returnflag"))
-        .agg(
-            F.sum(C("l_quantity")).alias("sum_qty"),
-            F.sum(C("l_extendedprice")).alias("sum_base_price"),
-            F.sum(disc_price).alias("sum_disc_price"),
-            F.sum(disc_price * (Lit(1) + C("l_tax"))).alias("sum_charge"),
-            F.avg(C("l_quantity")).alias("avg_qty"),
-            F.avg(C("l_extendedprice")).alias("avg_price"),
-            F.avg(C("l_discount")).alias("avg_disc"),
-            F.count().alias("count_order"),
-        )
-    )
-
-
 def _join_group(api, t):
-    C, F = api.Col, api.F
-    orders = api.DataFrame().table(t["orders"]).select(C("o_orderkey"), C("o_orderpriority"))
-    lineitem = api.DataFrame().table(t["lineitem"]).select(C("l_orderkey"), C("l_quantity"), C("l_extendedprice"))
-    return (
-        orders.join(lineitem, on=C("o_orderkey") == C("l_orderkey"), how="inner")
-        .group_by(C("o_orderpriority"))
-        .agg(F.count().alias("n"), F.sum(C("l_quantity")).alias("qty"), F.sum(C("l_extendedprice")).alias("revenue"),
-             F.max(C("l_extendedprice")).alias("max_price"))
-    )
+    return _wl.join_group(api, t["orders"], t["lineitem"])
 
 
 def _concat_like(api, t):
-    C, F = api.Col, api.F
-    return (
-        api.DataFrame().table(t["lineitem"])
-        .filter(C("l_shipmode").like("%AIR%"))
-        .select((C("l_returnflag") + "-" + C("l_shipmode")).alias("k"), C("l_quantity"), C("l_discount"))
-        .group_by(C("k"))
-        .agg(F.sum(C("l_quantity")).alias("qty"), F.avg(C("l_discount")).alias("avg_disc"), F.count())
-    )
+    return _wl.strkey_like(api, t["lineitem"])
 
 
 def _edge_minmax(api, t):
@@ -340,5 +299,3 @@ def case_by_name(name: str) -> Case:
     raise KeyError(name)
 
 
-def api_namespace(dataframe_cls: Any, col_cls: Any, functions_cls: Any, lit_cls: Any) -> SimpleNamespace:
-    return SimpleNamespace(DataFrame=dataframe_cls, Col=col_cls, F=functions_cls, Lit=lit_cls)

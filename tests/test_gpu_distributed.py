@@ -87,12 +87,12 @@ def test_random_queries_on_n_ranks_match_the_oracle(tmp_path, seed, world):
     assert_rows_match(_run_ranks(f"fuzz:{seed}", world, out, port, want), want, max_ulps=1)
 
 
-def _run_ranks(case: str, world: int, out, port: int, want: list) -> list:
+def _run_ranks(case: str, world: int, out, port: int, want: list, backend: str = "gloo") -> list:
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, str(ROOT / "tests" / "dist_worker.py"), case, str(out), "gloo"],
+        procs.append(subprocess.Popen([sys.executable, str(ROOT / "tests" / "dist_worker.py"), case, str(out), backend],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = [p.communicate(timeout=300)[0].decode() for p in procs]
     if any(p.returncode != 0 for p in procs):
@@ -134,3 +134,70 @@ def test_random_many_group_queries_on_n_ranks_match_the_oracle(tmp_path, seed, w
     want = run_query(_wide_query(random.Random(seed), api, str(tmp_path / "w.bin")).task)
     rows = _run_ranks(f"wide:{seed}", world, tmp_path / "rows.json", _free_port(), want)
     assert assert_rows_match(rows, want, max_ulps=1) <= 3
+
+
+# ---- the exchange form must not depend on what a rank's own rows look like -----------------
+def width_query(api, path):
+    C, F = api.Col, api.F
+    return api.DataFrame().table(path).group_by(C("s")).agg(F.sum(C("i")).alias("total"), F.count())
+
+
+def _width_table(path, blocks: list[list[str]]):
+    import numpy as np
+
+    from minispark_amd.constants import ColumnType as T
+    from minispark_amd.io import BlockFile, StrCol
+
+    schema = [("s", T.STRING), ("i", T.INTEGER)]
+    out, at = [], 0
+    for keys in blocks:
+        out.append([StrCol.from_strings(keys), np.arange(at, at + len(keys), dtype=np.int32)])
+        at += len(keys)
+    BlockFile(path).write_raw_blocks(schema, out)
+
+
+@pytest.mark.parametrize("variant,world", [("oneblock", 2), ("oneblock", 3), ("disagree", 2), ("disagree", 3)])
+def test_ranks_agree_on_the_exchange_form(tmp_path, variant, world):
+    """oneblock: a 1-block table with a 1-char key - the ranks without a block see fixed_len 0 and used to pick the
+    all-to-all while rank 0 picked the all-gather (hang).  disagree: block 0 holds only 2-char keys, the other blocks
+    mixed lengths - locally fixed-width on one rank, variable on the others."""
+    from minispark_amd.dataframe import DataFrame
+    from minispark_amd.sql import Col, Functions, Lit
+    from minispark_amd.workloads import api_namespace
+    from oracle.py_engine import run_query
+
+    if variant == "oneblock":
+        blocks = [[("A", "N", "R")[i % 3] for i in range(50)]]
+    else:
+        blocks = [[("ab", "cd")[i % 2] for i in range(40)], ["ab", "x", "cd", "long-key", ""] * 8, ["cd", "yy", "zzz"] * 5]
+    _width_table(tmp_path / "w.bin", blocks)
+    api = api_namespace(lambda: DataFrame(object()), Col, Functions, Lit)
+    want = run_query(width_query(api, str(tmp_path / "w.bin")).task)
+    rows = _run_ranks(f"width:{variant}", world, tmp_path / "rows.json", _free_port(), want)
+    assert assert_rows_match(rows, want) == 0
+
+
+# ---- RCCL itself (backend "nccl"): one rank per device, so world 1 on the one-GPU test box ----------------------------
+@pytest.mark.parametrize("case_name", ["q1_multiblock", "q1_ragged_blocks", "join_group", "concat_like", "many_groups",
+                                       "e2e_join_select", "fruit"])
+def test_rccl_world1_matches_reference(tmp_path, case_name):
+    """The collectives the 8-GPU run uses - all_gather_into_tensor of the slabs, all_to_all_single of rows, the
+    device-side count exchange and flag reduction - executed by RCCL in a fresh child process (world 1: RCCL refuses
+    two ranks per device).  Rows must equal the reference's goldens like on every other path."""
+    golden = load_golden(case_name)["rows"]
+    rows = _run_ranks(case_name, 1, tmp_path / "rows.json", _free_port(), golden, backend="nccl")
+    flips = assert_rows_match(rows, golden, max_ulps=1)
+    assert flips <= (2 if case_name == "many_groups" else 0)
+
+
+def test_bench_runs_over_rccl_world1(tmp_path):
+    """bench.py's multi-rank branch (init_process_group("nccl", device_id=...), barrier, all_reduce of the timings,
+    the engine's slab all-gather inside the recorded replay) at world 1, small table."""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()), HIPSPARK_FORCE_DIST="1")
+    proc = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--sf", "0.2", "--steps", "4", "--warmup", "1",
+                           "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
+    line = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["groups"] == 3
+    assert "all_gather" in line["config"]["exchange"] and "nccl" in line["config"]["exchange"]

@@ -10,7 +10,7 @@ from minispark_amd.lowering import lower_aggregate
 from minispark_amd.plan import PhysicalPlan
 from minispark_amd.sql import Col, Functions, Lit
 from tests.conftest import load_golden
-from tests.queries import api_namespace, q1
+from minispark_amd.workloads import api_namespace, q1
 
 lib = hs.load_library()
 g = load_golden("q1_multiblock")

@@ -5,7 +5,10 @@
     python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write <rows per launch> > profiles/rNN_pmc_hbm_traffic_q1_sf100.json
 FETCH_SIZE / WRITE_SIZE count KB; on gfx950 FETCH_SIZE reports half of a wide coalesced read stream (guide,
 section HBM), hence x2 on the read side."""
-import csv, glob, json, sys
+import csv, glob, json, subprocess, sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from bench import kernel_sources_sha
 
 def avg_counter(folder, counter, kernel_prefix="k_agg_jit"):
     vals = []
@@ -27,4 +30,7 @@ print(json.dumps({
     "FETCH_SIZE_KB_avg": fetch_kb, "hbm_read_bytes_per_launch (FETCH_SIZE*1024*2)": read_b,
     "WRITE_SIZE_KB_avg": write_kb, "hbm_write_bytes_per_launch": write_b,
     "algorithmic_bytes_per_launch (26 B/row)": algo, "traffic_over_algorithmic": (read_b + write_b) / algo,
+    # bench.py quotes these figures only while the device code is the code they were measured on
+    "kernel_sources_sha": kernel_sources_sha(),
+    "commit": subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "?",
 }, indent=1))

@@ -8,7 +8,7 @@ os.environ.setdefault("TZ", "UTC")
 from minispark_amd.dataframe import DataFrame
 from minispark_amd.sql import Col, Functions, Lit
 from oracle.py_engine import run_query
-from tests.queries import api_namespace
+from minispark_amd.workloads import api_namespace
 from tests.test_gpu_fuzz import make_table, random_query
 from tests.test_gpu_distributed import _free_port, _run_ranks
 

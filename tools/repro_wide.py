@@ -11,7 +11,7 @@ from minispark_amd.dataframe import DataFrame
 from minispark_amd.execution import HipExecutionEngine
 from minispark_amd.sql import Col, Functions, Lit
 from oracle.py_engine import run_query
-from tests.queries import api_namespace
+from minispark_amd.workloads import api_namespace
 from tests.test_gpu_shared_tier import _wide_query, _wide_table
 
 first, last = int(sys.argv[1]), int(sys.argv[2])

@@ -17,7 +17,7 @@ from minispark_amd.io import BlockFile
 from minispark_amd.sql import Col, Functions as F
 from minispark_amd.table import DeviceTable
 from oracle import q1_native
-from tests.queries import PRIORITIES, SHIPMODES
+from minispark_amd.workloads import PRIORITIES, SHIPMODES
 
 n_li = int(sys.argv[1]) if len(sys.argv) > 1 else 6_001_215
 n_ord = n_li // 4 + 1
