@@ -1,0 +1,416 @@
+// hs_join.hip - round-2 operators for the join / string-key paths of BASELINE configs 4 and 5:
+//
+//   hs_dict_build / hs_dict_assign   dictionary-encode a STRING column with few distinct values (table open): one
+//                                    u8 code per row; LIKE / comparisons / concatenation / GROUP BY then run on codes
+//   hs_dict_combine                  codes of a concatenation of dictionary-coded columns (mixed radix)
+//   hs_minmax_i32                    key range of a join's build side
+//   hs_join_build_unique / hs_join_probe_unique
+//                                    primary-key / foreign-key join: ONE 32-bit word per table slot holds the build
+//                                    row; direct addressing when the key range is dense (TPC-H order keys: 4 slots
+//                                    per key), multiplicative hashing + linear probing otherwise.  The probe leaves
+//                                    the probe side's rows in place and emits, per probe row, the matching build row
+//                                    and the row's shuffle partition hash(key) % n_parts (= the reference's JoinJob,
+//                                    plan.py:99-109) as a per-row UNIT id for the fused partial aggregate
+//                                    (hs_agg_shared_units): joined rows are never materialised or re-ordered.
+//
+// Reference loops replaced: BroadcastHashJoinTask.generate_chunks tasks.py:201-240 (zig-src/src/tasks.zig:70-194),
+// WriteToShufflePartitions.write tasks.py:347-375 for the two join inputs, LikeColumn / BinaryOperatorColumn on
+// strings sql.py:166-212, 262-266.  All HBM-bound integer / byte work.
+#include "hs_device.h"
+
+extern thread_local char g_hs_err[256];
+void hs_set_error(const char* fmt, ...);
+
+#define HSJ_CHECK_LAUNCH(name)                              \
+    if (hipGetLastError() != hipSuccess) {                  \
+        hs_set_error(name ": kernel launch failed");        \
+        return HS_E_LAUNCH;                                 \
+    }
+
+static unsigned hsj_grid(int64_t n, int per_block, int64_t max_blocks = 1 << 16) {
+    int64_t b = (n + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > max_blocks) b = max_blocks;
+    return (unsigned)b;
+}
+
+// =====================================================================================================
+// Dictionary encoding
+// =====================================================================================================
+// The table (global memory, L2-resident: cap slots x 16 bytes) is an open-addressing set of the column's distinct
+// strings: word = packed string (<= 7 bytes: exact) or a hash (then equality is decided on the bytes of the slot's
+// representative row).  Almost every row finds its string present: a read-only probe.
+__device__ __forceinline__ int hsj_dict_find_or_insert(uint64_t* words, int64_t* reps, uint32_t mask, const hs_col& c,
+                                                       int64_t row, bool insert, int32_t* count, bool& full) {
+    const HsStr s = hs_str_at(c, row);
+    const bool packed = s.len <= 7;
+    const uint64_t k = hs_key_at(c, row);
+    uint32_t h = (uint32_t)(hs_mix64(k) >> 24) & mask;
+    for (uint32_t probe = 0; probe <= mask; ++probe) {
+        long long rep = __hip_atomic_load(&reps[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (rep < 0) {
+            if (!insert) return -1;
+            rep = (long long)atomicCAS((unsigned long long*)&reps[h], (unsigned long long)(-1ll), (unsigned long long)row);
+            if (rep < 0) {  // claimed: publish the word (readers that see the rep but not yet the word compare bytes)
+                __hip_atomic_store(&words[h], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (atomicAdd(count, 1) >= 256) full = true;
+                return (int)h;
+            }
+        }
+        // occupied by row `rep`: same string?
+        const uint64_t w = __hip_atomic_load(&words[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (packed && w == k) return (int)h;
+        if (w == k || w == HS_EMPTY_KEY) {  // hashed mode, or the word is not published yet: the bytes decide
+            if (hs_rows_equal(c, (int64_t)rep, row)) return (int)h;
+        }
+        h = (h + 1) & mask;
+    }
+    full = true;
+    return -1;
+}
+
+__global__ void __launch_bounds__(256) k_dict_init(uint64_t* words, int64_t* reps, int32_t cap, int32_t* count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cap) {
+        words[i] = HS_EMPTY_KEY;
+        reps[i] = -1;
+    }
+    if (i == 0) *count = 0;
+}
+
+__global__ void __launch_bounds__(256) k_dict_build(const hs_col col, int64_t n, int32_t cap, uint64_t* words, int64_t* reps,
+                                                    int32_t* count, uint32_t* flags) {
+    __shared__ int s_stop;
+    bool full = false;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < n; base += (int64_t)gridDim.x * blockDim.x) {
+        // more than 256 distinct strings: the column is not encoded - stop reading it (uniform decision per round)
+        if (threadIdx.x == 0) s_stop = __hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 256;
+        __syncthreads();
+        if (s_stop) break;
+        const int64_t row = base + threadIdx.x;
+        if (row < n) hsj_dict_find_or_insert(words, reps, (uint32_t)cap - 1, col, row, true, count, full);
+        __syncthreads();
+    }
+    if (full) atomicOr(flags, HS_FLAG_DICT_FULL);
+}
+
+__global__ void __launch_bounds__(256) k_dict_assign(const hs_col col, int64_t n, int32_t cap, uint64_t* words, int64_t* reps,
+                                                     const uint8_t* slot_code, uint8_t* out, uint32_t* flags) {
+    bool full = false;
+    uint32_t err = 0;
+    for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < n; row += (int64_t)gridDim.x * blockDim.x) {
+        const int s = hsj_dict_find_or_insert(words, reps, (uint32_t)cap - 1, col, row, false, nullptr, full);
+        if (s < 0) err |= HS_FLAG_BAD_PROGRAM;  // cannot happen after a complete build
+        out[row] = s < 0 ? 0 : slot_code[s];
+    }
+    if (err) atomicOr(flags, err);
+}
+
+extern "C" int hs_dict_build(void* stream, const hs_col* col, int64_t nrows, int32_t cap, uint64_t* slot_words,
+                             int64_t* slot_reps, int32_t* count, uint32_t* flags) {
+    if (!col || col->kind != HS_STR || !slot_words || !slot_reps || !count || !flags || cap < 512 || (cap & (cap - 1)) ||
+        nrows < 0) {
+        hs_set_error("hs_dict_build: bad arguments (STRING column, cap = power of two >= 512)");
+        return HS_E_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_dict_init, dim3((cap + 255) / 256), dim3(256), 0, s, slot_words, slot_reps, cap, count);
+    if (nrows > 0)
+        hipLaunchKernelGGL(k_dict_build, dim3(hsj_grid(nrows, 256, 2048)), dim3(256), 0, s, *col, nrows, cap, slot_words,
+                           slot_reps, count, flags);
+    HSJ_CHECK_LAUNCH("hs_dict_build");
+    return HS_OK;
+}
+
+extern "C" int hs_dict_assign(void* stream, const hs_col* col, int64_t nrows, int32_t cap, uint64_t* slot_words,
+                              int64_t* slot_reps, const uint8_t* slot_code, uint8_t* out_codes, uint32_t* flags) {
+    if (!col || col->kind != HS_STR || !slot_words || !slot_reps || !slot_code || !out_codes || !flags || cap < 512 ||
+        (cap & (cap - 1)) || nrows < 0) {
+        hs_set_error("hs_dict_assign: bad arguments");
+        return HS_E_ARG;
+    }
+    if (nrows > 0)
+        hipLaunchKernelGGL(k_dict_assign, dim3(hsj_grid(nrows, 256, 4096)), dim3(256), 0, (hipStream_t)stream, *col, nrows, cap,
+                           slot_words, slot_reps, slot_code, out_codes, flags);
+    HSJ_CHECK_LAUNCH("hs_dict_assign");
+    return HS_OK;
+}
+
+// codes of `a + lit + b + ...` over dictionary-coded columns: out = sum_k codes_k * stride_k (mixed radix; the
+// caller builds the product dictionary in the same order).  Sixteen rows per lane with 16-byte loads and stores.
+struct DictCombineArgs {
+    const uint8_t* codes[4];
+    int32_t stride[4];
+    int32_t n_parts, pad;
+};
+__global__ void __launch_bounds__(256) k_dict_combine(const DictCombineArgs A, int64_t n, uint8_t* out) {
+    const int64_t ngroups = (n + 15) / 16;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t base = g * 16;
+        uint32_t acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0;
+        for (int k = 0; k < A.n_parts; ++k) {
+            const uint4 v = *reinterpret_cast<const uint4*>(A.codes[k] + base);  // buffers carry 64 bytes of slack
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] += ((w[j >> 2] >> (8 * (j & 3))) & 0xffu) * (uint32_t)A.stride[k];
+        }
+        uint32_t o[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o[j >> 2] |= (acc[j] & 0xffu) << (8 * (j & 3));
+        if (base + 16 <= n) {
+            *reinterpret_cast<uint4*>(out + base) = make_uint4(o[0], o[1], o[2], o[3]);
+        } else {
+            for (int j = 0; base + j < n; ++j) out[base + j] = (uint8_t)(o[j >> 2] >> (8 * (j & 3)));
+        }
+    }
+}
+extern "C" int hs_dict_combine(void* stream, int32_t n_parts, const uint8_t* const* codes, const int32_t* strides,
+                               int64_t nrows, uint8_t* out_codes) {
+    if (n_parts < 1 || n_parts > 4 || !codes || !strides || !out_codes || nrows < 0) {
+        hs_set_error("hs_dict_combine: bad arguments (1..4 parts)");
+        return HS_E_ARG;
+    }
+    DictCombineArgs A;
+    for (int k = 0; k < 4; ++k) {
+        A.codes[k] = k < n_parts ? codes[k] : nullptr;
+        A.stride[k] = k < n_parts ? strides[k] : 0;
+        if (k < n_parts && (!codes[k] || ((uintptr_t)codes[k] & 15) || strides[k] < 0)) {
+            hs_set_error("hs_dict_combine: part %d: null / unaligned codes or negative stride", k);
+            return HS_E_ARG;
+        }
+    }
+    if ((uintptr_t)out_codes & 15) {
+        hs_set_error("hs_dict_combine: output must be 16-byte aligned");
+        return HS_E_ARG;
+    }
+    A.n_parts = n_parts;
+    A.pad = 0;
+    if (nrows > 0)
+        hipLaunchKernelGGL(k_dict_combine, dim3(hsj_grid((nrows + 15) / 16, 256, 8192)), dim3(256), 0, (hipStream_t)stream, A,
+                           nrows, out_codes);
+    HSJ_CHECK_LAUNCH("hs_dict_combine");
+    return HS_OK;
+}
+
+// =====================================================================================================
+// Unique-key (PK - FK) join on INTEGER keys
+// =====================================================================================================
+__global__ void k_minmax_i32_init(int32_t* minmax) {
+    minmax[0] = 2147483647;
+    minmax[1] = (-2147483647 - 1);
+}
+__global__ void __launch_bounds__(256) k_minmax_i32(const int32_t* v, int64_t n, int32_t* minmax) {
+    int32_t lo = 2147483647, hi = (-2147483647 - 1);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t x = v[i];
+        lo = x < lo ? x : lo;
+        hi = x > hi ? x : hi;
+    }
+    for (int d = HS_WAVE / 2; d >= 1; d >>= 1) {
+        const int32_t l2 = __shfl_down(lo, d, HS_WAVE), h2 = __shfl_down(hi, d, HS_WAVE);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & (HS_WAVE - 1)) == 0) {
+        atomicMin(&minmax[0], lo);
+        atomicMax(&minmax[1], hi);
+    }
+}
+extern "C" int hs_minmax_i32(void* stream, const int32_t* values, int64_t n, int32_t* minmax) {
+    if (!values || !minmax || n < 0) {
+        hs_set_error("hs_minmax_i32: bad arguments");
+        return HS_E_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_minmax_i32_init, dim3(1), dim3(1), 0, s, minmax);
+    if (n > 0) hipLaunchKernelGGL(k_minmax_i32, dim3(hsj_grid(n, 256 * 8, 2048)), dim3(256), 0, s, values, n, minmax);
+    HSJ_CHECK_LAUNCH("hs_minmax_i32");
+    return HS_OK;
+}
+
+static constexpr uint32_t HSJ_EMPTY = 0xffffffffu;
+
+__device__ __forceinline__ uint64_t hsj_hash_slot(int32_t key, uint64_t mask) {
+    return (hs_mix64((uint64_t)(uint32_t)key) >> 7) & mask;
+}
+
+// Python: hash(int) % n (hash(-1) = -2, floor-mod) - the reference's shuffle partition of a row, tasks.py:362
+__device__ __forceinline__ uint32_t hsj_py_partition(int32_t key, int32_t n_parts) {
+    int64_t h = key == -1 ? -2 : (int64_t)key;
+    int64_t m = h % n_parts;
+    if (m < 0) m += n_parts;
+    return (uint32_t)m;
+}
+
+struct JoinUniqueArgs {
+    const int32_t* keys;   // build or probe keys
+    int64_t n;
+    uint32_t* table;       // [slots] build row per slot, HSJ_EMPTY = none
+    const int32_t* build_keys;  // hashed mode: the build side's key column (the table stores rows, keys live here)
+    int64_t slots;         // direct: key range; hashed: power of two
+    int32_t key_min;       // direct mode: slot = key - key_min
+    int32_t direct;
+    uint32_t* flags;
+};
+
+__global__ void __launch_bounds__(256) k_fill_u32(uint32_t* p, int64_t n, uint32_t v) {
+    // sixteen bytes per lane
+    const int64_t n4 = n / 4;
+    uint4* p4 = reinterpret_cast<uint4*>(p);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+        p4[i] = make_uint4(v, v, v, v);
+    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// direct addressing: plain stores (a duplicate key makes two rows race for one slot: one of them wins) ...
+__global__ void __launch_bounds__(256) k_join_scatter_direct(const JoinUniqueArgs A) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * blockDim.x)
+        A.table[(int64_t)A.keys[i] - (int64_t)A.key_min] = (uint32_t)i;
+}
+// ... and a second pass in which every row checks that it is the one in its slot: a loser means duplicate keys
+__global__ void __launch_bounds__(256) k_join_verify_direct(const JoinUniqueArgs A) {
+    bool dup = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * blockDim.x)
+        dup = dup || A.table[(int64_t)A.keys[i] - (int64_t)A.key_min] != (uint32_t)i;
+    if (dup) atomicOr(A.flags, HS_FLAG_JOIN_DUP);
+}
+// hashed: claim a slot with a 32-bit CAS; a slot whose row carries the same key is a duplicate
+__global__ void __launch_bounds__(256) k_join_insert_hashed(const JoinUniqueArgs A) {
+    const uint64_t mask = (uint64_t)A.slots - 1;
+    uint32_t err = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t key = A.keys[i];
+        uint64_t h = hsj_hash_slot(key, mask);
+        bool placed = false;
+        for (uint64_t probe = 0; probe <= mask && !placed; ++probe) {
+            uint32_t cur = __hip_atomic_load(&A.table[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == HSJ_EMPTY) {
+                cur = atomicCAS(&A.table[h], HSJ_EMPTY, (uint32_t)i);
+                if (cur == HSJ_EMPTY) {
+                    placed = true;
+                    break;
+                }
+            }
+            if (A.keys[cur] == key) {
+                err |= HS_FLAG_JOIN_DUP;
+                placed = true;
+                break;
+            }
+            h = (h + 1) & mask;
+        }
+        if (!placed) err |= HS_FLAG_DICT_FULL;
+    }
+    if (err) atomicOr(A.flags, err);
+}
+
+extern "C" int hs_join_build_unique(void* stream, const int32_t* build_keys, int64_t n_build, int32_t key_min,
+                                    int64_t slots, int32_t direct, uint32_t* table, uint32_t* flags) {
+    if (!build_keys || !table || !flags || n_build < 0 || n_build >= 0xffffffffll || slots < 1 ||
+        (!direct && (slots & (slots - 1)))) {
+        hs_set_error("hs_join_build_unique: bad arguments (hashed tables need a power-of-two slot count)");
+        return HS_E_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    JoinUniqueArgs A{build_keys, n_build, table, build_keys, slots, key_min, direct, flags};
+    hipLaunchKernelGGL(k_fill_u32, dim3(hsj_grid(slots / 4 + 1, 256, 8192)), dim3(256), 0, s, table, slots, HSJ_EMPTY);
+    if (n_build > 0) {
+        const unsigned grid = hsj_grid(n_build, 256 * 4, 8192);
+        if (direct) {
+            hipLaunchKernelGGL(k_join_scatter_direct, dim3(grid), dim3(256), 0, s, A);
+            hipLaunchKernelGGL(k_join_verify_direct, dim3(grid), dim3(256), 0, s, A);
+        } else {
+            hipLaunchKernelGGL(k_join_insert_hashed, dim3(grid), dim3(256), 0, s, A);
+        }
+    }
+    HSJ_CHECK_LAUNCH("hs_join_build_unique");
+    return HS_OK;
+}
+
+// Probe: four keys per lane (one 16-byte load), the four table reads in flight together.
+struct JoinProbeUniqueArgs {
+    JoinUniqueArgs t;       // t.keys = probe keys, t.n = probe rows
+    int32_t n_parts, pad;
+    int64_t* out_row;       // [n] matching build row (0 for a probe row without a match)
+    uint8_t* out_unit;      // [n] hash(key) % n_parts, 0xff = no match
+    const uint8_t* payload; // optional: a 1-byte column of the BUILD side (dictionary codes), gathered on the way
+    uint8_t* out_payload;   // [n]
+};
+__device__ __forceinline__ uint32_t hsj_lookup(const JoinUniqueArgs& T, int32_t key) {
+    if (T.direct) {
+        const int64_t off = (int64_t)key - (int64_t)T.key_min;
+        return off >= 0 && off < T.slots ? T.table[off] : HSJ_EMPTY;
+    }
+    const uint64_t mask = (uint64_t)T.slots - 1;
+    uint64_t h = hsj_hash_slot(key, mask);
+    for (uint64_t probe = 0; probe <= mask; ++probe) {
+        const uint32_t cur = T.table[h];
+        if (cur == HSJ_EMPTY) return HSJ_EMPTY;
+        if (T.build_keys[cur] == key) return cur;
+        h = (h + 1) & mask;
+    }
+    return HSJ_EMPTY;
+}
+__global__ void __launch_bounds__(256) k_join_probe_unique(const JoinProbeUniqueArgs A) {
+    const int64_t n = A.t.n, nquads = (n + 3) / 4;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquads; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t base = q * 4;
+        const int4 kv = *reinterpret_cast<const int4*>(A.t.keys + base);  // buffers carry slack past the last row
+        const int32_t k[4] = {kv.x, kv.y, kv.z, kv.w};
+        uint32_t r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = base + j < n ? hsj_lookup(A.t, k[j]) : HSJ_EMPTY;
+        uint8_t pay[4] = {0, 0, 0, 0};
+        if (A.payload) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pay[j] = r[j] != HSJ_EMPTY ? A.payload[r[j]] : 0;
+        }
+        uint32_t units = 0, pays = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t u = r[j] != HSJ_EMPTY ? hsj_py_partition(k[j], A.n_parts) : 0xffu;
+            units |= u << (8 * j);
+            pays |= (uint32_t)pay[j] << (8 * j);
+        }
+        if (base + 4 <= n) {
+            if (A.out_row) {
+                int64_t* o = A.out_row + base;
+                reinterpret_cast<longlong2*>(o)[0] = make_longlong2(r[0] != HSJ_EMPTY ? r[0] : 0, r[1] != HSJ_EMPTY ? r[1] : 0);
+                reinterpret_cast<longlong2*>(o)[1] = make_longlong2(r[2] != HSJ_EMPTY ? r[2] : 0, r[3] != HSJ_EMPTY ? r[3] : 0);
+            }
+            *reinterpret_cast<uint32_t*>(A.out_unit + base) = units;
+            if (A.out_payload) *reinterpret_cast<uint32_t*>(A.out_payload + base) = pays;
+        } else {
+            for (int j = 0; base + j < n; ++j) {
+                if (A.out_row) A.out_row[base + j] = r[j] != HSJ_EMPTY ? r[j] : 0;
+                A.out_unit[base + j] = (uint8_t)(units >> (8 * j));
+                if (A.out_payload) A.out_payload[base + j] = pay[j];
+            }
+        }
+    }
+}
+
+extern "C" int hs_join_probe_unique(void* stream, const int32_t* probe_keys, int64_t n_probe, const int32_t* build_keys,
+                                    int32_t key_min, int64_t slots, int32_t direct, const uint32_t* table, int32_t n_parts,
+                                    int64_t* out_build_row, uint8_t* out_unit, const uint8_t* build_payload,
+                                    uint8_t* out_payload) {
+    if (!probe_keys || !build_keys || !table || !out_unit || n_probe < 0 || slots < 1 || n_parts < 1 || n_parts > 127 ||
+        (!direct && (slots & (slots - 1))) || ((uintptr_t)probe_keys & 15) || (out_build_row && ((uintptr_t)out_build_row & 15)) ||
+        ((uintptr_t)out_unit & 3) || (!build_payload != !out_payload) || (out_payload && ((uintptr_t)out_payload & 3))) {
+        hs_set_error("hs_join_probe_unique: bad arguments (aligned buffers, 1..127 partitions)");
+        return HS_E_ARG;
+    }
+    JoinProbeUniqueArgs A;
+    A.t = JoinUniqueArgs{probe_keys, n_probe, const_cast<uint32_t*>(table), build_keys, slots, key_min, direct, nullptr};
+    A.n_parts = n_parts;
+    A.pad = 0;
+    A.out_row = out_build_row;
+    A.out_unit = out_unit;
+    A.payload = build_payload;
+    A.out_payload = out_payload;
+    if (n_probe > 0)
+        hipLaunchKernelGGL(k_join_probe_unique, dim3(hsj_grid((n_probe + 3) / 4, 256, 1 << 15)), dim3(256), 0, (hipStream_t)stream, A);
+    HSJ_CHECK_LAUNCH("hs_join_probe_unique");
+    return HS_OK;
+}

@@ -97,3 +97,52 @@ def test_row_comparison_pairs_tied_rows_consistently():
     assert assert_rows_match(a, [a[1], a[2], a[0]], max_ulps=1) == 0
     with pytest.raises(AssertionError):
         assert_rows_match(a, [a[0], a[0], a[1]])
+
+
+def _fixture_columns(path):
+    from oracle import blockfile as bfio
+
+    schema, blocks = bfio.read_blockfile(path)
+    return {n: [v for b in blocks for v in b[i]] for i, (n, _) in enumerate(schema)}, [len(b[0]) for b in blocks]
+
+
+def test_c_join_oracle_reproduces_reference():
+    """oracle/q45_oracle.c q4_run (config 4's checker and cpu_baseline port) against the reference-made golden."""
+    from oracle import q45_native
+
+    golden = load_golden("join_group")
+    orders, _ = _fixture_columns(golden["paths"]["orders"])
+    li, _ = _fixture_columns(golden["paths"]["lineitem"])
+    codes, priorities = q45_native.encode(orders["o_orderpriority"])
+    args = (np.array(orders["o_orderkey"]), codes, priorities, np.array(li["l_orderkey"]),
+            np.array(li["l_quantity"], np.float32), np.array(li["l_extendedprice"], np.float32))
+    rows = q45_native.run_join_group(*args)
+    assert_rows_match(rows, golden["rows"], max_ulps=0)
+    assert q45_native.run_join_group(*args, threads=4) == rows  # JoinJobs in parallel: same bits
+
+
+def test_c_strkey_oracle_reproduces_reference():
+    """q5_run (config 5: LIKE + CONCAT key GROUP BY) against the reference-made golden."""
+    from oracle import q45_native
+
+    golden = load_golden("concat_like")
+    li, block_rows = _fixture_columns(golden["paths"]["lineitem"])
+    mode_codes, modes = q45_native.encode(li["l_shipmode"])
+    flag = np.frombuffer("".join(li["l_returnflag"]).encode(), np.uint8)
+    args = (flag, mode_codes, modes, np.array(li["l_quantity"], np.float32), np.array(li["l_discount"], np.float32), block_rows)
+    rows = q45_native.run_strkey_like(*args)
+    assert_rows_match(rows, golden["rows"], max_ulps=0)
+    assert q45_native.run_strkey_like(*args, threads=3) == rows
+
+
+def test_orders_generator_is_a_permutation_of_the_key_space():
+    from oracle import q45_native
+
+    n = 4099
+    okey, code = q45_native.gen_orders(20251003, 0, n, n)
+    order = (okey.astype(np.int64) - 1) // 32 * 8 + (okey.astype(np.int64) - 1) % 32
+    assert sorted(order.tolist()) == list(range(n))  # every order exactly once
+    assert not np.array_equal(order, np.arange(n))    # ... but not in key order
+    tail_key, tail_code = q45_native.gen_orders(20251003, 1000, 500, n)
+    assert np.array_equal(tail_key, okey[1000:1500]) and np.array_equal(tail_code, code[1000:1500])
+    assert set(code.tolist()) == {0, 1, 2, 3, 4}
