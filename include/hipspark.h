@@ -51,6 +51,7 @@ extern "C" {
 #define HS_FLAG_TYPE_ASSERT 0x40u   /* a FLOAT MIN/MAX never left its int identity (MAX_INT / MIN_INT): the reference
                                      * then fails `assert type(val) is float` at the file write, io.py:93 */
 #define HS_FLAG_STR_TOO_LONG 0x20u /* a concatenated string exceeds 255 bytes (BlockFile length byte, io.py:18) */
+#define HS_FLAG_JOIN_DUP 0x80u     /* hs_join_build_unique met a key twice: the caller takes the general (CSR) join */
 
 /* ---- storage kinds of a device column ---- */
 #define HS_I32 0 /* INTEGER as stored in a BlockFile */
@@ -98,7 +99,10 @@ enum hs_op {
     HS_OP_FILTER = 32,  /* pop; the row survives iff nonzero (tasks.py:167-177) */
     HS_OP_AGG = 33,     /* pop; fold into accumulator a (tasks.py:295-310) */
     HS_OP_OUT = 34,     /* pop; store as output a (hs_eval) */
-    HS_OP_KEY = 35      /* resolve the GROUP BY slot of the surviving rows (between filters and AGGs) */
+    HS_OP_KEY = 35,     /* resolve the GROUP BY slot of the surviving rows (between filters and AGGs) */
+    HS_OP_DICTBIT = 36  /* a = slot of a dictionary-coded column (one code byte per row), b = index of the first of
+                           c (1..4) literal words holding one bit per dictionary entry; push bit[code]: LIKE and
+                           string comparisons with a literal, evaluated once per dictionary entry on the host */
 };
 
 typedef struct hs_program {
@@ -240,6 +244,17 @@ int hs_agg_shared(void* stream, const hs_col* cols, int32_t n_cols, int32_t key_
                   int64_t* out_rep, uint64_t* out_acc, int32_t* out_ngroups, void* ws, uint32_t* flags, void* ev_begin,
                   void* ev_end);
 
+/* The same with COMPUTED units: rows are not grouped by unit; cols[unit_col] (HS_U8, a preloaded slot < 8) gives
+ * every row's unit id in [0, n_unit_tables), 0xff = the row takes no part.  This is how the probe side of a join is
+ * aggregated per shuffle partition (the reference's JoinJob, plan.py:99-109) without ever being partitioned in
+ * memory: hs_join_probe_unique writes the id column.  chunks / geom: from hs_agg_shared_geom over the ONE row range
+ * [0, nrows); outputs sized for n_unit_tables units of geom->pad slots; ws: n_unit_tables * geom->pad * 8 + 256
+ * bytes.  The key must fit 56 bits of its key word (INTEGER, or a string of fixed length <= 6): HS_E_LIMIT else. */
+int hs_agg_shared_units(void* stream, const hs_col* cols, int32_t n_cols, int32_t key_col, int32_t unit_col,
+                        int32_t n_unit_tables, const hs_program* prog, const hs_agg_spec* spec, const hs_chunk* chunks,
+                        const hs_agg_geom* geom, int64_t* out_rep, uint64_t* out_acc, int32_t* out_ngroups, void* ws,
+                        uint32_t* flags, void* ev_begin, void* ev_end);
+
 /* Dense pack of the slot arrays: rows of unit u go to [pack_start[u], pack_start[u+1]).
  * out_cols[a] receives accumulator a as HS_F32 / HS_I32 storage (acc_kinds[a]) = the reference's
  * shuffle-file column; out_rep the representative rows (gather the key column with them).
@@ -322,6 +337,44 @@ int hs_join_fill(void* stream, const hs_col* left_key, const hs_col* right_key, 
                  int64_t table_cap, const uint64_t* table_keys, const int64_t* table_reps,
                  const int64_t* slot_start, const int64_t* rows, const int64_t* out_start, int64_t* out_left,
                  int64_t* out_right);
+/* ---- primary-key / foreign-key join on INTEGER keys (round 2; csrc/hs_join.hip) --------------------------------
+ * The build side's keys are expected to be unique (else HS_FLAG_JOIN_DUP is raised and the caller falls back to
+ * hs_join_build / count / fill).  table: `slots` 32-bit words, one build row per slot.  direct != 0: slot =
+ * key - key_min (slots = the key range; chosen by the caller when the range is dense - TPC-H order keys use 8 of
+ * every 32 values - plain stores + a verify pass, no atomics); else slots = a power of two >= 2 * n_build,
+ * multiplicative hashing + linear probing, one 32-bit CAS per build row.  minmax: device int32[2]. */
+int hs_minmax_i32(void* stream, const int32_t* values, int64_t n, int32_t* minmax);
+int hs_join_build_unique(void* stream, const int32_t* build_keys, int64_t n_build, int32_t key_min, int64_t slots,
+                         int32_t direct, uint32_t* table, uint32_t* flags);
+/* Probe rows stay where they are.  Per probe row i: out_build_row[i] (optional) = the matching build row (0 without a
+ * match), out_unit[i] = python_hash(key) % n_parts (the row's shuffle partition, tasks.py:362 - the unit id for
+ * hs_agg_shared_units) or 0xff without a match (inner join: the row is dropped), out_payload[i] (optional) =
+ * build_payload[build row], a 1-byte column of the build side gathered on the way (dictionary codes of a GROUP BY
+ * key).  probe_keys and the outputs must be 16- / 4-byte aligned; probe_keys may be read up to 3 elements past
+ * n_probe (buffers carry slack). */
+int hs_join_probe_unique(void* stream, const int32_t* probe_keys, int64_t n_probe, const int32_t* build_keys,
+                         int32_t key_min, int64_t slots, int32_t direct, const uint32_t* table, int32_t n_parts,
+                         int64_t* out_build_row, uint8_t* out_unit, const uint8_t* build_payload, uint8_t* out_payload);
+
+/* ---- dictionary-coded STRING columns (round 2; csrc/hs_join.hip) ------------------------------------------------
+ * A STRING column with at most 256 distinct values is re-coded at table open as one byte per row + its dictionary
+ * (reference strings stay what they are on disk: io.py:97-109).  LIKE / comparisons with literals then become a
+ * bit test on the code (HS_OP_DICTBIT), string concatenation a mixed-radix combination of codes, GROUP BY a
+ * 1-byte key.  hs_dict_build inserts every row's string into an open-addressing set (cap slots, power of two >=
+ * 512; slot_words[cap], slot_reps[cap] = a row holding the slot's string or -1; *count = occupied slots;
+ * HS_FLAG_DICT_FULL in *flags once the table is half full - the column is then left as it is).  Under contention a
+ * string may occupy more than one slot: the caller reads the slots' strings back through slot_reps, names codes BY
+ * STRING (duplicate slots share a code; more than 256 distinct strings = no encoding), uploads slot_code[cap] and
+ * calls hs_dict_assign, which looks every row's string up again (any of its slots gives the same code). */
+int hs_dict_build(void* stream, const hs_col* col, int64_t nrows, int32_t cap, uint64_t* slot_words, int64_t* slot_reps,
+                  int32_t* count, uint32_t* flags);
+int hs_dict_assign(void* stream, const hs_col* col, int64_t nrows, int32_t cap, uint64_t* slot_words, int64_t* slot_reps,
+                   const uint8_t* slot_code, uint8_t* out_codes, uint32_t* flags);
+/* out[i] = sum_k codes[k][i] * strides[k] (the code of a concatenation in the product dictionary); 1..4 parts,
+ * 16-byte aligned buffers that may be read up to 15 bytes past nrows. */
+int hs_dict_combine(void* stream, int32_t n_parts, const uint8_t* const* codes, const int32_t* strides, int64_t nrows,
+                    uint8_t* out_codes);
+
 /* Exclusive scan of int64 counts -> start[n+1] (start[n] = total).  ws: hs_scan_ws_bytes(n). */
 int hs_exclusive_scan_i64(void* stream, const int64_t* counts, int64_t n, int64_t* start, void* ws);
 
@@ -445,6 +498,11 @@ int hs_jit_compile_check_eval(const hs_col* cols, int32_t n_cols, const hs_progr
 int hs_gen_lineitem(void* stream, uint64_t seed, int64_t row0, int64_t nrows, float* quantity, float* extendedprice,
                     float* discount, float* tax, int64_t* shipdate, uint8_t* returnflag, uint8_t* flag_lens,
                     int32_t* orderkey, uint8_t* shipmode_code);
+
+/* Synthetic orders table of BASELINE config 4 (CPU twin: oracle/q45_oracle.c q4_gen_orders): o_orderkey = key(perm(row))
+ * for an affine bijection perm of [0, n_total), priority_code in [0, 5).  n_total < 2^31. */
+int hs_gen_orders(void* stream, uint64_t seed, int64_t row0, int64_t nrows, int64_t n_total, int32_t* orderkey,
+                  uint8_t* priority_code);
 
 #ifdef __cplusplus
 }

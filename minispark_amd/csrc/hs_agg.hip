@@ -761,7 +761,8 @@ static int program_depth(const hs_program* p) {
         int sp = (int)((p->ins[i] >> 8) & 0xff);
         int op = (int)(p->ins[i] & 0xff);
         int after = sp;
-        if (op == HS_OP_LD || op == HS_OP_LIT || op == HS_OP_STRCMP_LIT || op == HS_OP_STRCMP_COL || op == HS_OP_LIKE)
+        if (op == HS_OP_LD || op == HS_OP_LIT || op == HS_OP_STRCMP_LIT || op == HS_OP_STRCMP_COL || op == HS_OP_LIKE ||
+            op == HS_OP_DICTBIT)
             after = sp + 1;
         if (after > d) d = after;
         if (sp > d) d = sp;
@@ -1038,6 +1039,8 @@ static int agg_partial_impl(void* stream, const hs_col* cols, int32_t n_cols, in
     // fused_ok), a staging batch that fits that block.
     A.unit_arrivals = nullptr;
     A.unit = U;
+    A.unit_col = -1;
+    A.pad3 = 0;
     static const bool fuse_env = !(getenv("HIPSPARK_FUSE_UNIT") && getenv("HIPSPARK_FUSE_UNIT")[0] == '0');
     bool fused = false;
     if (fuse_env && geom->pad == HS_GEOM_FUSABLE && spec->n_acc > 0) {
@@ -1398,10 +1401,42 @@ extern "C" int hs_agg_shared_geom(const int64_t* host_unit_rows, int64_t n_units
     return HS_OK;
 }
 
+static int agg_shared_impl(void* stream, const hs_col* cols, int32_t n_cols, int32_t key_col, int32_t unit_col,
+                           const hs_program* prog, const hs_agg_spec* spec, const hs_chunk* chunks, int64_t n_units,
+                           const hs_agg_geom* geom, int64_t* out_rep, uint64_t* out_acc, int32_t* out_ngroups, void* ws,
+                           uint32_t* flags, void* ev_begin, void* ev_end);
+
 extern "C" int hs_agg_shared(void* stream, const hs_col* cols, int32_t n_cols, int32_t key_col, const hs_program* prog,
                              const hs_agg_spec* spec, const hs_chunk* chunks, int64_t n_units, const hs_agg_geom* geom,
                              int64_t* out_rep, uint64_t* out_acc, int32_t* out_ngroups, void* ws, uint32_t* flags,
                              void* ev_begin, void* ev_end) {
+    return agg_shared_impl(stream, cols, n_cols, key_col, -1, prog, spec, chunks, n_units, geom, out_rep, out_acc,
+                           out_ngroups, ws, flags, ev_begin, ev_end);
+}
+
+extern "C" int hs_agg_shared_units(void* stream, const hs_col* cols, int32_t n_cols, int32_t key_col, int32_t unit_col,
+                                   int32_t n_unit_tables, const hs_program* prog, const hs_agg_spec* spec,
+                                   const hs_chunk* chunks, const hs_agg_geom* geom, int64_t* out_rep, uint64_t* out_acc,
+                                   int32_t* out_ngroups, void* ws, uint32_t* flags, void* ev_begin, void* ev_end) {
+    if (!cols || unit_col < 0 || unit_col >= n_cols || unit_col >= HS_FUSED_COLS || cols[unit_col].kind != HS_U8 ||
+        n_unit_tables < 1 || n_unit_tables > 127 || key_col < 0 || key_col >= n_cols) {
+        hs_set_error("hs_agg_shared_units: the unit column must be a HS_U8 column in a preloaded slot, 1..127 units");
+        return HS_E_ARG;
+    }
+    const hs_col& kc = cols[key_col];
+    const bool key_ok = kc.kind == HS_I32 || kc.kind == HS_U8 || (kc.kind == HS_STR && kc.fixed_len >= 1 && kc.fixed_len <= 6);
+    if (!key_ok) {
+        hs_set_error("hs_agg_shared_units: the key must fit 56 bits (INTEGER, or a string of fixed length <= 6)");
+        return HS_E_LIMIT;
+    }
+    return agg_shared_impl(stream, cols, n_cols, key_col, unit_col, prog, spec, chunks, n_unit_tables, geom, out_rep,
+                           out_acc, out_ngroups, ws, flags, ev_begin, ev_end);
+}
+
+static int agg_shared_impl(void* stream, const hs_col* cols, int32_t n_cols, int32_t key_col, int32_t unit_col,
+                           const hs_program* prog, const hs_agg_spec* spec, const hs_chunk* chunks, int64_t n_units,
+                           const hs_agg_geom* geom, int64_t* out_rep, uint64_t* out_acc, int32_t* out_ngroups, void* ws,
+                           uint32_t* flags, void* ev_begin, void* ev_end) {
     if (!cols || !prog || !spec || !chunks || !geom || !out_rep || !out_acc || !out_ngroups || !ws || !flags ||
         key_col < 0 || key_col >= n_cols) {
         hs_set_error("hs_agg_shared: null or out-of-range argument");
@@ -1449,6 +1484,8 @@ extern "C" int hs_agg_shared(void* stream, const hs_col* cols, int32_t n_cols, i
     A.flags = flags;
     A.unit_arrivals = nullptr;  // this tier merges chunk tables with global atomics, there is no unit combine
     memset(&A.unit, 0, sizeof(A.unit));
+    A.unit_col = unit_col;  // -1: units are the chunks' row ranges; else n_units = number of unit tables
+    A.pad3 = 0;
     {  // the replica count the geometry sized the LDS block for
         const size_t per_replica = (size_t)geom->group_cap * (size_t)(spec->n_acc > 0 ? spec->n_acc : 1) * 8;
         const size_t r = (geom->lds_bytes - (size_t)geom->group_cap * 16) / per_replica;

@@ -215,7 +215,19 @@ struct AggMainArgs {
     // launch; the last arriver zeroes it again); NULL = the combine is a separate launch (k_agg_unit)
     uint32_t* unit_arrivals;
     AggUnitArgs unit;
+    // shared-dictionary tier with COMPUTED units (the probe side of a join, rows left in place): column slot of a
+    // preloaded HS_U8 column holding every row's unit id (< 128; 0xff = the row takes no part), or -1 = units are
+    // the row ranges of `chunks`.  The id rides in the top byte of the key word (hs_unit_key), so the workgroup's
+    // LDS dictionary holds (unit, key) pairs and the chunk merge files every entry under its own unit's table.
+    int32_t unit_col;
+    int32_t pad3;
 };
+
+// key word of (unit, key): valid for key words that carry their information in the low 56 bits - INTEGER keys
+// (32 significant bits), packed strings of a FIXED length <= 6 (the length byte is the same for every row)
+__device__ __forceinline__ uint64_t hs_unit_key(uint64_t k, uint32_t unit) {
+    return (k & 0x00ffffffffffffffull) | ((uint64_t)unit << 56);
+}
 
 // 64-bit wave shuffle-down
 __device__ __forceinline__ uint64_t hs_shfl_down64(uint64_t v, int delta) {
@@ -421,14 +433,19 @@ struct InterpProg {
             uint64_t kcell[HS_V];
             const bool pre = (kc.kind != HS_STR) || hs_str_preloads(kc);
             if (pre) load((uint32_t)A.key_col, kcell);
+            uint64_t ucell[HS_V] = {0, 0, 0, 0};
+            if (A.unit_col >= 0) load((uint32_t)A.unit_col, ucell);
 #pragma unroll
             for (int j = 0; j < HS_V; ++j) {
                 uint64_t k = 0;
+                if (A.unit_col >= 0 && ucell[j] == 0xffull) ctx.alive[j] = false;  // e.g. a probe row without a match
                 if (ctx.alive[j]) {
                     if (kc.kind == HS_STR) k = pre ? kcell[j] : hs_key_at(kc, ctx.row0 + j);
                     else k = hs_key_from_cell(kc.kind, kcell[j]);
+                    if (A.unit_col >= 0) k = hs_unit_key(k, (uint32_t)ucell[j]);
                 }
-                if (!HASHED && kc.kind == HS_STR && kc.fixed_len == 1) ctx.slot[j] = ctx.find_byte(kc, k, ctx.row0 + j, ctx.alive[j]);
+                if (!HASHED && kc.kind == HS_STR && kc.fixed_len == 1 && A.unit_col < 0)
+                    ctx.slot[j] = ctx.find_byte(kc, k, ctx.row0 + j, ctx.alive[j]);
                 else ctx.slot[j] = ctx.template find<HASHED>(kc, k, ctx.row0 + j, ctx.alive[j]);
             }
         }
@@ -834,16 +851,17 @@ __device__ __forceinline__ void hs_agg_shared_body(const AggMainArgs& A) {
     }
 
     // merge this chunk's groups into the unit's table
-    const int64_t unit = desc.unit;
     const int UC = A.pad;
-    uint64_t* ukeys = A.part_keys + unit * UC;
-    int64_t* ureps = A.part_rep + unit * UC;
-    uint64_t* uacc = A.part_acc + unit * (int64_t)UC * NA;
     const hs_col& kc = A.cols.c[A.key_col];
     for (int sl = tid; sl < GC; sl += nthr) {
         const int64_t rep = dreps[sl];
         if (rep < 0) continue;
         const uint64_t k = Prog::HASHED ? hs_key_at(kc, rep) : dkeys[sl];
+        // computed units: the entry says which unit it belongs to (never with hashed keys: the host refuses those)
+        const int64_t unit = A.unit_col >= 0 ? (int64_t)(k >> 56) : desc.unit;
+        uint64_t* ukeys = A.part_keys + unit * UC;
+        int64_t* ureps = A.part_rep + unit * UC;
+        uint64_t* uacc = A.part_acc + unit * (int64_t)UC * NA;
         const int64_t u = hs_unit_upsert(ukeys, ureps, (uint32_t)UC - 1, Prog::HASHED, kc, k, rep);
         if (u < 0) {
             ctx.err |= HS_FLAG_DICT_FULL;

@@ -296,6 +296,14 @@ __device__ __forceinline__ uint64_t hs_like_lit(const hs_program& P, const hs_co
     return (uint64_t)hs_like(hs_str_at(c, row), P.pool + (uint32_t)(ref >> 32), (uint32_t)ref);
 }
 
+// bit[code] of a dictionary-coded column: the literal words lit[first .. first + n_words) hold one bit per entry
+__device__ __forceinline__ uint64_t hs_dictbit(const hs_program& P, const hs_col& c, int64_t row, uint32_t first,
+                                               uint32_t n_words) {
+    const uint32_t code = ((const uint8_t*)c.data)[row];
+    const uint32_t w = code >> 6;
+    return w < n_words ? (P.lit[first + w] >> (code & 63u)) & 1ull : 0ull;
+}
+
 // ---- interpreter ---------------------------------------------------------------------------------
 // The program is straight-line, so the stack depth before every instruction is known when it is
 // lowered and travels in the instruction (sp).  Dispatch is two wave-uniform switches (sp, then op)
@@ -379,6 +387,13 @@ __device__ __forceinline__ void hs_exec_at(uint64_t w, const hs_program& P, cons
 #pragma unroll
                 for (int j = 0; j < V; ++j)
                     st[N][j] = sink.live(j) ? hs_like_lit(P, C.c[a], sink.row(j), hs_ins_b(w)) : 0;
+            }
+            break;
+        case HS_OP_DICTBIT:
+            if constexpr (SP < D) {
+#pragma unroll
+                for (int j = 0; j < V; ++j)
+                    st[N][j] = sink.live(j) ? hs_dictbit(P, C.c[a], sink.row(j), hs_ins_b(w), hs_ins_c(w)) : 0;
             }
             break;
         case HS_OP_FILTER:
@@ -477,6 +492,7 @@ __device__ __forceinline__ void hs_run_compact(const hs_program& P, const HsCols
             case HS_OP_STRCMP_LIT: st(nx) = live ? hs_strcmp_lit(P, C.c[a], sink.row(0), hs_ins_b(w), hs_ins_c(w)) : 0; break;
             case HS_OP_STRCMP_COL: st(nx) = live ? hs_strcmp_col(C.c[a], C.c[hs_ins_b(w)], sink.row(0), hs_ins_c(w)) : 0; break;
             case HS_OP_LIKE: st(nx) = live ? hs_like_lit(P, C.c[a], sink.row(0), hs_ins_b(w)) : 0; break;
+            case HS_OP_DICTBIT: st(nx) = live ? hs_dictbit(P, C.c[a], sink.row(0), hs_ins_b(w), hs_ins_c(w)) : 0; break;
             case HS_OP_FILTER: sink.filter(0, y != 0); break;
             case HS_OP_AGG: sink.agg(a, 0, y); break;
             case HS_OP_OUT: sink.out(a, 0, y); break;

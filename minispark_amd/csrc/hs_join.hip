@@ -37,13 +37,13 @@ static unsigned hsj_grid(int64_t n, int per_block, int64_t max_blocks = 1 << 16)
 // =====================================================================================================
 // Dictionary encoding
 // =====================================================================================================
-// The table (global memory, L2-resident: cap slots x 16 bytes) is an open-addressing set of the column's distinct
-// strings: word = packed string (<= 7 bytes: exact) or a hash (then equality is decided on the bytes of the slot's
-// representative row).  Almost every row finds its string present: a read-only probe.
+// The table (global memory, L2-resident) is an open-addressing set of the column's distinct strings, a slot = a
+// representative row.  Almost every row finds its string present: a read-only probe + one short byte compare.
 __device__ __forceinline__ int hsj_dict_find_or_insert(uint64_t* words, int64_t* reps, uint32_t mask, const hs_col& c,
                                                        int64_t row, bool insert, int32_t* count, bool& full) {
-    const HsStr s = hs_str_at(c, row);
-    const bool packed = s.len <= 7;
+    // the slot is claimed by CAS on its representative row; equality is ALWAYS decided on the bytes of that row
+    // (immutable input), exactly like the global dictionaries of the join / GROUP BY builds (hs_ops.hip gdict_upsert);
+    // words[] keeps the key word of the slot's string for information only
     const uint64_t k = hs_key_at(c, row);
     uint32_t h = (uint32_t)(hs_mix64(k) >> 24) & mask;
     for (uint32_t probe = 0; probe <= mask; ++probe) {
@@ -51,18 +51,13 @@ __device__ __forceinline__ int hsj_dict_find_or_insert(uint64_t* words, int64_t*
         if (rep < 0) {
             if (!insert) return -1;
             rep = (long long)atomicCAS((unsigned long long*)&reps[h], (unsigned long long)(-1ll), (unsigned long long)row);
-            if (rep < 0) {  // claimed: publish the word (readers that see the rep but not yet the word compare bytes)
-                __hip_atomic_store(&words[h], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (atomicAdd(count, 1) >= 256) full = true;
+            if (rep < 0) {
+                words[h] = k;
+                if (atomicAdd(count, 1) >= (int)(mask >> 1)) full = true;  // half full: give up (see k_dict_build)
                 return (int)h;
             }
         }
-        // occupied by row `rep`: same string?
-        const uint64_t w = __hip_atomic_load(&words[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (packed && w == k) return (int)h;
-        if (w == k || w == HS_EMPTY_KEY) {  // hashed mode, or the word is not published yet: the bytes decide
-            if (hs_rows_equal(c, (int64_t)rep, row)) return (int)h;
-        }
+        if (hs_rows_equal(c, (int64_t)rep, row)) return (int)h;
         h = (h + 1) & mask;
     }
     full = true;
@@ -83,8 +78,12 @@ __global__ void __launch_bounds__(256) k_dict_build(const hs_col col, int64_t n,
     __shared__ int s_stop;
     bool full = false;
     for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < n; base += (int64_t)gridDim.x * blockDim.x) {
-        // more than 256 distinct strings: the column is not encoded - stop reading it (uniform decision per round)
-        if (threadIdx.x == 0) s_stop = __hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 256;
+        // far more entries than a code byte can name: the column is not encoded - stop reading it (uniform decision
+        // per round).  The threshold is half the table, not 256: under heavy contention (millions of rows, a handful
+        // of strings, every workgroup inserting the same few at once) a string can end up in more than one slot, so
+        // `count` over-counts; the caller names codes by STRING (duplicate slots share a code) and applies the
+        // 256 limit to the distinct strings it reads back.
+        if (threadIdx.x == 0) s_stop = __hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > cap / 2;
         __syncthreads();
         if (s_stop) break;
         const int64_t row = base + threadIdx.x;
@@ -412,5 +411,62 @@ extern "C" int hs_join_probe_unique(void* stream, const int32_t* probe_keys, int
     if (n_probe > 0)
         hipLaunchKernelGGL(k_join_probe_unique, dim3(hsj_grid((n_probe + 3) / 4, 256, 1 << 15)), dim3(256), 0, (hipStream_t)stream, A);
     HSJ_CHECK_LAUNCH("hs_join_probe_unique");
+    return HS_OK;
+}
+
+// =====================================================================================================
+// Synthetic orders table of BASELINE config 4 (bench / tests only; CPU twin: oracle/q45_oracle.c q4_gen_orders).
+// Row j holds key(perm(j)), perm = an affine bijection of [0, n_total) (build order != key order), and a priority
+// code in [0, 5).  key(o) = 32 * (o / 8) + o % 8 + 1: sparse like TPC-H order keys (8 used of every 32).
+// =====================================================================================================
+__device__ __forceinline__ uint64_t hsj_splitmix(uint64_t x) {
+    x += 0x9e3779b97f4a7c15ull;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+}
+__global__ void __launch_bounds__(256) k_gen_orders(uint64_t seed, int64_t row0, int64_t n, uint64_t n_total, uint64_t mul,
+                                                    uint64_t add, int32_t* okey, uint8_t* prio) {
+    const uint64_t pseed = hsj_splitmix(seed + 0x7072696full);
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t j = (uint64_t)(row0 + k);
+        const uint64_t o = (mul * j + add) % n_total;  // mul, j < 2^31: no overflow
+        if (okey) okey[k] = (int32_t)(32 * (o / 8) + (o % 8) + 1);
+        if (prio) prio[k] = (uint8_t)(hsj_splitmix(pseed + j) % 5);
+    }
+}
+static uint64_t hsj_splitmix_host(uint64_t x) {
+    x += 0x9e3779b97f4a7c15ull;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+}
+extern "C" int hs_gen_orders(void* stream, uint64_t seed, int64_t row0, int64_t nrows, int64_t n_total, int32_t* orderkey,
+                             uint8_t* priority_code) {
+    if (nrows < 0 || row0 < 0 || n_total < 1 || n_total >= (1ll << 31) || row0 + nrows > n_total) {
+        hs_set_error("hs_gen_orders: bad arguments (n_total < 2^31)");
+        return HS_E_ARG;
+    }
+    uint64_t mul = 1;
+    if (n_total > 1) {
+        mul = hsj_splitmix_host(seed ^ 0x6f7264657273ull) % (uint64_t)n_total;
+        if (mul < 2) mul = 2;
+        for (;; ++mul) {
+            uint64_t a = mul, b = (uint64_t)n_total;
+            while (b) {
+                const uint64_t t = a % b;
+                a = b;
+                b = t;
+            }
+            if (a == 1) break;
+        }
+        mul %= (uint64_t)n_total;
+        if (!mul) mul = 1;
+    }
+    const uint64_t add = hsj_splitmix_host(seed + 77) % (uint64_t)n_total;
+    if (nrows > 0)
+        hipLaunchKernelGGL(k_gen_orders, dim3(hsj_grid(nrows, 256 * 4, 8192)), dim3(256), 0, (hipStream_t)stream, seed, row0, nrows,
+                           (uint64_t)n_total, mul, add, orderkey, priority_code);
+    HSJ_CHECK_LAUNCH("hs_gen_orders");
     return HS_OK;
 }

@@ -23,9 +23,24 @@ import torch
 from . import hipspark as hs
 from .constants import ColumnType, Schema
 from .io import StrCol
-from .lowering import ProgramBuilder, StringParts, lower_aggregate
+from .lowering import NeedsDecoded, ProgramBuilder, StringParts, lower_aggregate
 
 PAD = 64  # bytes of slack behind every buffer
+
+def _strcol_bytes(col: StrCol) -> list[bytes]:
+    data, out, pos = col.data.tobytes(), [], 0
+    for ln in col.lens.tolist():
+        out.append(data[pos: pos + ln])
+        pos += ln
+    return out
+
+
+def _decode_codes(codes: np.ndarray, entries: tuple) -> StrCol:
+    """Host side of the result hand-over: code bytes -> the raw STRING column a BlockFile holds."""
+    lens_of = np.array([len(e) for e in entries], dtype=np.uint8)
+    codes = np.asarray(codes, dtype=np.uint8)
+    return StrCol(lens_of[codes], np.frombuffer(b"".join(entries[c] for c in codes.tolist()), dtype=np.uint8).copy())
+
 
 _TORCH_DTYPE = {hs.I32: torch.int32, hs.F32: torch.float32, hs.I64: torch.int64, hs.F64: torch.float64,
                 hs.U8: torch.uint8}
@@ -42,6 +57,12 @@ class DCol:
     lens: torch.Tensor | None = None
     offs: torch.Tensor | None = None
     fixed_len: int = -1
+    # Dictionary-coded STRING column: `data` holds ONE CODE BYTE per row - to every kernel a string
+    # column of fixed length 1, so GROUP BY / gathers / the exchange slabs work on it unchanged - and `dict` the
+    # strings the codes stand for.  Whatever looks INSIDE the strings (LIKE, comparisons, concatenation, a join or
+    # partition key, the result hand-over) goes through the lowering's dictionary forms or decodes first.
+    dict: tuple | None = None
+    plain: "DCol | None" = None  # the same rows as real strings, where they exist anyway (table columns)
 
     def as_hs(self) -> hs.hs_col:
         c = hs.hs_col()
@@ -80,6 +101,9 @@ class DBatch:
     slab_cols: list[int] | None = None    # slab column holding each batch column (aggregates may share one)
     partitioned: bool = False             # multi-GPU: every rank holds DIFFERENT rows (else replicated)
     tail: dict | None = None              # partial rows emitted in slab form for aggregate_finish (the short tail)
+    unit_col: torch.Tensor | None = None  # COMPUTED units (probe side of a join, rows left in place): u8 unit id per
+    n_unit_ids: int = 0                   # row (0xff = dropped) and the number of units; unit_rows is then [0, nrows]
+    join_task_id: Any = None              # the join that produced the computed units (for the fall-back decision)
 
     def __post_init__(self) -> None:
         if self.nrows_dev is None and not self.unit_rows:
@@ -88,6 +112,10 @@ class DBatch:
     @property
     def kinds(self) -> list[int]:
         return [c.kind for c in self.cols]
+
+    @property
+    def dicts(self) -> list:
+        return [c.dict for c in self.cols]
 
     @property
     def lazy(self) -> bool:
@@ -332,6 +360,8 @@ class Device:
         """Device column (already in file storage kinds) -> raw numpy column."""
         if col.kind == hs.STR:
             n = col.n
+            if col.dict is not None:
+                return _decode_codes(col.data[:n].cpu().numpy(), col.dict)
             lens = col.lens[:n].cpu().numpy()
             total = int(lens.sum(dtype=np.int64)) if col.fixed_len < 0 else n * col.fixed_len
             return StrCol(lens.astype(np.uint8), col.data[:total].cpu().numpy().astype(np.uint8))
@@ -390,7 +420,10 @@ class Device:
                 pending_lens = host[off: off + size][:n].copy()
             elif tag == "sdata":
                 total = int(pending_lens.sum(dtype=np.int64))
-                raw.append(StrCol(pending_lens, host[off: off + size][:total].copy()))
+                if c.dict is not None:  # one code byte per row -> the strings they stand for
+                    raw.append(_decode_codes(host[off: off + size][:n], c.dict))
+                else:
+                    raw.append(StrCol(pending_lens, host[off: off + size][:total].copy()))
             elif tag == "col":
                 raw.append(host[off: off + size].view(np_dtype[c.kind])[:n].copy())
         return raw, n, flags
@@ -406,8 +439,13 @@ class Device:
                      n: int | None = None) -> list[tuple[DCol, str]]:
         """Evaluate numeric / boolean expressions -> in-flight columns (F64 / I64 / U8 mask)."""
         n = batch.nrows if n is None else n
-        b = ProgramBuilder(batch.schema, batch.kinds)
-        tags = [b.emit_out(i, e) for i, e in enumerate(exprs)]
+        while True:
+            b = ProgramBuilder(batch.schema, batch.kinds, batch.dicts)
+            try:
+                tags = [b.emit_out(i, e) for i, e in enumerate(exprs)]
+                break
+            except NeedsDecoded as e:  # a coded column used in a way that has no coded form
+                batch = self.decoded_batch(batch, [e.column])
         prog = b.finish()
         out_kinds = [hs.F64 if t == "F" else (hs.U8 if t == "B" else hs.I64) for t in tags]
         outs = [self.empty(n, _TORCH_DTYPE[k]) for k in out_kinds]
@@ -451,7 +489,7 @@ class Device:
             data = out if out is not None else self.empty(n * width, torch.uint8)
             hs.check(self.lib.hs_gather_fixed(self.stream, col.data.data_ptr(), width, col.n, idx.data_ptr(), n, n_dev_ptr,
                                               data.data_ptr(), self.flags.data_ptr()), "hs_gather_fixed")
-            return DCol(hs.STR, data, n, lens=self.const_lens(width, n), offs=None, fixed_len=width)
+            return DCol(hs.STR, data, n, lens=self.const_lens(width, n), offs=None, fixed_len=width, dict=col.dict)
         if col.kind == hs.STR:
             if n_dev is not None:
                 n = min(n, self.host_int(n_dev[0]))
@@ -516,7 +554,8 @@ class Device:
         for c in batch.cols:
             if c.kind == hs.STR:
                 cols.append(DCol(hs.STR, c.data, n, lens=c.lens[:n] if c.lens is not None else None,
-                                 offs=c.offs[: n + 1] if c.offs is not None else None, fixed_len=c.fixed_len))
+                                 offs=c.offs[: n + 1] if c.offs is not None else None, fixed_len=c.fixed_len,
+                                 dict=c.dict))
             else:
                 cols.append(DCol(c.kind, c.data[:n], n))
         return DBatch(list(batch.schema), cols, n, [0, n])
@@ -525,8 +564,129 @@ class Device:
         return DBatch(list(batch.schema), [self.gather_col(c, idx, n) for c in batch.cols], n,
                       unit_rows or [0, n])
 
+    # ---- dictionary-coded strings ---------------------------------------------------------------------------
+    DICT_SLOTS = 4096  # slots of the string set built on the device (a column with <= 256 distinct strings is coded)
+
+    def dict_encode(self, col: DCol) -> DCol | None:
+        """Try to re-code a STRING column as one byte per row + dictionary (at most 256 distinct strings; sorted, so
+        the codes do not depend on row order).  None = the column stays as it is.  Two passes over the column
+        (hs_dict_build / hs_dict_assign) and one small read-back: done once, when a table column is loaded."""
+        if col.kind != hs.STR or col.dict is not None or col.n == 0 or col.fixed_len == 1:
+            return None  # one-byte strings are already as narrow as a code
+        cap = self.DICT_SLOTS
+        words = self.empty(cap, torch.int64)
+        reps = self.empty(cap, torch.int64)
+        state = torch.zeros(2, dtype=torch.int32, device=self.device)  # [count, flags]
+        src = col.as_hs()
+        hs.check(self._raw_lib.hs_dict_build(self.stream, C.byref(src), col.n, cap, words.data_ptr(), reps.data_ptr(),
+                                             state[0:].data_ptr(), state[1:].data_ptr()), "hs_dict_build")
+        count, flags = (int(v) for v in state.tolist())
+        if flags or count == 0:
+            return None
+        slot_reps = reps.cpu().numpy()
+        slots = np.nonzero(slot_reps >= 0)[0]
+        rep_rows = torch.from_numpy(slot_reps[slots].astype(np.int64)).to(self.device)
+        texts = _strcol_bytes(self.download(self.gather_col(col, rep_rows, len(slots)), ColumnType.STRING))
+        # codes are named by STRING: a string that landed in several slots (hs_dict_build, contention) has one code
+        entries = sorted(set(texts))
+        if len(entries) > 256:
+            return None
+        code_of = {text: code for code, text in enumerate(entries)}
+        slot_code = np.zeros(cap, dtype=np.uint8)
+        for slot, text in zip(slots.tolist(), texts):
+            slot_code[slot] = code_of[text]
+        codes = self.empty(col.n, torch.uint8)
+        d_slot_code = torch.from_numpy(slot_code).to(self.device)
+        hs.check(self._raw_lib.hs_dict_assign(self.stream, C.byref(src), col.n, cap, words.data_ptr(), reps.data_ptr(),
+                                              d_slot_code.data_ptr(), codes.data_ptr(), state[1:].data_ptr()),
+                 "hs_dict_assign")
+        if int(state[1].item()):
+            return None
+        return DCol(hs.STR, codes, col.n, lens=self.const_lens(1, col.n), offs=None, fixed_len=1,
+                    dict=tuple(entries), plain=col)
+
+    def dict_column(self, entries: tuple) -> DCol:
+        """The dictionary's strings as a device STRING column (row = code): the source of decoding gathers."""
+        cache = self.__dict__.setdefault("_dict_columns", {})
+        hit = cache.get(entries)
+        if hit is None:
+            lens = np.array([len(e) for e in entries], dtype=np.uint8)
+            data = np.frombuffer(b"".join(entries) or b"\0", dtype=np.uint8)
+            recording, self.rec = self.rec, None  # a constant of the query shape, not host data of this run
+            try:
+                hit = self.string_col(self.to_device(lens, torch.uint8), self.to_device(data, torch.uint8), len(entries))
+            finally:
+                self.rec = recording
+            if len(cache) >= 64:
+                cache.pop(next(iter(cache)))
+            cache[entries] = hit
+        return hit
+
+    def decoded(self, col: DCol) -> DCol:
+        """A dictionary-coded column as real strings (lens + bytes [+ offsets]); any other column unchanged."""
+        if col.dict is None:
+            return col
+        if col.plain is not None and col.plain.n == col.n:
+            return col.plain
+        idx = self.empty(col.n, torch.int64)
+        idx.copy_(col.data[: col.n])  # code byte -> row of the dictionary column (widening copy: plumbing)
+        return self.gather_col(self.dict_column(col.dict), idx, col.n)
+
+    def decoded_batch(self, batch: DBatch, which: Sequence[int] | None = None) -> DBatch:
+        """The batch with its dictionary-coded columns (all, or the listed ones) decoded."""
+        import dataclasses  # noqa: PLC0415
+
+        todo = [i for i, c in enumerate(batch.cols) if c.dict is not None and (which is None or i in which)]
+        if not todo:
+            return batch
+        cols = list(batch.cols)
+        for i in todo:
+            cols[i] = self.decoded(cols[i])
+        return dataclasses.replace(batch, cols=cols)
+
+    def dict_concat(self, batch: DBatch, parts: StringParts, n: int) -> DCol | None:
+        """Concatenation whose column parts are all dictionary-coded: the result is coded too - codes combined in
+        mixed radix (one launch over code bytes), dictionary = the product of the parts' dictionaries with the
+        literals spliced in.  None when that product would not fit a code byte."""
+        col_parts = [(i, v) for i, (what, v) in enumerate(parts.parts) if what == "col"]
+        if not col_parts or any(batch.cols[v].dict is None for _, v in col_parts) or len(col_parts) > 4:
+            return None
+        sizes = [len(batch.cols[v].dict) for _, v in col_parts]
+        total = 1
+        for sz in sizes:
+            total *= sz
+        if total > 256:
+            return None
+        strides, acc = [], 1
+        for sz in reversed(sizes):  # the last column part varies fastest
+            strides.insert(0, acc)
+            acc *= sz
+        entries = []
+        for code in range(total):
+            text, k = b"", 0
+            for what, v in parts.parts:
+                if what == "col":
+                    text += batch.cols[v].dict[(code // strides[k]) % sizes[k]]
+                    k += 1
+                else:
+                    text += v
+            if len(text) > 255:
+                return None  # the reference fails at the file write; the generic path reports it per row
+            entries.append(text)
+        if any(batch.cols[v].data.data_ptr() % 16 for _, v in col_parts):
+            return None  # the combine reads 16 code bytes per lane
+        out = self.empty(n, torch.uint8)
+        ptrs = (C.c_void_p * len(col_parts))(*[batch.cols[v].data.data_ptr() for _, v in col_parts])
+        strd = (C.c_int32 * len(col_parts))(*strides)
+        hs.check(self.lib.hs_dict_combine(self.stream, len(col_parts), ptrs, strd, n, out.data_ptr()), "hs_dict_combine")
+        return DCol(hs.STR, out, n, lens=self.const_lens(1, n), offs=None, fixed_len=1, dict=tuple(entries))
+
     # ---- string concat -------------------------------------------------------------------------------
     def concat_strings(self, batch: DBatch, parts: StringParts, n: int) -> DCol:
+        coded = self.dict_concat(batch, parts, n)
+        if coded is not None:
+            return coded
+        batch = self.decoded_batch(batch, [v for what, v in parts.parts if what == "col"])
         if len(parts.parts) > hs.HS_MAX_PARTS:
             raise NotImplementedError(f"string concatenation of more than {hs.HS_MAX_PARTS} parts")
         arr = (hs.hs_col * len(parts.parts))()
@@ -608,6 +768,26 @@ class Device:
     def aggregate_partial(self, batch: DBatch, filters: Sequence[Any], group_by: Any, agg_columns: Sequence[Any],
                           out_schema: Schema, group_cap_hint: int = 4, cache_key: Any = None,
                           slab_rows: int | None = None, tail: bool = False, shared: bool = False) -> DBatch:
+        """_aggregate_partial over a batch whose dictionary-coded columns are decoded where the query uses them in a
+        way that has no coded form (remembered per query node, so later runs decode up front)."""
+        hints = self.__dict__.setdefault("_decode_hints", {})
+        todo = hints.get(cache_key) if cache_key is not None else None
+        if todo:
+            batch = self.decoded_batch(batch, todo)
+        while True:
+            try:
+                return self._aggregate_partial(batch, filters, group_by, agg_columns, out_schema, group_cap_hint,
+                                               cache_key, slab_rows, tail, shared)
+            except NeedsDecoded as e:
+                batch = self.decoded_batch(batch, [e.column])
+                if cache_key is not None:
+                    if len(hints) >= 64:
+                        hints.pop(next(iter(hints)))
+                    hints.setdefault(cache_key, set()).add(e.column)
+
+    def _aggregate_partial(self, batch: DBatch, filters: Sequence[Any], group_by: Any, agg_columns: Sequence[Any],
+                           out_schema: Schema, group_cap_hint: int = 4, cache_key: Any = None,
+                           slab_rows: int | None = None, tail: bool = False, shared: bool = False) -> DBatch:
         """Fused scan + WHERE + aggregate arguments + per-unit partial aggregate.
 
         Returns the partial rows exactly as the reference would have written them to its shuffle
@@ -627,7 +807,7 @@ class Device:
                    tuple((c.kind, c.fixed_len, c.data.data_ptr(), c.n, c.lens.data_ptr() if c.lens is not None else 0,
                           c.offs.data_ptr() if c.offs is not None else 0) for c in batch.cols),
                    tuple(batch.unit_rows), tuple(batch.unit_ids) if batch.unit_ids is not None else None, slab_rows,
-                   tail, shared)
+                   tail, shared, batch.unit_col.data_ptr() if batch.unit_col is not None else 0, batch.n_unit_ids)
         prep = self._partial_prepared.get(key) if key is not None else None
         if prep is None:
             prep = self._prepare_partial(batch, filters, group_by, agg_columns, cap, slab_rows, tail, out_schema, shared)
@@ -651,7 +831,15 @@ class Device:
             self.last_group_cap = cap
             return DBatch(list(out_schema), [], p["slots"], [0, p["slots"]], None, total_units=batch.total_units,
                           slab=p["slab"], slab_layout=p["layout"], tail=p["tail"])
-        if shared:
+        if shared and p.get("unit_slot") is not None:
+            # computed units (probe side of a join): the unit id column rides along as one more preloaded slot
+            hs.check(self.lib.hs_agg_shared_units(self.stream, p["cols"], p["n_cols"], p["key_slot"], p["unit_slot"],
+                                                  p["n_units"], C.byref(p["prog"]), C.byref(p["spec"]),
+                                                  p["d_units"].data_ptr(), C.byref(p["geom"]), p["out_rep"].data_ptr(),
+                                                  p["out_acc"].data_ptr(), p["ngroups"].data_ptr(), p["ws"].data_ptr(),
+                                                  self.flags.data_ptr(), self._event_handle(0), self._event_handle(1)),
+                     "hs_agg_shared_units")
+        elif shared:
             # tens to thousands of groups per unit: one LDS table per workgroup, LDS atomics
             hs.check(self.lib.hs_agg_shared(self.stream, p["cols"], p["n_cols"], p["key_slot"], C.byref(p["prog"]),
                                             C.byref(p["spec"]), p["d_units"].data_ptr(), p["n_units"], C.byref(p["geom"]),
@@ -693,7 +881,7 @@ class Device:
                        out_schema: Schema, slab_rows: int | None, tail: bool = False) -> DBatch:
         """Partial aggregate of zero rows (a rank that owns no block): no launch, but the same column /
         slab layout as the other ranks so the exchange stays symmetric."""
-        low = lower_aggregate(batch.schema, batch.kinds, filters, group_by, agg_columns)
+        low = lower_aggregate(batch.schema, batch.kinds, filters, group_by, agg_columns, batch.dicts)
         key_src = batch.cols[low.program.columns[low.key_slot]]
         acc_kinds = [hs.I32 if is_int else hs.F32 for is_int in low.acc_is_int]
         if tail:
@@ -701,7 +889,8 @@ class Device:
                 raise SlabUnsupported("an empty single-GPU input takes the general path")
             layout, slab, desc = self._tail_slab(key_src, out_schema, acc_kinds, slab_rows)
             info = {"desc": desc, "layout": layout, "slab": slab, "agg_to_acc": list(low.agg_to_acc),
-                    "acc_kinds": acc_kinds, "key_kind": key_src.kind, "key_len": key_src.fixed_len, "n_units": 0}
+                    "acc_kinds": acc_kinds, "key_kind": key_src.kind, "key_len": key_src.fixed_len, "n_units": 0,
+                    "key_dict": key_src.dict}
             return DBatch(list(out_schema), [], 0, [0, 0], None, total_units=batch.total_units, slab=slab,
                           slab_layout=layout, tail=info)
         if slab_rows is not None and key_src.kind == hs.STR and key_src.fixed_len not in (1, 2, 4, 8):
@@ -748,12 +937,25 @@ class Device:
     def _prepare_partial(self, batch: DBatch, filters: Sequence[Any], group_by: Any, agg_columns: Sequence[Any],
                          cap: int, slab_rows: int | None = None, tail: bool = False,
                          out_schema: Schema | None = None, shared: bool = False) -> dict:
-        low = lower_aggregate(batch.schema, batch.kinds, filters, group_by, agg_columns)
+        low = lower_aggregate(batch.schema, batch.kinds, filters, group_by, agg_columns, batch.dicts)
         if low.numeric_slots > hs.HS_FUSED_COLS:
             raise TierExceeded(f"aggregate reads more than {hs.HS_FUSED_COLS} numeric columns")
         n_units = batch.n_units
         n_acc = len(low.acc_ops)
-        host_units = (C.c_int64 * (n_units + 1))(*batch.unit_rows)
+        computed = batch.unit_col is not None
+        if computed:
+            # units are per-row ids: ONE row range for the chunking, batch.n_unit_ids unit tables for the outputs
+            if not shared or tail or slab_rows is not None:
+                raise TierExceeded("computed units run on the shared-dictionary tier only")
+            if len(low.program.columns) >= hs.HS_FUSED_COLS:
+                raise TierExceeded("no preloaded column slot left for the unit ids")
+            kc = batch.cols[low.program.columns[low.key_slot]]
+            if not (kc.kind in (hs.I32, hs.U8) or (kc.kind == hs.STR and 1 <= kc.fixed_len <= 6)):
+                raise TierExceeded("computed units need a GROUP BY key of at most 56 bits")
+            host_units = (C.c_int64 * 2)(0, batch.nrows)
+            n_units = 1
+        else:
+            host_units = (C.c_int64 * (n_units + 1))(*batch.unit_rows)
         geom = hs.hs_agg_geom()
         if shared:
             rc = self.lib.hs_agg_shared_geom(host_units, n_units, n_acc, cap, C.byref(geom))
@@ -772,6 +974,8 @@ class Device:
                                                 chunks.ctypes.data_as(C.POINTER(hs.hs_chunk)),
                                                 chunk0.ctypes.data_as(C.POINTER(C.c_int64))), "hs_agg_partial_chunks")
         unit_cap = int(geom.pad) if shared else cap  # slots per unit of the kernels' output arrays
+        if computed:
+            n_units = batch.n_unit_ids  # from here on: the unit tables
         slots = n_units * unit_cap
         acc_kinds = [hs.I32 if is_int else hs.F32 for is_int in low.acc_is_int]
         key_idx = low.program.columns[low.key_slot]
@@ -791,7 +995,8 @@ class Device:
                 "ws": self.workspace(geom.ws_bytes).zero_(),
                 "tail": {"desc": desc, "layout": layout, "slab": slab, "agg_to_acc": list(low.agg_to_acc),
                          "acc_kinds": acc_kinds, "key_kind": batch.cols[key_idx].kind,
-                         "key_len": batch.cols[key_idx].fixed_len, "n_units": n_units},
+                         "key_len": batch.cols[key_idx].fixed_len, "n_units": n_units,
+                         "key_dict": batch.cols[key_idx].dict},
                 "info": {"rows": batch.nrows, "chunks": int(geom.n_chunks), "chunk_rows": int(geom.chunk_rows),
                          "wg_threads": int(geom.wg_threads), "group_cap": cap, "lds_bytes": int(geom.lds_bytes)},
             }
@@ -820,15 +1025,24 @@ class Device:
             d_unit_ids = self.to_device(np.asarray(batch.unit_ids, dtype=np.int64))
             if out_unit is None:
                 out_unit = self.empty(max(slots, 1), torch.int64)
+        cols_arr, n_cols, unit_slot = self._cols_array(batch, low.program.columns), len(low.program.columns), None
+        ws_bytes = geom.ws_bytes
+        if computed:
+            cols_arr = (hs.hs_col * (n_cols + 1))()
+            for slot, idx in enumerate(low.program.columns):
+                cols_arr[slot] = batch.cols[idx].as_hs()
+            cols_arr[n_cols] = DCol(hs.U8, batch.unit_col, batch.nrows).as_hs()
+            unit_slot, n_cols = n_cols, n_cols + 1
+            ws_bytes = n_units * unit_cap * 8 + 256
         return {
             "slab": slab, "layout": layout, "key_out": key_out, "out_unit": out_unit, "d_unit_ids": d_unit_ids,
-            "cols": self._cols_array(batch, low.program.columns), "n_cols": len(low.program.columns),
+            "cols": cols_arr, "n_cols": n_cols, "unit_slot": unit_slot,
             "key_slot": low.key_slot, "key_idx": key_idx, "prog": low.program.to_struct(),
             "spec": low.spec(), "geom": geom, "n_units": n_units, "slots": slots, "unit_cap": unit_cap,
             "agg_to_acc": low.agg_to_acc,
             "d_units": self.to_device(chunks.reshape(-1)), "d_chunk0": self.to_device(chunk0),
             "out_rep": self.empty(slots, torch.int64), "out_acc": self.empty(max(slots * n_acc, 1), torch.int64),
-            "ngroups": self.empty(max(n_units, 1), torch.int32), "ws": self.workspace(geom.ws_bytes).zero_(),
+            "ngroups": self.empty(max(n_units, 1), torch.int32), "ws": self.workspace(ws_bytes).zero_(),
             "pack_start": self.empty(n_units + 1, torch.int64), "dense_rep": self.empty(max(slots, 1), torch.int64),
             "acc_kinds": acc_kinds, "acc_bufs": acc_bufs,
             "out_ptrs": (C.c_void_p * max(n_acc, 1))(*[t.data_ptr() for t in acc_bufs]),
@@ -918,6 +1132,7 @@ class Device:
         hs.check(rc, "hs_agg_finish")
         self.last_merge_cap = cap
         result, columns, mapped = p["result"], p["columns"], p["host_image"]
+        key_dict = tail.get("key_dict")
         stream = torch.cuda.current_stream(self.device)
 
         def finish() -> tuple[list[Any], int, int]:
@@ -939,7 +1154,10 @@ class Device:
             raw: list[Any] = []
             for off, kind, width in columns:
                 if kind == hs.STR:
-                    raw.append(StrCol(np.full(n, width, dtype=np.uint8), host[off: off + n * width].copy()))
+                    if key_dict is not None:
+                        raw.append(_decode_codes(host[off: off + n], key_dict))
+                    else:
+                        raw.append(StrCol(np.full(n, width, dtype=np.uint8), host[off: off + n * width].copy()))
                 else:
                     raw.append(host[off: off + n * width].view(_NP_DTYPE[kind]).copy())
             return raw, n, flags
@@ -1054,6 +1272,12 @@ class Device:
             return parts[0]
         kind = parts[0].kind
         n = sum(p.n for p in parts)
+        if kind == hs.STR and any(p.dict is not None for p in parts):
+            if all(p.dict == parts[0].dict for p in parts):  # pieces of one coded column: concatenate the codes
+                out = self.empty(n, torch.uint8)
+                out.copy_(torch.cat([p.data[: p.n] for p in parts]))
+                return DCol(hs.STR, out, n, lens=self.const_lens(1, n), offs=None, fixed_len=1, dict=parts[0].dict)
+            parts = [self.decoded(p) for p in parts]
         if kind == hs.STR:
             lens = torch.cat([p.lens[: p.n] for p in parts])
             sizes = [int(p.lens[: p.n].sum().item()) if p.fixed_len < 0 else p.n * p.fixed_len for p in parts]
@@ -1228,6 +1452,43 @@ class Device:
         hs.check(self.lib.hs_partition_ids(self.stream, C.byref(key), None, batch.nrows, n_parts, part.data_ptr()),
                  "hs_partition_ids")
         return part
+
+    # ---- primary-key / foreign-key join: rows stay in place, units are computed -----------------
+    DIRECT_JOIN_MAX_SPREAD = 16  # direct addressing while the build side's key range is <= this many slots per key
+
+    def join_probe_unique(self, build_key: DCol, probe_key: DCol, n_parts: int, payload: DCol | None = None,
+                          want_rows: bool = True):
+        """Inner equi-join of INTEGER keys whose build side is expected to hold every key once (HS_FLAG_JOIN_DUP in
+        the status word otherwise: the engine then re-runs the query through the general join).  ->
+        (build_row int64[n_probe] or None, unit u8[n_probe] with 0xff = no match, payload u8[n_probe] or None)."""
+        n_build, n_probe = build_key.n, probe_key.n
+        minmax = self.empty(2, torch.int32)
+        hs.check(self.lib.hs_minmax_i32(self.stream, build_key.data.data_ptr(), n_build, minmax.data_ptr()), "hs_minmax_i32")
+        if self.rec is not None:
+            self.rec.poisoned = True  # the table's shape depends on the key range learnt here
+        lo, hi = (int(v) for v in minmax.tolist())
+        spread = hi - lo + 1 if n_build else 1
+        direct = n_build > 0 and spread <= self.DIRECT_JOIN_MAX_SPREAD * n_build
+        if direct:
+            slots, key_min = spread, lo
+        else:
+            slots, key_min = 16, 0
+            while slots < 2 * max(n_build, 1):
+                slots *= 2
+        table = self.empty(slots, torch.int32)
+        hs.check(self.lib.hs_join_build_unique(self.stream, build_key.data.data_ptr(), n_build, key_min, slots,
+                                               1 if direct else 0, table.data_ptr(), self.flags.data_ptr()),
+                 "hs_join_build_unique")
+        rows = self.empty(n_probe, torch.int64) if want_rows else None
+        unit = self.empty(n_probe, torch.uint8)
+        pay = self.empty(n_probe, torch.uint8) if payload is not None else None
+        hs.check(self.lib.hs_join_probe_unique(self.stream, probe_key.data.data_ptr(), n_probe, build_key.data.data_ptr(),
+                                               key_min, slots, 1 if direct else 0, table.data_ptr(), n_parts,
+                                               rows.data_ptr() if rows is not None else None, unit.data_ptr(),
+                                               payload.data.data_ptr() if payload is not None else None,
+                                               pay.data_ptr() if pay is not None else None), "hs_join_probe_unique")
+        self.last_join = {"mode": "direct" if direct else "hashed", "slots": slots, "n_build": n_build, "n_probe": n_probe}
+        return rows, unit, pay
 
     # ---- hash join (A8) --------------------------------------------------------------------------------
     def join_indices(self, left_key: DCol, right_key: DCol) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, int]:

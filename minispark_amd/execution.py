@@ -125,6 +125,12 @@ class HipExecutionEngine(ExecutionEngine):
         self.replays = 0
         self.short_tail_enabled = os.environ.get("HIPSPARK_SHORT_TAIL", "1") != "0"
         self.shared_tier_enabled = os.environ.get("HIPSPARK_SHARED_TIER", "1") != "0"
+        # round 2: dictionary-coded string columns and the in-place unique-key join (4.6)
+        self.dict_enabled = os.environ.get("HIPSPARK_DICT", "1") != "0"
+        self.fused_join_enabled = os.environ.get("HIPSPARK_FUSED_JOIN", "1") != "0"
+        self._no_fused_join: set[Any] = set()  # join task ids whose build side turned out to hold duplicate keys
+        self._fused_join_tasks: set[Any] = set()  # join task ids the running query took the in-place path for
+        self.fused_joins = 0
         self._no_short_tail: set[Any] = set()  # partial AggregateTask ids that must take the general path
         self.short_tails = 0  # queries finished by the short tail (first runs and recordings; replays count in `replays`)
         self._plan_runs: dict[Any, int] = {}
@@ -189,7 +195,8 @@ class HipExecutionEngine(ExecutionEngine):
             from .lowering import lower_aggregate  # noqa: PLC0415
 
             try:
-                n_acc = len(lower_aggregate(batch.schema, batch.kinds, pending, task.group_by_column, task.agg_columns).acc_ops)
+                n_acc = len(lower_aggregate(batch.schema, batch.kinds, pending, task.group_by_column, task.agg_columns,
+                                            batch.dicts).acc_ops)
             except Exception:  # noqa: BLE001 - whatever lowering objects to is reported by the tier that runs it
                 n_acc = len(task.agg_columns)
             self._distinct_accs[_uid(task)] = n_acc
@@ -292,6 +299,7 @@ class HipExecutionEngine(ExecutionEngine):
                     return replayed
                 del self._recordings[rec_key]  # something data-dependent changed: take the full path again
             self.dev.reset_flags()
+            self._fused_join_tasks.clear()
             outputs: dict[int, Any] = {}
             results: list[JobResult] = []
             # record the second (cache-warm) run of a plan: by then every buffer it needs is prepared
@@ -437,8 +445,10 @@ class HipExecutionEngine(ExecutionEngine):
             if self.dist is not None:
                 batch = self._exchange_partials(batch) if batch.slab is not None else self._exchange_partial_rows(batch)
         elif kind == "BroadcastHashJoinTask":
+            first_real = next((t for t in consumers if _cls(t) != "FilterTask"), None)
+            feeds_aggregate = first_real is not None and _cls(first_real) == "AggregateTask" and first_real.before_shuffle
             batch = self._join(producer, outputs[id(stage.dependencies[0])], outputs[id(stage.dependencies[1])],
-                               self._needed_names(consumers))
+                               self._needed_names(consumers), feeds_aggregate)
         else:
             raise NotImplementedError(f"Job creation not implemented for {type(producer)}")
 
@@ -453,7 +463,21 @@ class HipExecutionEngine(ExecutionEngine):
             elif tname == "AggregateTask":
                 if task.before_shuffle and self.dist is not None:
                     batch = self._agree_key_width(batch, task)  # the exchange form must not depend on local rows
-                if task.before_shuffle and (_uid(task) in self._global_partial or self.group_cap_hint > SHARED_TIER_MAX):
+                if task.before_shuffle and batch.unit_col is not None:
+                    # rows of a join left in place, units = per-row partition ids: the shared-dictionary tier keys
+                    # its tables on (unit, key); anything it cannot hold sends the query back through the general join
+                    try:
+                        cap = 16
+                        while cap < max(self.group_cap_hint, 4) * batch.n_unit_ids:
+                            cap *= 2
+                        batch = self.dev.aggregate_partial(batch, pending, task.group_by_column, task.agg_columns,
+                                                           task.inferred_schema, min(cap, SHARED_TIER_MAX),
+                                                           cache_key=(_uid(task), "units"), shared=True)
+                    except TierExceeded:
+                        self._no_fused_join.add(batch.join_task_id)
+                        raise RestartQuery from None
+                    pending = []
+                elif task.before_shuffle and (_uid(task) in self._global_partial or self.group_cap_hint > SHARED_TIER_MAX):
                     self._global_partial.add(_uid(task))
                     batch = self.dev.aggregate_partial_global(batch, pending, task.group_by_column, task.agg_columns,
                                                               task.inferred_schema)
@@ -575,9 +599,27 @@ class HipExecutionEngine(ExecutionEngine):
         tbl.load_columns(self.dev, table, col_ids)
         if self.dist is not None:
             self._agree_table_widths(table, col_ids)
+        elif self.dict_enabled:
+            self._encode_string_columns(table, col_ids)
         batch = tbl.table_batch(table, col_ids, producer.alias)
         batch.partitioned = self.dist is not None
         return batch
+
+    def _encode_string_columns(self, table: Any, col_ids: Sequence[int]) -> None:
+        """Table open, string columns with few distinct values: one code byte per row + the dictionary (DCol.dict).
+        Tried once per column; the plain column stays attached (DCol.plain) for whoever needs the bytes.  (Single-GPU
+        engines only: ranks would have to agree on one dictionary per column first.)"""
+        from . import hipspark as hs  # noqa: PLC0415
+
+        tried = table.__dict__.setdefault("_hs_dict_tried", set())
+        for cid in col_ids:
+            col = table.columns[cid]
+            if cid in tried or col.kind != hs.STR:
+                continue
+            tried.add(cid)
+            coded = self.dev.dict_encode(col)
+            if coded is not None:
+                table.columns[cid] = coded
 
     def _agree_table_widths(self, table: Any, col_ids: Sequence[int]) -> None:
         """fixed_len of a stored STRING column becomes a FILE-global property (once per table and column): see
@@ -614,14 +656,24 @@ class HipExecutionEngine(ExecutionEngine):
                 return needed
         return None
 
-    def _join(self, task: Any, left: Any, right: Any, needed: set[str] | None = None) -> Any:
+    def _join(self, task: Any, left: Any, right: Any, needed: set[str] | None = None,
+              feeds_aggregate: bool = False) -> Any:
         """Partitioned inner hash join; output rows grouped by ``hash(key) % SHUFFLE_PARTITIONS`` so
         that a following partial aggregate sees the reference's JoinJob units (plan.py:99-109)."""
+        from . import hipspark as hs  # noqa: PLC0415
         from .device import DBatch  # noqa: PLC0415
 
         left, right = self.dev.resolve(left), self.dev.resolve(right)
         lkey = left.column_index(task.left_key.name)
         rkey = right.column_index(task.right_key.name)
+        # codes of two dictionaries do not compare: join keys are matched on the strings themselves
+        left, right = self.dev.decoded_batch(left, [lkey]), self.dev.decoded_batch(right, [rkey])
+        if (feeds_aggregate and self.fused_join_enabled and self.dist is None and needed is not None
+                and _uid(task) not in self._no_fused_join and left.nrows > 0 and right.nrows > 0
+                and left.cols[lkey].kind == hs.I32 and right.cols[rkey].kind == hs.I32
+                and left.nrows < 0xFFFFFFFF and constants.SHUFFLE_PARTITIONS <= 127
+                and right.cols[rkey].data.data_ptr() % 16 == 0):
+            return self._join_in_place(task, left, right, lkey, rkey, needed)
         if self.dist is not None:
             # both inputs travel to the owner of their key's partition (p % world), then a local join
             left, _ = self._exchange_by_key(left, lkey)
@@ -686,6 +738,46 @@ class HipExecutionEngine(ExecutionEngine):
         cols = list(batch.cols)
         cols[idx] = self.dev.with_string_width(col, width)
         return dataclasses.replace(batch, cols=cols)
+
+    def _join_in_place(self, task: Any, left: Any, right: Any, lkey: int, rkey: int, needed: set[str]) -> Any:
+        """Primary-key / foreign-key join feeding a partial aggregate (BASELINE config 4): the probe
+        side's rows stay where they are - no partitioning pass, no pair lists, no gather of its columns.  Per probe
+        row the probe kernel emits the matching build row and the row's shuffle partition hash(key) % 10 as a UNIT
+        id; the aggregate that follows keys its tables on (unit, group key), which yields exactly the reference's
+        per-JoinJob partial rows (plan.py:99-109).  Build-side columns the aggregate names are gathered by the build
+        row (a dictionary-coded one rides along inside the probe kernel, one byte per row).  Duplicate build keys
+        raise HS_FLAG_JOIN_DUP: the query is then re-run through the general join."""
+        from .device import DBatch, DCol  # noqa: PLC0415
+
+        dev = self.dev
+        wanted_left = [i for i, (name, _) in enumerate(left.schema) if name in needed]
+        payload_idx = next((i for i in wanted_left if left.cols[i].dict is not None), None)
+        others = [i for i in wanted_left if i != payload_idx]
+        rows, unit, pay = dev.join_probe_unique(left.cols[lkey], right.cols[rkey], constants.SHUFFLE_PARTITIONS,
+                                                payload=left.cols[payload_idx] if payload_idx is not None else None,
+                                                want_rows=bool(others))
+        schema, cols = [], []
+        n = right.nrows
+        for i in wanted_left:
+            schema.append(left.schema[i])
+            if i == payload_idx:
+                src = left.cols[i]
+                cols.append(DCol(src.kind, pay, n, lens=dev.const_lens(1, n), offs=None, fixed_len=1, dict=src.dict))
+            else:
+                cols.append(dev.gather_col(left.cols[i], rows, n))  # rows without a match read build row 0: dropped
+        for (name, ctype), col in zip(right.schema, right.cols):
+            if name in needed:
+                schema.append((name, ctype))
+                cols.append(col)
+        if not cols:  # e.g. COUNT only: a row count carrier
+            schema.append(right.schema[rkey])
+            cols.append(right.cols[rkey])
+        joined = DBatch(schema, cols, n, [0, n])
+        joined.unit_col, joined.n_unit_ids = unit, constants.SHUFFLE_PARTITIONS
+        joined.join_task_id = _uid(task)
+        self._fused_join_tasks.add(_uid(task))
+        self.fused_joins += 1
+        return joined
 
     def _exchange_partials(self, batch: Any) -> Any:
         """The shuffle between the two aggregation phases on N GPUs: all-gather the fixed-size slabs, then
@@ -887,6 +979,12 @@ class HipExecutionEngine(ExecutionEngine):
 
             flags = or_flags(self.dist, flags, self.dev.device, self.group)  # same decision on every rank
             self._generic_exchange_used = False
+        if os.environ.get("HIPSPARK_DEBUG_FLAGS"):
+            print(f"[hipspark] result flags {flags:#x} nrows {nrows} caps {self._caps}", flush=True)
+        if flags & hs.FLAG_JOIN_DUP:
+            # the in-place join met a build key twice: every join of this query takes the general path from now on
+            self._no_fused_join.update(self._fused_join_tasks)
+            raise RestartQuery
         if flags & hs.FLAG_DICT_FULL:
             raise RetryWithLargerDictionary
         self.dev.raise_for_flags(flags)

@@ -32,6 +32,7 @@ FLAG_DICT_FULL = 0x8
 FLAG_BAD_PROGRAM = 0x10
 FLAG_STR_TOO_LONG = 0x20
 FLAG_TYPE_ASSERT = 0x40
+FLAG_JOIN_DUP = 0x80
 
 AGG_SUM, AGG_MIN, AGG_MAX = 0, 1, 2
 
@@ -43,7 +44,7 @@ OP_LT_F, OP_LE_F, OP_GT_F, OP_GE_F, OP_EQ_F, OP_NE_F = 14, 15, 16, 17, 18, 19
 OP_LT_I, OP_LE_I, OP_GT_I, OP_GE_I, OP_EQ_I, OP_NE_I = 20, 21, 22, 23, 24, 25
 OP_AND, OP_OR, OP_I2F = 26, 27, 28
 OP_STRCMP_LIT, OP_STRCMP_COL, OP_LIKE = 29, 30, 31
-OP_FILTER, OP_AGG, OP_OUT, OP_KEY = 32, 33, 34, 35
+OP_FILTER, OP_AGG, OP_OUT, OP_KEY, OP_DICTBIT = 32, 33, 34, 35, 36
 
 
 class HipSparkError(RuntimeError):
@@ -158,6 +159,8 @@ SIGNATURES: dict[str, tuple] = {
     ),
     "hs_agg_shared_geom": (C.c_int, [C.POINTER(_I64), _I64, _I32, _I32, _GEOMP]),
     "hs_agg_shared": (C.c_int, [_P, _COLP, _I32, _I32, _PROGP, _SPECP, _P, _I64, _GEOMP, _P, _P, _P, _P, _P, _P, _P]),
+    "hs_agg_shared_units": (C.c_int, [_P, _COLP, _I32, _I32, _I32, _I32, _PROGP, _SPECP, _P, _GEOMP, _P, _P, _P, _P, _P,
+                                      _P, _P]),
     "hs_agg_partial_slab": (
         C.c_int,
         [_P, _COLP, _I32, _I32, _PROGP, _SPECP, _P, _P, _I64, _GEOMP, _P, _P, C.POINTER(hs_slab_desc), _P, _P, _P, _P],
@@ -181,6 +184,12 @@ SIGNATURES: dict[str, tuple] = {
     "hs_join_count": (C.c_int, [_P, _COLP, _COLP, _I64, _I64, _P, _P, _P, _P]),
     "hs_join_fill": (C.c_int, [_P, _COLP, _COLP, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),
     "hs_exclusive_scan_i64": (C.c_int, [_P, _P, _I64, _P, _P]),
+    "hs_minmax_i32": (C.c_int, [_P, _P, _I64, _P]),
+    "hs_join_build_unique": (C.c_int, [_P, _P, _I64, _I32, _I64, _I32, _P, _P]),
+    "hs_join_probe_unique": (C.c_int, [_P, _P, _I64, _P, _I32, _I64, _I32, _P, _I32, _P, _P, _P, _P]),
+    "hs_dict_build": (C.c_int, [_P, _COLP, _I64, _I32, _P, _P, _P, _P]),
+    "hs_dict_assign": (C.c_int, [_P, _COLP, _I64, _I32, _P, _P, _P, _P, _P]),
+    "hs_dict_combine": (C.c_int, [_P, _I32, C.POINTER(_P), C.POINTER(_I32), _I64, _P]),
     "hs_quantise": (C.c_int, [_P, _P, _I32, _I64, _P, _P, _P]),
     "hs_quantise_many": (C.c_int, [_P, _I32, C.POINTER(_P), C.POINTER(_I32), _I64, _P, C.POINTER(_P), _P]),
     "hs_slab_unpack": (C.c_int, [_P, _P, _I32, _I64, _I64, _I64, _I32, C.POINTER(_I64), C.POINTER(_I32),
@@ -193,6 +202,7 @@ SIGNATURES: dict[str, tuple] = {
     "hs_jit_compile_check_eval": (C.c_int, [_COLP, _I32, _PROGP, C.POINTER(_I32), _I32, C.c_char_p, C.POINTER(_I64),
                                             C.c_char_p, _I64]),
     "hs_gen_lineitem": (C.c_int, [_P, C.c_uint64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "hs_gen_orders": (C.c_int, [_P, C.c_uint64, _I64, _I64, _I64, _P, _P]),
 }
 
 _lib: C.CDLL | None = None

@@ -67,6 +67,25 @@ def expr_key(node: Any) -> tuple:
     raise LoweringError(f"unsupported expression node {name}")
 
 
+class NeedsDecoded(Exception):
+    """A dictionary-coded column is used in a way that has no coded form (compared with another column, part of a
+    concatenation whose product dictionary is too large, ...): the caller decodes batch column ``column`` and lowers
+    again."""
+
+    def __init__(self, column: int) -> None:
+        super().__init__(f"batch column {column} must be decoded")
+        self.column = column
+
+
+def dict_mask_words(entries: Sequence[bytes], predicate: Any) -> list[int]:
+    """One bit per dictionary entry (bit c of word c // 64 = predicate(entry c)) as 64-bit literal words."""
+    words = [0] * max(1, (len(entries) + 63) // 64)
+    for code, entry in enumerate(entries):
+        if predicate(entry.decode("utf-8")):
+            words[code // 64] |= 1 << (code % 64)
+    return words
+
+
 @dataclass
 class StringParts:
     """A STRING-valued expression flattened to the parts of a concatenation (columns or literals)."""
@@ -111,16 +130,21 @@ class Program:
         )
 
 
-_COL_OPS_A = {hs.OP_LD, hs.OP_STRCMP_LIT, hs.OP_LIKE}
+_COL_OPS_A = {hs.OP_LD, hs.OP_STRCMP_LIT, hs.OP_LIKE, hs.OP_DICTBIT}
+# comparison codes of HS_OP_STRCMP_* (0 lt, 1 le, 2 gt, 3 ge, 4 eq, 5 ne) on Python strings (ASCII: byte order)
+_STR_CMP = {0: lambda a, b: a < b, 1: lambda a, b: a <= b, 2: lambda a, b: a > b, 3: lambda a, b: a >= b,
+            4: lambda a, b: a == b, 5: lambda a, b: a != b}
 
 
 class ProgramBuilder:
     """Lowers expressions over one input batch.  ``schema`` names/types its columns, ``kinds`` are their
     device storage kinds (hs.I32 ... hs.STR)."""
 
-    def __init__(self, schema: Schema, kinds: Sequence[int]) -> None:
+    def __init__(self, schema: Schema, kinds: Sequence[int], dicts: Sequence[Any] | None = None) -> None:
         self.schema = list(schema)
         self.kinds = list(kinds)
+        # per batch column: the dictionary (tuple of bytes) of a dictionary-coded STRING column, else None
+        self.dicts = list(dicts) if dicts is not None else [None] * len(self.kinds)
         self.ins: list[tuple[int, int, int, int, int]] = []  # (op, sp, a, b, c) with a/b = BATCH col index
         self.lits: list[int] = []
         self.pool = bytearray()
@@ -144,6 +168,20 @@ class ProgramBuilder:
             return self.lits.index(word)
         self.lits.append(word)
         return len(self.lits) - 1
+
+    def _lit_run(self, words: Sequence[int]) -> int:
+        """Index of the first of len(words) CONSECUTIVE literal slots holding ``words`` (no de-duplication)."""
+        first = len(self.lits)
+        self.lits.extend(w & 0xFFFFFFFFFFFFFFFF for w in words)
+        return first
+
+    def _emit_dictbit(self, idx: int, predicate: Any) -> None:
+        """bit[code] of dictionary-coded column ``idx``: the predicate is evaluated once per dictionary entry here,
+        the rows only test a bit (HS_OP_DICTBIT)."""
+        words = dict_mask_words(self.dicts[idx], predicate)
+        if len(words) > 4:
+            raise NeedsDecoded(idx)
+        self._emit(hs.OP_DICTBIT, a=idx, b=self._lit_run(words), c=len(words), push=1)
 
     def _pool_ref(self, data: bytes) -> int:
         off = self.pool.find(data) if data else 0
@@ -185,6 +223,13 @@ class ProgramBuilder:
             idx = self.use_column(target.name)
             if self.kinds[idx] != hs.STR:
                 raise AssertionError("LIKE operator can only be applied to string columns")
+            if self.dicts[idx] is not None:
+                import re  # noqa: PLC0415
+
+                # the reference's own reading of the pattern (sql.py:178-179, 192-194), applied to every entry
+                regex = "^" + re.escape(node.pattern).replace("%", ".*").replace("_", ".") + "$"
+                self._emit_dictbit(idx, lambda text: re.match(regex, text) is not None)
+                return "B"
             self._emit(hs.OP_LIKE, a=idx, b=self._pool_ref(node.pattern.encode("utf-8")), push=1)
             return "B"
         if name == "BinaryOperatorColumn":
@@ -242,13 +287,19 @@ class ProgramBuilder:
         lcol = _cls(left) in ("Col", "SchemaCol")
         rcol = _cls(right) in ("Col", "SchemaCol")
         if lcol and rcol:
-            self._emit(hs.OP_STRCMP_COL, a=self.use_column(left.name), b=self.use_column(right.name), c=cmp_code, push=1)
-        elif lcol and _cls(right) == "Lit":
-            self._emit(hs.OP_STRCMP_LIT, a=self.use_column(left.name),
-                       b=self._pool_ref(str(right.value).encode("utf-8")), c=cmp_code, push=1)
-        elif rcol and _cls(left) == "Lit":
-            self._emit(hs.OP_STRCMP_LIT, a=self.use_column(right.name),
-                       b=self._pool_ref(str(left.value).encode("utf-8")), c=_FLIP[cmp_code], push=1)
+            a, b = self.use_column(left.name), self.use_column(right.name)
+            for idx in (a, b):
+                if self.dicts[idx] is not None:  # codes of two dictionaries do not compare
+                    raise NeedsDecoded(idx)
+            self._emit(hs.OP_STRCMP_COL, a=a, b=b, c=cmp_code, push=1)
+        elif (lcol and _cls(right) == "Lit") or (rcol and _cls(left) == "Lit"):
+            col, lit, code = (left, right, cmp_code) if lcol else (right, left, _FLIP[cmp_code])
+            idx = self.use_column(col.name)
+            text = str(lit.value)
+            if self.dicts[idx] is not None:
+                self._emit_dictbit(idx, lambda entry: _STR_CMP[code](entry, text))
+            else:
+                self._emit(hs.OP_STRCMP_LIT, a=idx, b=self._pool_ref(text.encode("utf-8")), c=code, push=1)
         else:
             raise LoweringError(f"string comparison of computed strings is not supported: {node}")
         return "B"
@@ -394,12 +445,12 @@ class AggregateLowering:
 
 
 def lower_aggregate(schema: Schema, kinds: Sequence[int], filters: Sequence[Any], group_by: Any,
-                    agg_columns: Sequence[Any]) -> AggregateLowering:
+                    agg_columns: Sequence[Any], dicts: Sequence[Any] | None = None) -> AggregateLowering:
     """[filter ... FILTER]* KEY [arg ... AGG acc]* for one partial-aggregate launch.
 
     Aggregates with the same function and structurally equal argument share an accumulator (Q1's
     eleven aggregate columns need six)."""
-    b = ProgramBuilder(schema, kinds)
+    b = ProgramBuilder(schema, kinds, dicts)
     for cond in filters:
         b.emit_filter(cond)
     key = unalias(group_by)

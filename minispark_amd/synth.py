@@ -48,8 +48,42 @@ def block_sizes(total_rows: int, rows_per_block: int | None = None) -> list[int]
     return sizes
 
 
+ORDERS_SCHEMA = [("o_orderkey", ColumnType.INTEGER), ("o_orderpriority", ColumnType.STRING)]
+
+
+def orders_rows(lineitem_total_rows: int) -> int:
+    """Four lineitems per order: sf=10 -> 14 996 513 orders."""
+    return (lineitem_total_rows + 3) // 4
+
+
+def strings_from_codes(dev: Device, codes: torch.Tensor, n: int, entries: list[str]) -> DCol:
+    """A plain STRING column (length bytes + payload + offsets, as a BlockFile reader would deliver it) holding
+    entries[codes[i]]: how the synthetic tables get their string columns - the engine then meets ordinary strings
+    and does its own dictionary encoding at table open."""
+    idx = dev.empty(n, torch.int64)
+    idx.copy_(codes[:n])
+    return dev.gather_col(dev.dict_column(tuple(e.encode() for e in entries)), idx, n)
+
+
+def make_orders(dev: Device, path: Path, n_orders: int, seed: int = SEED) -> DeviceTable:
+    """Synthetic orders of BASELINE config 4: o_orderkey = key(perm(row)) (every key once, build order != key order),
+    o_orderpriority one of the five TPC-H strings (5-15 bytes).  CPU twin: oracle/q45_oracle.c q4_gen_orders."""
+    from .workloads import PRIORITIES  # noqa: PLC0415
+
+    okey = dev.empty(n_orders, torch.int32)
+    code = dev.empty(n_orders, torch.uint8)
+    hs.check(dev.lib.hs_gen_orders(dev.stream, seed, 0, n_orders, n_orders, okey.data_ptr(), code.data_ptr()), "hs_gen_orders")
+    path = Path(path)
+    path.parent.mkdir(parents=True, exist_ok=True)
+    BlockFile(path, list(ORDERS_SCHEMA)).write_rows([])  # header only
+    table = DeviceTable(path, list(ORDERS_SCHEMA), block_sizes(n_orders), {}, ())
+    table.columns[0] = DCol(hs.I32, okey, n_orders)
+    table.columns[1] = strings_from_codes(dev, code, n_orders, PRIORITIES)
+    return table
+
+
 def make_lineitem(dev: Device, path: Path, total_rows: int, seed: int = SEED, rank: int = 0, world: int = 1,
-                  rows_per_block: int | None = None, with_orderkey: bool = False) -> DeviceTable:
+                  rows_per_block: int | None = None, with_orderkey: bool = False, with_shipmode: bool = False) -> DeviceTable:
     """Generate this rank's blocks (block b belongs to rank b % world) of a ``total_rows`` lineitem."""
     per = rows_per_block or constants.ROWS_PER_BLOCK
     sizes = block_sizes(total_rows, per)
@@ -63,17 +97,20 @@ def make_lineitem(dev: Device, path: Path, total_rows: int, seed: int = SEED, ra
     flag = dev.empty(n_local, torch.uint8)
     lens = dev.empty(n_local, torch.uint8)
     okey = dev.empty(n_local, torch.int32) if with_orderkey else None
+    mode = dev.empty(n_local, torch.uint8) if with_shipmode else None
     off = 0
     for b, n in mine:
         hs.check(dev.lib.hs_gen_lineitem(
             dev.stream, seed, b * per, n, qty[off:].data_ptr(), price[off:].data_ptr(), disc[off:].data_ptr(),
             tax[off:].data_ptr(), ship[off:].data_ptr(), flag[off:].data_ptr(), lens[off:].data_ptr(),
-            okey[off:].data_ptr() if okey is not None else None, None), "hs_gen_lineitem")
+            okey[off:].data_ptr() if okey is not None else None,
+            mode[off:].data_ptr() if mode is not None else None), "hs_gen_lineitem")
         off += n
     path = Path(path)
     path.parent.mkdir(parents=True, exist_ok=True)
-    BlockFile(path, list(LINEITEM_SCHEMA)).write_rows([])  # header only
-    table = DeviceTable(path, list(LINEITEM_SCHEMA), [n for _, n in mine], {}, ())
+    schema = list(LINEITEM_SCHEMA) + ([("l_shipmode", ColumnType.STRING)] if with_shipmode else [])
+    BlockFile(path, schema).write_rows([])  # header only
+    table = DeviceTable(path, schema, [n for _, n in mine], {}, ())
     table.global_blocks = [b for b, _ in mine]
     table.total_blocks = len(sizes)
     table.columns[1] = DCol(hs.F32, qty, n_local)
@@ -84,4 +121,8 @@ def make_lineitem(dev: Device, path: Path, total_rows: int, seed: int = SEED, ra
     table.columns[6] = DCol(hs.I64, ship, n_local)
     if okey is not None:
         table.columns[0] = DCol(hs.I32, okey, n_local)
+    if mode is not None:
+        from .workloads import SHIPMODES  # noqa: PLC0415
+
+        table.columns[7] = strings_from_codes(dev, mode, n_local, SHIPMODES)
     return table

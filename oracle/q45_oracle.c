@@ -276,7 +276,7 @@ void q4_gen_orders(uint64_t seed, int64_t row0, int64_t n_rows, int64_t n_total,
     const uint64_t c = splitmix45(seed + 77) % (uint64_t)(n_total > 0 ? n_total : 1);
     for (int64_t k = 0; k < n_rows; ++k) {
         const uint64_t j = (uint64_t)(row0 + k);
-        const uint64_t o = (uint64_t)(((unsigned __int128)a * j + c) % (uint64_t)n_total);
+        const uint64_t o = (a * j + c) % (uint64_t)n_total; /* a, j < 2^31 (n_total < 2^31): no overflow */
         if (okey) okey[k] = (int32_t)(32 * (o / 8) + (o % 8) + 1);
         if (prio_code) prio_code[k] = (uint8_t)(splitmix45(splitmix45(seed + 0x7072696full) + j) % 5);
     }

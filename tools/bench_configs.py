@@ -1,0 +1,277 @@
+"""BASELINE.json configs 4 and 5 as bench.py workloads (``bench.py --config join|strkey``), plus a stand-alone runner:
+
+    python tools/bench_configs.py [sf]        both configs once on one GPU, checked against the C oracle ports
+
+Config 4: orders JOIN lineitem ON l_orderkey = o_orderkey GROUP BY o_orderpriority (sf=10: 14 996 513 x 59 986 052).
+Config 5: lineitem WHERE l_shipmode LIKE '%AIR%' GROUP BY l_returnflag + '-' + l_shipmode.
+Tables are synthetic (counter-based generators with CPU twins in oracle/), resident in HBM before the timed region;
+the checkers are oracle/q45_oracle.c (pinned to the reference's goldens by tests/test_oracle_golden.py)."""
+
+from __future__ import annotations
+
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBPS = 8000.0
+
+
+class _EventPair:
+    """HIP events on the launch stream around one operator call (the library launches on torch's current stream)."""
+
+    def __init__(self) -> None:
+        import torch
+
+        self.begin, self.end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.begin.record()
+        self.end.record()
+
+    def ms(self) -> float:
+        return self.begin.elapsed_time(self.end)
+
+
+class _Workload:
+    metric = ""
+    dominant = ""
+
+    def __init__(self, engine, scratch: Path, args, rank: int, world: int) -> None:
+        from minispark_amd import synth
+
+        if world != 1:
+            raise SystemExit(f"--config {args.config} is a single-GPU bench line (the multi-GPU line is Q1)")
+        self.engine, self.scratch, self.args = engine, scratch, args
+        self.n_li = synth.lineitem_rows(args.sf)
+        self.total_units = self.n_li
+        self.timer = None
+
+    def exchange_ms(self) -> float:
+        return 0.0
+
+    def exchange_text(self, backend: str) -> str:
+        return "none"
+
+    def dominant_kernel_ms(self) -> float:
+        return self.engine.dev.scan_kernel_ms()
+
+    def _time_dominant(self, method_name: str) -> None:
+        """Bracket every call of Device.<method_name> with an event pair (read after the step's host sync)."""
+        dev = self.engine.dev
+        inner = getattr(dev, method_name)
+        self.timer = _EventPair()
+        timer = self.timer
+
+        def timed(*a, **k):
+            timer.begin.record()
+            out = inner(*a, **k)
+            timer.end.record()
+            return out
+
+        setattr(dev, method_name, timed)
+
+
+class JoinWorkload(_Workload):
+    """Config 4.  Byte accounting: orders (4 + 1 + len(priority)) + lineitem (4 + 4 + 4 referenced payload),
+    read once, + one 64-byte random access per probe row."""
+
+    metric = "orders JOIN lineitem GROUP BY o_orderpriority (BASELINE config 4): lineitem probe rows/sec"
+
+    def __init__(self, engine, scratch, args, rank, world) -> None:
+        super().__init__(engine, scratch, args, rank, world)
+        from minispark_amd import synth, workloads
+
+        self.n_ord = synth.orders_rows(self.n_li)
+        self.li_path, self.ord_path = scratch / "lineitem.bin", scratch / "orders.bin"
+        li = synth.make_lineitem(engine.dev, self.li_path, self.n_li, with_orderkey=True)
+        engine.attach_device_table(self.li_path, li)
+        orders = synth.make_orders(engine.dev, self.ord_path, self.n_ord)
+        engine.attach_device_table(self.ord_path, orders)
+        self.prio_bytes = sum(len(p) for p in workloads.PRIORITIES) / len(workloads.PRIORITIES)
+        self.frame = workloads.join_group(workloads.engine_api(engine), str(self.ord_path), str(self.li_path))
+        self._time_dominant("join_probe_unique")  # build + probe of the in-place join
+
+    def dominant_kernel_ms(self) -> float:
+        return self.timer.ms()
+
+    def algorithmic_bytes_per_launch(self) -> float:
+        return self.n_ord * (4 + 1 + self.prio_bytes) + self.n_li * (4 + 4 + 4) + self.n_li * 64.0
+
+    def config(self, rows) -> dict:
+        return {"workload": f"SELECT o_orderpriority, COUNT(), SUM(l_quantity), SUM(l_extendedprice), MAX(l_extendedprice) "
+                            f"FROM orders JOIN lineitem ON o_orderkey = l_orderkey GROUP BY o_orderpriority, synthetic sf={self.args.sf:g}",
+                "rows": self.n_li, "orders": self.n_ord, "groups": len(rows or []),
+                "join": getattr(self.engine.dev, "last_join", None), "fused_joins": self.engine.fused_joins}
+
+    def roofline(self, kernel_avg_ms: float) -> dict:
+        # the join operator (key range scan + table build + probe): orders keys + codes read, table written and read
+        # at random (one 64-byte sector per access), lineitem keys read, unit + payload bytes written
+        join_bytes = self.n_ord * (4 + 4 + 1) + self.n_ord * 64.0 + self.n_li * (4 + 64.0 + 1 + 1)
+        achieved = join_bytes / (kernel_avg_ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": "in-place join: k_minmax_i32 + k_join_scatter/verify (or insert_hashed) + k_join_probe_unique",
+                "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "kernel_ms": kernel_avg_ms, "rows_per_launch": self.n_li,
+                "accounting": "orders 9 B/row streamed + one 64 B sector per table store; lineitem 4 B key + one 64 B sector per "
+                              "probe + 2 B written (SURVEY 8d: >= 1 random 64 B access per probe)"}
+
+    def _host_columns(self):
+        from minispark_amd import synth
+        from oracle import q1_native, q45_native
+
+        cols = q1_native.gen(synth.SEED, 0, self.n_li, orderkey=True)
+        okey, ocode = q45_native.gen_orders(synth.SEED, 0, self.n_ord, self.n_ord)
+        return cols, okey, ocode
+
+    def full_check(self, rows) -> dict:
+        from minispark_amd import workloads
+        from oracle import q1_native, q45_native
+        from oracle.compare import assert_rows_match
+
+        t0 = time.perf_counter()
+        cols, okey, ocode = self._host_columns()
+        threads = min(q1_native.host_threads(), 10)
+        want = q45_native.run_join_group(okey, ocode, workloads.PRIORITIES, cols["l_orderkey"], cols["l_quantity"],
+                                         cols["l_extendedprice"], threads=threads)
+        dt = time.perf_counter() - t0
+        try:
+            flips, ok, why = assert_rows_match(rows, want, max_ulps=1), True, None
+        except AssertionError as e:
+            flips, ok, why = None, False, str(e)[:400]
+        out = {"gpu_matches_oracle_full": ok, "f32_ulp_flips_full": flips, "rows_checked": self.n_li,
+               "oracle": f"oracle/q45_oracle.c q4_run on {threads} host threads, {dt:.1f} s (table generation included)"}
+        if why:
+            out["mismatch"] = why
+        return out
+
+    def cpu_baseline(self) -> dict:
+        from minispark_amd import workloads
+        from oracle import q1_native, q45_native
+
+        cols, okey, ocode = self._host_columns()
+        threads = min(q1_native.host_threads(), 10)  # one JoinJob per shuffle partition
+        t0 = time.perf_counter()
+        q45_native.run_join_group(okey, ocode, workloads.PRIORITIES, cols["l_orderkey"], cols["l_quantity"],
+                                  cols["l_extendedprice"], threads=threads)
+        dt = time.perf_counter() - t0
+        return {"value": self.n_li / dt, "unit": "rows/s", "cores": threads, "kind": "port",
+                "sample": f"the whole sf={self.args.sf:g} tables, one pass ({dt:.1f} s) of oracle/q45_oracle.c q4_run, "
+                          f"{threads} threads (one per JoinJob)"}
+
+
+class StrKeyWorkload(_Workload):
+    """Config 5.  Byte accounting: 4 (qty) + 4 (discount) + (1 + len) for l_returnflag and l_shipmode."""
+
+    metric = "LIKE + CONCAT-key GROUP BY on lineitem (BASELINE config 5): lineitem rows/sec"
+
+    def __init__(self, engine, scratch, args, rank, world) -> None:
+        super().__init__(engine, scratch, args, rank, world)
+        from minispark_amd import synth, workloads
+
+        self.li_path = scratch / "lineitem.bin"
+        self.table = synth.make_lineitem(engine.dev, self.li_path, self.n_li, with_shipmode=True)
+        engine.attach_device_table(self.li_path, self.table)
+        self.mode_bytes = sum(len(m) for m in workloads.SHIPMODES) / len(workloads.SHIPMODES)
+        self.frame = workloads.strkey_like(workloads.engine_api(engine), str(self.li_path))
+        self._time_dominant("filter_select")  # LIKE on codes -> mask -> compaction: reads every row
+
+    def dominant_kernel_ms(self) -> float:
+        return self.timer.ms()
+
+    def algorithmic_bytes_per_launch(self) -> float:
+        return self.n_li * (4 + 4 + 2 + 1 + self.mode_bytes)
+
+    def config(self, rows) -> dict:
+        coded = {self.table.schema[c][0]: (col.dict is not None) for c, col in self.table.columns.items()
+                 if self.table.schema[c][1].name == "STRING"}
+        return {"workload": f"SELECT k, SUM(l_quantity), AVG(l_discount), COUNT() FROM (SELECT l_returnflag + '-' + l_shipmode AS k, "
+                            f"... FROM lineitem WHERE l_shipmode LIKE '%AIR%') GROUP BY k, synthetic sf={self.args.sf:g}",
+                "rows": self.n_li, "groups": len(rows or []), "dictionary_coded": coded}
+
+    def roofline(self, kernel_avg_ms: float) -> dict:
+        # WHERE: the predicate reads the shipmode of every row (algorithmic: 1 length byte + the string)
+        bytes_ = self.n_li * (1 + self.mode_bytes)
+        achieved = bytes_ / (kernel_avg_ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": "WHERE l_shipmode LIKE: predicate -> mask -> stable compaction (hs_eval + hs_compact)",
+                "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "kernel_ms": kernel_avg_ms, "rows_per_launch": self.n_li,
+                "algorithmic_bytes_per_row": 1 + self.mode_bytes, "moved_bytes_per_row": 1 + 1 + 1 + 8 * 2 / 7,
+                "accounting": "algorithmic = the shipmode strings; moved = 1 code byte read, 1 mask byte written and read, "
+                              "8-byte row ids written for the ~2/7 surviving rows"}
+
+    def _host_columns(self):
+        from minispark_amd import synth
+        from oracle import q1_native
+
+        return q1_native.gen(synth.SEED, 0, self.n_li, shipmode=True)
+
+    def _oracle(self, cols, threads: int):
+        from minispark_amd import synth, workloads
+        from oracle import q45_native
+
+        return q45_native.run_strkey_like(cols["l_returnflag"], cols["l_shipmode_code"], workloads.SHIPMODES, cols["l_quantity"],
+                                          cols["l_discount"], synth.block_sizes(self.n_li), threads=threads)
+
+    def full_check(self, rows) -> dict:
+        from oracle import q1_native
+        from oracle.compare import assert_rows_match
+
+        t0 = time.perf_counter()
+        threads = q1_native.host_threads()
+        want = self._oracle(self._host_columns(), threads)
+        dt = time.perf_counter() - t0
+        try:
+            flips, ok, why = assert_rows_match(rows, want, max_ulps=1), True, None
+        except AssertionError as e:
+            flips, ok, why = None, False, str(e)[:400]
+        out = {"gpu_matches_oracle_full": ok, "f32_ulp_flips_full": flips, "rows_checked": self.n_li,
+               "oracle": f"oracle/q45_oracle.c q5_run on {threads} host threads, {dt:.1f} s (table generation included)"}
+        if why:
+            out["mismatch"] = why
+        return out
+
+    def cpu_baseline(self) -> dict:
+        from oracle import q1_native
+
+        cols = self._host_columns()
+        threads = q1_native.host_threads()
+        t0 = time.perf_counter()
+        self._oracle(cols, threads)
+        dt = time.perf_counter() - t0
+        return {"value": self.n_li / dt, "unit": "rows/s", "cores": threads, "kind": "port",
+                "sample": f"the whole sf={self.args.sf:g} table, one pass ({dt:.2f} s) of oracle/q45_oracle.c q5_run, {threads} threads"}
+
+
+def main() -> None:
+    import tempfile
+    from types import SimpleNamespace
+
+    os.environ.setdefault("TZ", "UTC")
+    time.tzset()
+    import torch
+
+    from minispark_amd import constants
+    from minispark_amd.execution import HipExecutionEngine
+
+    sf = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+    scratch = Path(tempfile.mkdtemp(prefix="hs_cfg_", dir="/dev/shm"))
+    constants.SHUFFLE_FOLDER = scratch / "shuffle"
+    for name, cls in (("join", JoinWorkload), ("strkey", StrKeyWorkload)):
+        engine = HipExecutionEngine(0)
+        wl = cls(engine, scratch / name, SimpleNamespace(sf=sf, config=name), 0, 1)
+        rows = None
+        times = []
+        for _ in range(6):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rows = wl.frame.collect()
+            times.append(time.perf_counter() - t0)
+        check = wl.full_check(rows)
+        print(f"{name}: sf={sf:g}  best {min(times) * 1e3:.2f} ms  runs {[round(t * 1e3, 2) for t in times]}  "
+              f"dominant {wl.dominant_kernel_ms():.3f} ms  {wl.config(rows)}\n   check {check}", flush=True)
+        engine.__exit__(None, None, None)
+
+
+if __name__ == "__main__":
+    main()
