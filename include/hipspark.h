@@ -248,8 +248,9 @@ int hs_agg_shared(void* stream, const hs_col* cols, int32_t n_cols, int32_t key_
  * every row's unit id in [0, n_unit_tables), 0xff = the row takes no part.  This is how the probe side of a join is
  * aggregated per shuffle partition (the reference's JoinJob, plan.py:99-109) without ever being partitioned in
  * memory: hs_join_probe_unique writes the id column.  chunks / geom: from hs_agg_shared_geom over the ONE row range
- * [0, nrows); outputs sized for n_unit_tables units of geom->pad slots; ws: n_unit_tables * geom->pad * 8 + 256
- * bytes.  The key must fit 56 bits of its key word (INTEGER, or a string of fixed length <= 6): HS_E_LIMIT else. */
+ * [0, nrows); geom->pad = slots of ONE unit's table, which the caller may lower (power of two >= 16) to what a unit
+ * is expected to hold - HS_FLAG_DICT_FULL reports a unit that outgrew it; outputs sized for n_unit_tables units of
+ * geom->pad slots; ws: n_unit_tables * geom->pad * 8 + 256 bytes.  The key must fit 56 bits of its key word (INTEGER, or a string of fixed length <= 6): HS_E_LIMIT else. */
 int hs_agg_shared_units(void* stream, const hs_col* cols, int32_t n_cols, int32_t key_col, int32_t unit_col,
                         int32_t n_unit_tables, const hs_program* prog, const hs_agg_spec* spec, const hs_chunk* chunks,
                         const hs_agg_geom* geom, int64_t* out_rep, uint64_t* out_acc, int32_t* out_ngroups, void* ws,
@@ -341,8 +342,10 @@ int hs_join_fill(void* stream, const hs_col* left_key, const hs_col* right_key, 
  * The build side's keys are expected to be unique (else HS_FLAG_JOIN_DUP is raised and the caller falls back to
  * hs_join_build / count / fill).  table: `slots` 32-bit words, one build row per slot.  direct != 0: slot =
  * key - key_min (slots = the key range; chosen by the caller when the range is dense - TPC-H order keys use 8 of
- * every 32 values - plain stores + a verify pass, no atomics); else slots = a power of two >= 2 * n_build,
- * multiplicative hashing + linear probing, one 32-bit CAS per build row.  minmax: device int32[2]. */
+ * every 32 values - plain stores, then a streaming count of the occupied slots: fewer than n_build = two rows met
+ * in one slot; no atomics on the table; the table buffer must hold slots + 4 words, the count lives behind it);
+ * else slots = a power of two >= 2 * n_build, multiplicative hashing + linear probing, one 32-bit CAS per build
+ * row.  minmax: device int32[2]; values 16-byte aligned, read up to 3 elements past n. */
 int hs_minmax_i32(void* stream, const int32_t* values, int64_t n, int32_t* minmax);
 int hs_join_build_unique(void* stream, const int32_t* build_keys, int64_t n_build, int32_t key_min, int64_t slots,
                          int32_t direct, uint32_t* table, uint32_t* flags);
@@ -485,6 +488,11 @@ const char* hs_jit_last_log(void);
 int hs_jit_compile_check(const hs_col* cols, int32_t n_cols, int32_t key_col, const hs_program* prog,
                          const hs_agg_spec* spec, const char* arch, int64_t* code_bytes, char* src_out,
                          int64_t src_cap);
+/* The same for the shared-dictionary tier's kernel (hs_agg_shared / hs_agg_shared_units; unit_col = -1: row-range
+ * units). */
+int hs_jit_compile_check_shared(const hs_col* cols, int32_t n_cols, int32_t key_col, int32_t unit_col,
+                                const hs_program* prog, const hs_agg_spec* spec, const char* arch, int64_t* code_bytes,
+                                char* src_out, int64_t src_cap);
 /* The same for an expression program of hs_eval (the compiled form evaluates four rows per lane with 16-byte
  * loads and stores; hs_eval uses it when sel == NULL and the numeric buffers are 16-byte aligned, and then reads
  * up to 3 rows past nrows of every column it loads - buffers carry that slack). */

@@ -1446,7 +1446,10 @@ static int agg_shared_impl(void* stream, const hs_col* cols, int32_t n_cols, int
         hs_set_error("hs_agg_shared: program too long");
         return HS_E_LIMIT;
     }
-    if (geom->wg_threads != HS_SHARED_WG || geom->pad < geom->group_cap || (geom->pad & (geom->pad - 1))) {
+    // slots of a unit's table: with row-range units at least the LDS table's (a unit sees every group of its chunks);
+    // with computed units the caller sizes it for the groups ONE unit holds (an overflow raises HS_FLAG_DICT_FULL)
+    if (geom->wg_threads != HS_SHARED_WG || (geom->pad & (geom->pad - 1)) ||
+        (unit_col < 0 ? geom->pad < geom->group_cap : geom->pad < 16)) {
         hs_set_error("hs_agg_shared: geometry not made by hs_agg_shared_geom");
         return HS_E_ARG;
     }

@@ -571,8 +571,8 @@ class Device:
         """Try to re-code a STRING column as one byte per row + dictionary (at most 256 distinct strings; sorted, so
         the codes do not depend on row order).  None = the column stays as it is.  Two passes over the column
         (hs_dict_build / hs_dict_assign) and one small read-back: done once, when a table column is loaded."""
-        if col.kind != hs.STR or col.dict is not None or col.n == 0 or col.fixed_len == 1:
-            return None  # one-byte strings are already as narrow as a code
+        if col.kind != hs.STR or col.dict is not None or col.n == 0:
+            return None
         cap = self.DICT_SLOTS
         words = self.empty(cap, torch.int64)
         reps = self.empty(cap, torch.int64)
@@ -973,6 +973,15 @@ class Device:
         hs.check(self.lib.hs_agg_partial_chunks(host_units, n_units, C.byref(geom),
                                                 chunks.ctypes.data_as(C.POINTER(hs.hs_chunk)),
                                                 chunk0.ctypes.data_as(C.POINTER(C.c_int64))), "hs_agg_partial_chunks")
+        if computed:
+            # a unit's table holds the groups of ONE unit: sized from the per-unit share of the capacity (x4: open
+            # addressing), not from the LDS table that holds every (unit, key) pair - the partial rows' upper bound
+            # n_units x unit_cap then stays small enough for the on-chip final merge
+            per_unit = max(4, cap // max(batch.n_unit_ids, 1))
+            small = 16
+            while small < 4 * per_unit:
+                small *= 2
+            geom.pad = min(int(geom.pad), small)
         unit_cap = int(geom.pad) if shared else cap  # slots per unit of the kernels' output arrays
         if computed:
             n_units = batch.n_unit_ids  # from here on: the unit tables
@@ -1462,11 +1471,16 @@ class Device:
         the status word otherwise: the engine then re-runs the query through the general join).  ->
         (build_row int64[n_probe] or None, unit u8[n_probe] with 0xff = no match, payload u8[n_probe] or None)."""
         n_build, n_probe = build_key.n, probe_key.n
-        minmax = self.empty(2, torch.int32)
-        hs.check(self.lib.hs_minmax_i32(self.stream, build_key.data.data_ptr(), n_build, minmax.data_ptr()), "hs_minmax_i32")
-        if self.rec is not None:
-            self.rec.poisoned = True  # the table's shape depends on the key range learnt here
-        lo, hi = (int(v) for v in minmax.tolist())
+        # the key range of a column is a property of the column: learnt once (one small read-back), so the join itself
+        # runs without the host learning anything - and can be recorded and replayed like any other query
+        span = build_key.__dict__.get("_hs_minmax")
+        if span is None:
+            minmax = self.empty(2, torch.int32)
+            hs.check(self._raw_lib.hs_minmax_i32(self.stream, build_key.data.data_ptr(), n_build, minmax.data_ptr()), "hs_minmax_i32")
+            if self.rec is not None:
+                self.rec.poisoned = True  # this run learnt the range on the way; the next one finds it cached
+            span = build_key.__dict__["_hs_minmax"] = tuple(int(v) for v in minmax.tolist())
+        lo, hi = span
         spread = hi - lo + 1 if n_build else 1
         direct = n_build > 0 and spread <= self.DIRECT_JOIN_MAX_SPREAD * n_build
         if direct:
@@ -1475,7 +1489,7 @@ class Device:
             slots, key_min = 16, 0
             while slots < 2 * max(n_build, 1):
                 slots *= 2
-        table = self.empty(slots, torch.int32)
+        table = self.empty(slots + 8, torch.int32)  # + the occupied-slot counter of the direct build
         hs.check(self.lib.hs_join_build_unique(self.stream, build_key.data.data_ptr(), n_build, key_min, slots,
                                                1 if direct else 0, table.data_ptr(), self.flags.data_ptr()),
                  "hs_join_build_unique")

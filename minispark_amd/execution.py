@@ -453,11 +453,18 @@ class HipExecutionEngine(ExecutionEngine):
             raise NotImplementedError(f"Job creation not implemented for {type(producer)}")
 
         pending: list[Any] = []  # WHERE conditions not yet applied to `batch`
-        for task in consumers:
+        for position, task in enumerate(consumers):
             tname = _cls(task)
             if tname == "FilterTask":
                 pending.append(task.condition)
             elif tname == "ProjectTask":
+                follower = consumers[position + 1] if position + 1 < len(consumers) else None
+                if (pending and follower is not None and _cls(follower) == "AggregateTask" and follower.before_shuffle
+                        and batch.unit_col is None):
+                    lazy = self._project_keeping_filters(batch, pending, task)
+                    if lazy is not None:  # the WHERE stays pending: the aggregate applies it while it scans
+                        batch = lazy
+                        continue
                 batch = self._project(batch, pending, task)
                 pending = []
             elif tname == "AggregateTask":
@@ -921,6 +928,46 @@ class HipExecutionEngine(ExecutionEngine):
         if batch.order is not None:
             out.order = self.dev.gather_col(DCol(hs.I64, batch.order, batch.nrows), sel, count).data
         return out
+
+    def _project_keeping_filters(self, batch: Any, pending: Sequence[Any], task: Any) -> Any:
+        """WHERE -> SELECT -> GROUP BY without the compaction in between (BASELINE config 5): when every selected
+        column is a plain column or a concatenation of dictionary-coded columns (nothing that could raise on a row
+        the WHERE drops), the projection is computed over ALL rows - a pass over code bytes - and the conditions stay
+        pending for the fused scan + aggregate kernel.  The columns they name ride along behind the selected ones.
+        None = not applicable (the caller filters, gathers and projects as usual)."""
+        from .device import DBatch  # noqa: PLC0415
+        from .lowering import ProgramBuilder, unalias  # noqa: PLC0415
+
+        if batch.lazy:
+            return None
+        helper = ProgramBuilder(batch.schema, batch.kinds, batch.dicts)
+        out_cols: list[Any] = []
+        for col in task.columns:
+            bare = unalias(col)
+            if _cls(bare) in ("Col", "SchemaCol"):
+                out_cols.append(batch.cols[batch.column_index(bare.name)])
+            elif helper.string_tag(bare):
+                coded = self.dev.dict_concat(batch, helper.string_parts(bare), batch.nrows)
+                if coded is None:
+                    return None
+                out_cols.append(coded)
+            else:
+                return None  # arithmetic may divide by zero on rows the WHERE would have dropped
+        schema = list(task.inferred_schema)
+        names = {name: i for i, (name, _) in enumerate(schema)}
+        for cond in pending:
+            for name in _plain_names(cond):
+                src = batch.cols[batch.column_index(name)]
+                if name in names:
+                    if out_cols[names[name]] is not src:
+                        return None  # the SELECT re-uses the name for something else
+                    continue
+                names[name] = len(schema)
+                schema.append(batch.schema[batch.column_index(name)])
+                out_cols.append(src)
+        return DBatch(schema, out_cols, batch.nrows, list(batch.unit_rows) if batch.unit_rows else None, None,
+                      unit_ids=batch.unit_ids, total_units=batch.total_units, order=batch.order,
+                      partitioned=batch.partitioned)
 
     def _project(self, batch: Any, pending: Sequence[Any], task: Any) -> Any:
         from . import hipspark as hs  # noqa: PLC0415

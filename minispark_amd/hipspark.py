@@ -199,6 +199,8 @@ SIGNATURES: dict[str, tuple] = {
     "hs_jit_stats": (None, [C.POINTER(_I32)]),
     "hs_jit_last_log": (C.c_char_p, []),
     "hs_jit_compile_check": (C.c_int, [_COLP, _I32, _I32, _PROGP, _SPECP, C.c_char_p, C.POINTER(_I64), C.c_char_p, _I64]),
+    "hs_jit_compile_check_shared": (C.c_int, [_COLP, _I32, _I32, _I32, _PROGP, _SPECP, C.c_char_p, C.POINTER(_I64),
+                                              C.c_char_p, _I64]),
     "hs_jit_compile_check_eval": (C.c_int, [_COLP, _I32, _PROGP, C.POINTER(_I32), _I32, C.c_char_p, C.POINTER(_I64),
                                             C.c_char_p, _I64]),
     "hs_gen_lineitem": (C.c_int, [_P, C.c_uint64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -136,3 +136,36 @@ def test_expression_programs_translate_and_compile_for_gfx950_without_a_gpu():
     text = src.value.decode()
     assert size.value > 1000 and "k_eval_jit" in text and "hs_f32x4" in text and "hs_like_lit" in text
     assert "__builtin_nontemporal_store" in text  # f64 / i64 outputs leave with 16-byte stores
+
+
+def test_shared_tier_programs_with_computed_units_and_dictionary_predicates_compile_without_a_gpu():
+    """Round 2: the shared-dictionary kernel of the in-place join (per-row unit ids in the key word, runs of equal
+    slots folded in registers before the LDS atomics) and a LIKE on a dictionary-coded column (HS_OP_DICTBIT)."""
+    from minispark_amd.constants import ColumnType as T
+    from minispark_amd.lowering import lower_aggregate
+    from minispark_amd.sql import Col, Functions as F
+
+    lib = hs.load_library()
+    schema = [("o_orderpriority", T.STRING), ("l_shipmode", T.STRING), ("l_quantity", T.FLOAT), ("l_extendedprice", T.FLOAT)]
+    kinds = [hs.STR, hs.STR, hs.F32, hs.F32]
+    dicts = [(b"1-URGENT", b"2-HIGH"), (b"AIR", b"MAIL", b"REG AIR"), None, None]
+    low = lower_aggregate(schema, kinds, [Col("l_shipmode").like("%AIR%")], Col("o_orderpriority"),
+                          [F.count().alias("n"), F.sum(Col("l_quantity")).alias("q"), F.max(Col("l_extendedprice")).alias("m")],
+                          dicts)
+    assert any((w & 0xFF) == hs.OP_DICTBIT for w in low.program.ins)
+    assert low.program.lits[(low.program.ins[0] >> 32) & 0xFFFF] == 0b101  # AIR and REG AIR match, MAIL does not
+    n = len(low.program.columns)
+    cols = (hs.hs_col * (n + 1))()
+    for slot, ci in enumerate(low.program.columns):
+        cols[slot].kind, cols[slot].fixed_len = kinds[ci], (1 if kinds[ci] == hs.STR else -1)
+    cols[n].kind, cols[n].fixed_len = hs.U8, -1  # the unit id column
+    prog, spec = low.program.to_struct(), low.spec()
+    src = C.create_string_buffer(1 << 16)
+    nbytes = C.c_int64(0)
+    for unit_col in (n, -1):
+        rc = lib.hs_jit_compile_check_shared(cols, n + 1, low.key_slot, unit_col, C.byref(prog), C.byref(spec), b"gfx950",
+                                             C.byref(nbytes), src, len(src))
+        assert rc == 0, (lib.hs_last_error(), lib.hs_jit_last_log()[:3000])
+        text = src.value.decode()
+        assert "hs_agg_shared_body<JitProg>" in text and "hs_dictbit(" in text and "run_slot" in text
+        assert ("hs_unit_key(" in text) == (unit_col >= 0)

@@ -1,9 +1,12 @@
-"""Kernel timeline of the last full step from a rocprofv3 --kernel-trace CSV: python tools/timeline.py <kernel_trace.csv>
-Prints every launch of the last step (start relative to the scan kernel's start, duration, gap to the previous launch)."""
+"""Kernel timeline of the last full step from a rocprofv3 --kernel-trace CSV:
+    python tools/timeline.py <kernel_trace.csv> [marker kernel-name prefix ...]
+Prints every launch of the last step (start relative to the marker kernel's start, duration, gap to the previous
+launch).  A step begins at a launch of the marker (default: the Q1 scan kernel)."""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-scan = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_agg_jit") or r["Kernel_Name"].startswith("void k_agg_main")]
+markers = tuple(sys.argv[2:]) or ("k_agg_jit", "void k_agg_main")
+scan = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith(markers)]
 if len(scan) < 3:
     raise SystemExit("need at least three steps in the trace")
 a, b = scan[-2], scan[-1]
