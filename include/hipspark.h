@@ -250,7 +250,9 @@ int hs_agg_shared(void* stream, const hs_col* cols, int32_t n_cols, int32_t key_
  * memory: hs_join_probe_unique writes the id column.  chunks / geom: from hs_agg_shared_geom over the ONE row range
  * [0, nrows); geom->pad = slots of ONE unit's table, which the caller may lower (power of two >= 16) to what a unit
  * is expected to hold - HS_FLAG_DICT_FULL reports a unit that outgrew it; outputs sized for n_unit_tables units of
- * geom->pad slots; ws: n_unit_tables * geom->pad * 8 + 256 bytes.  The key must fit 56 bits of its key word (INTEGER, or a string of fixed length <= 6): HS_E_LIMIT else. */
+ * geom->pad slots; ws: (n_unit_tables * geom->pad * 8 + 256, rounded up to 16) + geom->n_chunks * n_unit_tables *
+ * geom->pad * n_acc * 8 bytes (every chunk leaves its cells in its own slice, a small kernel folds them per unit
+ * cell: no contended global atomics).  The key must fit 56 bits of its key word (INTEGER, or a string of fixed length <= 6): HS_E_LIMIT else. */
 int hs_agg_shared_units(void* stream, const hs_col* cols, int32_t n_cols, int32_t key_col, int32_t unit_col,
                         int32_t n_unit_tables, const hs_program* prog, const hs_agg_spec* spec, const hs_chunk* chunks,
                         const hs_agg_geom* geom, int64_t* out_rep, uint64_t* out_acc, int32_t* out_ngroups, void* ws,

@@ -50,6 +50,32 @@ __global__ void __launch_bounds__(256) k_agg_shared_init(const SharedInitArgs A)
         for (int a = 0; a < NA; ++a) A.acc[i * NA + a] = hs_acc_identity(A.spec.op[a], A.spec.is_int[a] != 0);
     }
 }
+// computed units: unit cell (unit, slot, a) = fold over the chunks' own cells.  One wave per (unit, slot): lane l folds
+// chunks l, l + 64, ... in ascending order, then a fixed shuffle tree - the same order every run.
+struct SharedFoldArgs {
+    const uint64_t* chunk_acc;  // [n_chunks][n_units][unit_cap][n_acc]
+    const int64_t* reps;        // [n_units][unit_cap]
+    uint64_t* acc;              // [n_units][unit_cap][n_acc]
+    int64_t n_chunks;
+    int32_t n_units, unit_cap;
+    hs_agg_spec spec;
+};
+__global__ void __launch_bounds__(256) k_agg_shared_fold_chunks(const SharedFoldArgs A) {
+    const int NA = A.spec.n_acc;
+    const int lane = threadIdx.x & (HS_WAVE - 1);
+    const int64_t cell = (int64_t)blockIdx.x * (blockDim.x / HS_WAVE) + threadIdx.x / HS_WAVE;  // (unit, slot)
+    if (cell >= (int64_t)A.n_units * A.unit_cap || A.reps[cell] < 0) return;  // wave-uniform
+    const int64_t stride = (int64_t)A.n_units * A.unit_cap * NA;
+    for (int a = 0; a < NA; ++a) {
+        const uint32_t op = A.spec.op[a];
+        const bool is_int = A.spec.is_int[a] != 0;
+        uint64_t v = hs_acc_identity(op, is_int);
+        for (int64_t c = lane; c < A.n_chunks; c += HS_WAVE) v = hs_acc_fold(op, is_int, v, A.chunk_acc[c * stride + cell * NA + a]);
+        for (int d = HS_WAVE / 2; d >= 1; d >>= 1) v = hs_acc_fold(op, is_int, v, hs_shfl_down64(v, d));
+        if (lane == 0) A.acc[cell * NA + a] = v;
+    }
+}
+
 // after the scan: cells -> what the reference's shuffle file holds (f32 / i32 rounding, overflow and type flags),
 // groups per unit.  One workgroup per unit.
 struct SharedFinishArgs {
@@ -1041,6 +1067,7 @@ static int agg_partial_impl(void* stream, const hs_col* cols, int32_t n_cols, in
     A.unit = U;
     A.unit_col = -1;
     A.pad3 = 0;
+    A.chunk_acc = nullptr;
     static const bool fuse_env = !(getenv("HIPSPARK_FUSE_UNIT") && getenv("HIPSPARK_FUSE_UNIT")[0] == '0');
     bool fused = false;
     if (fuse_env && geom->pad == HS_GEOM_FUSABLE && spec->n_acc > 0) {
@@ -1489,6 +1516,8 @@ static int agg_shared_impl(void* stream, const hs_col* cols, int32_t n_cols, int
     memset(&A.unit, 0, sizeof(A.unit));
     A.unit_col = unit_col;  // -1: units are the chunks' row ranges; else n_units = number of unit tables
     A.pad3 = 0;
+    // computed units: per-chunk cells behind the unit tables' key words in `ws` (hs_agg_shared_units documents the size)
+    A.chunk_acc = unit_col >= 0 ? (uint64_t*)((char*)ws + (((size_t)n_units * (size_t)geom->pad * 8 + 256 + 15) & ~(size_t)15)) : nullptr;
     {  // the replica count the geometry sized the LDS block for
         const size_t per_replica = (size_t)geom->group_cap * (size_t)(spec->n_acc > 0 ? spec->n_acc : 1) * 8;
         const size_t r = (geom->lds_bytes - (size_t)geom->group_cap * 16) / per_replica;
@@ -1531,6 +1560,18 @@ static int agg_shared_impl(void* stream, const hs_col* cols, int32_t n_cols, int
         hipLaunchKernelGGL((k_agg_shared<false, 4>), grid, block, geom->lds_bytes, s, A);
     } else {
         hipLaunchKernelGGL((k_agg_shared<false, 8>), grid, block, geom->lds_bytes, s, A);
+    }
+    if (A.chunk_acc) {
+        SharedFoldArgs G;
+        G.chunk_acc = A.chunk_acc;
+        G.reps = out_rep;
+        G.acc = out_acc;
+        G.n_chunks = geom->n_chunks;
+        G.n_units = (int32_t)n_units;
+        G.unit_cap = geom->pad;
+        G.spec = *spec;
+        const int64_t cells = n_units * (int64_t)geom->pad;
+        hipLaunchKernelGGL(k_agg_shared_fold_chunks, dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, s, G);
     }
     if (ev_end) (void)hipEventRecord((hipEvent_t)ev_end, s);
     SharedFinishArgs F;

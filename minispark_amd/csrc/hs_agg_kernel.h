@@ -221,6 +221,10 @@ struct AggMainArgs {
     // LDS dictionary holds (unit, key) pairs and the chunk merge files every entry under its own unit's table.
     int32_t unit_col;
     int32_t pad3;
+    // computed units: chunk_acc[chunk][unit][geom pad][n_acc] - every chunk leaves its cells HERE with plain stores and
+    // a small kernel folds them per (unit, slot): with ONE row range every chunk holds the same few (unit, key)
+    // groups, and ~900 workgroups adding into the same 200 global cells at the end of the scan serialised to 3 ms
+    uint64_t* chunk_acc;
 };
 
 // key word of (unit, key): valid for key words that carry their information in the low 56 bits - INTEGER keys
@@ -853,6 +857,12 @@ __device__ __forceinline__ void hs_agg_shared_body(const AggMainArgs& A) {
     // merge this chunk's groups into the unit's table
     const int UC = A.pad;
     const hs_col& kc = A.cols.c[A.key_col];
+    if (A.chunk_acc) {  // this chunk's cells start as identities (most (unit, slot) pairs stay that way)
+        uint64_t* mine = A.chunk_acc + (int64_t)blockIdx.x * A.n_units * (int64_t)UC * NA;
+        const int cells = (int)A.n_units * UC * NA;
+        for (int i = tid; i < cells; i += nthr) mine[i] = hs_acc_identity(A.spec.op[i % NA], A.spec.is_int[i % NA] != 0);
+        __syncthreads();  // (drains the stores: a cell overwritten below must not be overtaken by its identity)
+    }
     for (int sl = tid; sl < GC; sl += nthr) {
         const int64_t rep = dreps[sl];
         if (rep < 0) continue;
@@ -867,12 +877,14 @@ __device__ __forceinline__ void hs_agg_shared_body(const AggMainArgs& A) {
             ctx.err |= HS_FLAG_DICT_FULL;
             continue;
         }
+        uint64_t* mine = A.chunk_acc ? A.chunk_acc + ((int64_t)blockIdx.x * A.n_units + unit) * (int64_t)UC * NA : nullptr;
         for (int a = 0; a < NA; ++a) {
             const uint32_t op = A.spec.op[a];
             const bool is_int = A.spec.is_int[a] != 0;
             uint64_t v = acc[(sl * R) * NA + a];
             for (int r = 1; r < R; ++r) v = hs_acc_fold(op, is_int, v, acc[(sl * R + r) * NA + a]);  // replicas, in order
-            HS_DISPATCH_FOLD(hs_atomic_fold_global, op, is_int, &uacc[u * NA + a], v);
+            if (mine) mine[u * NA + a] = v;  // this chunk's own cell: no contention (k_agg_shared_fold_chunks adds them up)
+            else HS_DISPATCH_FOLD(hs_atomic_fold_global, op, is_int, &uacc[u * NA + a], v);
         }
     }
     if (ctx.err) atomicOr(A.flags, ctx.err);

@@ -221,6 +221,7 @@ class Device:
         self.rec: Recording | None = None
         self.scan_events = None
         self.exchange_events = None
+        self.join_events = None
 
     # ---- recording ------------------------------------------------------------------------------------
     def start_recording(self) -> Recording:
@@ -269,6 +270,19 @@ class Device:
 
     def exchange_ms(self) -> float:
         return self.exchange_events[0].elapsed_time(self.exchange_events[1])
+
+    def time_join(self, enable: bool = True) -> None:
+        """Bracket the in-place join operator (table build + probe) of every following query with events on the
+        launch stream - recorded as part of the run, so replayed runs are timed too; read with join_ms()."""
+        if enable:
+            self.join_events = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+            for ev in self.join_events:
+                ev.record()
+        else:
+            self.join_events = None
+
+    def join_ms(self) -> float:
+        return self.join_events[0].elapsed_time(self.join_events[1])
 
     def _event_handle(self, i: int):
         ev = getattr(self, "scan_events", None)
@@ -981,7 +995,8 @@ class Device:
             small = 16
             while small < 4 * per_unit:
                 small *= 2
-            geom.pad = min(int(geom.pad), small)
+            if os.environ.get("HIPSPARK_SMALL_UNIT_TABLES", "1") != "0":
+                geom.pad = min(int(geom.pad), small)
         unit_cap = int(geom.pad) if shared else cap  # slots per unit of the kernels' output arrays
         if computed:
             n_units = batch.n_unit_ids  # from here on: the unit tables
@@ -1042,7 +1057,7 @@ class Device:
                 cols_arr[slot] = batch.cols[idx].as_hs()
             cols_arr[n_cols] = DCol(hs.U8, batch.unit_col, batch.nrows).as_hs()
             unit_slot, n_cols = n_cols, n_cols + 1
-            ws_bytes = n_units * unit_cap * 8 + 256
+            ws_bytes = ((n_units * unit_cap * 8 + 256 + 15) & ~15) + int(geom.n_chunks) * n_units * unit_cap * max(n_acc, 1) * 8
         return {
             "slab": slab, "layout": layout, "key_out": key_out, "out_unit": out_unit, "d_unit_ids": d_unit_ids,
             "cols": cols_arr, "n_cols": n_cols, "unit_slot": unit_slot,
@@ -1490,6 +1505,8 @@ class Device:
             while slots < 2 * max(n_build, 1):
                 slots *= 2
         table = self.empty(slots + 8, torch.int32)  # + the occupied-slot counter of the direct build
+        if self.join_events is not None:
+            self.op(self.join_events[0].record)
         hs.check(self.lib.hs_join_build_unique(self.stream, build_key.data.data_ptr(), n_build, key_min, slots,
                                                1 if direct else 0, table.data_ptr(), self.flags.data_ptr()),
                  "hs_join_build_unique")
@@ -1501,6 +1518,8 @@ class Device:
                                                rows.data_ptr() if rows is not None else None, unit.data_ptr(),
                                                payload.data.data_ptr() if payload is not None else None,
                                                pay.data_ptr() if pay is not None else None), "hs_join_probe_unique")
+        if self.join_events is not None:
+            self.op(self.join_events[1].record)
         self.last_join = {"mode": "direct" if direct else "hashed", "slots": slots, "n_build": n_build, "n_probe": n_probe}
         return rows, unit, pay
 
