@@ -98,7 +98,7 @@ def q1_cpu_baseline(table, sample_blocks: int, gpu_rows_for_sample, cutoff: str 
     sizes = table.block_rows[:sample_blocks]
     n = sum(sizes)
     names = {1: "l_quantity", 2: "l_extendedprice", 3: "l_discount", 4: "l_tax", 5: "l_returnflag", 6: "l_shipdate"}
-    cols = {name: table.columns[cid].data[:n].cpu().numpy() for cid, name in names.items()}
+    cols = {name: table.stored_column(cid).data[:n].cpu().numpy() for cid, name in names.items()}
     cutoff_us = bfio.to_us(datetime.fromisoformat(cutoff))
     threads = q1_native.host_threads()
     q1_native.run(cols, sizes, cutoff_us, threads=threads)  # warm-up (page in, build)

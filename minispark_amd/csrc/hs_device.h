@@ -297,11 +297,13 @@ __device__ __forceinline__ uint64_t hs_like_lit(const hs_program& P, const hs_co
 }
 
 // bit[code] of a dictionary-coded column: the literal words lit[first .. first + n_words) hold one bit per entry
-__device__ __forceinline__ uint64_t hs_dictbit(const hs_program& P, const hs_col& c, int64_t row, uint32_t first,
-                                               uint32_t n_words) {
-    const uint32_t code = ((const uint8_t*)c.data)[row];
+__device__ __forceinline__ uint64_t hs_dictbit_code(const hs_program& P, uint32_t code, uint32_t first, uint32_t n_words) {
     const uint32_t w = code >> 6;
     return w < n_words ? (P.lit[first + w] >> (code & 63u)) & 1ull : 0ull;
+}
+__device__ __forceinline__ uint64_t hs_dictbit(const hs_program& P, const hs_col& c, int64_t row, uint32_t first,
+                                               uint32_t n_words) {
+    return hs_dictbit_code(P, ((const uint8_t*)c.data)[row], first, n_words);
 }
 
 // ---- interpreter ---------------------------------------------------------------------------------

@@ -443,10 +443,12 @@ class Device:
         return raw, n, flags
 
     # ---- expression evaluation (A4) ---------------------------------------------------------------------
-    def _cols_array(self, batch: DBatch, order: Sequence[int]):
+    def _cols_array(self, batch: DBatch, order: Sequence[int], code_columns: Sequence[int] = ()):
         arr = (hs.hs_col * max(len(order), 1))()
         for s, idx in enumerate(order):
             arr[s] = batch.cols[idx].as_hs()
+            if idx in code_columns:  # only its code bytes are read (HS_OP_DICTBIT): a plain byte column to the kernels
+                arr[s].kind, arr[s].fixed_len = hs.U8, -1
         return arr
 
     def eval_numeric(self, batch: DBatch, exprs: Sequence[Any], sel: torch.Tensor | None = None,
@@ -464,7 +466,7 @@ class Device:
         out_kinds = [hs.F64 if t == "F" else (hs.U8 if t == "B" else hs.I64) for t in tags]
         outs = [self.empty(n, _TORCH_DTYPE[k]) for k in out_kinds]
         if n > 0:
-            cols = self._cols_array(batch, prog.columns)
+            cols = self._cols_array(batch, prog.columns, prog.code_columns)
             out_ptrs = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
             kinds = (C.c_int32 * len(outs))(*out_kinds)
             pstruct = prog.to_struct()
@@ -1012,7 +1014,7 @@ class Device:
             d_unit_ids = self.to_device(np.asarray(batch.unit_ids, dtype=np.int64)) if batch.unit_ids is not None else None
             return {
                 "slab": slab, "layout": layout, "desc": desc, "d_unit_ids": d_unit_ids,
-                "cols": self._cols_array(batch, low.program.columns), "n_cols": len(low.program.columns),
+                "cols": self._cols_array(batch, low.program.columns, low.program.code_columns), "n_cols": len(low.program.columns),
                 "key_slot": low.key_slot, "prog": low.program.to_struct(), "spec": low.spec(), "geom": geom,
                 "n_units": n_units, "slots": slots,
                 "d_units": self.to_device(chunks.reshape(-1)), "d_chunk0": self.to_device(chunk0),
@@ -1049,12 +1051,14 @@ class Device:
             d_unit_ids = self.to_device(np.asarray(batch.unit_ids, dtype=np.int64))
             if out_unit is None:
                 out_unit = self.empty(max(slots, 1), torch.int64)
-        cols_arr, n_cols, unit_slot = self._cols_array(batch, low.program.columns), len(low.program.columns), None
+        cols_arr, n_cols, unit_slot = (self._cols_array(batch, low.program.columns, low.program.code_columns),
+                                       len(low.program.columns), None)
         ws_bytes = geom.ws_bytes
         if computed:
             cols_arr = (hs.hs_col * (n_cols + 1))()
-            for slot, idx in enumerate(low.program.columns):
-                cols_arr[slot] = batch.cols[idx].as_hs()
+            base_arr = self._cols_array(batch, low.program.columns, low.program.code_columns)
+            for slot in range(n_cols):
+                cols_arr[slot] = base_arr[slot]
             cols_arr[n_cols] = DCol(hs.U8, batch.unit_col, batch.nrows).as_hs()
             unit_slot, n_cols = n_cols, n_cols + 1
             ws_bytes = ((n_units * unit_cap * 8 + 256 + 15) & ~15) + int(geom.n_chunks) * n_units * unit_cap * max(n_acc, 1) * 8

@@ -100,6 +100,7 @@ class Program:
     pool: bytearray = field(default_factory=bytearray)
     columns: list[int] = field(default_factory=list)  # slot -> batch column index
     max_depth: int = 0
+    code_columns: list[int] = field(default_factory=list)  # batch columns to hand over as HS_U8 (code bytes only)
 
     def to_struct(self) -> hs.hs_program:
         if len(self.ins) > hs.HS_MAX_INS:
@@ -151,6 +152,8 @@ class ProgramBuilder:
         self.sp = 0
         self.max_depth = 0
         self.used: list[int] = []  # batch column indices in first-use order
+        self.code_reads: set[int] = set()    # coded columns read as a code byte (HS_OP_DICTBIT)
+        self.string_reads: set[int] = set()  # columns read as strings (LIKE, comparisons)
 
     # ---- emit helpers ------------------------------------------------------------------------------
     def _emit(self, op: int, a: int = 0, b: int = 0, c: int = 0, push: int = 0) -> None:
@@ -181,6 +184,7 @@ class ProgramBuilder:
         words = dict_mask_words(self.dicts[idx], predicate)
         if len(words) > 4:
             raise NeedsDecoded(idx)
+        self.code_reads.add(idx)
         self._emit(hs.OP_DICTBIT, a=idx, b=self._lit_run(words), c=len(words), push=1)
 
     def _pool_ref(self, data: bytes) -> int:
@@ -230,6 +234,7 @@ class ProgramBuilder:
                 regex = "^" + re.escape(node.pattern).replace("%", ".*").replace("_", ".") + "$"
                 self._emit_dictbit(idx, lambda text: re.match(regex, text) is not None)
                 return "B"
+            self.string_reads.add(idx)
             self._emit(hs.OP_LIKE, a=idx, b=self._pool_ref(node.pattern.encode("utf-8")), push=1)
             return "B"
         if name == "BinaryOperatorColumn":
@@ -291,6 +296,7 @@ class ProgramBuilder:
             for idx in (a, b):
                 if self.dicts[idx] is not None:  # codes of two dictionaries do not compare
                     raise NeedsDecoded(idx)
+            self.string_reads.update((a, b))
             self._emit(hs.OP_STRCMP_COL, a=a, b=b, c=cmp_code, push=1)
         elif (lcol and _cls(right) == "Lit") or (rcol and _cls(left) == "Lit"):
             col, lit, code = (left, right, cmp_code) if lcol else (right, left, _FLIP[cmp_code])
@@ -299,6 +305,7 @@ class ProgramBuilder:
             if self.dicts[idx] is not None:
                 self._emit_dictbit(idx, lambda entry: _STR_CMP[code](entry, text))
             else:
+                self.string_reads.add(idx)
                 self._emit(hs.OP_STRCMP_LIT, a=idx, b=self._pool_ref(text.encode("utf-8")), c=code, push=1)
         else:
             raise LoweringError(f"string comparison of computed strings is not supported: {node}")
@@ -407,8 +414,11 @@ class ProgramBuilder:
             raise AssertionError("unbalanced program")
         if key_column is not None and key_column not in self.used:
             self.used.append(key_column)
-        numeric = [i for i in self.used if self.kinds[i] != hs.STR or i == key_column]
-        strings = [i for i in self.used if self.kinds[i] == hs.STR and i != key_column]
+        # a coded column that is only ever read as its code byte travels as a HS_U8 column: preloaded with the numeric
+        # ones (one 4-byte load per row quad) instead of one byte load per row
+        as_bytes = {i for i in self.code_reads if i not in self.string_reads and i != key_column}
+        numeric = [i for i in self.used if self.kinds[i] != hs.STR or i == key_column or i in as_bytes]
+        strings = [i for i in self.used if self.kinds[i] == hs.STR and i != key_column and i not in as_bytes]
         order = numeric + strings
         if len(order) > hs.HS_MAX_COLS:
             raise LoweringError(f"expression reads {len(order)} columns (> {hs.HS_MAX_COLS})")
@@ -420,7 +430,7 @@ class ProgramBuilder:
             elif op == hs.OP_STRCMP_COL:
                 a, b = slot[a], slot[b]
             words.append(op | (sp << 8) | (a << 16) | (b << 32) | (c << 48))
-        return Program(words, list(self.lits), bytearray(self.pool), order, self.max_depth)
+        return Program(words, list(self.lits), bytearray(self.pool), order, self.max_depth, sorted(as_bytes))
 
 
 AGG_CODES = {"sum": hs.AGG_SUM, "min": hs.AGG_MIN, "max": hs.AGG_MAX}
@@ -476,5 +486,5 @@ def lower_aggregate(schema: Schema, kinds: Sequence[int], filters: Sequence[Any]
             acc_is_int.append(tag in ("I", "B"))
         agg_to_acc.append(acc_index[ident])
     prog = b.finish(key_column=key_col)
-    numeric_slots = sum(1 for c in prog.columns if kinds[c] != hs.STR or c == key_col)
+    numeric_slots = sum(1 for c in prog.columns if kinds[c] != hs.STR or c == key_col or c in prog.code_columns)
     return AggregateLowering(prog, prog.columns.index(key_col), acc_ops, acc_is_int, agg_to_acc, numeric_slots)

@@ -45,6 +45,11 @@ class DeviceTable:
     def nrows(self) -> int:
         return sum(self.block_rows)
 
+    def stored_column(self, cid: int) -> DCol:
+        """Column ``cid`` as the file stores it (a dictionary-coded string column gives its plain form)."""
+        col = self.columns[cid]
+        return col.plain if col.plain is not None else col
+
     @property
     def unit_rows(self) -> list[int]:
         out = [0]

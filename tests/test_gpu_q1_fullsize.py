@@ -35,10 +35,33 @@ def test_q1_at_baseline_sizes(tmp_path, rows, cutoff):
         assert frame.collect() == got and frame.collect() == got  # full path, recorded run, replay: same bits
         # the oracle reads the very columns the GPU scanned (device generator == CPU twin is tested elsewhere)
         names = {1: "l_quantity", 2: "l_extendedprice", 3: "l_discount", 4: "l_tax", 5: "l_returnflag", 6: "l_shipdate"}
-        cols = {name: table.columns[cid].data[:rows].cpu().numpy() for cid, name in names.items()}
+        cols = {name: table.stored_column(cid).data[:rows].cpu().numpy() for cid, name in names.items()}
     cutoff_us = bfio.to_us(datetime.fromisoformat(cutoff))
     want = q1_native.run(cols, table.block_rows, cutoff_us, threads=q1_native.host_threads())
     flips = assert_rows_match(got, want, max_ulps=1)
     assert flips <= 1, f"{flips} values off by one f32 ulp"
     assert sum(r["count_order"] for r in got) == int((cols["l_shipdate"] <= cutoff_us).sum())
     assert [r["l_returnflag"] for r in sorted(got, key=lambda r: r["l_returnflag"])] == ["A", "N", "R"]
+
+
+def test_q1_sf100_matches_the_streamed_oracle(tmp_path):
+    """BASELINE config 3's size (sf=100: 600 037 902 rows, 287 blocks, 15.6 GB of referenced columns in HBM) against
+    the C oracle over the WHOLE table: the oracle regenerates the synthetic table block by block with the generator's
+    CPU twin and runs the reference's algorithm (q1_run_synth) - the check bench.py applies to its timed result."""
+    from minispark_amd import constants, synth, workloads
+    from minispark_amd.execution import HipExecutionEngine
+    from oracle import blockfile as bfio
+    from oracle import q1_native
+
+    rows = synth.LINEITEM_ROWS[100]
+    constants.SHUFFLE_FOLDER = tmp_path / "shuffle"
+    with HipExecutionEngine(0) as engine:
+        path = tmp_path / "lineitem.bin"
+        engine.attach_device_table(path, synth.make_lineitem(engine.dev, path, rows))
+        frame = workloads.q1(workloads.engine_api(engine), str(path))
+        got = frame.collect()
+        assert frame.collect() == got and frame.collect() == got and engine.replays >= 1
+    want = q1_native.run_synth(synth.SEED, rows, constants.ROWS_PER_BLOCK, bfio.to_us(datetime.fromisoformat("1998-12-01")),
+                               threads=q1_native.host_threads())
+    assert assert_rows_match(got, want, max_ulps=1) <= 1
+    assert sum(r["count_order"] for r in got) == rows  # the reference's cutoff keeps every row of this generator
