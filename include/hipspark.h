@@ -502,6 +502,19 @@ int hs_jit_compile_check_eval(const hs_col* cols, int32_t n_cols, const hs_progr
                               int32_t n_outs, const char* arch, int64_t* code_bytes, char* src_out, int64_t src_cap);
 
 /* =================================================================================================
+ * Launch capture: the native replay of a recorded query (reference: the Zig worker re-runs its compiled plan per job,
+ * zig-src/src/job.zig:3-57; here a whole query's device work is re-issued by one call).  Between hs_capture_begin()
+ * and hs_capture_end() every kernel launch / event record / memset the library makes ON THIS THREAD is executed as
+ * usual and also appended to a list with a private copy of its arguments; hs_capture_replay() issues that list on
+ * `stream` - no argument marshalling, validation or JIT look-ups - and is valid while the buffers the captured calls
+ * were given stay alive and in place.  *n_ops (optional) = launches captured.
+ * ===============================================================================================*/
+int hs_capture_begin(void);
+int hs_capture_end(void** handle, int32_t* n_ops);
+int hs_capture_replay(void* handle, void* stream);
+void hs_capture_free(void* handle);
+
+/* =================================================================================================
  * Synthetic TPC-H-shaped data (bench / tests only).  Counter-based: the value of
  * row i depends only on (seed, column, i), so any row range can be generated independently.
  * ===============================================================================================*/

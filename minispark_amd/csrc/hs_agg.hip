@@ -1079,7 +1079,7 @@ static int agg_partial_impl(void* stream, const hs_col* cols, int32_t n_cols, in
             fused = true;
         }
     }
-    if (ev_begin) (void)hipEventRecord((hipEvent_t)ev_begin, s);
+    if (ev_begin) hs_event_record((hipEvent_t)ev_begin, s);
     const int jit_rc = hs_jit_launch_agg_main(&A, hashed, grid.x, block.x, geom->lds_bytes, s);
     if (jit_rc == HS_OK) {
         // launched the program compiled for exactly this bytecode
@@ -1090,7 +1090,7 @@ static int agg_partial_impl(void* stream, const hs_col* cols, int32_t n_cols, in
     } else {
         hipLaunchKernelGGL((k_agg_main<false, 8>), grid, block, geom->lds_bytes, s, A);
     }
-    if (ev_end) (void)hipEventRecord((hipEvent_t)ev_end, s);
+    if (ev_end) hs_event_record((hipEvent_t)ev_end, s);
     if (!fused) {
         static unsigned long long unit_attr = 0;
         if (hs_first_on_device(unit_attr)) allow_big_lds(k_agg_unit);
@@ -1550,7 +1550,7 @@ static int agg_shared_impl(void* stream, const hs_col* cols, int32_t n_cols, int
         allow_big_lds(k_agg_shared<false, 8>);
     }
     dim3 grid((unsigned)geom->n_chunks), block((unsigned)HS_SHARED_WG);
-    if (ev_begin) (void)hipEventRecord((hipEvent_t)ev_begin, s);
+    if (ev_begin) hs_event_record((hipEvent_t)ev_begin, s);
     const int jit_rc = hs_jit_launch_agg_shared(&A, hashed, grid.x, block.x, geom->lds_bytes, s);
     if (jit_rc == HS_OK) {
         // launched the program compiled for exactly this bytecode
@@ -1573,7 +1573,7 @@ static int agg_shared_impl(void* stream, const hs_col* cols, int32_t n_cols, int
         const int64_t cells = n_units * (int64_t)geom->pad;
         hipLaunchKernelGGL(k_agg_shared_fold_chunks, dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, s, G);
     }
-    if (ev_end) (void)hipEventRecord((hipEvent_t)ev_end, s);
+    if (ev_end) hs_event_record((hipEvent_t)ev_end, s);
     SharedFinishArgs F;
     F.reps = out_rep;
     F.acc = out_acc;

@@ -28,6 +28,10 @@ typedef unsigned long long uint64_t;
 #include "../../include/hipspark.h"
 #endif
 
+#ifndef HS_JIT_BUILD
+#include "hs_capture.h" /* host builds: every launch of the library is capturable */
+#endif
+
 #define HS_WAVE 64
 #define HS_V 4 /* rows per lane per step in the vectorised kernels */
 

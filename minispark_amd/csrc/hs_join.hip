@@ -360,7 +360,7 @@ extern "C" int hs_join_build_unique(void* stream, const int32_t* build_keys, int
         if (direct) {
             unsigned long long* occupied = reinterpret_cast<unsigned long long*>(table + ((slots + 1) & ~(int64_t)1));
             hipLaunchKernelGGL(k_join_scatter_direct, dim3(grid), dim3(256), 0, s, A);
-            (void)hipMemsetAsync(occupied, 0, 8, s);
+            hs_memset_async(occupied, 0, 8, s);
             hipLaunchKernelGGL(k_join_count_occupied, dim3(hsj_grid(slots / 4 + 1, 256 * 4, 4096)), dim3(256), 0, s, table, slots, occupied);
             hipLaunchKernelGGL(k_join_check_occupied, dim3(1), dim3(1), 0, s, occupied, n_build, flags);
         } else {

@@ -36,6 +36,54 @@ extern "C" size_t hs_sizeof(int32_t which) {
 }
 extern "C" int hs_version(void) { return HS_VERSION; }
 
+// ---- launch capture (hs_capture.h) ---------------------------------------------------------------------------
+extern "C" int hs_capture_begin(void) {
+    if (g_hs_capture) {
+        hs_set_error("hs_capture_begin: a capture is already open on this thread");
+        return HS_E_ARG;
+    }
+    g_hs_capture = new HsCapture();
+    return HS_OK;
+}
+extern "C" int hs_capture_end(void** handle, int32_t* n_ops) {
+    if (!g_hs_capture || !handle) {
+        hs_set_error("hs_capture_end: no open capture");
+        return HS_E_ARG;
+    }
+    HsCapture* cap = g_hs_capture;
+    g_hs_capture = nullptr;
+    if (n_ops) *n_ops = (int32_t)cap->ops.size();
+    *handle = cap;
+    return HS_OK;
+}
+extern "C" int hs_capture_replay(void* handle, void* stream) {
+    if (!handle) {
+        hs_set_error("hs_capture_replay: null handle");
+        return HS_E_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    for (HsCapOp& op : ((HsCapture*)handle)->ops) {
+        hipError_t rc = hipSuccess;
+        switch (op.kind) {
+            case HsCapOp::KERNEL: rc = hipLaunchKernel(op.fn, op.grid, op.block, op.argv.data(), op.lds, s); break;
+            case HsCapOp::MODULE: {
+                size_t sz = op.blob.size();
+                void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, op.blob.data(), HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+                rc = hipModuleLaunchKernel(op.mfn, op.grid.x, 1, 1, op.block.x, 1, 1, (unsigned)op.lds, s, nullptr, extra);
+                break;
+            }
+            case HsCapOp::EVENT: rc = hipEventRecord(op.ev, s); break;
+            case HsCapOp::MEMSET: rc = hipMemsetAsync(op.ptr, op.value, op.bytes, s); break;
+        }
+        if (rc != hipSuccess) {
+            hs_set_error("hs_capture_replay: %s", hipGetErrorString(rc));
+            return HS_E_LAUNCH;
+        }
+    }
+    return HS_OK;
+}
+extern "C" void hs_capture_free(void* handle) { delete (HsCapture*)handle; }
+
 #define HS_CHECK_LAUNCH(name)                                                              \
     do {                                                                                   \
         const hipError_t e_ = hipGetLastError();                                           \
@@ -866,7 +914,7 @@ extern "C" int hs_partition_perm(void* stream, const uint8_t* part, int64_t nrow
         hipLaunchKernelGGL(k_part_scatter, dim3((unsigned)ntiles), dim3(SCAN_WG), 0, s, part, nrows, n_parts, ntiles,
                            hist_scanned, perm);
     } else {
-        hipMemsetAsync(part_start, 0, (size_t)(n_parts + 1) * 8, s);
+        hs_memset_async(part_start, 0, (size_t)(n_parts + 1) * 8, s);
     }
     HS_CHECK_LAUNCH("hs_partition_perm");
     return HS_OK;
@@ -1085,7 +1133,7 @@ static int group_build(void* stream, const hs_col* left_key, const int64_t* sel,
     hipLaunchKernelGGL(k_fill_u64, dim3(grid_for(table_cap, 256)), dim3(256), 0, s, table_keys, table_cap, HS_EMPTY_KEY);
     hipLaunchKernelGGL(k_fill_u64, dim3(grid_for(table_cap, 256)), dim3(256), 0, s, (uint64_t*)table_reps, table_cap,
                        ~0ull);
-    hipMemsetAsync(slot_count, 0, (size_t)table_cap * 16, s);  // slot_count + cursor
+    hs_memset_async(slot_count, 0, (size_t)table_cap * 16, s);  // slot_count + cursor
     if (n_left > 0)
         hipLaunchKernelGGL(k_join_slots, dim3(grid_for(n_left, 256)), dim3(256), 0, s, *left_key, sel, row0, n_left,
                            table_cap, table_keys, table_reps, slot_of_row, slot_count, flags);
@@ -1097,7 +1145,7 @@ static int group_build(void* stream, const hs_col* left_key, const int64_t* sel,
                            cursor, rows);
         int64_t* long_count = (int64_t*)((char*)scan_ws + ((hs_scan_ws_bytes(table_cap) + 63) & ~(size_t)63));
         int64_t* long_list = long_count + 1;
-        hipMemsetAsync(long_count, 0, 8, s);
+        hs_memset_async(long_count, 0, 8, s);
         hipLaunchKernelGGL(k_join_sort, dim3(grid_for(table_cap, 256)), dim3(256), 0, s, slot_start, table_cap, rows,
                            long_list, long_count);
         static unsigned long long attr_set = 0;

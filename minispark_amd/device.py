@@ -155,10 +155,12 @@ class DeviceError(RuntimeError):
 
 
 class Recording:
-    """The device work of one query run as a flat list of calls (library entry points and a few tensor
-    copies), with every buffer they touch kept alive.  Replaying the list re-runs the query without any
-    planning / lowering / allocation on the host.  A run that had to learn a size on the host mid-way
-    (``poisoned``) is data-dependent and is not replayable."""
+    """The device work of one query run, with every buffer it touches kept alive.  Library calls made while recording
+    are captured INSIDE the library as the launches they perform (include/hipspark.h hs_capture_*): a run of
+    consecutive library calls becomes one ``hs_capture_replay(handle, stream)`` entry of ``calls``; the few tensor
+    ops in between (a fill, the exchange collective) are entries of their own.  Replaying the list re-runs the query
+    without any planning / lowering / allocation / argument marshalling on the host.  A run that had to learn a size
+    on the host mid-way (``poisoned``) is data-dependent and is not replayable."""
 
     def __init__(self) -> None:
         self.calls: list[tuple[Any, tuple]] = []
@@ -167,6 +169,8 @@ class Recording:
         self.finish: Any = None  # () -> (raw columns, nrows, flags)
         self.result: Any = None  # (schema, stage_id) of the writer
         self.self_cleaning = False  # the run's last launch resets the status words itself (no zeroing before a replay)
+        self.segments: list[Any] = []  # capture handles owned by this recording
+        self._free: Any = None
 
     def replay(self) -> bool:
         for fn, args in self.calls:
@@ -175,13 +179,20 @@ class Recording:
                 return False
         return True
 
+    def __del__(self) -> None:
+        if self._free is not None:
+            for handle in self.segments:
+                self._free(handle)
+            self.segments = []
+
 
 def _call_void(fn: Any, *args: Any) -> None:
     fn(*args)  # tensor ops return the tensor; a replayed call must report "no error"
 
 
 class _RecordingLib:
-    """Stands in for the ctypes library while a run is being recorded."""
+    """Stands in for the ctypes library while a run is being recorded: the calls go through unchanged (the library
+    itself captures their launches), their argument objects are kept alive with the recording."""
 
     def __init__(self, lib: Any, rec: Recording) -> None:
         self._lib, self._rec = lib, rec
@@ -192,7 +203,6 @@ class _RecordingLib:
             return fn  # queries (sizes, error text) and host-side helpers are not device work
 
         def recorded(*args: Any) -> int:
-            self._rec.calls.append((fn, args))
             self._rec.keep.append(args)
             return fn(*args)
 
@@ -226,18 +236,35 @@ class Device:
     # ---- recording ------------------------------------------------------------------------------------
     def start_recording(self) -> Recording:
         self.rec = Recording()
+        self.rec._free = self._raw_lib.hs_capture_free
         self.lib = _RecordingLib(self._raw_lib, self.rec)
+        hs.check(self._raw_lib.hs_capture_begin(), "hs_capture_begin")
         return self.rec
 
+    def _cut_segment(self, reopen: bool) -> None:
+        """Close the library's open launch capture; the launches since the last cut become one replayable entry."""
+        handle, n_ops = C.c_void_p(), C.c_int32(0)
+        if self._raw_lib.hs_capture_end(C.byref(handle), C.byref(n_ops)) == 0 and handle.value:
+            if n_ops.value > 0 and self.rec is not None:
+                self.rec.segments.append(handle)
+                self.rec.calls.append((self._raw_lib.hs_capture_replay, (handle, self.stream)))
+            else:
+                self._raw_lib.hs_capture_free(handle)
+        if reopen:
+            hs.check(self._raw_lib.hs_capture_begin(), "hs_capture_begin")
+
     def stop_recording(self) -> Recording | None:
+        if self.rec is not None:
+            self._cut_segment(reopen=False)
         rec, self.rec = self.rec, None
         self.lib = self._raw_lib
         return rec
 
     def op(self, fn: Any, *args: Any) -> None:
-        """Run a small tensor op (fill / copy) now and, when recording, on every replay."""
+        """Run a small tensor op (fill / copy / collective) now and, when recording, on every replay."""
         fn(*args)
         if self.rec is not None:
+            self._cut_segment(reopen=True)  # keep the order: library launches so far, then this op
             self.rec.calls.append((_call_void, (fn, *args)))
 
     def host_int(self, t: torch.Tensor) -> int:
@@ -322,6 +349,9 @@ class Device:
         for prep in self._partial_prepared.values():  # slab headers of a run that did not reach its finish launch
             if prep.get("tail") is not None:
                 prep["slab"][:4].zero_()
+        for prep in self._finish_prepared.values():  # ... and "done" words nobody read
+            if prep["host_image"] is not None:
+                prep["host_image"][4:8] = 0
 
     def read_flags(self) -> int:
         if self.rec is not None:
@@ -1149,8 +1179,8 @@ class Device:
                 self._finish_prepared[key] = prep
         p = prep
         desc = p["desc"]
-        if p["host_image"] is not None:
-            self.op(p["host_image"][4:8].fill, 0)  # "done" word: cleared by the host before every launch
+        # the "done" word of a mapped result image is cleared by the host right after it has read the result (finish()
+        # below; reset_flags() for runs that never got there): nothing sits between the scan's and this launch
         rc = self.lib.hs_agg_finish(self.stream, gathered.data_ptr(), world, C.byref(desc), C.byref(p["fin"]),
                                     C.byref(p["prog"]) if p["prog"] is not None else None, n_order, cap,
                                     p["result_ptr"], p["scratch"].data_ptr(), self.flags.data_ptr(),
@@ -1188,6 +1218,8 @@ class Device:
                         raw.append(StrCol(np.full(n, width, dtype=np.uint8), host[off: off + n * width].copy()))
                 else:
                     raw.append(host[off: off + n * width].view(_NP_DTYPE[kind]).copy())
+            if mapped is not None:
+                done[0] = 0  # ready for the next launch into this image
             return raw, n, flags
 
         if self.rec is not None:

@@ -203,6 +203,10 @@ SIGNATURES: dict[str, tuple] = {
                                               C.c_char_p, _I64]),
     "hs_jit_compile_check_eval": (C.c_int, [_COLP, _I32, _PROGP, C.POINTER(_I32), _I32, C.c_char_p, C.POINTER(_I64),
                                             C.c_char_p, _I64]),
+    "hs_capture_begin": (C.c_int, []),
+    "hs_capture_end": (C.c_int, [C.POINTER(_P), C.POINTER(_I32)]),
+    "hs_capture_replay": (C.c_int, [_P, _P]),
+    "hs_capture_free": (None, [_P]),
     "hs_gen_lineitem": (C.c_int, [_P, C.c_uint64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "hs_gen_orders": (C.c_int, [_P, C.c_uint64, _I64, _I64, _I64, _P, _P]),
 }
