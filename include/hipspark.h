@@ -127,7 +127,8 @@ typedef struct hs_agg_spec {
 const char* hs_last_error(void);
 int hs_version(void);
 /* sizeof() of ABI structure `which` as compiled: 0 hs_col, 1 hs_program, 2 hs_agg_spec, 3 hs_agg_geom, 4 hs_chunk,
- * 5 hs_slab_desc, 6 hs_finish_out, 7 hs_finish_spec (0 for anything else) - lets a binding verify its mirror. */
+ * 5 hs_slab_desc, 6 hs_finish_out, 7 hs_finish_spec, 8 hs_stage_plan, 9 hs_result_col (0 for anything else) - lets a
+ * binding verify its mirror. */
 size_t hs_sizeof(int32_t which);
 
 /* =================================================================================================
@@ -500,6 +501,80 @@ int hs_jit_compile_check_shared(const hs_col* cols, int32_t n_cols, int32_t key_
  * up to 3 rows past nrows of every column it loads - buffers carry that slack). */
 int hs_jit_compile_check_eval(const hs_col* cols, int32_t n_cols, const hs_program* prog, const int32_t* out_kinds,
                               int32_t n_outs, const char* arch, int64_t* code_bytes, char* src_out, int64_t src_cap);
+
+/* =================================================================================================
+ * Stage-level ABI (csrc/hs_engine.hip): a GROUP BY query over one BlockFile table, end to end, without Python.
+ * Replaces the reference's process boundary - jobs shipped to a worker over stdin, src/mini_spark/execution.py:182-219,
+ * jobs.py:45-79, zig-src/src/job.zig:3-57 - for the hot path: the host (Python engine, cgo / JNI / FFI binding:
+ * INTEGRATION.md section 4) lowers the query once into a PLAN BLOB and then calls
+ *
+ *   hs_engine_create -> hs_table_open -> hs_stage_prepare -> hs_stage_run (any number of times)
+ *                    -> hs_result_columns / hs_result_write_blockfile -> hs_stage_destroy / hs_table_close / hs_engine_destroy
+ *
+ * The library owns everything in between: the native BlockFile reader (header / footer / column spans, column pruning,
+ * parallel pread into pinned staging, async host-to-device copies; reference block_file.zig:225-306), chunk geometry,
+ * the exchange slab and result-image layouts, workspaces, the capacity retry on a dictionary overflow, the
+ * steady-state replay of a run's launches, and the zero-copy result hand-over.  Queries that do not fit the on-chip
+ * tiers of this path (variable-length GROUP BY keys, > 4096 groups, > 8 numeric columns) return HS_E_LIMIT.
+ * ===============================================================================================*/
+typedef struct hs_engine hs_engine;
+typedef struct hs_table hs_table;
+typedef struct hs_stage hs_stage;
+
+#define HS_STAGE_PLAN_VERSION 1
+/* The plan of [scan -> WHERE -> partial aggregate per file block] + [final merge -> projection -> result write]
+ * (reference plan.py:182-204), as minispark_amd/stage.py lowers it from the reference's task objects. */
+typedef struct hs_stage_plan {
+    int32_t version;               /* HS_STAGE_PLAN_VERSION */
+    int32_t n_cols;                /* column slots of `prog` */
+    int32_t col_ids[HS_MAX_COLS];  /* table column behind every slot (only these are read from the file) */
+    int32_t key_slot;              /* slot of the GROUP BY column */
+    int32_t group_cap, merge_cap;  /* starting dictionary capacities (powers of two; 0 = 4 / 16); grown on overflow */
+    hs_program prog;               /* [filter ... FILTER]* KEY [argument ... AGG acc]* */
+    hs_agg_spec spec;              /* the accumulators of `prog` */
+    hs_finish_spec fin;            /* folds of the final merge + the result columns (offsets are filled in here) */
+    hs_program fin_prog;           /* projection after the merge (AVG = sum / count ...); n_ins 0 = none */
+    int32_t out_types[HS_FINISH_MAX_OUT];    /* BlockFile type code of every result column (0 INTEGER 1 STRING 2 FLOAT 3 TIMESTAMP) */
+    char out_names[HS_FINISH_MAX_OUT][64];   /* ... and its name (hs_result_write_blockfile) */
+} hs_stage_plan;
+
+typedef struct hs_result_col {
+    int32_t kind;        /* HS_F32 / HS_I32 / HS_I64, or HS_STR of fixed byte width `width` (the GROUP BY key) */
+    int32_t width;       /* bytes per row */
+    const void* data;    /* HOST memory (the stage's result image): n_rows x width bytes, valid until the next run */
+    int64_t n_rows;
+} hs_result_col;
+
+int hs_engine_create(int32_t device, hs_engine** out);
+void hs_engine_destroy(hs_engine* engine);
+/* Parses header, footer and the column spans of the blocks this rank owns (block b -> rank b % world). */
+int hs_table_open(hs_engine* engine, const char* path, int32_t rank, int32_t world, hs_table** out);
+void hs_table_close(hs_table* table);
+int hs_table_info(const hs_table* table, int32_t* n_cols, int64_t* n_rows, int32_t* n_blocks, int32_t* total_blocks);
+int hs_table_schema(const hs_table* table, int32_t col, int32_t* type, char* name, int32_t name_cap);
+/* Reads only the listed columns' byte spans into HBM (idempotent per column). */
+int hs_table_load(hs_engine* engine, hs_table* table, const int32_t* col_ids, int32_t n);
+int hs_table_column(const hs_table* table, int32_t col, hs_col* out, int64_t* n_rows);
+/* Caller-owned device columns as a table (types: BlockFile type codes; cols[c].data NULL = column absent). */
+int hs_table_attach(hs_engine* engine, int32_t n_cols, const hs_col* cols, const int32_t* types, const int64_t* block_rows,
+                    int32_t n_blocks, hs_table** out);
+/* plan_bytes must be sizeof(hs_stage_plan) (a binding's mirror is checked that way); loads the plan's columns. */
+int hs_stage_prepare(hs_engine* engine, hs_table* table, const hs_stage_plan* plan, size_t plan_bytes, int32_t world,
+                     hs_stage** out);
+void hs_stage_destroy(hs_stage* stage);
+/* world 1: launches, waits for the result image, retries with larger dictionaries on HS_FLAG_DICT_FULL.  *flags_out:
+ * the remaining HS_FLAG_* bits (division by zero, overflow at a file write ...) for the host to raise. */
+int hs_stage_run(hs_stage* stage, void* stream, uint32_t* flags_out, int64_t* n_rows_out);
+/* world > 1: scan into this rank's slab | the caller all-gathers the slabs (RCCL) | finish over the gathered slabs. */
+int hs_stage_launch_partial(hs_stage* stage, void* stream);
+void* hs_stage_slab(hs_stage* stage, int64_t* bytes);
+int hs_stage_launch_finish(hs_stage* stage, void* stream, const void* gathered, int32_t world);
+int hs_stage_wait(hs_stage* stage, void* stream, uint32_t* flags_out, int64_t* n_rows_out);
+int hs_stage_grow(hs_stage* stage);
+/* stats[6]: runs, replayed runs, capacity growths, group_cap, merge_cap, scan chunks */
+int hs_stage_stats(const hs_stage* stage, int64_t* stats);
+int hs_result_columns(const hs_stage* stage, hs_result_col* out, int32_t cap, int32_t* n);
+int hs_result_write_blockfile(const hs_stage* stage, const char* path);
 
 /* =================================================================================================
  * Launch capture: the native replay of a recorded query (reference: the Zig worker re-runs its compiled plan per job,

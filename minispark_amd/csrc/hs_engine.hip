@@ -1,0 +1,811 @@
+// hs_engine.hip - the stage-level C ABI: a GROUP BY query over one BlockFile table, end to end, without Python.
+//
+// What the reference does per query: the driver turns the physical plan into jobs, ships them to a worker process
+// over stdin (src/mini_spark/execution.py:182-219, jobs.py:45-79) and the worker (zig-src/src/job.zig:3-57) reads
+// BlockFile blocks (block_file.zig:225-306), runs the stage's task chain and writes shuffle / result files.  Here a
+// host - the Python engine, or a cgo / JNI / FFI binding - hands over a PLAN BLOB (hs_stage_plan:
+// the lowered programs of [scan -> WHERE -> partial aggregate] and [final merge -> projection -> result]) and gets the
+// result columns back:
+//
+//   hs_engine_create -> hs_table_open (native BlockFile reader: header / footer / column spans, column pruning,
+//   parallel pread into pinned staging, async H2D) -> hs_stage_prepare -> hs_stage_run -> hs_result_columns /
+//   hs_result_write_blockfile.
+//
+// Everything that lived in minispark_amd/device.py for this path lives here too: slab and result-image layout, chunk
+// geometry, workspace management, the capacity retry (a dictionary overflow grows the capacities and re-runs), the
+// steady-state replay (the launches of a run are captured, hs_capture.h, and re-issued by later runs), and the
+// zero-copy hand-over (result image in mapped pinned memory, "done" word polled by the host).  Queries that do not
+// fit the on-chip tiers return HS_E_LIMIT: the caller takes the general operator sequence.
+#include <fcntl.h>
+#include <stdio.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "hs_device.h"
+
+void hs_set_error(const char* fmt, ...);
+
+namespace {
+
+constexpr size_t kPad = 64;  // slack behind every device buffer (16-byte row-quad loads run past the last row)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) {
+        o.p = nullptr;
+        o.bytes = 0;
+    }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) {
+            release();
+            p = o.p;
+            bytes = o.bytes;
+            o.p = nullptr;
+            o.bytes = 0;
+        }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    bool alloc(size_t n, bool zero = false) {
+        release();
+        if (hipMalloc(&p, n + kPad) != hipSuccess) {
+            p = nullptr;
+            return false;
+        }
+        bytes = n;
+        if (zero && hipMemset(p, 0, n + kPad) != hipSuccess) return false;
+        return true;
+    }
+};
+
+struct Column {
+    int32_t type = 0;  // BlockFile type code: 0 INTEGER, 1 STRING, 2 FLOAT, 3 TIMESTAMP (constants.py:19-22)
+    std::string name;
+    bool loaded = false;
+    hs_col col{};
+    DevBuf data, lens, offs;
+};
+
+struct Span {
+    int64_t off = 0, bytes = 0;
+};
+
+}  // namespace
+
+struct hs_engine {
+    int device = 0;
+    DevBuf flags;  // one status word
+};
+
+struct hs_table {
+    hs_engine* engine = nullptr;
+    std::string path;
+    std::vector<Column> cols;
+    std::vector<int64_t> block_rows;     // local blocks
+    std::vector<int32_t> file_blocks;    // their global ids
+    std::vector<std::vector<Span>> spans;  // [local block][column] byte span of the payload
+    int32_t total_blocks = 0;
+    int64_t nrows = 0;
+    bool attached = false;  // columns are caller-owned device memory
+};
+
+namespace {
+
+bool read_exact(int fd, void* dst, size_t n, int64_t off) {
+    size_t done = 0;
+    while (done < n) {
+        const ssize_t got = pread(fd, (char*)dst + done, n - done, off + (int64_t)done);
+        if (got <= 0) return false;
+        done += (size_t)got;
+    }
+    return true;
+}
+
+int kind_of_type(int32_t type) { return type == 0 ? HS_I32 : type == 2 ? HS_F32 : type == 3 ? HS_I64 : HS_STR; }
+int elem_bytes(int kind) { return kind == HS_I64 || kind == HS_F64 ? 8 : kind == HS_U8 ? 1 : 4; }
+
+}  // namespace
+
+extern "C" int hs_engine_create(int32_t device, hs_engine** out) {
+    if (!out) {
+        hs_set_error("hs_engine_create: null argument");
+        return HS_E_ARG;
+    }
+    if (hipSetDevice(device) != hipSuccess) {
+        hs_set_error("hs_engine_create: no such GPU (%d) - there is no CPU execution path", device);
+        return HS_E_LAUNCH;
+    }
+    hs_engine* e = new hs_engine();
+    e->device = device;
+    if (!e->flags.alloc(16, true)) {
+        delete e;
+        hs_set_error("hs_engine_create: out of device memory");
+        return HS_E_LAUNCH;
+    }
+    *out = e;
+    return HS_OK;
+}
+
+extern "C" void hs_engine_destroy(hs_engine* e) { delete e; }
+
+// ---- BlockFile reader (format: SURVEY.md appendix A; reference io.py:47-170, zig block_file.zig:225-306) --------------
+extern "C" int hs_table_open(hs_engine* e, const char* path, int32_t rank, int32_t world, hs_table** out) {
+    if (!e || !path || !out || world < 1 || rank < 0 || rank >= world) {
+        hs_set_error("hs_table_open: bad arguments");
+        return HS_E_ARG;
+    }
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) {
+        hs_set_error("hs_table_open: cannot open %s", path);
+        return HS_E_ARG;
+    }
+    struct stat st;
+    fstat(fd, &st);
+    const int64_t size = st.st_size;
+    auto fail = [&](const char* what) {
+        close(fd);
+        hs_set_error("hs_table_open: %s: %s", path, what);
+        return HS_E_ARG;
+    };
+    uint8_t ncols = 0;
+    if (size < 5 || !read_exact(fd, &ncols, 1, 0)) return fail("not a BlockFile (too short)");
+    hs_table* t = new hs_table();
+    t->engine = e;
+    t->path = path;
+    int64_t pos = 1;
+    for (int c = 0; c < ncols; ++c) {
+        uint8_t hdr[2];
+        if (!read_exact(fd, hdr, 2, pos)) {
+            delete t;
+            return fail("truncated header");
+        }
+        std::string name(hdr[1], '\0');
+        if (hdr[1] && !read_exact(fd, &name[0], hdr[1], pos + 2)) {
+            delete t;
+            return fail("truncated header");
+        }
+        pos += 2 + hdr[1];
+        Column col;
+        col.type = hdr[0];
+        col.name = name;
+        if (hdr[0] > 3) {
+            delete t;
+            return fail("unknown column type");
+        }
+        t->cols.push_back(std::move(col));
+    }
+    uint32_t nblocks = 0;
+    if (!read_exact(fd, &nblocks, 4, size - 4) || (int64_t)nblocks * 8 + 4 + pos > size) {
+        delete t;
+        return fail("bad footer");
+    }
+    std::vector<uint64_t> starts(nblocks);
+    if (nblocks && !read_exact(fd, starts.data(), (size_t)nblocks * 8, size - 4 - (int64_t)nblocks * 8)) {
+        delete t;
+        return fail("bad footer");
+    }
+    t->total_blocks = (int32_t)nblocks;
+    for (uint32_t b = 0; b < nblocks; ++b) {
+        if ((int32_t)(b % (uint32_t)world) != rank) continue;  // block b lives on rank b % world (plan.py:90-93: independent jobs)
+        uint32_t rows = 0;
+        int64_t p = (int64_t)starts[b];
+        if (!read_exact(fd, &rows, 4, p)) {
+            delete t;
+            return fail("truncated block");
+        }
+        p += 4;
+        std::vector<Span> spans(ncols);
+        for (int c = 0; c < ncols; ++c) {
+            uint64_t bytes = 0;
+            if (!read_exact(fd, &bytes, 8, p)) {
+                delete t;
+                return fail("truncated block");
+            }
+            spans[c] = Span{p + 8, (int64_t)bytes};
+            p += 8 + (int64_t)bytes;
+            const int kind = kind_of_type(t->cols[c].type);
+            if ((kind != HS_STR && (int64_t)bytes != (int64_t)rows * elem_bytes(kind)) || (kind == HS_STR && (int64_t)bytes < rows) ||
+                p > size) {
+                delete t;
+                return fail("column payload size does not match the block's row count");
+            }
+        }
+        t->block_rows.push_back(rows);
+        t->file_blocks.push_back((int32_t)b);
+        t->spans.push_back(std::move(spans));
+        t->nrows += rows;
+    }
+    close(fd);
+    *out = t;
+    return HS_OK;
+}
+
+extern "C" void hs_table_close(hs_table* t) { delete t; }
+
+extern "C" int hs_table_info(const hs_table* t, int32_t* n_cols, int64_t* n_rows, int32_t* n_blocks, int32_t* total_blocks) {
+    if (!t) {
+        hs_set_error("hs_table_info: null table");
+        return HS_E_ARG;
+    }
+    if (n_cols) *n_cols = (int32_t)t->cols.size();
+    if (n_rows) *n_rows = t->nrows;
+    if (n_blocks) *n_blocks = (int32_t)t->block_rows.size();
+    if (total_blocks) *total_blocks = t->total_blocks;
+    return HS_OK;
+}
+
+extern "C" int hs_table_schema(const hs_table* t, int32_t col, int32_t* type, char* name, int32_t name_cap) {
+    if (!t || col < 0 || col >= (int32_t)t->cols.size()) {
+        hs_set_error("hs_table_schema: no such column");
+        return HS_E_ARG;
+    }
+    if (type) *type = t->cols[col].type;
+    if (name && name_cap > 0) {
+        strncpy(name, t->cols[col].name.c_str(), (size_t)name_cap - 1);
+        name[name_cap - 1] = 0;
+    }
+    return HS_OK;
+}
+
+extern "C" int hs_table_column(const hs_table* t, int32_t col, hs_col* out, int64_t* n_rows) {
+    if (!t || !out || col < 0 || col >= (int32_t)t->cols.size() || !t->cols[col].loaded) {
+        hs_set_error("hs_table_column: column not loaded");
+        return HS_E_ARG;
+    }
+    *out = t->cols[col].col;
+    if (n_rows) *n_rows = t->nrows;
+    return HS_OK;
+}
+
+// Caller-owned device columns as a table (synthetic data, or columns another reader placed in HBM).
+extern "C" int hs_table_attach(hs_engine* e, int32_t n_cols, const hs_col* cols, const int32_t* types, const int64_t* block_rows,
+                               int32_t n_blocks, hs_table** out) {
+    if (!e || !cols || !types || !block_rows || !out || n_cols < 1 || n_blocks < 0) {
+        hs_set_error("hs_table_attach: bad arguments");
+        return HS_E_ARG;
+    }
+    hs_table* t = new hs_table();
+    t->engine = e;
+    t->attached = true;
+    for (int c = 0; c < n_cols; ++c) {
+        Column col;
+        col.type = types[c];
+        col.name = "c" + std::to_string(c);
+        col.col = cols[c];
+        col.loaded = cols[c].data != nullptr;
+        t->cols.push_back(std::move(col));
+    }
+    for (int b = 0; b < n_blocks; ++b) {
+        t->block_rows.push_back(block_rows[b]);
+        t->file_blocks.push_back(b);
+        t->nrows += block_rows[b];
+    }
+    t->total_blocks = n_blocks;
+    *out = t;
+    return HS_OK;
+}
+
+namespace {
+
+struct Piece {
+    int64_t file_off, bytes;
+    char* dst;  // device address
+};
+
+// Reader threads: each owns two pinned staging slots and a stream; it preads a piece into a slot while the previous
+// slot's H2D copy is in flight.  Disk / page cache and PCIe overlap; nothing is copied twice on the host.
+bool run_pieces(const std::string& path, const std::vector<Piece>& pieces, int device, std::string& err) {
+    if (pieces.empty()) return true;
+    int64_t max_piece = 0;
+    for (const Piece& p : pieces) max_piece = p.bytes > max_piece ? p.bytes : max_piece;
+    const int n_threads = (int)(pieces.size() < 8 ? pieces.size() : 8);
+    std::atomic<size_t> next{0};
+    std::atomic<bool> failed{false};
+    std::vector<std::thread> threads;
+    for (int w = 0; w < n_threads; ++w) {
+        threads.emplace_back([&, w]() {
+            (void)w;
+            if (hipSetDevice(device) != hipSuccess) {
+                failed = true;
+                return;
+            }
+            const int fd = open(path.c_str(), O_RDONLY);
+            void* slot[2] = {nullptr, nullptr};
+            hipStream_t stream = nullptr;
+            hipEvent_t ev[2] = {nullptr, nullptr};
+            bool ok = fd >= 0 && hipHostMalloc(&slot[0], (size_t)max_piece + 64, hipHostMallocDefault) == hipSuccess &&
+                      hipHostMalloc(&slot[1], (size_t)max_piece + 64, hipHostMallocDefault) == hipSuccess &&
+                      hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess &&
+                      hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess &&
+                      hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess;
+            bool used[2] = {false, false};
+            for (int turn = 0; ok && !failed; turn ^= 1) {
+                const size_t i = next.fetch_add(1);
+                if (i >= pieces.size()) break;
+                const Piece& p = pieces[i];
+                if (used[turn]) ok = hipEventSynchronize(ev[turn]) == hipSuccess;  // the slot's previous copy has left it
+                ok = ok && read_exact(fd, slot[turn], (size_t)p.bytes, p.file_off);
+                ok = ok && hipMemcpyAsync(p.dst, slot[turn], (size_t)p.bytes, hipMemcpyHostToDevice, stream) == hipSuccess;
+                ok = ok && hipEventRecord(ev[turn], stream) == hipSuccess;
+                used[turn] = true;
+            }
+            if (stream) ok = (hipStreamSynchronize(stream) == hipSuccess) && ok;
+            if (!ok) failed = true;
+            if (ev[0]) (void)hipEventDestroy(ev[0]);
+            if (ev[1]) (void)hipEventDestroy(ev[1]);
+            if (stream) (void)hipStreamDestroy(stream);
+            if (slot[0]) (void)hipHostFree(slot[0]);
+            if (slot[1]) (void)hipHostFree(slot[1]);
+            if (fd >= 0) close(fd);
+        });
+    }
+    for (std::thread& th : threads) th.join();
+    if (failed) err = "read or host-to-device copy failed";
+    return !failed;
+}
+
+}  // namespace
+
+// Load the byte spans of the listed columns (column pruning: nothing else is read) into one contiguous device buffer
+// per column across all local blocks; STRING columns get their offsets from a device prefix sum and fixed_len when every
+// row has the same length.  Idempotent per column.
+extern "C" int hs_table_load(hs_engine* e, hs_table* t, const int32_t* col_ids, int32_t n) {
+    if (!e || !t || !col_ids || n < 0) {
+        hs_set_error("hs_table_load: bad arguments");
+        return HS_E_ARG;
+    }
+    if (hipSetDevice(e->device) != hipSuccess) return HS_E_LAUNCH;
+    std::vector<Piece> pieces;
+    std::vector<int> fresh;
+    for (int k = 0; k < n; ++k) {
+        const int c = col_ids[k];
+        if (c < 0 || c >= (int)t->cols.size()) {
+            hs_set_error("hs_table_load: no such column %d", c);
+            return HS_E_ARG;
+        }
+        Column& col = t->cols[c];
+        if (col.loaded) continue;
+        if (t->attached) {
+            hs_set_error("hs_table_load: column %d of an attached table has no device data", c);
+            return HS_E_ARG;
+        }
+        const int kind = kind_of_type(col.type);
+        const size_t nb = t->block_rows.size();
+        bool ok = true;
+        if (kind == HS_STR) {
+            int64_t payload = 0;
+            for (size_t b = 0; b < nb; ++b) payload += t->spans[b][c].bytes - t->block_rows[b];
+            ok = col.lens.alloc((size_t)t->nrows) && col.data.alloc((size_t)payload);
+            int64_t row = 0, byte = 0;
+            for (size_t b = 0; ok && b < nb; ++b) {
+                const Span& s = t->spans[b][c];
+                const int64_t rows = t->block_rows[b];
+                if (rows) pieces.push_back(Piece{s.off, rows, (char*)col.lens.p + row});
+                if (s.bytes > rows) pieces.push_back(Piece{s.off + rows, s.bytes - rows, (char*)col.data.p + byte});
+                row += rows;
+                byte += s.bytes - rows;
+            }
+        } else {
+            ok = col.data.alloc((size_t)t->nrows * (size_t)elem_bytes(kind));
+            int64_t byte = 0;
+            for (size_t b = 0; ok && b < nb; ++b) {
+                const Span& s = t->spans[b][c];
+                if (s.bytes) pieces.push_back(Piece{s.off, s.bytes, (char*)col.data.p + byte});
+                byte += s.bytes;
+            }
+        }
+        if (!ok) {
+            hs_set_error("hs_table_load: out of device memory");
+            return HS_E_LAUNCH;
+        }
+        fresh.push_back(c);
+    }
+    std::string err;
+    if (!run_pieces(t->path, pieces, e->device, err)) {
+        hs_set_error("hs_table_load: %s: %s", t->path.c_str(), err.c_str());
+        return HS_E_LAUNCH;
+    }
+    for (int c : fresh) {
+        Column& col = t->cols[c];
+        const int kind = kind_of_type(col.type);
+        col.col = hs_col{kind, -1, col.data.p, nullptr, nullptr};
+        if (kind == HS_STR) {
+            col.col.lens = (const uint8_t*)col.lens.p;
+            int32_t minmax[2] = {0, 0};
+            if (t->nrows > 0) {
+                DevBuf ws, mm;
+                if (!col.offs.alloc((size_t)(t->nrows + 1) * 8) || !ws.alloc(hs_scan_ws_bytes(t->nrows)) || !mm.alloc(8)) {
+                    hs_set_error("hs_table_load: out of device memory");
+                    return HS_E_LAUNCH;
+                }
+                const int rc = hs_str_offsets(nullptr, (const uint8_t*)col.lens.p, t->nrows, (int64_t*)col.offs.p, (int32_t*)mm.p, ws.p);
+                if (rc) return rc;
+                if (hipMemcpy(minmax, mm.p, 8, hipMemcpyDeviceToHost) != hipSuccess) return HS_E_LAUNCH;
+            }
+            if (t->nrows == 0 || minmax[0] == minmax[1]) {  // every row has the same length: no offsets needed
+                col.col.fixed_len = t->nrows == 0 ? 0 : minmax[0];
+                col.offs.release();
+            } else {
+                col.col.offs = (const int64_t*)col.offs.p;
+            }
+        }
+        col.loaded = true;
+    }
+    return HS_OK;
+}
+
+// =====================================================================================================
+// Stages
+// =====================================================================================================
+struct hs_stage {
+    hs_engine* engine = nullptr;
+    hs_table* table = nullptr;
+    hs_stage_plan plan{};
+    int32_t group_cap = 4, merge_cap = 16;
+    int32_t world = 1, n_order = 1;
+    // prepared state (rebuilt when a capacity grows)
+    bool ready = false;
+    hs_col cols[HS_MAX_COLS];
+    hs_agg_geom geom{};
+    hs_slab_desc desc{};
+    hs_finish_spec fin{};
+    int32_t key_bytes = 0;
+    int64_t n_units = 0, slab_bytes = 0, image_bytes = 0;
+    DevBuf chunks, chunk0, unit_ids, slab, ws, scratch;
+    void* image_host = nullptr;  // pinned, mapped
+    void* image_dev = nullptr;
+    void* capture = nullptr;     // steady state: the launches of one run
+    int64_t runs = 0, replays = 0, grows = 0;
+    // last result
+    uint32_t last_flags = 0;
+    int64_t last_rows = 0;
+    ~hs_stage() {
+        if (capture) hs_capture_free(capture);
+        if (image_host) (void)hipHostFree(image_host);
+    }
+};
+
+namespace {
+
+int stage_prepare(hs_stage* s) {
+    hs_table* t = s->table;
+    const hs_stage_plan& P = s->plan;
+    if (s->capture) {
+        hs_capture_free(s->capture);
+        s->capture = nullptr;
+    }
+    s->ready = false;
+    for (int i = 0; i < P.n_cols; ++i) s->cols[i] = t->cols[P.col_ids[i]].col;
+    const hs_col& kc = s->cols[P.key_slot];
+    // the exchange slab holds keys in their stored kinds, packed into the 64-bit key word by the finish launch
+    if (kc.kind == HS_STR) {
+        if (kc.fixed_len != 1 && kc.fixed_len != 2 && kc.fixed_len != 4) {
+            hs_set_error("hs_stage: a string GROUP BY key needs a fixed length of 1, 2 or 4 bytes on this path");
+            return HS_E_LIMIT;
+        }
+        s->key_bytes = kc.fixed_len;
+    } else if (kc.kind == HS_I32 || kc.kind == HS_F32 || kc.kind == HS_I64) {
+        s->key_bytes = elem_bytes(kc.kind);
+    } else {
+        hs_set_error("hs_stage: GROUP BY key is not a stored column kind");
+        return HS_E_LIMIT;
+    }
+    // units = the table's local blocks (reference: one ScanJob per block, plan.py:90-93)
+    s->n_units = (int64_t)t->block_rows.size();
+    std::vector<int64_t> unit_rows(s->n_units + 1, 0);
+    for (int64_t u = 0; u < s->n_units; ++u) unit_rows[u + 1] = unit_rows[u] + t->block_rows[u];
+    int rc = hs_agg_partial_geom(unit_rows.data(), s->n_units, P.spec.n_acc, s->group_cap, &s->geom);
+    if (rc) return rc;  // HS_E_LIMIT: the private-table tier does not hold this query
+    std::vector<hs_chunk> chunks((size_t)(s->geom.n_chunks > 0 ? s->geom.n_chunks : 1));
+    std::vector<int64_t> chunk0((size_t)s->n_units + 1, 0);
+    rc = hs_agg_partial_chunks(unit_rows.data(), s->n_units, &s->geom, chunks.data(), chunk0.data());
+    if (rc) return rc;
+    std::vector<int64_t> ids(t->file_blocks.begin(), t->file_blocks.end());
+    bool ok = s->chunks.alloc(chunks.size() * sizeof(hs_chunk)) && s->chunk0.alloc(chunk0.size() * 8) &&
+              s->unit_ids.alloc((ids.size() ? ids.size() : 1) * 8) && s->ws.alloc(s->geom.ws_bytes, true);
+    ok = ok && hipMemcpy(s->chunks.p, chunks.data(), chunks.size() * sizeof(hs_chunk), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(s->chunk0.p, chunk0.data(), chunk0.size() * 8, hipMemcpyHostToDevice) == hipSuccess &&
+         (ids.empty() || hipMemcpy(s->unit_ids.p, ids.data(), ids.size() * 8, hipMemcpyHostToDevice) == hipSuccess);
+    // slab: [flags u32][pad][row count i64] | order key i64 x M | key column | accumulator columns (4 bytes per row)
+    const int64_t max_local = (t->total_blocks + s->world - 1) / s->world;
+    const int64_t M = (s->n_units > max_local ? s->n_units : max_local) * s->group_cap;
+    hs_slab_desc& d = s->desc;
+    memset(&d, 0, sizeof(d));
+    d.slab_rows = M > 0 ? M : s->group_cap;
+    int64_t pos = 16;
+    d.order_off = pos;
+    pos += 8 * d.slab_rows;
+    pos = (pos + 15) & ~(int64_t)15;
+    d.key_off = pos;
+    pos += (int64_t)s->key_bytes * d.slab_rows;
+    d.n_acc = P.spec.n_acc;
+    for (int a = 0; a < P.spec.n_acc; ++a) {
+        pos = (pos + 15) & ~(int64_t)15;
+        d.acc_off[a] = pos;
+        d.acc_kind[a] = P.spec.is_int[a] ? HS_I32 : HS_F32;
+        pos += 4 * d.slab_rows;
+    }
+    s->slab_bytes = (pos + 15) & ~(int64_t)15;
+    d.stride = s->slab_bytes;
+    d.key_kind = kc.kind;
+    d.key_len = kc.kind == HS_STR ? kc.fixed_len : 0;
+    std::vector<uint8_t> slab_image((size_t)s->slab_bytes, 0);
+    for (int64_t r = 0; r < d.slab_rows; ++r) ((int64_t*)(slab_image.data() + d.order_off))[r] = -1;
+    ok = ok && s->slab.alloc((size_t)s->slab_bytes) &&
+         hipMemcpy(s->slab.p, slab_image.data(), slab_image.size(), hipMemcpyHostToDevice) == hipSuccess;
+    // result image: header 16 bytes, then every column at a 16-byte aligned offset, cap elements each
+    s->fin = P.fin;
+    pos = 16;
+    for (int o = 0; o < s->fin.n_out; ++o) {
+        hs_finish_out& out = s->fin.outs[o];
+        const int width = out.src == 0 ? s->key_bytes : (out.kind == HS_I64 ? 8 : 4);
+        out.offset = pos;
+        pos = (pos + (int64_t)s->merge_cap * width + 15) & ~(int64_t)15;
+    }
+    s->image_bytes = pos;
+    if (s->image_host) (void)hipHostFree(s->image_host);
+    s->image_host = s->image_dev = nullptr;
+    ok = ok && hipHostMalloc(&s->image_host, (size_t)s->image_bytes + kPad, hipHostMallocMapped) == hipSuccess &&
+         hipHostGetDevicePointer(&s->image_dev, s->image_host, 0) == hipSuccess && s->image_dev;
+    if (ok) memset(s->image_host, 0, (size_t)s->image_bytes + kPad);
+    ok = ok && s->scratch.alloc(hs_agg_finish_scratch_bytes(s->merge_cap, s->fin.n_fold), true);
+    if (!ok) {
+        hs_set_error("hs_stage: out of device / pinned memory");
+        return HS_E_LAUNCH;
+    }
+    s->n_order = t->total_blocks > 0 ? t->total_blocks : 1;
+    s->ready = true;
+    return HS_OK;
+}
+
+uint32_t* engine_flags(hs_stage* s) { return (uint32_t*)s->engine->flags.p; }
+
+int launch_partial(hs_stage* s, void* stream) {
+    const hs_stage_plan& P = s->plan;
+    if (s->n_units == 0) return HS_OK;
+    return hs_agg_partial_slab(stream, s->cols, P.n_cols, P.key_slot, &P.prog, &P.spec, (const hs_chunk*)s->chunks.p,
+                               (const int64_t*)s->chunk0.p, s->n_units, &s->geom, (const int64_t*)s->unit_ids.p,
+                               (uint8_t*)s->slab.p, &s->desc, s->ws.p, engine_flags(s), nullptr, nullptr);
+}
+
+int launch_finish(hs_stage* s, void* stream, const void* gathered, int32_t world) {
+    const hs_stage_plan& P = s->plan;
+    return hs_agg_finish(stream, (const uint8_t*)(gathered ? gathered : s->slab.p), world, &s->desc, &s->fin,
+                         P.fin_prog.n_ins ? &P.fin_prog : nullptr, s->n_order, s->merge_cap, (uint8_t*)s->image_dev,
+                         s->scratch.p, engine_flags(s), (uint32_t*)s->slab.p);
+}
+
+int wait_result(hs_stage* s, void* stream) {
+    volatile uint32_t* done = (volatile uint32_t*)s->image_host + 1;
+    for (int64_t spins = 0; *done == 0; ++spins) {
+        if (spins > 2000000) {  // a long scan: let the runtime wait instead of this core
+            if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess || *done == 0) {
+                hs_set_error("hs_stage_run: the finish launch did not hand its result over");
+                return HS_E_LAUNCH;
+            }
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    s->last_flags = *(volatile uint32_t*)s->image_host;
+    const int64_t n = *(volatile int64_t*)((char*)s->image_host + 8);
+    s->last_rows = n < s->merge_cap ? n : s->merge_cap;
+    *done = 0;  // ready for the next launch into this image
+    return HS_OK;
+}
+
+}  // namespace
+
+extern "C" int hs_stage_prepare(hs_engine* e, hs_table* t, const hs_stage_plan* plan, size_t plan_bytes, int32_t world,
+                                hs_stage** out) {
+    if (!e || !t || !plan || !out || plan_bytes != sizeof(hs_stage_plan) || plan->version != HS_STAGE_PLAN_VERSION ||
+        plan->n_cols < 1 || plan->n_cols > HS_MAX_COLS || plan->key_slot < 0 || plan->key_slot >= plan->n_cols || world < 1) {
+        hs_set_error("hs_stage_prepare: bad plan blob (size %zu, expected %zu)", plan_bytes, sizeof(hs_stage_plan));
+        return HS_E_ARG;
+    }
+    if (hipSetDevice(e->device) != hipSuccess) return HS_E_LAUNCH;
+    int rc = hs_table_load(e, t, plan->col_ids, plan->n_cols);
+    if (rc) return rc;
+    hs_stage* s = new hs_stage();
+    s->engine = e;
+    s->table = t;
+    s->plan = *plan;
+    s->world = world;
+    s->group_cap = plan->group_cap > 0 ? plan->group_cap : 4;
+    s->merge_cap = plan->merge_cap > 0 ? plan->merge_cap : 16;
+    rc = stage_prepare(s);
+    if (rc) {
+        delete s;
+        return rc;
+    }
+    *out = s;
+    return HS_OK;
+}
+
+extern "C" void hs_stage_destroy(hs_stage* s) { delete s; }
+
+// One query on one GPU: scan + partial aggregate -> final merge + projection -> result image on the host.  A dictionary
+// overflow (HS_FLAG_DICT_FULL) grows the capacities and runs again; capacities beyond the on-chip tiers: HS_E_LIMIT.
+extern "C" int hs_stage_run(hs_stage* s, void* stream, uint32_t* flags_out, int64_t* n_rows_out) {
+    if (!s) {
+        hs_set_error("hs_stage_run: null stage");
+        return HS_E_ARG;
+    }
+    if (s->world != 1) {
+        hs_set_error("hs_stage_run: a multi-rank stage runs as hs_stage_launch_partial / collective / hs_stage_launch_finish");
+        return HS_E_ARG;
+    }
+    for (int attempt = 0; attempt < 10; ++attempt) {
+        int rc = HS_OK;
+        if (!s->ready) rc = stage_prepare(s);
+        if (rc) return rc;
+        if (s->capture) {
+            rc = hs_capture_replay(s->capture, stream);
+            ++s->replays;
+        } else {
+            const bool record = s->runs >= 1;  // the second run with these capacities is the one that is kept
+            if (record) rc = hs_capture_begin();
+            if (!rc) rc = launch_partial(s, stream);
+            if (!rc) rc = launch_finish(s, stream, nullptr, 1);
+            if (record) {
+                int32_t n_ops = 0;
+                void* handle = nullptr;
+                const int rc2 = hs_capture_end(&handle, &n_ops);
+                if (!rc && !rc2 && n_ops > 0) s->capture = handle;
+                else if (handle) hs_capture_free(handle);
+            }
+        }
+        if (rc) return rc;
+        rc = wait_result(s, stream);
+        if (rc) return rc;
+        ++s->runs;
+        if (s->last_flags & HS_FLAG_DICT_FULL) {
+            // more groups than the dictionaries were sized for: x2 per workgroup while per-lane tables apply, x4 for the merge
+            if (s->group_cap >= 16 && s->merge_cap >= 4096) {
+                hs_set_error("hs_stage_run: GROUP BY cardinality exceeds the on-chip tiers of this path");
+                return HS_E_LIMIT;
+            }
+            if (s->group_cap < 16) s->group_cap *= 2;
+            if (s->merge_cap < 4096) s->merge_cap *= 4;
+            s->ready = false;
+            s->runs = 0;
+            ++s->grows;
+            continue;
+        }
+        if (flags_out) *flags_out = s->last_flags;
+        if (n_rows_out) *n_rows_out = s->last_rows;
+        return HS_OK;
+    }
+    hs_set_error("hs_stage_run: capacities did not settle");
+    return HS_E_LIMIT;
+}
+
+// Multi-rank form: launch the rank's scan into its slab, let the caller all-gather the slabs (hs_stage_slab: device
+// pointer + bytes), then launch the finish over the gathered slabs and wait.
+extern "C" int hs_stage_launch_partial(hs_stage* s, void* stream) {
+    if (!s) return HS_E_ARG;
+    if (!s->ready) {
+        const int rc = stage_prepare(s);
+        if (rc) return rc;
+    }
+    return launch_partial(s, stream);
+}
+extern "C" void* hs_stage_slab(hs_stage* s, int64_t* bytes) {
+    if (!s || !s->ready) return nullptr;
+    if (bytes) *bytes = s->slab_bytes;
+    return s->slab.p;
+}
+extern "C" int hs_stage_launch_finish(hs_stage* s, void* stream, const void* gathered, int32_t world) {
+    if (!s || !s->ready || world < 1) return HS_E_ARG;
+    return launch_finish(s, stream, gathered, world);
+}
+extern "C" int hs_stage_wait(hs_stage* s, void* stream, uint32_t* flags_out, int64_t* n_rows_out) {
+    if (!s || !s->ready) return HS_E_ARG;
+    const int rc = wait_result(s, stream);
+    if (rc) return rc;
+    if (flags_out) *flags_out = s->last_flags;
+    if (n_rows_out) *n_rows_out = s->last_rows;
+    return HS_OK;
+}
+// After HS_FLAG_DICT_FULL in the multi-rank form (every rank sees the same flags): grow and prepare again.
+extern "C" int hs_stage_grow(hs_stage* s) {
+    if (!s) return HS_E_ARG;
+    if (s->group_cap >= 16 && s->merge_cap >= 4096) return HS_E_LIMIT;
+    if (s->group_cap < 16) s->group_cap *= 2;
+    if (s->merge_cap < 4096) s->merge_cap *= 4;
+    s->ready = false;
+    ++s->grows;
+    return stage_prepare(s);
+}
+
+extern "C" int hs_stage_stats(const hs_stage* s, int64_t* stats) {
+    if (!s || !stats) return HS_E_ARG;
+    stats[0] = s->runs;
+    stats[1] = s->replays;
+    stats[2] = s->grows;
+    stats[3] = s->group_cap;
+    stats[4] = s->merge_cap;
+    stats[5] = s->geom.n_chunks;
+    return HS_OK;
+}
+
+// ---- results -----------------------------------------------------------------------------------------------
+extern "C" int hs_result_columns(const hs_stage* s, hs_result_col* out, int32_t cap, int32_t* n) {
+    if (!s || !s->ready || !out || !n) {
+        hs_set_error("hs_result_columns: bad arguments");
+        return HS_E_ARG;
+    }
+    *n = s->fin.n_out;
+    for (int o = 0; o < s->fin.n_out && o < cap; ++o) {
+        const hs_finish_out& d = s->fin.outs[o];
+        out[o].kind = d.src == 0 ? s->desc.key_kind : d.kind;
+        out[o].width = d.src == 0 ? s->key_bytes : (d.kind == HS_I64 ? 8 : 4);
+        out[o].data = (const uint8_t*)s->image_host + d.offset;
+        out[o].n_rows = s->last_rows;
+    }
+    return HS_OK;
+}
+
+// The result as a one-block BlockFile (reference: WriteToLocalFileTask.write tasks.py:400-410, io.py:47-109): what
+// `collect_results` reads back.  Column names / types come from the plan blob.
+extern "C" int hs_result_write_blockfile(const hs_stage* s, const char* path) {
+    if (!s || !s->ready || !path) {
+        hs_set_error("hs_result_write_blockfile: bad arguments");
+        return HS_E_ARG;
+    }
+    if (s->last_rows == 0) return HS_OK;  // empty result: the reference writes no file (tasks.py:405)
+    FILE* f = fopen(path, "wb");
+    if (!f) {
+        hs_set_error("hs_result_write_blockfile: cannot create %s", path);
+        return HS_E_ARG;
+    }
+    const int n_out = s->fin.n_out;
+    const uint8_t nc = (uint8_t)n_out;
+    fwrite(&nc, 1, 1, f);
+    for (int o = 0; o < n_out; ++o) {
+        const uint8_t type = (uint8_t)s->plan.out_types[o];
+        const uint8_t len = (uint8_t)strnlen(s->plan.out_names[o], sizeof(s->plan.out_names[o]));
+        fwrite(&type, 1, 1, f);
+        fwrite(&len, 1, 1, f);
+        fwrite(s->plan.out_names[o], 1, len, f);
+    }
+    const uint64_t block_start = (uint64_t)ftell(f);
+    const uint32_t rows = (uint32_t)s->last_rows;
+    fwrite(&rows, 4, 1, f);
+    for (int o = 0; o < n_out; ++o) {
+        const hs_finish_out& d = s->fin.outs[o];
+        const uint8_t* col = (const uint8_t*)s->image_host + d.offset;
+        const bool is_key_string = d.src == 0 && s->desc.key_kind == HS_STR;
+        const int width = d.src == 0 ? s->key_bytes : (d.kind == HS_I64 ? 8 : 4);
+        const uint64_t bytes = (uint64_t)rows * (uint64_t)width + (is_key_string ? rows : 0);
+        fwrite(&bytes, 8, 1, f);
+        if (is_key_string) {  // STRING payload: the length bytes, then the strings
+            const uint8_t w = (uint8_t)width;
+            for (uint32_t r = 0; r < rows; ++r) fwrite(&w, 1, 1, f);
+        }
+        fwrite(col, 1, (size_t)rows * (size_t)width, f);
+    }
+    fwrite(&block_start, 8, 1, f);
+    const uint32_t nblocks = 1;
+    fwrite(&nblocks, 4, 1, f);
+    const bool ok = fclose(f) == 0;
+    if (!ok) {
+        hs_set_error("hs_result_write_blockfile: write to %s failed", path);
+        return HS_E_ARG;
+    }
+    return HS_OK;
+}

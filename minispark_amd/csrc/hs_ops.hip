@@ -31,6 +31,8 @@ extern "C" size_t hs_sizeof(int32_t which) {
         case 5: return sizeof(hs_slab_desc);
         case 6: return sizeof(hs_finish_out);
         case 7: return sizeof(hs_finish_spec);
+        case 8: return sizeof(hs_stage_plan);
+        case 9: return sizeof(hs_result_col);
         default: return 0;
     }
 }

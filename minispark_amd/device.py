@@ -1230,79 +1230,15 @@ class Device:
 
     def _prepare_finish(self, tail: dict, agg_columns: Sequence[Any], merged_schema: Schema,
                         project: Sequence[Any] | None, out_schema: Schema, cap: int) -> dict:
-        from .lowering import unalias  # noqa: PLC0415
+        from .lowering import FinishUnsupported, lower_finish  # noqa: PLC0415
 
-        ops = {"sum": hs.AGG_SUM, "min": hs.AGG_MIN, "max": hs.AGG_MAX}
-        fin = hs.hs_finish_spec()
-        folds: dict[tuple[int, int], int] = {}
-        col_fold: list[int] = []  # merged column i + 1 -> fold
-        for i, agg in enumerate(agg_columns):
-            pair = (tail["agg_to_acc"][i], ops[agg.type])
-            if pair not in folds:
-                if len(folds) >= hs.HS_MAX_ACC:
-                    raise TierExceeded("too many aggregates for the fused tail")
-                folds[pair] = len(folds)
-                fin.fold_src[folds[pair]], fin.fold_op[folds[pair]] = pair
-            col_fold.append(folds[pair])
-        fin.n_fold = len(folds)
         key_kind = tail["key_kind"]
         key_bytes = tail["key_len"] if key_kind == hs.STR else hs.KIND_BYTES[key_kind]
-        merged_kinds = [key_kind] + [hs.I64 if tail["acc_kinds"][tail["agg_to_acc"][i]] == hs.I32 else hs.F64
-                                     for i in range(len(agg_columns))]
-        if len(merged_schema) != len(merged_kinds):
-            raise AssertionError(f"merge schema {merged_schema} does not match {len(agg_columns)} aggregates")
-
-        def stored(in_kind: int, col_type: ColumnType) -> int:
-            want = FILE_KIND[col_type]
-            if (in_kind, want) in ((hs.F64, hs.F32), (hs.I64, hs.I32), (hs.I64, hs.I64)):
-                return want
-            raise AssertionError(f"column of kind {in_kind} cannot be stored as {col_type}")
-
-        outs: list[tuple[int, int, int]] = []  # (src, index, stored kind)
-        prog = None
-        if project is None:
-            if len(out_schema) != len(merged_kinds):
-                raise AssertionError(f"writer schema {out_schema} does not match merged columns {merged_schema}")
-            outs.append((0, 0, key_kind))
-            for i in range(len(agg_columns)):
-                outs.append((1, col_fold[i], stored(merged_kinds[i + 1], out_schema[i + 1][1])))
-        else:
-            if len(out_schema) != len(project):
-                raise AssertionError(f"writer schema {out_schema} does not match the projection")
-            b = ProgramBuilder(list(merged_schema), merged_kinds)
-            names = [n for n, _ in merged_schema]
-            n_prog = 0
-            for o, col in enumerate(project):
-                bare = unalias(col)
-                if type(bare).__name__ in ("Col", "SchemaCol"):
-                    idx = names.index(bare.name) if bare.name in names else -1
-                    if idx < 0:
-                        raise ValueError(f'Column "{bare.name}" not found in schema {merged_schema}')
-                    if idx == 0:
-                        outs.append((0, 0, key_kind))
-                    else:
-                        outs.append((1, col_fold[idx - 1], stored(merged_kinds[idx], out_schema[o][1])))
-                    continue
-                if b.string_tag(bare):
-                    raise TierExceeded("string expression after the merge")
-                if n_prog >= hs.HS_MAX_OUTS:
-                    raise TierExceeded("too many computed columns for the fused tail")
-                tag = b.emit_out(n_prog, col)
-                if tag == "B":
-                    raise AssertionError("a comparison cannot be selected as a column (the reference has no BOOL type)")
-                fin.prog_out[n_prog] = o
-                outs.append((2, n_prog, stored(hs.F64 if tag == "F" else hs.I64, out_schema[o][1])))
-                n_prog += 1
-            if n_prog:
-                lowered = b.finish()
-                for slot, idx in enumerate(lowered.columns):
-                    if idx == 0 and key_kind == hs.STR:
-                        raise TierExceeded("expression over a string key after the merge")
-                    fin.prog_src[slot] = -1 if idx == 0 else col_fold[idx - 1]
-                prog = lowered.to_struct()
-        if len(outs) > hs.HS_FINISH_MAX_OUT:
-            raise TierExceeded("too many result columns for the fused tail")
-        fin.n_out = len(outs)
+        try:
+            fin, prog, outs = lower_finish(tail["agg_to_acc"], tail["acc_kinds"], key_kind, agg_columns, merged_schema,
+                                           project, out_schema)
+        except FinishUnsupported as e:
+            raise TierExceeded(str(e)) from None
         pos = 16
         columns: list[tuple[int, int, int]] = []  # (offset, stored kind, bytes per row)
         for o, (src, index, kind) in enumerate(outs):

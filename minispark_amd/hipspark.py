@@ -129,6 +129,29 @@ class hs_finish_spec(C.Structure):
     ]
 
 
+class hs_stage_plan(C.Structure):
+    _fields_ = [
+        ("version", C.c_int32),
+        ("n_cols", C.c_int32),
+        ("col_ids", C.c_int32 * HS_MAX_COLS),
+        ("key_slot", C.c_int32),
+        ("group_cap", C.c_int32),
+        ("merge_cap", C.c_int32),
+        ("prog", hs_program),
+        ("spec", hs_agg_spec),
+        ("fin", hs_finish_spec),
+        ("fin_prog", hs_program),
+        ("out_types", C.c_int32 * HS_FINISH_MAX_OUT),
+        ("out_names", (C.c_char * 64) * HS_FINISH_MAX_OUT),
+    ]
+
+
+class hs_result_col(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("width", C.c_int32), ("data", C.c_void_p), ("n_rows", C.c_int64)]
+
+
+HS_STAGE_PLAN_VERSION = 1
+
 _P = C.c_void_p
 _I64 = C.c_int64
 _I32 = C.c_int32
@@ -203,6 +226,26 @@ SIGNATURES: dict[str, tuple] = {
                                               C.c_char_p, _I64]),
     "hs_jit_compile_check_eval": (C.c_int, [_COLP, _I32, _PROGP, C.POINTER(_I32), _I32, C.c_char_p, C.POINTER(_I64),
                                             C.c_char_p, _I64]),
+    "hs_engine_create": (C.c_int, [_I32, C.POINTER(_P)]),
+    "hs_engine_destroy": (None, [_P]),
+    "hs_table_open": (C.c_int, [_P, C.c_char_p, _I32, _I32, C.POINTER(_P)]),
+    "hs_table_close": (None, [_P]),
+    "hs_table_info": (C.c_int, [_P, C.POINTER(_I32), C.POINTER(_I64), C.POINTER(_I32), C.POINTER(_I32)]),
+    "hs_table_schema": (C.c_int, [_P, _I32, C.POINTER(_I32), C.c_char_p, _I32]),
+    "hs_table_load": (C.c_int, [_P, _P, C.POINTER(_I32), _I32]),
+    "hs_table_column": (C.c_int, [_P, _I32, _COLP, C.POINTER(_I64)]),
+    "hs_table_attach": (C.c_int, [_P, _I32, _COLP, C.POINTER(_I32), C.POINTER(_I64), _I32, C.POINTER(_P)]),
+    "hs_stage_prepare": (C.c_int, [_P, _P, C.POINTER(hs_stage_plan), C.c_size_t, _I32, C.POINTER(_P)]),
+    "hs_stage_destroy": (None, [_P]),
+    "hs_stage_run": (C.c_int, [_P, _P, C.POINTER(C.c_uint32), C.POINTER(_I64)]),
+    "hs_stage_launch_partial": (C.c_int, [_P, _P]),
+    "hs_stage_slab": (_P, [_P, C.POINTER(_I64)]),
+    "hs_stage_launch_finish": (C.c_int, [_P, _P, _P, _I32]),
+    "hs_stage_wait": (C.c_int, [_P, _P, C.POINTER(C.c_uint32), C.POINTER(_I64)]),
+    "hs_stage_grow": (C.c_int, [_P]),
+    "hs_stage_stats": (C.c_int, [_P, C.POINTER(_I64)]),
+    "hs_result_columns": (C.c_int, [_P, C.POINTER(hs_result_col), _I32, C.POINTER(_I32)]),
+    "hs_result_write_blockfile": (C.c_int, [_P, C.c_char_p]),
     "hs_capture_begin": (C.c_int, []),
     "hs_capture_end": (C.c_int, [C.POINTER(_P), C.POINTER(_I32)]),
     "hs_capture_replay": (C.c_int, [_P, _P]),

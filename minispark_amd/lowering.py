@@ -488,3 +488,90 @@ def lower_aggregate(schema: Schema, kinds: Sequence[int], filters: Sequence[Any]
     prog = b.finish(key_column=key_col)
     numeric_slots = sum(1 for c in prog.columns if kinds[c] != hs.STR or c == key_col or c in prog.code_columns)
     return AggregateLowering(prog, prog.columns.index(key_col), acc_ops, acc_is_int, agg_to_acc, numeric_slots)
+
+
+class FinishUnsupported(Exception):
+    """The final merge + projection does not fit the one-launch tail (the caller takes the general operator sequence)."""
+
+
+_FILE_KIND = {ColumnType.INTEGER: hs.I32, ColumnType.FLOAT: hs.F32, ColumnType.TIMESTAMP: hs.I64, ColumnType.STRING: hs.STR}
+
+
+def lower_finish(agg_to_acc: Sequence[int], acc_kinds: Sequence[int], key_kind: int, agg_columns: Sequence[Any],
+                 merged_schema: Schema, project: Sequence[Any] | None, out_schema: Schema) -> tuple:
+    """The final stage - merge of the partial rows (reference tasks.py:290-292), the projection after it
+    (plan.py:190-203: AVG = sum / count, renames) and the stored kinds of the result file (io.py:87-94) - as the
+    description hs_agg_finish takes: -> (hs_finish_spec without offsets, hs_program or None, [(src, index, stored kind)]).
+    Pure lowering (no device): used by the engine's short tail and by the stage-level ABI (minispark_amd/stage.py)."""
+    ops = {"sum": hs.AGG_SUM, "min": hs.AGG_MIN, "max": hs.AGG_MAX}
+    fin = hs.hs_finish_spec()
+    folds: dict[tuple[int, int], int] = {}
+    col_fold: list[int] = []  # merged column i + 1 -> fold
+    for i, agg in enumerate(agg_columns):
+        pair = (agg_to_acc[i], ops[agg.type])
+        if pair not in folds:
+            if len(folds) >= hs.HS_MAX_ACC:
+                raise FinishUnsupported("too many aggregates for the fused tail")
+            folds[pair] = len(folds)
+            fin.fold_src[folds[pair]], fin.fold_op[folds[pair]] = pair
+        col_fold.append(folds[pair])
+    fin.n_fold = len(folds)
+    merged_kinds = [key_kind] + [hs.I64 if acc_kinds[agg_to_acc[i]] == hs.I32 else hs.F64
+                                 for i in range(len(agg_columns))]
+    if len(merged_schema) != len(merged_kinds):
+        raise AssertionError(f"merge schema {merged_schema} does not match {len(agg_columns)} aggregates")
+
+    def stored(in_kind: int, col_type: ColumnType) -> int:
+        want = _FILE_KIND[col_type]
+        if (in_kind, want) in ((hs.F64, hs.F32), (hs.I64, hs.I32), (hs.I64, hs.I64)):
+            return want
+        raise AssertionError(f"column of kind {in_kind} cannot be stored as {col_type}")
+
+    outs: list[tuple[int, int, int]] = []  # (src, index, stored kind)
+    prog = None
+    if project is None:
+        if len(out_schema) != len(merged_kinds):
+            raise AssertionError(f"writer schema {out_schema} does not match merged columns {merged_schema}")
+        outs.append((0, 0, key_kind))
+        for i in range(len(agg_columns)):
+            outs.append((1, col_fold[i], stored(merged_kinds[i + 1], out_schema[i + 1][1])))
+    else:
+        if len(out_schema) != len(project):
+            raise AssertionError(f"writer schema {out_schema} does not match the projection")
+        b = ProgramBuilder(list(merged_schema), merged_kinds)
+        names = [n for n, _ in merged_schema]
+        n_prog = 0
+        for o, col in enumerate(project):
+            bare = unalias(col)
+            if _cls(bare) in ("Col", "SchemaCol"):
+                idx = names.index(bare.name) if bare.name in names else -1
+                if idx < 0:
+                    raise ValueError(f'Column "{bare.name}" not found in schema {merged_schema}')
+                if idx == 0:
+                    outs.append((0, 0, key_kind))
+                else:
+                    outs.append((1, col_fold[idx - 1], stored(merged_kinds[idx], out_schema[o][1])))
+                continue
+            if b.string_tag(bare):
+                raise FinishUnsupported("string expression after the merge")
+            if n_prog >= hs.HS_MAX_OUTS:
+                raise FinishUnsupported("too many computed columns for the fused tail")
+            tag = b.emit_out(n_prog, col)
+            if tag == "B":
+                raise AssertionError("a comparison cannot be selected as a column (the reference has no BOOL type)")
+            fin.prog_out[n_prog] = o
+            outs.append((2, n_prog, stored(hs.F64 if tag == "F" else hs.I64, out_schema[o][1])))
+            n_prog += 1
+        if n_prog:
+            lowered = b.finish()
+            for slot, idx in enumerate(lowered.columns):
+                if idx == 0 and key_kind == hs.STR:
+                    raise FinishUnsupported("expression over a string key after the merge")
+                fin.prog_src[slot] = -1 if idx == 0 else col_fold[idx - 1]
+            prog = lowered.to_struct()
+    if len(outs) > hs.HS_FINISH_MAX_OUT:
+        raise FinishUnsupported("too many result columns for the fused tail")
+    fin.n_out = len(outs)
+    for o, (src, index, kind) in enumerate(outs):
+        fin.outs[o].src, fin.outs[o].index, fin.outs[o].kind = src, index, kind
+    return fin, prog, outs

@@ -1,0 +1,185 @@
+"""Host side of the stage-level C ABI (include/hipspark.h, csrc/hs_engine.hip): lower a GROUP BY query into the plan
+blob, and a thin handle over ``hs_engine_* / hs_table_* / hs_stage_* / hs_result_*``.
+
+No torch, no :class:`minispark_amd.device.Device`: this is the whole host a cgo / JNI / FFI binding has to reproduce
+ - everything else (BlockFile reading, buffers, geometry, retries, replay, hand-over) happens
+behind the ABI.  The query shape it covers is the hot path's: ``table -> [filter]* -> group_by(col).agg(...)``, i.e. the
+reference's two stages [Load -> Filter* -> Aggregate(before) -> shuffle] + [shuffle -> Aggregate(after) -> (Project) ->
+result] (plan.py:182-204).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+from typing import Any
+
+import numpy as np
+
+from . import hipspark as hs
+from .constants import ColumnType, Row, Schema
+from .io import BlockFile, StrCol, rows_from_raw
+from .lowering import lower_aggregate, lower_finish
+
+_FILE_KIND = {ColumnType.INTEGER: hs.I32, ColumnType.FLOAT: hs.F32, ColumnType.TIMESTAMP: hs.I64, ColumnType.STRING: hs.STR}
+_TYPE_CODE = {ColumnType.INTEGER: 0, ColumnType.STRING: 1, ColumnType.FLOAT: 2, ColumnType.TIMESTAMP: 3}
+_NP = {hs.I32: np.int32, hs.F32: np.float32, hs.I64: np.int64}
+
+
+class StageUnsupported(NotImplementedError):
+    """The query is not of the shape the stage-level path runs (the engine's general path takes it)."""
+
+
+def _cls(obj: Any) -> str:
+    return type(obj).__name__
+
+
+def lower_stage_plan(full_task: Any, plan: Any = None) -> tuple[hs.hs_stage_plan, Path, Schema]:
+    """Task tree (reference or this package's classes) -> (plan blob, table path, result schema)."""
+    if plan is None:
+        from .plan import PhysicalPlan  # noqa: PLC0415
+
+        plan = PhysicalPlan.generate_physical_plan(full_task)
+    stages = list(plan.stages)
+    if len(stages) != 2:
+        raise StageUnsupported(f"{len(stages)} stages: the stage-level path runs scan + GROUP BY queries")
+    scan, final = (stages if _cls(stages[0].producer) == "LoadTableBlockTask" else stages[::-1])
+    if _cls(scan.producer) != "LoadTableBlockTask" or _cls(final.producer) != "LoadShuffleFilesTask":
+        raise StageUnsupported("not a scan stage feeding a final stage")
+    filters, partial = [], None
+    for task in scan.consumers:
+        if _cls(task) == "FilterTask" and partial is None:
+            filters.append(task.condition)
+        elif _cls(task) == "AggregateTask" and task.before_shuffle and partial is None:
+            partial = task
+        else:
+            raise StageUnsupported(f"{_cls(task)} in the scan stage")
+    consumers = list(final.consumers)
+    if partial is None or not consumers or _cls(consumers[0]) != "AggregateTask" or consumers[0].before_shuffle:
+        raise StageUnsupported("no partial / final aggregate pair")
+    if len(consumers) > 2 or (len(consumers) == 2 and _cls(consumers[1]) != "ProjectTask"):
+        raise StageUnsupported("more than a projection after the final aggregate")
+    merge = consumers[0]
+    project = list(consumers[1].columns) if len(consumers) == 2 else None
+    out_schema = list(final.writer.inferred_schema)
+
+    table_schema = list(scan.producer.inferred_schema)
+    prefix = f"{scan.producer.alias}." if getattr(scan.producer, "alias", "") else ""
+    kinds = [_FILE_KIND[t] for _, t in table_schema]
+    low = lower_aggregate(table_schema, kinds, filters, partial.group_by_column, partial.agg_columns)
+    if low.numeric_slots > hs.HS_FUSED_COLS:
+        raise StageUnsupported(f"more than {hs.HS_FUSED_COLS} numeric columns")
+    acc_kinds = [hs.I32 if is_int else hs.F32 for is_int in low.acc_is_int]
+    key_idx = low.program.columns[low.key_slot]
+    fin, fin_prog, outs = lower_finish(low.agg_to_acc, acc_kinds, kinds[key_idx], merge.agg_columns, merge.inferred_schema,
+                                       project, out_schema)
+    blob = hs.hs_stage_plan()
+    blob.version = hs.HS_STAGE_PLAN_VERSION
+    blob.n_cols = len(low.program.columns)
+    for slot, idx in enumerate(low.program.columns):
+        blob.col_ids[slot] = idx
+    blob.key_slot = low.key_slot
+    blob.group_cap, blob.merge_cap = 4, 16
+    blob.prog = low.program.to_struct()
+    blob.spec = low.spec()
+    blob.fin = fin
+    if fin_prog is not None:
+        blob.fin_prog = fin_prog
+    for o, (name, ctype) in enumerate(out_schema):
+        blob.out_types[o] = _TYPE_CODE[ctype]
+        blob.out_names[o].value = name[len(prefix):].encode()[:63] if prefix and name.startswith(prefix) else name.encode()[:63]
+    return blob, Path(scan.producer.file_path), out_schema
+
+
+class NativeEngine:
+    """hs_engine + the tables it has open."""
+
+    def __init__(self, device: int = 0) -> None:
+        self.lib = hs.load_library()
+        self.handle = C.c_void_p()
+        hs.check(self.lib.hs_engine_create(device, C.byref(self.handle)), "hs_engine_create")
+        self._tables: dict[tuple, C.c_void_p] = {}
+
+    def table(self, path: Path | str, rank: int = 0, world: int = 1) -> C.c_void_p:
+        key = (str(Path(path).resolve()), rank, world)
+        if key not in self._tables:
+            t = C.c_void_p()
+            hs.check(self.lib.hs_table_open(self.handle, key[0].encode(), rank, world, C.byref(t)), "hs_table_open")
+            self._tables[key] = t
+        return self._tables[key]
+
+    def close(self) -> None:
+        for t in self._tables.values():
+            self.lib.hs_table_close(t)
+        self._tables.clear()
+        if self.handle:
+            self.lib.hs_engine_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __enter__(self) -> "NativeEngine":
+        return self
+
+    def __exit__(self, *exc: Any) -> None:
+        self.close()
+
+
+class NativeStage:
+    """A prepared query: ``run()`` -> result rows; ``write(path)`` -> the result BlockFile."""
+
+    def __init__(self, engine: NativeEngine, full_task: Any, plan: Any = None, world: int = 1, rank: int = 0) -> None:
+        self.engine, self.lib = engine, engine.lib
+        self.blob, self.table_path, self.schema = lower_stage_plan(full_task, plan)
+        self.handle = C.c_void_p()
+        hs.check(self.lib.hs_stage_prepare(engine.handle, engine.table(self.table_path, rank, world), C.byref(self.blob),
+                                           C.sizeof(self.blob), world, C.byref(self.handle)), "hs_stage_prepare")
+
+    def run(self, stream: int | None = None) -> list[Row]:
+        flags, nrows = C.c_uint32(0), C.c_int64(0)
+        hs.check(self.lib.hs_stage_run(self.handle, stream, C.byref(flags), C.byref(nrows)), "hs_stage_run")
+        raise_for_flags(flags.value)
+        return list(rows_from_raw(self.schema, self.raw_columns()))
+
+    def raw_columns(self) -> list[Any]:
+        cols = (hs.hs_result_col * hs.HS_FINISH_MAX_OUT)()
+        n = C.c_int32(0)
+        hs.check(self.lib.hs_result_columns(self.handle, cols, hs.HS_FINISH_MAX_OUT, C.byref(n)), "hs_result_columns")
+        raw: list[Any] = []
+        for o in range(n.value):
+            c = cols[o]
+            rows, nbytes = int(c.n_rows), int(c.n_rows) * int(c.width)
+            buf = np.frombuffer((C.c_uint8 * nbytes).from_address(c.data), dtype=np.uint8).copy() if nbytes else np.zeros(0, np.uint8)
+            raw.append(StrCol(np.full(rows, c.width, np.uint8), buf) if c.kind == hs.STR else buf.view(_NP[c.kind]))
+        return raw
+
+    def write(self, path: Path | str) -> Path:
+        Path(path).parent.mkdir(parents=True, exist_ok=True)
+        hs.check(self.lib.hs_result_write_blockfile(self.handle, str(path).encode()), "hs_result_write_blockfile")
+        return Path(path)
+
+    def stats(self) -> dict:
+        s = (C.c_int64 * 6)()
+        hs.check(self.lib.hs_stage_stats(self.handle, s), "hs_stage_stats")
+        return dict(zip(("runs", "replays", "grows", "group_cap", "merge_cap", "chunks"), (int(v) for v in s)))
+
+    def close(self) -> None:
+        if self.handle:
+            self.lib.hs_stage_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
+def raise_for_flags(flags: int) -> None:
+    """Data-dependent failures surface as the exceptions the reference's Python raises (same table as Device)."""
+    if flags & hs.FLAG_DIV_ZERO:
+        raise ZeroDivisionError("division by zero")
+    if flags & hs.FLAG_INT_OVERFLOW:
+        raise OverflowError("int too big to convert")
+    if flags & hs.FLAG_FLT_OVERFLOW:
+        raise OverflowError("float too large to pack with f format")
+    if flags & hs.FLAG_TYPE_ASSERT:
+        raise AssertionError("FLOAT column holds int")
+    if flags & hs.FLAG_BAD_PROGRAM:
+        raise RuntimeError("internal error: device interpreter rejected the program")
+
+
+def read_result_file(path: Path | str) -> list[Row]:
+    return list(BlockFile(Path(path)).read_data_rows())

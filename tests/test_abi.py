@@ -37,7 +37,7 @@ def test_struct_layouts_match_the_header():
     # and the sizes the library was compiled with
     lib = hs.load_library()
     mirrors = [hs.hs_col, hs.hs_program, hs.hs_agg_spec, hs.hs_agg_geom, hs.hs_chunk, hs.hs_slab_desc, hs.hs_finish_out,
-               hs.hs_finish_spec]
+               hs.hs_finish_spec, hs.hs_stage_plan, hs.hs_result_col]
     for which, mirror in enumerate(mirrors):
         assert lib.hs_sizeof(which) == C.sizeof(mirror), mirror.__name__
     assert lib.hs_sizeof(len(mirrors)) == 0
@@ -169,3 +169,23 @@ def test_shared_tier_programs_with_computed_units_and_dictionary_predicates_comp
         text = src.value.decode()
         assert "hs_agg_shared_body<JitProg>" in text and "hs_dictbit(" in text and "run_slot" in text
         assert ("hs_unit_key(" in text) == (unit_col >= 0)
+
+
+def test_stage_plan_blob_lowers_without_a_gpu_and_matches_the_library_mirror():
+    """minispark_amd/stage.py: Q1 -> hs_stage_plan (what a cgo / JNI host would build); the ctypes mirrors of the
+    stage-level structures have the sizes the library was compiled with."""
+    from minispark_amd.dataframe import DataFrame
+    from minispark_amd.sql import Col, Functions, Lit
+    from minispark_amd.stage import lower_stage_plan
+    from minispark_amd.workloads import api_namespace, q1
+
+    lib = hs.load_library()
+    assert lib.hs_sizeof(8) == C.sizeof(hs.hs_stage_plan) and lib.hs_sizeof(9) == C.sizeof(hs.hs_result_col)
+    g = load_golden("q1_multiblock")
+    api = api_namespace(lambda: DataFrame(engine=object()), Col, Functions, Lit)
+    blob, path, schema = lower_stage_plan(q1(api, g["paths"]["lineitem"]).task)
+    assert str(path) == g["paths"]["lineitem"] and blob.version == hs.HS_STAGE_PLAN_VERSION
+    assert blob.n_cols == 6 and blob.spec.n_acc == 6 and blob.fin.n_fold == 6 and blob.fin.n_out == len(schema) == 9
+    assert blob.fin_prog.n_ins > 0  # the three AVG = sum / count projections
+    assert [blob.out_names[o].value.decode() for o in range(9)] == [n for n, _ in schema]
+    assert blob.out_types[0] == 1 and blob.out_types[8] == 0  # STRING key ... INTEGER count

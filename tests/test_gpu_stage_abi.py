@@ -1,0 +1,125 @@
+"""The stage-level C ABI (include/hipspark.h: hs_engine_* / hs_table_* / hs_stage_* / hs_result_*) driven through
+minispark_amd/stage.py alone - no Device class, no torch tensors: the native BlockFile reader loads the reference-written
+golden files, the library runs scan -> partial aggregate -> final merge -> projection, and the rows must equal the
+reference's golden rows; the result BlockFile it writes must read back to the same rows."""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+from tests.conftest import assert_rows_match, load_golden
+from tests.queries import case_by_name
+
+pytestmark = pytest.mark.gpu
+
+CASES = ["q1_multiblock", "q1_selective", "q1_ragged_blocks", "edge_int_key", "e2e_group_avg_float", "edge_minmax"]
+
+
+def _api():
+    from minispark_amd.dataframe import DataFrame
+    from minispark_amd.sql import Col, Functions, Lit
+    from minispark_amd.workloads import api_namespace
+
+    return api_namespace(lambda: DataFrame(object()), Col, Functions, Lit)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_stage_abi_reproduces_reference_goldens(tmp_path, name):
+    from minispark_amd.hipspark import HipSparkError
+    from minispark_amd.stage import NativeEngine, NativeStage, StageUnsupported, read_result_file
+
+    golden = load_golden(name)
+    task = case_by_name(name).build(_api(), golden["paths"]).task
+    with NativeEngine(0) as engine:
+        try:
+            stage = NativeStage(engine, task)
+        except (StageUnsupported, HipSparkError) as e:
+            # not this path's shape (a variable-length string key: HS_E_LIMIT; more than a projection after the merge):
+            # the engine's general path takes such queries - but the Q1 shapes must run here
+            assert name in ("edge_minmax", "e2e_group_avg_float"), (name, e)
+            return
+        rows = None
+        for _ in range(4):  # first run, recorded run, replays of the captured launches
+            rows = stage.run()
+            assert_rows_match(rows, golden["rows"], max_ulps=1)
+        stats = stage.stats()
+        assert stats["replays"] >= 1 and stats["runs"] >= 3
+        out = stage.write(tmp_path / "result.bin")
+        assert_rows_match(read_result_file(out), rows)  # the file the reference's collect_results would read
+        stage.close()
+
+
+def test_stage_abi_grows_its_dictionaries(tmp_path):
+    """More groups than the starting capacities (4 per workgroup, 16 in the merge): HS_FLAG_DICT_FULL -> the library
+    grows and re-runs by itself."""
+    from minispark_amd.constants import ColumnType as T
+    from minispark_amd.io import BlockFile
+    from minispark_amd.stage import NativeEngine, NativeStage
+    from oracle.py_engine import run_query
+
+    rng = np.random.default_rng(4)
+    n = 30_000
+    key = rng.integers(0, 13, n).astype(np.int32)
+    val = rng.uniform(-5, 5, n).astype(np.float32)
+    path = tmp_path / "t.bin"
+    BlockFile(path).write_raw_blocks([("k", T.INTEGER), ("v", T.FLOAT)], [[key[:9000], val[:9000]], [key[9000:], val[9000:]]])
+    api = _api()
+    frame = api.DataFrame().table(str(path)).filter(api.Col("v") > -4.5).group_by(api.Col("k")).agg(
+        api.F.sum(api.Col("v")).alias("s"), api.F.avg(api.Col("v") * 2).alias("a"), api.F.count(), api.F.min(api.Col("v")).alias("lo"))
+    want = run_query(frame.task)
+    with NativeEngine(0) as engine:
+        stage = NativeStage(engine, frame.task)
+        for _ in range(3):
+            assert_rows_match(stage.run(), want, max_ulps=1)
+        stats = stage.stats()
+        assert stats["grows"] >= 1 and stats["group_cap"] >= 16
+        stage.close()
+
+
+def test_native_reader_prunes_and_matches_the_python_reader(tmp_path):
+    """hs_table_open / hs_table_load against minispark_amd.io: schema, block ownership b % world, column bytes."""
+    import ctypes as C
+
+    import torch
+
+    from minispark_amd import hipspark as hs
+    from minispark_amd.io import BlockFile
+    from minispark_amd.stage import NativeEngine
+
+    golden = load_golden("q1_ragged_blocks")
+    path = golden["paths"]["lineitem"]
+    bf = BlockFile(path)
+    rows_per_block = bf.block_rows()
+    with NativeEngine(0) as engine:
+        lib = engine.lib
+        for rank, world in ((0, 1), (1, 2), (2, 3)):
+            t = engine.table(path, rank, world)
+            ncols, nrows, nblocks, total = C.c_int32(), C.c_int64(), C.c_int32(), C.c_int32()
+            hs.check(lib.hs_table_info(t, C.byref(ncols), C.byref(nrows), C.byref(nblocks), C.byref(total)), "hs_table_info")
+            mine = [b for b in range(len(rows_per_block)) if b % world == rank]
+            assert ncols.value == len(bf.file_schema) and total.value == len(rows_per_block)
+            assert nblocks.value == len(mine) and nrows.value == sum(rows_per_block[b] for b in mine)
+        t = engine.table(path)
+        names = []
+        for c in range(len(bf.file_schema)):
+            ctype, name = C.c_int32(), C.create_string_buffer(64)
+            hs.check(lib.hs_table_schema(t, c, C.byref(ctype), name, 64), "hs_table_schema")
+            names.append(name.value.decode())
+        assert names == [n for n, _ in bf.file_schema]
+        want = bf.read_raw_columns() if hasattr(bf, "read_raw_columns") else None
+        ids = (C.c_int32 * 2)(names.index("l_quantity"), names.index("l_shipdate"))
+        hs.check(lib.hs_table_load(engine.handle, t, ids, 2), "hs_table_load")
+        col, n = hs.hs_col(), C.c_int64()
+        hs.check(lib.hs_table_column(t, ids[0], C.byref(col), C.byref(n)), "hs_table_column")
+        assert col.kind == hs.F32 and n.value == sum(rows_per_block)
+        host = torch.empty(n.value, dtype=torch.float32)
+        assert torch.cuda.is_available()
+        torch.cuda.synchronize()
+        # copy the device column back through torch's allocator-agnostic memcpy
+        dev = torch.empty(n.value, dtype=torch.float32, device="cuda")
+        C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(dev.data_ptr()), C.c_void_p(col.data), C.c_size_t(n.value * 4), 3)
+        host.copy_(dev)
+        rows = list(bf.read_data_rows())
+        assert np.array_equal(host.numpy(), np.array([r["l_quantity"] for r in rows], np.float32))
+        assert lib.hs_table_column(t, names.index("l_tax"), C.byref(col), C.byref(n)) != 0  # never loaded: pruned
