@@ -319,6 +319,18 @@ int hs_join_build(void* stream, const hs_col* left_key, int64_t n_left, int64_t 
 int hs_group_build(void* stream, const hs_col* key, const int64_t* sel, int64_t row0, int64_t n, int64_t table_cap,
                    uint64_t* table_keys, int64_t* table_reps, int64_t* slot_start, int64_t* positions, void* ws,
                    uint32_t* flags);
+/* hs_group_build over EVERY unit of a batch in one pass (round 2: the HBM tier no longer loops over units on the
+ * host): unit u owns positions [unit_bounds[u], unit_bounds[u + 1]) of the input and the table region
+ * [region_base[u], region_base[u + 1]) - a power of two of slots, at least twice the unit's rows; table_cap =
+ * region_base[n_units] (device arrays of n_units + 1 entries).  A key is looked up inside its unit's region only, so
+ * the non-empty slots in ascending order are the groups in unit order. */
+int hs_group_build_units(void* stream, const hs_col* key, const int64_t* sel, int64_t row0, int64_t n,
+                         const int64_t* unit_bounds, const int64_t* region_base, int32_t n_units, int64_t table_cap,
+                         uint64_t* table_keys, int64_t* table_reps, int64_t* slot_start, int64_t* positions, void* ws,
+                         uint32_t* flags);
+/* out[q] = how many elements of the ascending list sorted[0 .. n) are < queries[q] (device arrays; n_dev optional). */
+int hs_lower_bound_i64(void* stream, const int64_t* sorted, int64_t n, const int64_t* n_dev, const int64_t* queries,
+                       int64_t n_queries, int64_t* out);
 /* mask[s] = 1 for non-empty slots (compact it with hs_compact to get the dense slot list). */
 int hs_group_mask(void* stream, const int64_t* slot_start, int64_t table_cap, uint8_t* mask);
 /* One lane per group folds val_cols[a][position] over the group's positions front to back - the reference's

@@ -998,6 +998,32 @@ __global__ void __launch_bounds__(256) k_join_slots(const hs_col key, const int6
         else if (!inserted) atomicAdd((unsigned long long*)&slot_extra[s], 1ull);  // rows beyond a slot's first
     }
 }
+// The same with one table REGION per unit: position i belongs to the unit whose position range holds it (binary search
+// over unit_bounds), its key is looked up inside that unit's region [region_base[u], region_base[u + 1]) (a power of
+// two of slots) only - so every slot belongs to one unit, and walking the slots in order walks the groups unit by
+// unit.  One build over a whole batch instead of one per unit (hs_group_build_units).
+__global__ void __launch_bounds__(256) k_join_slots_units(const hs_col key, const int64_t* sel, int64_t row0, int64_t n,
+                                                          const int64_t* unit_bounds, const int64_t* region_base,
+                                                          int32_t n_units, uint64_t* tkeys, int64_t* treps,
+                                                          int64_t* slot_of_row, int64_t* slot_extra, uint32_t* flags) {
+    const bool hashed = !hs_col_packs(key);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int lo = 0, hi = n_units;  // last unit whose first position is <= i
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (unit_bounds[mid] <= i) lo = mid;
+            else hi = mid;
+        }
+        const int64_t base = region_base[lo], size = region_base[lo + 1] - base;
+        const int64_t row = sel ? sel[i] : row0 + i;
+        bool inserted;
+        int64_t s = size > 0 ? gdict_upsert(tkeys + base, treps + base, (uint64_t)size - 1, key, hashed, hs_key_at(key, row), row, inserted) : -1;
+        if (s >= 0) s += base;
+        slot_of_row[i] = s;
+        if (s < 0) atomicOr(flags, HS_FLAG_DICT_FULL);
+        else if (!inserted) atomicAdd((unsigned long long*)&slot_extra[s], 1ull);
+    }
+}
 // rows of slot s = 1 for the row that claimed it + slot_extra[s]
 struct InSlotCount {
     const uint64_t* tkeys;
@@ -1102,7 +1128,8 @@ extern "C" size_t hs_join_build_ws_bytes(int64_t n_left, int64_t table_cap) {
 
 static int group_build(void* stream, const hs_col* left_key, const int64_t* sel, int64_t row0, int64_t n_left,
                        int64_t table_cap, uint64_t* table_keys, int64_t* table_reps, int64_t* slot_start, int64_t* rows,
-                       void* ws, uint32_t* flags);
+                       void* ws, uint32_t* flags, const int64_t* unit_bounds = nullptr, const int64_t* region_base = nullptr,
+                       int32_t n_units = 0);
 
 extern "C" int hs_join_build(void* stream, const hs_col* left_key, int64_t n_left, int64_t table_cap,
                              uint64_t* table_keys, int64_t* table_reps, int64_t* slot_start, int64_t* rows, void* ws,
@@ -1119,11 +1146,27 @@ extern "C" int hs_group_build(void* stream, const hs_col* key, const int64_t* se
     return group_build(stream, key, sel, row0, n, table_cap, table_keys, table_reps, slot_start, positions, ws, flags);
 }
 
+// One build over every unit of a batch (the HBM tier of GROUP BY in a single pass): unit u owns positions
+// [unit_bounds[u], unit_bounds[u + 1]) and the table region [region_base[u], region_base[u + 1]) - a power of two of
+// slots, at least twice the unit's rows; table_cap = region_base[n_units].  Slots in ascending order are groups in
+// unit order.
+extern "C" int hs_group_build_units(void* stream, const hs_col* key, const int64_t* sel, int64_t row0, int64_t n,
+                                    const int64_t* unit_bounds, const int64_t* region_base, int32_t n_units,
+                                    int64_t table_cap, uint64_t* table_keys, int64_t* table_reps, int64_t* slot_start,
+                                    int64_t* positions, void* ws, uint32_t* flags) {
+    if (!unit_bounds || !region_base || n_units < 1) {
+        hs_set_error("hs_group_build_units: bad unit description");
+        return HS_E_ARG;
+    }
+    return group_build(stream, key, sel, row0, n, table_cap, table_keys, table_reps, slot_start, positions, ws, flags,
+                       unit_bounds, region_base, n_units);
+}
+
 static int group_build(void* stream, const hs_col* left_key, const int64_t* sel, int64_t row0, int64_t n_left,
                        int64_t table_cap, uint64_t* table_keys, int64_t* table_reps, int64_t* slot_start, int64_t* rows,
-                       void* ws, uint32_t* flags) {
+                       void* ws, uint32_t* flags, const int64_t* unit_bounds, const int64_t* region_base, int32_t n_units) {
     if (!left_key || !table_keys || !table_reps || !slot_start || (!rows && n_left > 0) || !ws || !flags ||
-        n_left < 0 || table_cap < 1 || (table_cap & (table_cap - 1))) {
+        n_left < 0 || table_cap < 1 || (!unit_bounds && (table_cap & (table_cap - 1)))) {
         hs_set_error("hs_join_build: bad arguments (table_cap must be a power of two)");
         return HS_E_ARG;
     }
@@ -1136,7 +1179,10 @@ static int group_build(void* stream, const hs_col* left_key, const int64_t* sel,
     hipLaunchKernelGGL(k_fill_u64, dim3(grid_for(table_cap, 256)), dim3(256), 0, s, (uint64_t*)table_reps, table_cap,
                        ~0ull);
     hs_memset_async(slot_count, 0, (size_t)table_cap * 16, s);  // slot_count + cursor
-    if (n_left > 0)
+    if (n_left > 0 && unit_bounds)
+        hipLaunchKernelGGL(k_join_slots_units, dim3(grid_for(n_left, 256)), dim3(256), 0, s, *left_key, sel, row0, n_left,
+                           unit_bounds, region_base, n_units, table_keys, table_reps, slot_of_row, slot_count, flags);
+    else if (n_left > 0)
         hipLaunchKernelGGL(k_join_slots, dim3(grid_for(n_left, 256)), dim3(256), 0, s, *left_key, sel, row0, n_left,
                            table_cap, table_keys, table_reps, slot_of_row, slot_count, flags);
     int rc = run_scan(s, InSlotCount{table_keys, table_reps, slot_count, !hs_col_packs(*left_key)}, table_cap,
@@ -1160,6 +1206,38 @@ static int group_build(void* stream, const hs_col* left_key, const int64_t* sel,
                            long_count);
     }
     HS_CHECK_LAUNCH("hs_join_build");
+    return HS_OK;
+}
+
+// out[q] = number of elements of the ascending list sorted[0 .. n) that are < queries[q] (lower bound): unit
+// boundaries inside a row-index list, groups per unit inside a slot list.  n_dev (optional) caps n.
+__global__ void __launch_bounds__(256) k_lower_bound_i64(const int64_t* sorted, int64_t n, const int64_t* n_dev,
+                                                         const int64_t* queries, int64_t nq, int64_t* out) {
+    if (n_dev) {
+        const int64_t d = *n_dev;
+        n = d < n ? d : n;
+    }
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t x = queries[q];
+        int64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (sorted[mid] < x) lo = mid + 1;
+            else hi = mid;
+        }
+        out[q] = lo;
+    }
+}
+extern "C" int hs_lower_bound_i64(void* stream, const int64_t* sorted, int64_t n, const int64_t* n_dev,
+                                  const int64_t* queries, int64_t n_queries, int64_t* out) {
+    if ((!sorted && n > 0) || !queries || !out || n < 0 || n_queries < 0) {
+        hs_set_error("hs_lower_bound_i64: bad arguments");
+        return HS_E_ARG;
+    }
+    if (n_queries > 0)
+        hipLaunchKernelGGL(k_lower_bound_i64, dim3(grid_for(n_queries, 256)), dim3(256), 0, (hipStream_t)stream, sorted, n, n_dev,
+                           queries, n_queries, out);
+    HS_CHECK_LAUNCH("hs_lower_bound_i64");
     return HS_OK;
 }
 

@@ -1330,11 +1330,20 @@ class Device:
             cols.append(DCol(hs.I64, raw, n_groups) if integer else DCol(hs.F64, raw.view(torch.float64), n_groups))
         return rep_row, cols
 
+    def lower_bound(self, sorted_list: torch.Tensor, n: int, queries: torch.Tensor) -> torch.Tensor:
+        """out[q] = number of elements of the ascending list sorted_list[:n] that are < queries[q] (device)."""
+        out = self.empty(queries.numel(), torch.int64)
+        hs.check(self.lib.hs_lower_bound_i64(self.stream, sorted_list.data_ptr() if n > 0 else None, n, None,
+                                             queries.data_ptr(), queries.numel(), out.data_ptr()), "hs_lower_bound_i64")
+        return out
+
     def aggregate_partial_global(self, batch: DBatch, filters: Sequence[Any], group_by: Any,
                                  agg_columns: Sequence[Any], out_schema: Schema) -> DBatch:
-        """Partial aggregate for any number of groups: per unit, an HBM dictionary over the surviving rows'
-        keys with per-group row lists, then one lane per group folds the aggregate arguments in row order
-        (bit-identical to the reference's sequential Python sums).  Used when the on-chip tiers do not fit."""
+        """Partial aggregate for any number of groups, ONE pass over all units: an HBM dictionary with one table region
+        per unit over the surviving rows' keys, per-group row lists in ascending row order, then one lane per group
+        folds the aggregate arguments in row order (bit-identical to the reference's sequential Python sums).  Used
+        when the on-chip tiers do not fit.  (Round 1 looped over the units on the host: a dozen launches and two
+        host round trips per file block.)"""
         from .lowering import AGG_CODES, expr_key, unalias  # noqa: PLC0415
 
         batch = self.resolve(batch)
@@ -1350,46 +1359,57 @@ class Device:
                 args.append(agg.original_col)
                 ops.append(AGG_CODES[agg.type])
             agg_to_acc.append(acc_of[ident])
+        n_units = batch.n_units
+        d_unit_rows = self.to_device(np.asarray(batch.unit_rows, dtype=np.int64))
         if filters:
-            sel_all, count = self.filter_select(batch, filters)
-            bounds = torch.searchsorted(sel_all[:count].contiguous(),
-                                        torch.tensor(batch.unit_rows, dtype=torch.int64, device=self.device)).tolist()
+            sel, n = self.filter_select(batch, filters)  # ascending row list + its length (the pass's first read-back)
+            bounds = self.lower_bound(sel, n, d_unit_rows)  # unit boundaries as POSITIONS in the row list
         else:
-            sel_all, bounds = None, list(batch.unit_rows)
-        key_parts: list[DCol] = []
-        acc_parts: list[list[DCol]] = [[] for _ in args]
-        unit_rows = [0]
-        for u in range(batch.n_units):
-            lo, hi = int(bounds[u]), int(bounds[u + 1])
-            n = hi - lo
-            if n > 0:
-                sel = sel_all[lo:hi] if sel_all is not None else torch.arange(lo, hi, dtype=torch.int64, device=self.device)
-                sel = sel.contiguous()
-                vals = self.eval_numeric(batch, args, sel=sel, n=n)
-                is_int = [tag in ("I", "B") for _, tag in vals]
-                slot_start, positions, slot_list, ng = self._group_build(batch.cols[key_idx], sel, n)
-                rep_row, cols = self._group_fold([v for v, _ in vals], ops, is_int, slot_start, positions, slot_list, ng,
-                                                 sel, quantise=True)
-                key_parts.append(self.gather_col(batch.cols[key_idx], rep_row, ng))
-                types = [ColumnType.INTEGER if i else ColumnType.FLOAT for i in is_int]
-                for a, col in enumerate(self.quantise_cols(cols, types)):
-                    acc_parts[a].append(col)
-                unit_rows.append(unit_rows[-1] + ng)
-            else:
-                unit_rows.append(unit_rows[-1])
-        total = unit_rows[-1]
-        if total == 0:
-            empty_key = self.gather_col(batch.cols[key_idx], self.empty(0, torch.int64), 0)
+            sel, n, bounds = None, batch.nrows, d_unit_rows
+        key = batch.cols[key_idx]
+        if n == 0:
+            empty_key = self.gather_col(key, self.empty(0, torch.int64), 0)
             out_cols = [empty_key] + [DCol(FILE_KIND[t], self.empty(0, _TORCH_DTYPE[FILE_KIND[t]]), 0)
                                       for _, t in out_schema[1:]]
-            return DBatch(list(out_schema), out_cols, 0, unit_rows)
-        key_col = self.concat_cols(key_parts)
-        accs = [self.concat_cols(parts) for parts in acc_parts]
+            return DBatch(list(out_schema), out_cols, 0, [0] * (n_units + 1))
+        vals = self.eval_numeric(batch, args, sel=sel, n=n)
+        is_int = [tag in ("I", "B") for _, tag in vals]
+        # one table region per unit, sized from the unit's UNFILTERED rows (known on the host): >= 2 slots per row
+        region_base = [0]
+        for u in range(n_units):
+            rows_u, size = batch.unit_rows[u + 1] - batch.unit_rows[u], 16
+            while size < 2 * rows_u:
+                size *= 2
+            region_base.append(region_base[-1] + (size if rows_u > 0 else 0))
+        cap = max(region_base[-1], 16)
+        d_region_base = self.to_device(np.asarray(region_base, dtype=np.int64))
+        tkeys, treps = self.empty(cap, torch.int64), self.empty(cap, torch.int64)
+        slot_start, positions = self.empty(cap + 1, torch.int64), self.empty(max(n, 1), torch.int64)
+        ws = self.workspace(self.lib.hs_join_build_ws_bytes(n, cap))
+        k = key.as_hs()
+        hs.check(self.lib.hs_group_build_units(self.stream, C.byref(k), sel.data_ptr() if sel is not None else None, 0, n,
+                                               bounds.data_ptr(), d_region_base.data_ptr(), n_units, cap, tkeys.data_ptr(),
+                                               treps.data_ptr(), slot_start.data_ptr(), positions.data_ptr(), ws.data_ptr(),
+                                               self.flags.data_ptr()), "hs_group_build_units")
+        mask = self.empty(cap, torch.uint8)
+        hs.check(self.lib.hs_group_mask(self.stream, slot_start.data_ptr(), cap, mask.data_ptr()), "hs_group_mask")
+        slot_list, d_groups = self.empty(cap, torch.int64), self.empty(1, torch.int64)
+        ws2 = self.workspace(self.lib.hs_scan_ws_bytes(cap))
+        hs.check(self.lib.hs_compact(self.stream, mask.data_ptr(), cap, slot_list.data_ptr(), d_groups.data_ptr(),
+                                     ws2.data_ptr()), "hs_compact")
+        ng = self.host_int(d_groups)  # sizes the outputs (second read-back)
+        rep_row, cols = self._group_fold([v for v, _ in vals], ops, is_int, slot_start, positions, slot_list, ng, sel,
+                                         quantise=True)
+        key_col = self.gather_col(key, rep_row, ng)
+        types = [ColumnType.INTEGER if i else ColumnType.FLOAT for i in is_int]
+        accs = self.quantise_cols(cols, types)
+        # groups per unit: the slot list is ascending, a unit's groups sit in its region
+        unit_rows = [int(v) for v in self.lower_bound(slot_list, ng, d_region_base).tolist()]
         order = None
         if batch.unit_ids is not None:  # multi-GPU: remember which global unit every partial row came from
-            counts = torch.tensor([unit_rows[u + 1] - unit_rows[u] for u in range(batch.n_units)], device=self.device)
+            counts = torch.tensor([unit_rows[u + 1] - unit_rows[u] for u in range(n_units)], device=self.device)
             order = torch.repeat_interleave(torch.tensor(batch.unit_ids, dtype=torch.int64, device=self.device), counts)
-        return DBatch(list(out_schema), [key_col] + [accs[a] for a in agg_to_acc], total, unit_rows, order=order,
+        return DBatch(list(out_schema), [key_col] + [accs[a] for a in agg_to_acc], ng, unit_rows, order=order,
                       total_units=batch.total_units)
 
     def aggregate_merge_global(self, batch: DBatch, agg_columns: Sequence[Any], out_schema: Schema) -> DBatch:

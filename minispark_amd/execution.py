@@ -953,15 +953,15 @@ class HipExecutionEngine(ExecutionEngine):
         """Apply deferred WHERE conditions: compaction to a row list, then gather every column."""
         if not pending:
             return batch
-        import torch  # noqa: PLC0415
+        import numpy as np  # noqa: PLC0415
 
         from . import hipspark as hs  # noqa: PLC0415
         from .device import DCol  # noqa: PLC0415
 
         batch = self.dev.resolve(batch)
         sel, count = self.dev.filter_select(batch, pending)
-        bounds = torch.tensor(batch.unit_rows, dtype=torch.int64, device=sel.device)
-        unit_rows = [int(v) for v in torch.searchsorted(sel[:count].contiguous(), bounds).tolist()]
+        bounds = self.dev.to_device(np.asarray(batch.unit_rows, dtype=np.int64))
+        unit_rows = [int(v) for v in self.dev.lower_bound(sel, count, bounds).tolist()]
         out = self.dev.gather_batch(batch, sel, count, unit_rows)
         out.unit_ids, out.total_units, out.partitioned = batch.unit_ids, batch.total_units, batch.partitioned
         if batch.order is not None:

@@ -202,6 +202,8 @@ SIGNATURES: dict[str, tuple] = {
     "hs_join_build_ws_bytes": (C.c_size_t, [_I64, _I64]),
     "hs_join_build": (C.c_int, [_P, _COLP, _I64, _I64, _P, _P, _P, _P, _P, _P]),
     "hs_group_build": (C.c_int, [_P, _COLP, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P]),
+    "hs_group_build_units": (C.c_int, [_P, _COLP, _P, _I64, _I64, _P, _P, _I32, _I64, _P, _P, _P, _P, _P, _P]),
+    "hs_lower_bound_i64": (C.c_int, [_P, _P, _I64, _P, _P, _I64, _P]),
     "hs_group_mask": (C.c_int, [_P, _P, _I64, _P]),
     "hs_group_fold": (C.c_int, [_P, _COLP, _SPECP, _P, _I64, _P, _P, _P, _P, _I64, _I32, _P, _P, _P]),
     "hs_join_count": (C.c_int, [_P, _COLP, _COLP, _I64, _I64, _P, _P, _P, _P]),
