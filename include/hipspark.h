@@ -596,6 +596,18 @@ int hs_result_write_blockfile(const hs_stage* stage, const char* path);
  * `stream` - no argument marshalling, validation or JIT look-ups - and is valid while the buffers the captured calls
  * were given stay alive and in place.  *n_ops (optional) = launches captured.
  * ===============================================================================================*/
+/* Per-launch GPU slices for the query trace (reference utils.py:85-135 wraps stages and jobs in perfetto slices and
+ * merges the workers' traces, :69-79): between hs_trace_begin(stream) and hs_trace_end(stream, ...) every launch of
+ * the library on THIS thread - first runs and captured replays alike - is bracketed by an event pair on the launch
+ * stream.  hs_trace_end waits for the stream and returns the launches in order: kernel name, start and duration in
+ * microseconds relative to the moment of hs_trace_begin on the stream. */
+typedef struct hs_trace_slice {
+    char name[96];
+    double start_us, dur_us;
+} hs_trace_slice;
+int hs_trace_begin(void* stream);
+int hs_trace_end(void* stream, hs_trace_slice* out, int32_t cap, int32_t* n);
+
 int hs_capture_begin(void);
 int hs_capture_end(void** handle, int32_t* n_ops);
 int hs_capture_replay(void* handle, void* stream);

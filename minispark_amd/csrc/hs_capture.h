@@ -40,6 +40,32 @@ struct HsCapture {
 };
 inline thread_local HsCapture* g_hs_capture = nullptr;
 
+// ---- per-launch GPU slices for the query trace (hs_trace_begin / hs_trace_end; reference utils.py:85-135) ----------
+struct HsTraceLaunch {
+    const void* fn = nullptr;     // host stub (name via hipKernelNameRefByPtr) ...
+    hipFunction_t mfn = nullptr;  // ... or module function (hipKernelNameRef)
+    hipEvent_t begin = nullptr, end = nullptr;
+};
+struct HsTrace {
+    hipEvent_t base = nullptr;
+    std::vector<HsTraceLaunch> launches;
+};
+inline thread_local HsTrace* g_hs_trace = nullptr;
+
+inline HsTraceLaunch* hs_trace_open(const void* fn, hipFunction_t mfn, hipStream_t stream) {
+    if (!g_hs_trace) return nullptr;
+    HsTraceLaunch t;
+    t.fn = fn;
+    t.mfn = mfn;
+    if (hipEventCreate(&t.begin) != hipSuccess || hipEventCreate(&t.end) != hipSuccess) return nullptr;
+    (void)hipEventRecord(t.begin, stream);
+    g_hs_trace->launches.push_back(t);
+    return &g_hs_trace->launches.back();
+}
+inline void hs_trace_close(HsTraceLaunch* t, hipStream_t stream) {
+    if (t) (void)hipEventRecord(t->end, stream);
+}
+
 template <typename Tuple, size_t... I>
 inline void hs_tuple_addresses(Tuple& t, std::vector<void*>& out, std::index_sequence<I...>) {
     (out.push_back((void*)&std::get<I>(t)), ...);
@@ -58,7 +84,9 @@ inline void hs_launch(void (*kernel)(K...), dim3 grid, dim3 block, size_t lds, h
         op.lds = lds;
         hs_tuple_addresses(*held, op.argv, std::index_sequence_for<K...>{});
         op.hold = held;
+        HsTraceLaunch* tr = hs_trace_open(op.fn, nullptr, stream);
         (void)hipLaunchKernel(op.fn, grid, block, op.argv.data(), lds, stream);
+        hs_trace_close(tr, stream);
         g_hs_capture->ops.push_back(std::move(op));
         return;
     }
@@ -69,7 +97,9 @@ inline void hs_launch(void (*kernel)(K...), dim3 grid, dim3 block, size_t lds, h
         hs_tuple_addresses(args, tmp, std::index_sequence_for<K...>{});
         for (size_t i = 0; i < tmp.size(); ++i) argv[i] = tmp[i];
     }
+    HsTraceLaunch* tr = hs_trace_open((const void*)kernel, nullptr, stream);
     (void)hipLaunchKernel((const void*)kernel, grid, block, argv, lds, stream);
+    hs_trace_close(tr, stream);
 }
 
 inline hipError_t hs_module_launch(hipFunction_t fn, unsigned grid, unsigned block, size_t lds, hipStream_t stream,
@@ -77,7 +107,9 @@ inline hipError_t hs_module_launch(hipFunction_t fn, unsigned grid, unsigned blo
     std::vector<char> blob((const char*)args, (const char*)args + size);
     size_t sz = size;
     void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, blob.data(), HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+    HsTraceLaunch* tr = hs_trace_open(nullptr, fn, stream);
     const hipError_t rc = hipModuleLaunchKernel(fn, grid, 1, 1, block, 1, 1, (unsigned)lds, stream, nullptr, extra);
+    hs_trace_close(tr, stream);
     if (rc == hipSuccess && g_hs_capture) {
         HsCapOp op;
         op.kind = HsCapOp::MODULE;

@@ -8,6 +8,7 @@
 // gathers.  That keeps one implementation per reference loop (cited at each kernel).
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 
 #include "hs_agg_kernel.h"
 
@@ -67,11 +68,18 @@ extern "C" int hs_capture_replay(void* handle, void* stream) {
     for (HsCapOp& op : ((HsCapture*)handle)->ops) {
         hipError_t rc = hipSuccess;
         switch (op.kind) {
-            case HsCapOp::KERNEL: rc = hipLaunchKernel(op.fn, op.grid, op.block, op.argv.data(), op.lds, s); break;
+            case HsCapOp::KERNEL: {
+                HsTraceLaunch* tr = hs_trace_open(op.fn, nullptr, s);
+                rc = hipLaunchKernel(op.fn, op.grid, op.block, op.argv.data(), op.lds, s);
+                hs_trace_close(tr, s);
+                break;
+            }
             case HsCapOp::MODULE: {
                 size_t sz = op.blob.size();
                 void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, op.blob.data(), HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+                HsTraceLaunch* tr = hs_trace_open(nullptr, op.mfn, s);
                 rc = hipModuleLaunchKernel(op.mfn, op.grid.x, 1, 1, op.block.x, 1, 1, (unsigned)op.lds, s, nullptr, extra);
+                hs_trace_close(tr, s);
                 break;
             }
             case HsCapOp::EVENT: rc = hipEventRecord(op.ev, s); break;
@@ -85,6 +93,50 @@ extern "C" int hs_capture_replay(void* handle, void* stream) {
     return HS_OK;
 }
 extern "C" void hs_capture_free(void* handle) { delete (HsCapture*)handle; }
+
+// ---- per-launch GPU slices (N4: the trace bridge) -------------------------------------------------------------------
+extern "C" int hs_trace_begin(void* stream) {
+    if (g_hs_trace) {
+        hs_set_error("hs_trace_begin: a trace is already open on this thread");
+        return HS_E_ARG;
+    }
+    HsTrace* t = new HsTrace();
+    if (hipEventCreate(&t->base) != hipSuccess || hipEventRecord(t->base, (hipStream_t)stream) != hipSuccess) {
+        delete t;
+        hs_set_error("hs_trace_begin: cannot record the base event");
+        return HS_E_LAUNCH;
+    }
+    g_hs_trace = t;
+    return HS_OK;
+}
+extern "C" int hs_trace_end(void* stream, hs_trace_slice* out, int32_t cap, int32_t* n) {
+    if (!g_hs_trace || !n || (cap > 0 && !out)) {
+        hs_set_error("hs_trace_end: no open trace");
+        return HS_E_ARG;
+    }
+    HsTrace* t = g_hs_trace;
+    g_hs_trace = nullptr;
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    int32_t k = 0;
+    for (HsTraceLaunch& l : t->launches) {
+        float t0 = 0.f, t1 = 0.f;
+        const bool ok = hipEventElapsedTime(&t0, t->base, l.begin) == hipSuccess && hipEventElapsedTime(&t1, t->base, l.end) == hipSuccess;
+        if (ok && k < cap) {
+            const char* name = l.fn ? hipKernelNameRefByPtr(l.fn, (hipStream_t)stream) : hipKernelNameRef(l.mfn);
+            strncpy(out[k].name, name ? name : "?", sizeof(out[k].name) - 1);
+            out[k].name[sizeof(out[k].name) - 1] = 0;
+            out[k].start_us = (double)t0 * 1e3;
+            out[k].dur_us = (double)(t1 - t0) * 1e3;
+            ++k;
+        }
+        (void)hipEventDestroy(l.begin);
+        (void)hipEventDestroy(l.end);
+    }
+    (void)hipEventDestroy(t->base);
+    *n = k;
+    delete t;
+    return HS_OK;
+}
 
 #define HS_CHECK_LAUNCH(name)                                                              \
     do {                                                                                   \

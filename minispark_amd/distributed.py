@@ -148,6 +148,19 @@ def exchange_counts(dist: Any, send_counts: list[int], device: torch.device, gro
     return [int(v) for v in out.tolist()]
 
 
+def exchange_size_matrix(dist: Any, mine: list[list[int]], device: torch.device, group: Any = None) -> list[list[int]]:
+    """mine[d] = the k sizes this rank sends to rank d (rows, payload bytes ...); -> theirs[s] = the k sizes rank s
+    sends here.  One tiny all-to-all (+ the read-back the split sizes of the data collective need anyway)."""
+    world, k = len(mine), len(mine[0]) if mine else 0
+    backend = dist.get_backend(group)
+    dev = torch.device("cpu") if backend == "gloo" else device
+    inp = torch.tensor(mine, dtype=torch.int64, device=dev).reshape(world * k)
+    out = torch.empty(world * k, dtype=torch.int64, device=dev)
+    dist.all_to_all_single(out, inp, group=group)
+    flat = [int(v) for v in out.tolist()]
+    return [flat[s * k: (s + 1) * k] for s in range(world)]
+
+
 def all_to_all_rows(dist: Any, send: torch.Tensor, send_counts: list[int], recv_counts: list[int], elems_per_row: int = 1,
                     group: Any = None) -> torch.Tensor:
     """Rows of ``send`` are grouped by destination rank (send_counts rows each); returns the rows received,

@@ -146,6 +146,10 @@ class hs_stage_plan(C.Structure):
     ]
 
 
+class hs_trace_slice(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("start_us", C.c_double), ("dur_us", C.c_double)]
+
+
 class hs_result_col(C.Structure):
     _fields_ = [("kind", C.c_int32), ("width", C.c_int32), ("data", C.c_void_p), ("n_rows", C.c_int64)]
 
@@ -248,6 +252,8 @@ SIGNATURES: dict[str, tuple] = {
     "hs_stage_stats": (C.c_int, [_P, C.POINTER(_I64)]),
     "hs_result_columns": (C.c_int, [_P, C.POINTER(hs_result_col), _I32, C.POINTER(_I32)]),
     "hs_result_write_blockfile": (C.c_int, [_P, C.c_char_p]),
+    "hs_trace_begin": (C.c_int, [_P]),
+    "hs_trace_end": (C.c_int, [_P, C.POINTER(hs_trace_slice), _I32, C.POINTER(_I32)]),
     "hs_capture_begin": (C.c_int, []),
     "hs_capture_end": (C.c_int, [C.POINTER(_P), C.POINTER(_I32)]),
     "hs_capture_replay": (C.c_int, [_P, _P]),

@@ -5,6 +5,11 @@ Same call surface - ``new_track``, ``start``, ``end``, ``save`` - but the output
 format, which https://ui.perfetto.dev opens directly and needs no protobuf dependency.  The HIP engine records a
 span per query, per stage and per replayed launch sequence on the host track, and the scan kernel's duration
 (HIP events) on a GPU track, when constructed with ``trace_file=...`` or run with ``HIPSPARK_TRACE=<file>``.
+
+Round 2: EVERY launch of a traced query - scan, unit combine, finish, gathers, join build / probe,
+partition ... also inside replayed recordings - appears as a slice on the GPU track (the library brackets its launches
+with event pairs between hs_trace_begin / hs_trace_end, include/hipspark.h), and ``add_rocprof_kernel_trace`` merges a
+rocprofv3 kernel-trace CSV as a further track.
 """
 
 from __future__ import annotations
@@ -48,6 +53,28 @@ class Tracer:
         if args:
             ev["args"] = args
         self.events.append(ev)
+
+    def add_rocprof_kernel_trace(self, csv_path: str | Path, track_name: str = "GPU (rocprofv3 --kernel-trace)",
+                                 align_to_ns: int | None = None) -> int:
+        """Merge a ``rocprofv3 --kernel-trace --output-format csv`` file as one more GPU track (the reference merges
+        its workers' trace files the same way, utils.py:69-79).  rocprofv3 stamps kernels on its own clock: the
+        first kernel is placed at ``align_to_ns`` (default: the start of the first slice already in this trace).
+        -> number of kernels added."""
+        import csv  # noqa: PLC0415
+
+        rows = sorted(csv.DictReader(open(csv_path)), key=lambda r: int(r["Start_Timestamp"]))
+        if not rows:
+            return 0
+        if align_to_ns is None:
+            starts = [e["ts"] for e in self.events if e.get("ph") == "X"]
+            align_to_ns = int(min(starts) * 1e3) if starts else time.time_ns()
+        shift = align_to_ns - int(rows[0]["Start_Timestamp"])
+        track = self.new_track(track_name)
+        for r in rows:
+            t0, t1 = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            self.complete(r["Kernel_Name"][:96], t0 + shift, t1 - t0, track, grid=r.get("Grid_Size_X", r.get("Grid_Size", "")),
+                          workgroup=r.get("Workgroup_Size_X", r.get("Workgroup_Size", "")))
+        return len(rows)
 
     def save(self, filename: str | Path) -> None:
         Path(filename).write_text(json.dumps({"traceEvents": self.events, "displayTimeUnit": "ns"}))

@@ -78,3 +78,36 @@ def test_block_ownership():
     assert local_blocks(7, 1, 2) == [1, 3, 5]
     assert sorted(b for r in range(8) for b in local_blocks(287, r, 8)) == list(range(287))
     assert max_local_units(287, 8) == 36 and max_local_units(6, 2) == 3 and max_local_units(1, 8) == 1
+
+
+def _matrix_worker(rank: int, world: int, port: int, result):
+    from minispark_amd.distributed import all_to_all_rows, exchange_size_matrix
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # rank r sends to rank d: (10 * r + d) rows and (100 * r + d) payload bytes
+    mine = [[10 * rank + d, 100 * rank + d] for d in range(world)]
+    theirs = exchange_size_matrix(dist, mine, torch.device("cpu"))
+    # the data collective with those split sizes: one byte buffer, destination-major
+    send_counts = [m[0] for m in mine]
+    recv_counts = [t[0] for t in theirs]
+    send = torch.cat([torch.full((c,), 16 * rank + d, dtype=torch.uint8) for d, c in enumerate(send_counts)])
+    got = all_to_all_rows(dist, send, send_counts, recv_counts, 1)
+    result[rank] = (theirs, got.tolist())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_size_matrix_and_single_data_collective_world3():
+    """The generic row exchange's two collectives (execution._exchange_rows): a size matrix, then ONE all-to-all of
+    bytes with those split sizes - under gloo on CPU, world 3."""
+    world = 3
+    manager = mp.Manager()
+    result = manager.dict()
+    mp.spawn(_matrix_worker, args=(world, _free_port(), result), nprocs=world, join=True)
+    for r in range(world):
+        theirs, got = result[r]
+        assert theirs == [[10 * s + r, 100 * s + r] for s in range(world)]
+        want = [v for s in range(world) for v in [16 * s + r] * (10 * s + r)]
+        assert got == want

@@ -180,6 +180,34 @@ def test_trace_file_holds_query_stage_replay_and_kernel_slices(tmp_path):
     assert any(n.startswith("replay") for n in names)
     kernels = [e for e in events if e["ph"] == "X" and e["name"].startswith("scan kernel")]
     assert len(kernels) == 4 and all(0 < e["dur"] < 1e5 and e["args"]["rows"] == 300_000 for e in kernels)
+    # every launch of every run (first runs and captured replays) as its own GPU slice: scan kernel + finish launch
+    track_names = {e["tid"]: e["args"]["name"] for e in events if e["ph"] == "M"}
+    gpu = [e for e in events if e["ph"] == "X" and "every launch" in track_names.get(e["tid"], "")]
+    scans = [e for e in gpu if e["name"].startswith(("k_agg_jit", "void k_agg_main"))]
+    finishes = [e for e in gpu if "k_agg_finish" in e["name"]]
+    assert len(scans) == 4 and len(finishes) == 4 and all(e["dur"] > 0 for e in scans + finishes)
+    for sc, fi in zip(scans, finishes):
+        assert fi["ts"] >= sc["ts"] + sc["dur"] - 1e-3  # in stream order, not overlapping
+
+
+def test_rocprof_kernel_trace_merges_into_a_trace(tmp_path):
+    """Tracer.add_rocprof_kernel_trace: a rocprofv3 --kernel-trace CSV becomes one more GPU track."""
+    import json
+
+    from minispark_amd.tracing import Tracer
+
+    csv_path = tmp_path / "kernel_trace.csv"
+    csv_path.write_text("Kind,Agent_Id,Queue_Id,Kernel_Id,Kernel_Name,Start_Timestamp,End_Timestamp,Grid_Size_X,Workgroup_Size_X\n"
+                        "KERNEL_DISPATCH,1,1,7,k_agg_jit,1000000,1300000,192512,256\n"
+                        "KERNEL_DISPATCH,1,1,9,void k_agg_finish<true>(AggFinishArgs),1305000,1326000,256,256\n")
+    tr = Tracer()
+    tr.start("query")
+    tr.end()
+    assert tr.add_rocprof_kernel_trace(csv_path) == 2
+    tr.save(tmp_path / "t.json")
+    events = json.loads((tmp_path / "t.json").read_text())["traceEvents"]
+    merged = [e for e in events if e["ph"] == "X" and e["name"].startswith(("k_agg_jit", "void k_agg_finish"))]
+    assert [round(e["dur"]) for e in merged] == [300, 21] and merged[1]["ts"] - merged[0]["ts"] == pytest.approx(305.0)
 
 
 def test_capacity_hints_are_per_query_shape(tmp_path):
