@@ -130,6 +130,9 @@ class HipExecutionEngine(ExecutionEngine):
         self.fused_join_enabled = os.environ.get("HIPSPARK_FUSED_JOIN", "1") != "0"
         self._no_fused_join: set[Any] = set()  # join task ids whose build side turned out to hold duplicate keys
         self._fused_join_tasks: set[Any] = set()  # join task ids the running query took the in-place path for
+        budget = os.environ.get("HIPSPARK_HBM_BUDGET")
+        self.hbm_budget: int | None = int(float(budget)) if budget else None  # bytes of referenced columns kept resident
+        self.streamed_ranges = 0
         self._version = 0  # bumped by everything that could invalidate a validated recording (see _execute_full_task)
         self.fused_joins = 0
         self._no_short_tail: set[Any] = set()  # partial AggregateTask ids that must take the general path
@@ -494,6 +497,9 @@ class HipExecutionEngine(ExecutionEngine):
         producer, consumers, writer = stage.producer, list(stage.consumers), stage.writer
         kind = _cls(producer)
         if kind == "LoadTableBlockTask":
+            ranges = self._stream_ranges(producer, consumers)
+            if ranges is not None:
+                return self._run_scan_stage_streamed(stage, outputs, ranges)
             batch = self._scan(producer, consumers, writer)
         elif kind == "LoadShuffleFilesTask":
             batch = outputs[id(stage.dependencies[0])]
@@ -508,6 +514,25 @@ class HipExecutionEngine(ExecutionEngine):
                                self._needed_names(consumers), feeds_aggregate)
         else:
             raise NotImplementedError(f"Job creation not implemented for {type(producer)}")
+
+        batch = self._consume(batch, consumers)
+
+        wname = _cls(writer)
+        schema = writer.inferred_schema
+        if wname == "WriteToShufflePartitions":
+            # the "shuffle file" stays in HBM; data-dependent errors surface at the query's final read-back
+            outputs[id(stage)] = batch if batch.tail is not None else self._quantise_batch(batch, schema)
+            self._job_seq += 1
+            return [JobResult(f"{self._job_prefix}-{self._job_seq}", self._executor_id, [])]
+        if wname == "WriteToLocalFileTask":
+            if self.dist is not None and batch.partitioned:
+                batch = self._gather_to_root(batch)
+            return [self._write_result(batch, schema, stage.stage_id)]
+        raise NotImplementedError(f"writer {wname}")
+
+    def _consume(self, batch: Any, consumers: Sequence[Any]) -> Any:
+        """Run a stage's consumer tasks (filters, projections, aggregates) over one batch."""
+        from .device import SlabUnsupported, TierExceeded  # noqa: PLC0415
 
         pending: list[Any] = []  # WHERE conditions not yet applied to `batch`
         for position, task in enumerate(consumers):
@@ -619,22 +644,125 @@ class HipExecutionEngine(ExecutionEngine):
                     batch.partitioned = was_partitioned
             else:
                 raise NotImplementedError(f"consumer {tname}")
-        batch = self._materialise(batch, pending)
-
-        wname = _cls(writer)
-        schema = writer.inferred_schema
-        if wname == "WriteToShufflePartitions":
-            # the "shuffle file" stays in HBM; data-dependent errors surface at the query's final read-back
-            outputs[id(stage)] = batch if batch.tail is not None else self._quantise_batch(batch, schema)
-            self._job_seq += 1
-            return [JobResult(f"{self._job_prefix}-{self._job_seq}", self._executor_id, [])]
-        if wname == "WriteToLocalFileTask":
-            if self.dist is not None and batch.partitioned:
-                batch = self._gather_to_root(batch)
-            return [self._write_result(batch, schema, stage.stage_id)]
-        raise NotImplementedError(f"writer {wname}")
+        return self._materialise(batch, pending)
 
     # ---- producers -------------------------------------------------------------------------------------
+    # ---- tables beyond HBM: the scan stage in block ranges -------------------------------------------------
+    def _scan_columns(self, table: Any, alias: str, consumers: Sequence[Any]) -> list[int]:
+        prefix = f"{alias}." if alias else ""
+        names = [prefix + n for n, _ in table.schema]
+        needed = self._needed_names(consumers)
+        col_ids = list(range(len(names))) if needed is None else sorted({names.index(n) for n in needed if n in names})
+        return col_ids or [0]
+
+    def _stream_ranges(self, producer: Any, consumers: Sequence[Any]) -> list[list[int]] | None:
+        """Block ranges to stream a scan in, or None when the referenced columns fit the budget (the usual case: they
+        are loaded once and stay resident).  Budget = engine.hbm_budget bytes (HIPSPARK_HBM_BUDGET), default half of
+        the free device memory; a range holds as many consecutive blocks as fit half of it."""
+        from . import table as tbl  # noqa: PLC0415
+
+        key = str(Path(producer.file_path).resolve())
+        cached = self._tables.get(key)
+        if cached is not None and cached.stamp == ():
+            return None  # attached device tables are resident by definition
+        table = self._table(producer.file_path)
+        col_ids = self._scan_columns(table, producer.alias, consumers)
+        if all(c in table.columns for c in col_ids):
+            return None
+        budget = self.hbm_budget
+        if budget is None:
+            import torch  # noqa: PLC0415
+
+            budget = torch.cuda.mem_get_info(self.dev.device)[0] // 2
+        per_block = tbl.referenced_block_bytes(table, col_ids)
+        if sum(per_block) <= budget:
+            return None
+        ranges, cur, cur_bytes = [], [], 0
+        for b, nbytes in enumerate(per_block):
+            if cur and cur_bytes + nbytes > budget // 2:
+                ranges.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(b)
+            cur_bytes += nbytes
+        if cur:
+            ranges.append(cur)
+        return ranges
+
+    def _run_scan_stage_streamed(self, stage: Any, outputs: dict[int, Any], ranges: list[list[int]]) -> list[JobResult]:
+        """A scan stage over a table that does not fit HBM: block range by block range through the ingest pipeline
+        (pruned reads -> pinned staging -> HBM), the stage's consumers run on every range, and
+        * partial-aggregate rows (the stage's "shuffle file") accumulate on the device across the ranges - units stay
+          file blocks, so the final merge sees exactly the rows and the order of the resident run;
+        * rows of a non-aggregating stage are appended, range after range, to the result BlockFile with the reference's
+          append-merge rule (io.py:231-252: a short last block is re-written, then new blocks follow), so the file
+          stays readable by the reference.
+        The range's columns are freed before the next range is read."""
+        from . import table as tbl  # noqa: PLC0415
+        from .device import DBatch  # noqa: PLC0415
+
+        producer, consumers, writer = stage.producer, list(stage.consumers), stage.writer
+        table = self._table(producer.file_path)
+        col_ids = self._scan_columns(table, producer.alias, consumers)
+        if self.dev.rec is not None:
+            self.dev.rec.poisoned = True  # host data flows in on every run
+        for task in consumers:  # the one-launch tail wants every unit's slab rows in ONE launch
+            if _cls(task) == "AggregateTask" and task.before_shuffle:
+                self._no_short_tail.add(_uid(task))
+        schema = writer.inferred_schema
+        to_file = _cls(writer) == "WriteToLocalFileTask"
+        parts: list[Any] = []
+        out_path, rows_written = None, 0
+        self.streamed_ranges += len(ranges)
+        for blocks in ranges:
+            sub = tbl.sub_table(table, blocks)
+            tbl.load_columns(self.dev, sub, col_ids)
+            batch = tbl.table_batch(sub, col_ids, producer.alias)
+            batch.partitioned = self.dist is not None
+            batch = self.dev.resolve(self._consume(batch, consumers))
+            quantised = self.dev.resolve(self._quantise_batch(batch, schema))
+            if not to_file:
+                parts.append(quantised)
+                continue
+            raw, nrows, flags = self.dev.download_batch(quantised, schema, None)
+            self.dev.raise_for_flags(flags & ~0x8)
+            if nrows:
+                if out_path is None:
+                    out_path = self._result_path(stage.stage_id)
+                    out_path.parent.mkdir(parents=True, exist_ok=True)
+                    out_path.unlink(missing_ok=True)
+                BlockFile(out_path, list(schema)).append_raw(raw)
+                rows_written += nrows
+            del sub, batch, quantised
+        self._job_seq += 1
+        job_id = f"{self._job_prefix}-{self._job_seq}"
+        if to_file:
+            from .jobs import OutputFile  # noqa: PLC0415
+
+            files = [OutputFile(out_path)] if rows_written and self.rank == 0 else []
+            return [JobResult(job_id, self._executor_id, files)]
+        n = sum(p.nrows for p in parts)
+        cols = [self.dev.concat_cols([p.cols[c] for p in parts]) for c in range(len(schema))] if parts else []
+        order = None
+        if parts and all(p.order is not None for p in parts):
+            import torch  # noqa: PLC0415
+
+            order = torch.cat([p.order[: p.nrows] for p in parts])
+        merged = DBatch(list(schema), cols, n, [0, n], order=order,
+                        total_units=table.total_blocks if table.total_blocks is not None else len(table.block_rows),
+                        partitioned=self.dist is not None)
+        outputs[id(stage)] = merged
+        return [JobResult(job_id, self._executor_id, [])]
+
+    def _result_path(self, stage_id: str) -> Path:
+        if self._result_root is None:
+            base = Path(self._work_folder) if self._work_folder else constants.SHUFFLE_FOLDER
+            self._result_root = base / f"hip-{uuid.uuid4().hex[:12]}"
+            self._owned_dirs.add(self._result_root)
+        out_file = self._result_paths.get(stage_id)
+        if out_file is None:
+            out_file = self._result_paths[stage_id] = self._result_root / str(stage_id) / "result.bin"
+        return out_file
+
     def _scan(self, producer: Any, consumers: Sequence[Any], writer: Any) -> Any:
         from . import table as tbl  # noqa: PLC0415
 

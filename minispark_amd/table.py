@@ -75,6 +75,22 @@ def open_table(path: Path, rank: int = 0, world: int = 1, distributed: bool = Fa
                        global_blocks=mine, total_blocks=len(rows))
 
 
+def referenced_block_bytes(table: DeviceTable, col_ids: list[int]) -> list[int]:
+    """Bytes the listed columns occupy in each of the table's (local) blocks - what a scan has to bring into HBM."""
+    bf = BlockFile(table.path)
+    blocks = table.global_blocks if table.global_blocks is not None else list(range(len(table.block_rows)))
+    with table.path.open("rb") as f:
+        return [sum(bf.block_layout(b, f).spans[c][1] for c in col_ids) for b in blocks]
+
+
+def sub_table(table: DeviceTable, local_blocks: list[int]) -> DeviceTable:
+    """The table restricted to some of its local blocks (columns not loaded): one range of a streamed scan."""
+    file_blocks = table.global_blocks if table.global_blocks is not None else list(range(len(table.block_rows)))
+    return DeviceTable(table.path, list(table.schema), [table.block_rows[b] for b in local_blocks], {}, table.stamp,
+                       global_blocks=[file_blocks[b] for b in local_blocks],
+                       total_blocks=table.total_blocks if table.total_blocks is not None else len(table.block_rows))
+
+
 # ---- BlockFile -> HBM ingest (SURVEY section 8f N1) ---------------------------------------------------------
 # Column pruning first (only the referenced columns' byte spans are read), then a pipeline: reader threads
 # preadv() every (block, column) span straight into pinned staging slots (the GIL is released during the read),
