@@ -331,6 +331,32 @@ int hs_group_build_units(void* stream, const hs_col* key, const int64_t* sel, in
 /* out[q] = how many elements of the ascending list sorted[0 .. n) are < queries[q] (device arrays; n_dev optional). */
 int hs_lower_bound_i64(void* stream, const int64_t* sorted, int64_t n, const int64_t* n_dev, const int64_t* queries,
                        int64_t n_queries, int64_t* out);
+/* ---- the HBM tier as a radix partition + on-chip ordered fold (csrc/hs_radix.hip; reference tasks.py:284-310) ----
+ * GROUP BY of any cardinality over every unit of a batch, INTEGER / TIMESTAMP keys: the (key, value...) tuples are moved
+ * by one or two stable partition passes on hash bits of the key until a partition (a few hundred rows of one unit, still
+ * in row order) fits a wave's LDS dictionary; one wave folds a partition's rows in order - the reference's sequential
+ * fp64 / int sums, bit for bit - and the groups are made dense.  Three calls:
+ *   hs_group_radix_plan   host only: fan-out, dictionary size and workspace layout from the row count n (> 0), the
+ *                         number of units and the largest unit's row count.  val_kinds[a]: kind of aggregate a's value
+ *                         column (HS_I32 / F32 / I64 / F64 / U8), or -1 for a constant argument (COUNT's 1);
+ *   hs_group_radix_run    position i of the input is row sel[i] of `key` (row0 + i when sel is NULL); unit u owns
+ *                         positions [unit_bounds[u], unit_bounds[u+1]) (device, [0] = 0, [n_units] = n).  val_cols[a]
+ *                         are indexed by POSITION; data == NULL marks a constant whose accumulator cell is
+ *                         const_cells[a].  quantise (plan): results as the shuffle file holds them (f32 / i32) or as
+ *                         f64 / i64.  out_unit_groups[u] (device, n_units + 1) = groups before unit u, [n_units] = all.
+ *                         A partition with more distinct keys than its dictionary raises HS_FLAG_DICT_FULL;
+ *   hs_group_radix_emit   after the caller has read out_unit_groups[n_units]: dense key column (the key's kind) and one
+ *                         array per aggregate (4 B f32 / i32 when quantising, else 8 B), groups in unit order. */
+typedef struct hs_radix_plan {
+    int64_t f[48]; /* opaque */
+} hs_radix_plan;
+int hs_group_radix_plan(int32_t key_kind, int64_t n, int32_t n_units, int64_t max_unit_rows, const int32_t* val_kinds,
+                        const hs_agg_spec* spec, int32_t quantise, hs_radix_plan* plan);
+size_t hs_group_radix_ws_bytes(const hs_radix_plan* plan);
+int hs_group_radix_run(void* stream, const hs_radix_plan* plan, const hs_col* key, const int64_t* sel, int64_t row0,
+                       const int64_t* unit_bounds, const hs_col* val_cols, const uint64_t* const_cells,
+                       const hs_agg_spec* spec, void* ws, int64_t* out_unit_groups, uint32_t* flags);
+int hs_group_radix_emit(void* stream, const hs_radix_plan* plan, void* ws, void* out_key, void* const* out_acc);
 /* mask[s] = 1 for non-empty slots (compact it with hs_compact to get the dense slot list). */
 int hs_group_mask(void* stream, const int64_t* slot_start, int64_t table_cap, uint8_t* mask);
 /* One lane per group folds val_cols[a][position] over the group's positions front to back - the reference's

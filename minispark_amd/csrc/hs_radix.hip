@@ -1,0 +1,612 @@
+// hs_radix.hip - the HBM tier of GROUP BY as a radix partition + on-chip ordered fold (round 2).
+//
+// Reference loop replaced: AggregateTask over a block, tasks.py:284-310 - a Python dict per block, every row folded
+// into its group's accumulators in row order (fp64 / int), written to the shuffle file at the block's end.
+//
+// Round 1 kept one hash table for all rows in HBM: three passes of random 8-16 B accesses (insert, count, place) over
+// a table twice the size of the input, then one lane per group walking its row list - bound by the rate of random
+// HBM transactions, ~3 G rows/s.  Here rows are MOVED instead, in streams:
+//
+//   pass 1, pass 2   stable radix partition of the (key, value...) tuples on hash bits of the key, inside every unit
+//                    (file block): histogram per 8192-row tile, one exclusive scan over (segment, bin, tile), scatter.
+//                    After the passes every final partition holds <= ~cap/2 rows of ONE unit, still in row order.
+//   fold             ONE WAVE per partition: a dictionary + accumulators private to the wave in LDS, rows taken 64 at a
+//                    time in order; rows of one step that share a group are ranked (ballots over the slot bits) and
+//                    folded in rank order - each group's values are added in ascending row order, i.e. exactly the
+//                    reference's sequential fold, bit for bit.  The partition's groups go to a provisional place (the
+//                    partition's own start), a scan over the partitions' group counts and a copy make them dense.
+//
+// Everything is sized on the host from the row count and the largest unit; no host round trip inside
+// hs_group_radix_run.  A partition that meets more distinct keys than its dictionary holds raises HS_FLAG_DICT_FULL
+// (the caller takes the round-1 path).  Keys: INTEGER / TIMESTAMP (the key word is the value).
+#include "hs_device.h"
+
+#include <cstring>
+
+extern thread_local char g_hs_err[256];
+void hs_set_error(const char* fmt, ...);
+extern "C" size_t hs_scan_ws_bytes(int64_t nrows);
+extern "C" int hs_exclusive_scan_i64(void* stream, const int64_t* counts, int64_t n, int64_t* start, void* ws);
+
+#define RX_CHECK_LAUNCH(name)                        \
+    if (hipGetLastError() != hipSuccess) {           \
+        hs_set_error(name ": kernel launch failed"); \
+        return HS_E_LAUNCH;                          \
+    }
+
+constexpr int RX_THREADS = 1024;               // a partition-pass workgroup
+constexpr int RX_PER = 8;                      // rows per thread and tile
+constexpr int RX_TILE = RX_THREADS * RX_PER;   // 8192 rows
+constexpr int RX_WAVES = RX_THREADS / HS_WAVE;
+constexpr int RX_SUB = RX_TILE / RX_WAVES;     // rows of a tile one wave ranks (512, contiguous)
+constexpr int RX_MAX_BITS = 8;                 // fan-out of one pass <= 256
+constexpr int RX_COLS = 1 + HS_MAX_ACC;        // key + value columns
+
+static_assert(sizeof(hs_radix_plan) % 8 == 0, "hs_radix_plan");
+
+// ---- segments -> tiles ------------------------------------------------------------------------------------------
+// tile_base[s] = number of tiles of the segments before s (a tile never straddles two segments)
+__global__ void __launch_bounds__(1024) k_rx_tiles(const int64_t* seg_start, int64_t n_seg, int64_t* tile_base) {
+    __shared__ int64_t s_part[16];
+    const int tid = threadIdx.x, lane = tid & (HS_WAVE - 1), w = tid / HS_WAVE;
+    const int64_t per = (n_seg + blockDim.x - 1) / blockDim.x;
+    const int64_t s0 = tid * per < n_seg ? tid * per : n_seg, s1 = (s0 + per) < n_seg ? (s0 + per) : n_seg;
+    int64_t mine = 0;
+    for (int64_t s = s0; s < s1; ++s) mine += (seg_start[s + 1] - seg_start[s] + RX_TILE - 1) / RX_TILE;
+    int64_t x = mine;
+    for (int d = 1; d < HS_WAVE; d <<= 1) {
+        const int64_t t = __shfl_up(x, d, HS_WAVE);
+        if (lane >= d) x += t;
+    }
+    if (lane == HS_WAVE - 1) s_part[w] = x;
+    __syncthreads();
+    int64_t base = 0, all = 0;
+    for (int k = 0; k < (int)(blockDim.x / HS_WAVE); ++k) {
+        if (k < w) base += s_part[k];
+        all += s_part[k];
+    }
+    int64_t run = x + base - mine;
+    for (int64_t s = s0; s < s1; ++s) {
+        tile_base[s] = run;
+        run += (seg_start[s + 1] - seg_start[s] + RX_TILE - 1) / RX_TILE;
+    }
+    if (tid == 0) tile_base[n_seg] = all;
+}
+
+// tile -> (segment, tile inside the segment); false past the last tile.  Uniform over the workgroup.
+__device__ __forceinline__ bool rx_find_tile(const int64_t* tile_base, int64_t n_seg, int64_t tile, int64_t& seg, int64_t& t) {
+    if (tile >= tile_base[n_seg]) return false;
+    int64_t lo = 0, hi = n_seg;  // the last s with tile_base[s] <= tile owns it (empty segments share a later base)
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (tile_base[mid] <= tile) lo = mid;
+        else hi = mid;
+    }
+    seg = lo;
+    t = tile - tile_base[lo];
+    return true;
+}
+
+struct RxPass {
+    const int64_t* seg_start;  // [n_seg + 1] positions in the row list
+    const int64_t* tile_base;  // [n_seg + 1]
+    int64_t n_seg;
+    int32_t shift, bits;       // bin = (mix(key word) >> shift) & (2^bits - 1)
+    int32_t n_cols, first;     // columns that travel (0 = key); first pass reads the key through `key` / `sel`
+    hs_col key;
+    const int64_t* sel;
+    int64_t row0;
+    const void* src[RX_COLS];  // position-indexed raw arrays (src[0] unused in the first pass)
+    void* dst[RX_COLS];
+    int32_t esize[RX_COLS];    // bytes per element: 1, 4 or 8
+    int64_t* counters;         // [(tiles) << bits] laid out (segment, bin, tile): counts, then their exclusive scan
+};
+
+__device__ __forceinline__ uint64_t rx_key(const RxPass& A, int64_t i) {
+    if (A.first) return hs_key_at(A.key, A.sel ? A.sel[i] : A.row0 + i);
+    return A.esize[0] == 4 ? (uint64_t)(int64_t)((const int32_t*)A.src[0])[i] : ((const uint64_t*)A.src[0])[i];
+}
+__device__ __forceinline__ uint32_t rx_bin(uint64_t word, int shift, int bits) {
+    return (uint32_t)(hs_mix64(word) >> shift) & ((1u << bits) - 1u);
+}
+__device__ __forceinline__ void rx_move(const void* src, void* dst, int esize, int64_t from, int64_t to) {
+    if (esize == 4) ((uint32_t*)dst)[to] = ((const uint32_t*)src)[from];
+    else if (esize == 8) ((uint64_t*)dst)[to] = ((const uint64_t*)src)[from];
+    else ((uint8_t*)dst)[to] = ((const uint8_t*)src)[from];
+}
+
+__global__ void __launch_bounds__(RX_THREADS) k_rx_hist(const RxPass A_kernarg) {
+    HS_KERNARG(RxPass, A);
+    __shared__ uint32_t hist[1 << RX_MAX_BITS];
+    int64_t seg, t;
+    if (!rx_find_tile(A.tile_base, A.n_seg, blockIdx.x, seg, t)) return;
+    const int tid = threadIdx.x, F = 1 << A.bits;
+    if (tid < F) hist[tid] = 0;
+    __syncthreads();
+    const int64_t b = A.seg_start[seg] + t * RX_TILE;
+    const int64_t seg_end = A.seg_start[seg + 1];
+    const int64_t e = (b + RX_TILE) < seg_end ? (b + RX_TILE) : seg_end;
+    for (int64_t i = b + tid; i < e; i += RX_THREADS) atomicAdd(&hist[rx_bin(rx_key(A, i), A.shift, A.bits)], 1u);
+    __syncthreads();
+    const int64_t nt = A.tile_base[seg + 1] - A.tile_base[seg];
+    if (tid < F) A.counters[(A.tile_base[seg] << A.bits) + (int64_t)tid * nt + t] = hist[tid];
+}
+
+// Stable scatter of a tile.  Wave w ranks rows [w * 512, (w + 1) * 512) of the tile, 64 at a time in order: a row's
+// rank among the rows of its bin = the wave's running count of the bin + its rank among this step's equal-bin lanes
+// (the AND of one ballot per bin bit).  A scan over the waves per bin and the tile's scanned counter finish the address.
+__global__ void __launch_bounds__(RX_THREADS) k_rx_scatter(const RxPass A_kernarg) {
+    HS_KERNARG(RxPass, A);
+    __shared__ uint32_t whist[RX_WAVES][1 << RX_MAX_BITS];
+    __shared__ int64_t gbase[1 << RX_MAX_BITS];
+    int64_t seg, t;
+    if (!rx_find_tile(A.tile_base, A.n_seg, blockIdx.x, seg, t)) return;
+    const int tid = threadIdx.x, lane = tid & (HS_WAVE - 1), w = tid / HS_WAVE, F = 1 << A.bits;
+    for (int i = tid; i < RX_WAVES * F; i += RX_THREADS) whist[i / F][i % F] = 0;
+    __syncthreads();
+    const int64_t b = A.seg_start[seg] + t * RX_TILE;
+    const int64_t seg_end = A.seg_start[seg + 1];
+    const int64_t e = (b + RX_TILE) < seg_end ? (b + RX_TILE) : seg_end;
+    uint64_t word[RX_PER];
+    uint32_t bin[RX_PER], local[RX_PER];
+    const uint64_t below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < RX_PER; ++j) {
+        const int64_t i = b + (int64_t)w * RX_SUB + j * HS_WAVE + lane;
+        const bool valid = i < e;
+        word[j] = valid ? rx_key(A, i) : 0;
+        bin[j] = valid ? rx_bin(word[j], A.shift, A.bits) : 0u;
+        uint64_t peers = __ballot(valid);
+        for (int bit = 0; bit < A.bits; ++bit) {
+            const bool on = (bin[j] >> bit) & 1u;
+            const uint64_t bal = __ballot(valid && on);
+            peers &= on ? bal : ~bal;
+        }
+        uint32_t prior = 0;
+        if (valid) prior = whist[w][bin[j]];
+        const uint32_t rank = (uint32_t)__popcll(peers & below);
+        local[j] = prior + rank;
+        if (valid && rank == 0) whist[w][bin[j]] = prior + (uint32_t)__popcll(peers);  // the bin's first lane of the step
+    }
+    __syncthreads();
+    const int64_t nt = A.tile_base[seg + 1] - A.tile_base[seg];
+    if (tid < F) {
+        uint32_t run = 0;
+        for (int k = 0; k < RX_WAVES; ++k) {
+            const uint32_t c = whist[k][tid];
+            whist[k][tid] = run;
+            run += c;
+        }
+        gbase[tid] = A.counters[(A.tile_base[seg] << A.bits) + (int64_t)tid * nt + t];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RX_PER; ++j) {
+        const int64_t i = b + (int64_t)w * RX_SUB + j * HS_WAVE + lane;
+        if (i >= e) continue;
+        const int64_t to = gbase[bin[j]] + whist[w][bin[j]] + local[j];
+        if (A.esize[0] == 4) ((int32_t*)A.dst[0])[to] = (int32_t)word[j];
+        else ((uint64_t*)A.dst[0])[to] = word[j];
+        for (int c = 1; c < A.n_cols; ++c) rx_move(A.src[c], A.dst[c], A.esize[c], i, to);
+    }
+}
+
+// the partition pass's output segments: (segment, bin) starts where the first tile's counter of that bin points
+__global__ void __launch_bounds__(256) k_rx_next(const int64_t* seg_start, const int64_t* tile_base, int64_t n_seg, int32_t bits,
+                                                 const int64_t* scanned, int64_t n, int64_t* out) {
+    const int64_t total = n_seg << bits;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx <= total; idx += (int64_t)gridDim.x * blockDim.x) {
+        if (idx == total) {
+            out[idx] = n;
+            continue;
+        }
+        const int64_t s = idx >> bits, bin = idx & ((1ll << bits) - 1);
+        const int64_t nt = tile_base[s + 1] - tile_base[s];
+        out[idx] = nt ? scanned[(tile_base[s] << bits) + bin * nt] : seg_start[s];
+    }
+}
+
+// ---- the fold ---------------------------------------------------------------------------------------------------
+struct RxAgg {
+    const int64_t* seg_start;  // [n_parts + 1]
+    int64_t n_parts;
+    const void* src[RX_COLS];      // the partitioned tuples
+    int32_t esize[RX_COLS];
+    int32_t val_kind[HS_MAX_ACC];  // kind of the carried column behind aggregate a (HS_I32 / F32 / I64 / F64 / U8)
+    int32_t carried[HS_MAX_ACC];   // aggregate a -> column 1.. of src, 0: the constant const_cell[a]
+    uint64_t const_cell[HS_MAX_ACC];
+    hs_agg_spec spec;
+    int32_t cap, quantise;
+    uint64_t* prov_key;            // [n] a partition's groups, from the partition's own start
+    void* prov_acc[HS_MAX_ACC];    // [n] each: f32 / i32 when quantising, f64 / i64 bits otherwise
+    int64_t* pcount;               // [n_parts] groups of the partition
+    uint32_t* flags;
+};
+
+__device__ __forceinline__ uint64_t rx_cell(const void* src, int kind, int64_t i) {
+    switch (kind) {
+        case HS_I32: return (uint64_t)(int64_t)((const int32_t*)src)[i];
+        case HS_F32: return hs_d2u((double)((const float*)src)[i]);
+        case HS_U8: return (uint64_t)((const uint8_t*)src)[i];
+        default: return ((const uint64_t*)src)[i];  // HS_I64 / HS_F64: the cell itself
+    }
+}
+
+__global__ void __launch_bounds__(256) k_rx_fold(const RxAgg A_kernarg) {
+    HS_KERNARG(RxAgg, A);
+    extern __shared__ __align__(16) uint64_t rx_lds[];
+    const int lane = threadIdx.x & (HS_WAVE - 1), w = threadIdx.x / HS_WAVE, wpb = blockDim.x / HS_WAVE;
+    const int NA = A.spec.n_acc, cap = A.cap;
+    uint64_t* keys = rx_lds + (size_t)w * cap * (1 + NA);  // [cap]
+    uint64_t* acc = keys + cap;                             // [NA][cap]
+    const uint32_t mask = (uint32_t)cap - 1u;
+    const uint64_t below = (1ull << lane) - 1ull;
+    int slot_bits = 0;
+    while ((1 << slot_bits) < cap) ++slot_bits;
+    uint32_t err = 0;
+    for (int64_t p = (int64_t)blockIdx.x * wpb + w; p < A.n_parts; p += (int64_t)gridDim.x * wpb) {
+        const int64_t b = A.seg_start[p], e = A.seg_start[p + 1];
+        if (b >= e) {
+            if (lane == 0) A.pcount[p] = 0;
+            continue;
+        }
+        for (int s = lane; s < cap; s += HS_WAVE) keys[s] = HS_EMPTY_KEY;
+        for (int a = 0; a < NA; ++a) {
+            const uint64_t id = hs_acc_identity(A.spec.op[a], A.spec.is_int[a] != 0);
+            for (int s = lane; s < cap; s += HS_WAVE) acc[a * cap + s] = id;
+        }
+        for (int64_t base = b; base < e; base += HS_WAVE) {
+            const int64_t i = base + lane;
+            bool valid = i < e;
+            int slot = 0;
+            if (valid) {
+                const uint64_t k = A.esize[0] == 4 ? (uint64_t)(int64_t)((const int32_t*)A.src[0])[i] : ((const uint64_t*)A.src[0])[i];
+                uint32_t h = (uint32_t)(hs_mix64(k) >> 36) & mask;
+                slot = -1;
+                for (uint32_t probe = 0; probe <= mask; ++probe) {
+                    uint64_t cur = __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (cur == HS_EMPTY_KEY) {
+                        cur = atomicCAS((unsigned long long*)&keys[h], (unsigned long long)HS_EMPTY_KEY, (unsigned long long)k);
+                        if (cur == HS_EMPTY_KEY) cur = k;
+                    }
+                    if (cur == k) {
+                        slot = (int)h;
+                        break;
+                    }
+                    h = (h + 1) & mask;
+                }
+            }
+            if (__ballot(valid && slot < 0) != 0ull) {  // more distinct keys than slots: the caller takes the other path
+                err |= HS_FLAG_DICT_FULL;
+                break;
+            }
+            // lanes of this step in the same group, and my rank among them (row order = lane order)
+            uint64_t peers = __ballot(valid);
+            for (int bit = 0; bit < slot_bits; ++bit) {
+                const bool on = (slot >> bit) & 1;
+                const uint64_t bal = __ballot(valid && on);
+                peers &= on ? bal : ~bal;
+            }
+            const int rank = __popcll(peers & below);
+            for (int a = 0; a < NA; ++a) {
+                const uint32_t op = A.spec.op[a];
+                const bool is_int = A.spec.is_int[a] != 0;
+                const int c = A.carried[a];
+                const uint64_t x = !valid ? 0 : (c ? rx_cell(A.src[c], A.val_kind[a], i) : A.const_cell[a]);
+                for (int r = 0; __ballot(valid && rank >= r) != 0ull; ++r)
+                    if (valid && rank == r) acc[a * cap + slot] = hs_acc_fold(op, is_int, acc[a * cap + slot], x);
+            }
+        }
+        // the partition's groups, in slot order, from the partition's own start
+        int64_t running = 0;
+        for (int s0 = 0; s0 < cap; s0 += HS_WAVE) {
+            const int s = s0 + lane;
+            const uint64_t k = keys[s];
+            const bool occ = k != HS_EMPTY_KEY;
+            const uint64_t bal = __ballot(occ);
+            if (occ) {
+                const int64_t at = b + running + __popcll(bal & below);
+                A.prov_key[at] = k;
+                for (int a = 0; a < NA; ++a) {
+                    const bool is_int = A.spec.is_int[a] != 0;
+                    uint64_t v = acc[a * cap + s];
+                    if (hs_float_identity_left(A.spec.op[a], is_int, v)) err |= HS_FLAG_TYPE_ASSERT;
+                    if (A.quantise) {
+                        v = hs_quantise_cell(is_int, v, err);
+                        if (is_int) ((int32_t*)A.prov_acc[a])[at] = (int32_t)(int64_t)v;
+                        else ((float*)A.prov_acc[a])[at] = (float)hs_u2d(v);
+                    } else {
+                        ((uint64_t*)A.prov_acc[a])[at] = v;
+                    }
+                }
+            }
+            running += __popcll(bal);
+        }
+        if (lane == 0) A.pcount[p] = running;
+    }
+    if (err) atomicOr(A.flags, err);
+}
+
+// ---- dense output -----------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_rx_unit_groups(const int64_t* pscan, int64_t parts_per_unit, int32_t n_units,
+                                                        int64_t* out) {
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u <= n_units) out[u] = pscan[(int64_t)u * parts_per_unit];
+}
+
+struct RxEmit {
+    const int64_t* seg_start;
+    const int64_t* pscan;
+    int64_t n_parts;
+    const uint64_t* prov_key;
+    const void* prov_acc[HS_MAX_ACC];
+    int32_t n_acc, osize, key_kind, pad;
+    void* out_key;
+    void* out_acc[HS_MAX_ACC];
+};
+__global__ void __launch_bounds__(256) k_rx_emit(const RxEmit A_kernarg) {
+    HS_KERNARG(RxEmit, A);
+    const int lane = threadIdx.x & (HS_WAVE - 1), wpb = blockDim.x / HS_WAVE;
+    for (int64_t p = (int64_t)blockIdx.x * wpb + threadIdx.x / HS_WAVE; p < A.n_parts; p += (int64_t)gridDim.x * wpb) {
+        const int64_t from = A.seg_start[p], to = A.pscan[p], cnt = A.pscan[p + 1] - to;
+        for (int64_t q = lane; q < cnt; q += HS_WAVE) {
+            const uint64_t k = A.prov_key[from + q];
+            if (A.key_kind == HS_I32) ((int32_t*)A.out_key)[to + q] = (int32_t)(int64_t)k;
+            else ((uint64_t*)A.out_key)[to + q] = k;
+            for (int a = 0; a < A.n_acc; ++a) rx_move(A.prov_acc[a], A.out_acc[a], A.osize, from + q, to + q);
+        }
+    }
+}
+
+// ---- host -------------------------------------------------------------------------------------------------------
+static int rx_esize(int32_t kind) {
+    switch (kind) {
+        case HS_I32:
+        case HS_F32: return 4;
+        case HS_I64:
+        case HS_F64: return 8;
+        case HS_U8: return 1;
+        default: return 0;
+    }
+}
+static size_t rx_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// field use of the public plan (include/hipspark.h keeps it opaque: int64 f[48])
+enum {
+    PL_N, PL_UNITS, PL_BITS1, PL_BITS2, PL_CAP, PL_NA, PL_NCARRIED, PL_QUANTISE, PL_KEYKIND, PL_NSEG1, PL_PARTS, PL_TILES1,
+    PL_TILES2, PL_COUNTERS, PL_OSIZE, PL_WS, PL_OFF_BUF_A, PL_OFF_BUF_B, PL_OFF_SEG1, PL_OFF_SEG2, PL_OFF_TB0, PL_OFF_TB1,
+    PL_OFF_CNT, PL_OFF_SCAN, PL_OFF_SCANWS, PL_OFF_PKEY, PL_OFF_PACC, PL_OFF_PCOUNT, PL_OFF_PSCAN, PL_TUPLE, PL_ESIZE0 /* .. +16 */
+};
+
+extern "C" int hs_group_radix_plan(int32_t key_kind, int64_t n, int32_t n_units, int64_t max_unit_rows, const int32_t* val_kinds,
+                                   const hs_agg_spec* spec, int32_t quantise, hs_radix_plan* plan) {
+    if (!plan || !spec || n < 1 || n_units < 1 || max_unit_rows < 1 || spec->n_acc < 0 || spec->n_acc > HS_MAX_ACC ||
+        (spec->n_acc > 0 && !val_kinds) || (key_kind != HS_I32 && key_kind != HS_I64)) {
+        hs_set_error("hs_group_radix_plan: bad arguments (keys: HS_I32 / HS_I64)");
+        return HS_E_ARG;
+    }
+    int64_t* f = plan->f;
+    for (int i = 0; i < 48; ++i) f[i] = 0;
+    const int NA = spec->n_acc;
+    int cap = 2048;
+    while (cap > 64 && (size_t)cap * 8 * (1 + NA) > 65536) cap >>= 1;
+    int bits = 0;
+    while (bits < 2 * RX_MAX_BITS && ((int64_t)(cap / 2) << bits) < max_unit_rows) ++bits;
+    const int bits1 = bits <= RX_MAX_BITS ? bits : (bits + 1) / 2, bits2 = bits - bits1;
+    f[PL_N] = n;
+    f[PL_UNITS] = n_units;
+    f[PL_BITS1] = bits1;
+    f[PL_BITS2] = bits2;
+    f[PL_CAP] = cap;
+    f[PL_NA] = NA;
+    f[PL_QUANTISE] = quantise ? 1 : 0;
+    f[PL_KEYKIND] = key_kind;
+    f[PL_NSEG1] = (int64_t)n_units << bits1;
+    f[PL_PARTS] = (int64_t)n_units << bits;
+    f[PL_TILES1] = n / RX_TILE + n_units + 1;
+    f[PL_TILES2] = bits2 ? n / RX_TILE + f[PL_NSEG1] + 1 : 0;
+    const int64_t c1 = f[PL_TILES1] << bits1, c2 = f[PL_TILES2] << bits2;
+    f[PL_COUNTERS] = c1 > c2 ? c1 : c2;
+    f[PL_OSIZE] = quantise ? 4 : 8;
+    f[PL_ESIZE0] = key_kind == HS_I32 ? 4 : 8;
+    int64_t tuple = f[PL_ESIZE0];
+    int carried = 0;
+    for (int a = 0; a < NA; ++a) {
+        if (val_kinds[a] < 0) continue;  // a constant: does not travel
+        const int es = rx_esize(val_kinds[a]);
+        if (!es) {
+            hs_set_error("hs_group_radix_plan: value column %d has kind %d", a, (int)val_kinds[a]);
+            return HS_E_ARG;
+        }
+        f[PL_ESIZE0 + 1 + carried] = es;
+        tuple += es;
+        ++carried;
+    }
+    f[PL_NCARRIED] = carried;
+    f[PL_TUPLE] = tuple;
+    size_t off = 0;
+    auto take = [&](int field, size_t bytes) {
+        f[field] = (int64_t)off;
+        off += rx_align(bytes);
+    };
+    // a buffer set = the columns back to back, each n elements
+    size_t set_bytes = 0;
+    for (int c = 0; c <= carried; ++c) set_bytes += rx_align((size_t)n * f[PL_ESIZE0 + c]);
+    take(PL_OFF_BUF_A, set_bytes);
+    take(PL_OFF_BUF_B, bits2 ? set_bytes : 0);
+    take(PL_OFF_SEG1, (size_t)(f[PL_NSEG1] + 1) * 8);
+    take(PL_OFF_SEG2, bits2 ? (size_t)(f[PL_PARTS] + 1) * 8 : 0);
+    take(PL_OFF_TB0, (size_t)(n_units + 1) * 8);
+    take(PL_OFF_TB1, bits2 ? (size_t)(f[PL_NSEG1] + 1) * 8 : 0);
+    take(PL_OFF_CNT, (size_t)f[PL_COUNTERS] * 8);
+    take(PL_OFF_SCAN, (size_t)(f[PL_COUNTERS] + 1) * 8);
+    const int64_t scan_n = f[PL_COUNTERS] > f[PL_PARTS] ? f[PL_COUNTERS] : f[PL_PARTS];
+    take(PL_OFF_SCANWS, hs_scan_ws_bytes(scan_n));
+    take(PL_OFF_PKEY, (size_t)n * 8);
+    take(PL_OFF_PACC, (size_t)NA * rx_align((size_t)n * f[PL_OSIZE]));
+    take(PL_OFF_PCOUNT, (size_t)f[PL_PARTS] * 8);
+    take(PL_OFF_PSCAN, (size_t)(f[PL_PARTS] + 1) * 8);
+    f[PL_WS] = (int64_t)off;
+    return HS_OK;
+}
+
+extern "C" size_t hs_group_radix_ws_bytes(const hs_radix_plan* plan) { return plan ? (size_t)plan->f[PL_WS] : 0; }
+
+static void rx_set_cols(const int64_t* f, uint8_t* ws, int field, void** cols) {
+    size_t off = (size_t)f[field];
+    for (int c = 0; c <= (int)f[PL_NCARRIED]; ++c) {
+        cols[c] = ws + off;
+        off += rx_align((size_t)f[PL_N] * f[PL_ESIZE0 + c]);
+    }
+}
+
+extern "C" int hs_group_radix_run(void* stream_, const hs_radix_plan* plan, const hs_col* key, const int64_t* sel, int64_t row0,
+                                  const int64_t* unit_bounds, const hs_col* val_cols, const uint64_t* const_cells,
+                                  const hs_agg_spec* spec, void* ws_, int64_t* out_unit_groups, uint32_t* flags) {
+    if (!plan || !key || !unit_bounds || !spec || !ws_ || !out_unit_groups || !flags || spec->n_acc != (int)plan->f[PL_NA] ||
+        key->kind != (int32_t)plan->f[PL_KEYKIND] || (spec->n_acc > 0 && (!val_cols || !const_cells))) {
+        hs_set_error("hs_group_radix_run: bad arguments");
+        return HS_E_ARG;
+    }
+    const int64_t* f = plan->f;
+    hipStream_t stream = (hipStream_t)stream_;
+    uint8_t* ws = (uint8_t*)ws_;
+    const int NA = (int)f[PL_NA], bits1 = (int)f[PL_BITS1], bits2 = (int)f[PL_BITS2], n_units = (int)f[PL_UNITS];
+    const int64_t n = f[PL_N];
+    void* buf_a[RX_COLS];
+    void* buf_b[RX_COLS];
+    rx_set_cols(f, ws, PL_OFF_BUF_A, buf_a);
+    if (bits2) rx_set_cols(f, ws, PL_OFF_BUF_B, buf_b);
+    int64_t* seg1 = (int64_t*)(ws + f[PL_OFF_SEG1]);
+    int64_t* seg2 = bits2 ? (int64_t*)(ws + f[PL_OFF_SEG2]) : seg1;
+    int64_t* tb0 = (int64_t*)(ws + f[PL_OFF_TB0]);
+    int64_t* tb1 = (int64_t*)(ws + f[PL_OFF_TB1]);
+    int64_t* counters = (int64_t*)(ws + f[PL_OFF_CNT]);
+    int64_t* scanned = (int64_t*)(ws + f[PL_OFF_SCAN]);
+    void* scan_ws = ws + f[PL_OFF_SCANWS];
+
+    RxAgg G;
+    std::memset(&G, 0, sizeof(G));
+    RxPass P;
+    std::memset(&P, 0, sizeof(P));
+    P.n_cols = 1 + (int)f[PL_NCARRIED];
+    P.key = *key;
+    P.sel = sel;
+    P.row0 = row0;
+    for (int c = 0; c < P.n_cols; ++c) P.esize[c] = (int)f[PL_ESIZE0 + c];
+    int carried = 0;
+    for (int a = 0; a < NA; ++a) {
+        if (val_cols[a].data == nullptr) {
+            G.carried[a] = 0;
+            G.const_cell[a] = const_cells[a];
+            continue;
+        }
+        ++carried;
+        if (carried > (int)f[PL_NCARRIED] || rx_esize(val_cols[a].kind) != (int)f[PL_ESIZE0 + carried]) {
+            hs_set_error("hs_group_radix_run: value column %d does not match the plan", a);
+            return HS_E_ARG;
+        }
+        P.src[carried] = val_cols[a].data;
+        G.carried[a] = carried;
+        G.val_kind[a] = val_cols[a].kind;
+    }
+    if (carried != (int)f[PL_NCARRIED]) {
+        hs_set_error("hs_group_radix_run: %d travelling value columns, the plan has %d", carried, (int)f[PL_NCARRIED]);
+        return HS_E_ARG;
+    }
+
+    auto pass = [&](const int64_t* seg_start, int64_t n_seg, int64_t* tile_base, int64_t max_tiles, int shift, int bits, bool first,
+                    void* const* src, void* const* dst, int64_t* next_seg) -> int {
+        hipLaunchKernelGGL(k_rx_tiles, dim3(1), dim3(1024), 0, stream, seg_start, n_seg, tile_base);
+        RX_CHECK_LAUNCH("hs_group_radix_run (tiles)");
+        const int64_t ncnt = max_tiles << bits;
+        hs_memset_async(counters, 0, (size_t)ncnt * 8, stream);
+        P.seg_start = seg_start;
+        P.tile_base = tile_base;
+        P.n_seg = n_seg;
+        P.shift = shift;
+        P.bits = bits;
+        P.first = first ? 1 : 0;
+        if (!first)
+            for (int c = 0; c < P.n_cols; ++c) P.src[c] = src[c];
+        for (int c = 0; c < P.n_cols; ++c) P.dst[c] = dst[c];
+        P.counters = counters;
+        hipLaunchKernelGGL(k_rx_hist, dim3((unsigned)max_tiles), dim3(RX_THREADS), 0, stream, P);
+        RX_CHECK_LAUNCH("hs_group_radix_run (histogram)");
+        const int rc = hs_exclusive_scan_i64(stream, counters, ncnt, scanned, scan_ws);
+        if (rc != HS_OK) return rc;
+        P.counters = scanned;
+        hipLaunchKernelGGL(k_rx_scatter, dim3((unsigned)max_tiles), dim3(RX_THREADS), 0, stream, P);
+        RX_CHECK_LAUNCH("hs_group_radix_run (scatter)");
+        const int64_t nout = (n_seg << bits) + 1;
+        hipLaunchKernelGGL(k_rx_next, dim3((unsigned)((nout + 255) / 256 > 4096 ? 4096 : (nout + 255) / 256)), dim3(256), 0, stream,
+                           seg_start, (const int64_t*)tile_base, n_seg, (int32_t)bits, (const int64_t*)scanned, n, next_seg);
+        RX_CHECK_LAUNCH("hs_group_radix_run (segments)");
+        return HS_OK;
+    };
+    int rc = pass(unit_bounds, n_units, tb0, f[PL_TILES1], 0, bits1, true, nullptr, buf_a, seg1);
+    if (rc != HS_OK) return rc;
+    void* const* tuples = buf_a;
+    if (bits2) {
+        rc = pass(seg1, f[PL_NSEG1], tb1, f[PL_TILES2], bits1, bits2, false, buf_a, buf_b, seg2);
+        if (rc != HS_OK) return rc;
+        tuples = buf_b;
+    }
+
+    const int64_t parts = f[PL_PARTS];
+    G.seg_start = seg2;
+    G.n_parts = parts;
+    for (int c = 0; c < P.n_cols; ++c) {
+        G.src[c] = tuples[c];
+        G.esize[c] = P.esize[c];
+    }
+    G.spec = *spec;
+    G.cap = (int)f[PL_CAP];
+    G.quantise = (int)f[PL_QUANTISE];
+    G.prov_key = (uint64_t*)(ws + f[PL_OFF_PKEY]);
+    for (int a = 0; a < NA; ++a) G.prov_acc[a] = ws + f[PL_OFF_PACC] + (size_t)a * rx_align((size_t)n * f[PL_OSIZE]);
+    G.pcount = (int64_t*)(ws + f[PL_OFF_PCOUNT]);
+    G.flags = flags;
+    const size_t per_wave = (size_t)G.cap * 8 * (1 + NA);
+    int wpb = (int)(65536 / per_wave);
+    wpb = wpb < 1 ? 1 : (wpb > 4 ? 4 : wpb);
+    int64_t grid = (parts + wpb - 1) / wpb;
+    if (grid > 256 * 64) grid = 256 * 64;
+    hipLaunchKernelGGL(k_rx_fold, dim3((unsigned)grid), dim3(HS_WAVE * wpb), per_wave * wpb, stream, G);
+    RX_CHECK_LAUNCH("hs_group_radix_run (fold)");
+    int64_t* pscan = (int64_t*)(ws + f[PL_OFF_PSCAN]);
+    rc = hs_exclusive_scan_i64(stream, G.pcount, parts, pscan, scan_ws);
+    if (rc != HS_OK) return rc;
+    hipLaunchKernelGGL(k_rx_unit_groups, dim3((unsigned)((n_units + 256) / 256)), dim3(256), 0, stream, (const int64_t*)pscan,
+                       (int64_t)1 << (bits1 + bits2), (int32_t)n_units, out_unit_groups);
+    RX_CHECK_LAUNCH("hs_group_radix_run (unit groups)");
+    return HS_OK;
+}
+
+extern "C" int hs_group_radix_emit(void* stream_, const hs_radix_plan* plan, void* ws_, void* out_key, void* const* out_acc) {
+    if (!plan || !ws_ || !out_key || (plan->f[PL_NA] > 0 && !out_acc)) {
+        hs_set_error("hs_group_radix_emit: bad arguments");
+        return HS_E_ARG;
+    }
+    const int64_t* f = plan->f;
+    uint8_t* ws = (uint8_t*)ws_;
+    RxEmit E;
+    std::memset(&E, 0, sizeof(E));
+    E.seg_start = (const int64_t*)(ws + (f[PL_BITS2] ? f[PL_OFF_SEG2] : f[PL_OFF_SEG1]));
+    E.pscan = (const int64_t*)(ws + f[PL_OFF_PSCAN]);
+    E.n_parts = f[PL_PARTS];
+    E.prov_key = (const uint64_t*)(ws + f[PL_OFF_PKEY]);
+    E.n_acc = (int)f[PL_NA];
+    E.osize = (int)f[PL_OSIZE];
+    E.key_kind = (int)f[PL_KEYKIND];
+    E.out_key = out_key;
+    for (int a = 0; a < E.n_acc; ++a) {
+        E.prov_acc[a] = ws + f[PL_OFF_PACC] + (size_t)a * rx_align((size_t)f[PL_N] * f[PL_OSIZE]);
+        E.out_acc[a] = out_acc[a];
+    }
+    int64_t grid = (E.n_parts + 3) / 4;
+    if (grid > 256 * 64) grid = 256 * 64;
+    hipLaunchKernelGGL(k_rx_emit, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream_, E);
+    RX_CHECK_LAUNCH("hs_group_radix_emit");
+    return HS_OK;
+}

@@ -223,6 +223,7 @@ class Device:
         self.device = torch.device("cuda", index)
         torch.cuda.set_device(self.device)
         self.flags = torch.zeros(4, dtype=torch.int32, device=self.device)
+        self.last_global_tier = ""  # "radix" / "hash": what the last HBM-tier partial aggregate ran on
         self._partial_prepared: dict[Any, dict] = {}
         self._finish_prepared: dict[Any, dict] = {}
         self.zero_copy_results = os.environ.get("HIPSPARK_ZERO_COPY", "1") != "0"
@@ -1337,6 +1338,83 @@ class Device:
                                              queries.data_ptr(), queries.numel(), out.data_ptr()), "hs_lower_bound_i64")
         return out
 
+    # ---- HBM tier by radix partition (csrc/hs_radix.hip) ------------------------------------------------------
+    radix_enabled = os.environ.get("HIPSPARK_RADIX", "1") != "0"
+
+    def _radix_values(self, batch: DBatch, args: Sequence[Any], sel: torch.Tensor | None, n: int):
+        """Aggregate arguments for the radix tier -> per argument (value column | None, constant cell, is_int).
+        A literal (COUNT's 1) does not travel with the rows; a stored numeric column of an unfiltered batch travels as it
+        is (4 B); anything else is evaluated first (8 B cells, one launch for all of them)."""
+        import struct  # noqa: PLC0415
+
+        from .lowering import unalias  # noqa: PLC0415
+
+        out: list[Any] = [None] * len(args)
+        todo: list[int] = []
+        for i, raw in enumerate(args):
+            e = unalias(raw)
+            cls = type(e).__name__
+            if cls == "Lit" and isinstance(e.value, (bool, int)) and -2**63 <= int(e.value) < 2**63:
+                out[i] = (None, int(e.value) & (2**64 - 1), True)
+            elif cls == "Lit" and isinstance(e.value, float):
+                out[i] = (None, struct.unpack("<Q", struct.pack("<d", e.value))[0], False)
+            elif cls == "Col" and sel is None and any(name == e.name for name, _ in batch.schema):
+                col = batch.cols[batch.column_index(e.name)]
+                if col.kind in (hs.I32, hs.F32, hs.I64) and col.dict is None:
+                    out[i] = (col, 0, col.kind != hs.F32)
+                else:
+                    todo.append(i)
+            else:
+                todo.append(i)
+        if todo:
+            for i, (col, tag) in zip(todo, self.eval_numeric(batch, [args[i] for i in todo], sel=sel, n=n)):
+                out[i] = (col, 0, tag in ("I", "B"))
+        return out
+
+    def group_radix(self, key: DCol, sel: torch.Tensor | None, n: int, bounds: torch.Tensor, n_units: int,
+                    max_unit_rows: int, values: Sequence[tuple], ops: Sequence[int], quantise: bool):
+        """hs_group_radix_plan / run / emit -> (key column, accumulator columns, groups before every unit) or None when
+        a partition outgrew its dictionary (the caller takes the hash-table path)."""
+        na = len(values)
+        spec = hs.hs_agg_spec()
+        spec.n_acc = na
+        kinds = (C.c_int32 * max(na, 1))()
+        consts = (C.c_uint64 * max(na, 1))()
+        cols = (hs.hs_col * max(na, 1))()
+        for a, ((col, cell, integer), op) in enumerate(zip(values, ops)):
+            spec.op[a] = op
+            spec.is_int[a] = 1 if integer else 0
+            kinds[a] = col.kind if col is not None else -1
+            consts[a] = cell
+            cols[a] = col.as_hs() if col is not None else hs.hs_col(hs.U8, -1, None, None, None)
+        plan = hs.hs_radix_plan()
+        hs.check(self.lib.hs_group_radix_plan(key.kind, n, n_units, max(int(max_unit_rows), 1), kinds, C.byref(spec),
+                                              1 if quantise else 0, C.byref(plan)), "hs_group_radix_plan")
+        ws = self.workspace(self.lib.hs_group_radix_ws_bytes(C.byref(plan)))
+        unit_groups = self.empty(n_units + 1, torch.int64)
+        radix_flags = self.empty(1, torch.int32)  # own word: an overflow here is answered by the other path, not raised
+        radix_flags.zero_()
+        k = key.as_hs()
+        hs.check(self.lib.hs_group_radix_run(self.stream, C.byref(plan), C.byref(k), sel.data_ptr() if sel is not None else None,
+                                             0, bounds.data_ptr(), cols, consts, C.byref(spec), ws.data_ptr(),
+                                             unit_groups.data_ptr(), radix_flags.data_ptr()), "hs_group_radix_run")
+        if self.rec is not None:
+            self.rec.poisoned = True  # the group count sizes the outputs
+        flags = int(radix_flags.item())
+        if flags & hs.FLAG_DICT_FULL:
+            return None
+        if flags:
+            self.flags[0:1] |= radix_flags  # data-dependent errors surface where the other operators' do
+        unit_rows = [int(v) for v in unit_groups.tolist()]
+        ng = unit_rows[-1]
+        out_key = self.empty(max(ng, 1), _TORCH_DTYPE[key.kind])
+        okind = [(hs.I32 if integer else hs.F32) if quantise else (hs.I64 if integer else hs.F64) for _, _, integer in values]
+        outs = [self.empty(max(ng, 1), _TORCH_DTYPE[kd]) for kd in okind]
+        ptrs = (C.c_void_p * max(na, 1))(*[o.data_ptr() for o in outs])
+        hs.check(self.lib.hs_group_radix_emit(self.stream, C.byref(plan), ws.data_ptr(), out_key.data_ptr(), ptrs),
+                 "hs_group_radix_emit")
+        return DCol(key.kind, out_key, ng), [DCol(kd, o, ng) for kd, o in zip(okind, outs)], unit_rows
+
     def aggregate_partial_global(self, batch: DBatch, filters: Sequence[Any], group_by: Any,
                                  agg_columns: Sequence[Any], out_schema: Schema) -> DBatch:
         """Partial aggregate for any number of groups, ONE pass over all units: an HBM dictionary with one table region
@@ -1372,6 +1450,20 @@ class Device:
             out_cols = [empty_key] + [DCol(FILE_KIND[t], self.empty(0, _TORCH_DTYPE[FILE_KIND[t]]), 0)
                                       for _, t in out_schema[1:]]
             return DBatch(list(out_schema), out_cols, 0, [0] * (n_units + 1))
+        if self.radix_enabled and key.kind in (hs.I32, hs.I64) and key.dict is None:
+            biggest = max(batch.unit_rows[u + 1] - batch.unit_rows[u] for u in range(n_units))
+            done = self.group_radix(key, sel, n, bounds, n_units, biggest, self._radix_values(batch, args, sel, n), ops,
+                                    quantise=True)
+            if done is not None:
+                key_col, accs, unit_rows = done
+                self.last_global_tier = "radix"
+                order = None
+                if batch.unit_ids is not None:  # multi-GPU: remember which global unit every partial row came from
+                    counts = torch.tensor([unit_rows[u + 1] - unit_rows[u] for u in range(n_units)], device=self.device)
+                    order = torch.repeat_interleave(torch.tensor(batch.unit_ids, dtype=torch.int64, device=self.device), counts)
+                return DBatch(list(out_schema), [key_col] + [accs[a] for a in agg_to_acc], unit_rows[-1], unit_rows, order=order,
+                              total_units=batch.total_units)
+        self.last_global_tier = "hash"
         vals = self.eval_numeric(batch, args, sel=sel, n=n)
         is_int = [tag in ("I", "B") for _, tag in vals]
         # one table region per unit, sized from the unit's UNFILTERED rows (known on the host): >= 2 slots per row
@@ -1427,6 +1519,15 @@ class Device:
         ops = [{"sum": hs.AGG_SUM, "min": hs.AGG_MIN, "max": hs.AGG_MAX}[a.type] for a in agg_columns]
         vals = batch.cols[1: 1 + len(agg_columns)]
         is_int = [v.kind in (hs.I32, hs.I64) for v in vals]
+        key = batch.cols[0]
+        if (self.radix_enabled and sel is None and n > 0 and key.kind in (hs.I32, hs.I64) and key.dict is None
+                and all(v.kind in (hs.I32, hs.F32, hs.I64, hs.F64) and v.dict is None for v in vals)):
+            # single GPU: the partial rows already sit in unit order = the reference's merge order; ONE unit of n rows
+            bounds = self.to_device(np.asarray([0, n], dtype=np.int64))
+            done = self.group_radix(key, None, n, bounds, 1, n, [(v, 0, i) for v, i in zip(vals, is_int)], ops, quantise=False)
+            if done is not None:
+                key_col, cols, unit_rows = done
+                return DBatch(list(out_schema), [key_col] + cols, unit_rows[-1], [0, unit_rows[-1]])
         if sel is not None:  # fold reads values by POSITION: bring them into visiting order
             vals = [self.gather_col(v, sel, n) for v in vals]
         slot_start, positions, slot_list, ng = self._group_build(batch.cols[0], sel, n)

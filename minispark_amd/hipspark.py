@@ -154,6 +154,10 @@ class hs_result_col(C.Structure):
     _fields_ = [("kind", C.c_int32), ("width", C.c_int32), ("data", C.c_void_p), ("n_rows", C.c_int64)]
 
 
+class hs_radix_plan(C.Structure):
+    _fields_ = [("f", C.c_int64 * 48)]
+
+
 HS_STAGE_PLAN_VERSION = 1
 
 _P = C.c_void_p
@@ -208,6 +212,10 @@ SIGNATURES: dict[str, tuple] = {
     "hs_group_build": (C.c_int, [_P, _COLP, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P]),
     "hs_group_build_units": (C.c_int, [_P, _COLP, _P, _I64, _I64, _P, _P, _I32, _I64, _P, _P, _P, _P, _P, _P]),
     "hs_lower_bound_i64": (C.c_int, [_P, _P, _I64, _P, _P, _I64, _P]),
+    "hs_group_radix_plan": (C.c_int, [_I32, _I64, _I32, _I64, _P, _SPECP, _I32, _P]),
+    "hs_group_radix_ws_bytes": (C.c_size_t, [_P]),
+    "hs_group_radix_run": (C.c_int, [_P, _P, _COLP, _P, _I64, _P, _COLP, _P, _SPECP, _P, _P, _P]),
+    "hs_group_radix_emit": (C.c_int, [_P, _P, _P, _P, _P]),
     "hs_group_mask": (C.c_int, [_P, _P, _I64, _P]),
     "hs_group_fold": (C.c_int, [_P, _COLP, _SPECP, _P, _I64, _P, _P, _P, _P, _I64, _I32, _P, _P, _P]),
     "hs_join_count": (C.c_int, [_P, _COLP, _COLP, _I64, _I64, _P, _P, _P, _P]),

@@ -1,0 +1,182 @@
+"""The HBM tier of GROUP BY by radix partitioning (csrc/hs_radix.hip: hs_group_radix_plan / run / emit) against a
+numpy restatement of the reference's per-block dictionary fold (tasks.py:284-310): every group's values are folded in
+ascending row order in fp64 / int, so ``np.add.at`` (unbuffered, in index order) IS the expected result - bit for bit,
+also through the f32 / i32 quantisation of the shuffle write."""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from minispark_amd.execution import HipExecutionEngine
+
+    with HipExecutionEngine(0) as e:
+        yield e.dev
+
+
+def _expected(keys, vals, ops, is_int, bounds, quantise):
+    """-> per unit {key: tuple of accumulators}"""
+    from minispark_amd import hipspark as hs
+
+    out = []
+    for lo, hi in zip(bounds, bounds[1:]):
+        uniq, inv = np.unique(keys[lo:hi], return_inverse=True)
+        accs = []
+        for v, op, integer in zip(vals, ops, is_int):
+            x = (np.full(hi - lo, v) if np.isscalar(v) else v[lo:hi]).astype(np.int64 if integer else np.float64)
+            if op == hs.AGG_SUM:
+                acc = np.zeros(len(uniq), x.dtype)
+                np.add.at(acc, inv, x)
+            elif op == hs.AGG_MIN:
+                acc = np.full(len(uniq), 2147483647, x.dtype)
+                np.minimum.at(acc, inv, x)
+            else:
+                acc = np.full(len(uniq), -2147483648, x.dtype)
+                np.maximum.at(acc, inv, x)
+            if quantise:
+                acc = acc.astype(np.int32 if integer else np.float32)
+            accs.append(acc)
+        out.append({int(k): tuple(a[i].item() for a in accs) for i, k in enumerate(uniq)})
+    return out
+
+
+def _run(dev, keys, key_kind, sel, bounds, values, ops, quantise):
+    import torch
+
+    from minispark_amd import hipspark as hs
+    from minispark_amd.device import DCol
+
+    tk = torch.from_numpy(keys).cuda()
+    key = DCol(key_kind, tk, len(keys))
+    tsel = torch.from_numpy(sel).cuda() if sel is not None else None
+    n = len(sel) if sel is not None else len(keys)
+    vals = []
+    for v in values:
+        if np.isscalar(v):
+            vals.append((None, int(v) & (2**64 - 1), True))
+        else:
+            kind = {np.dtype(np.int32): hs.I32, np.dtype(np.float32): hs.F32, np.dtype(np.int64): hs.I64,
+                    np.dtype(np.float64): hs.F64}[v.dtype]
+            vals.append((DCol(kind, torch.from_numpy(v).cuda(), len(v)), 0, kind in (hs.I32, hs.I64)))
+    tb = torch.from_numpy(np.asarray(bounds, dtype=np.int64)).cuda()
+    biggest = max(b - a for a, b in zip(bounds, bounds[1:]))
+    done = dev.group_radix(key, tsel, n, tb, len(bounds) - 1, biggest, vals, ops, quantise)
+    assert done is not None, "a partition outgrew its dictionary"
+    key_col, accs, unit_rows = done
+    torch.cuda.synchronize()
+    assert dev.read_flags() == 0
+    k = key_col.data[: key_col.n].cpu().numpy()
+    a = [c.data[: c.n].cpu().numpy() for c in accs]
+    got = []
+    for lo, hi in zip(unit_rows, unit_rows[1:]):
+        unit = {int(k[i]): tuple(x[i].item() for x in a) for i in range(lo, hi)}
+        assert len(unit) == hi - lo, "a key twice in one unit"
+        got.append(unit)
+    return got
+
+
+def _same(got, want):
+    assert len(got) == len(want)
+    for u, (g, w) in enumerate(zip(got, want)):
+        assert g.keys() == w.keys(), f"unit {u}: {len(g)} groups, expected {len(w)}"
+        for key, accs in w.items():
+            for x, y in zip(g[key], accs):
+                assert x == y and np.signbit(x) == np.signbit(y), (u, key, g[key], accs)
+
+
+@pytest.mark.parametrize(("n", "units", "groups", "seed"), [
+    (1, 1, 1, 0), (700, 3, 40, 1), (50_000, 4, 30_000, 2), (300_000, 3, 200_000, 3),  # one pass
+    (3_000_000, 1, 700_000, 4), (3_000_000, 2, 50, 5), (2_500_000, 5, 2_000_000, 6),   # two passes; few / many groups
+])
+@pytest.mark.parametrize("quantise", [True, False])
+def test_radix_tier_matches_the_ordered_fold(dev, n, units, groups, seed, quantise):
+    from minispark_amd import hipspark as hs
+
+    rng = np.random.default_rng(seed)
+    keys = rng.integers(-groups // 2, groups - groups // 2, n).astype(np.int32)
+    f = (rng.normal(0, 1, n) * np.exp2(rng.integers(-8, 8, n))).astype(np.float32)
+    d = rng.normal(0, 1e3, n)  # an evaluated expression: fp64 cells
+    i = rng.integers(-1000, 1000, n).astype(np.int32)
+    cuts = np.sort(rng.integers(0, n + 1, units - 1)).tolist()
+    bounds = [0] + cuts + [n]  # units of any size, empty ones included
+    values = [f, d, i, 1, f, i]
+    ops = [hs.AGG_SUM, hs.AGG_SUM, hs.AGG_SUM, hs.AGG_SUM, hs.AGG_MIN, hs.AGG_MAX]
+    is_int = [False, False, True, True, False, True]
+    got = _run(dev, keys, hs.I32, None, bounds, values, ops, quantise)
+    _same(got, _expected(keys, values, ops, is_int, bounds, quantise))
+
+
+def test_radix_tier_over_a_selection_and_timestamp_keys(dev):
+    """WHERE survivors arrive as an ascending row list; the key is read through it, values are position-indexed."""
+    from minispark_amd import hipspark as hs
+
+    rng = np.random.default_rng(9)
+    rows = 400_000
+    all_keys = (rng.integers(0, 90_000, rows) * 86_400_000_000 - 2**40).astype(np.int64)
+    sel = np.flatnonzero(rng.random(rows) < 0.4).astype(np.int64)
+    n = len(sel)
+    v = rng.normal(0, 50, n).astype(np.float32)
+    unit_row_bounds = [0, 150_000, 150_000, 310_000, rows]
+    bounds = [int(np.searchsorted(sel, b)) for b in unit_row_bounds]
+    values, ops, is_int = [v, 1], [hs.AGG_SUM, hs.AGG_SUM], [False, True]
+    got = _run(dev, all_keys, hs.I64, sel, bounds, values, ops, True)
+    _same(got, _expected(all_keys[sel], values, ops, is_int, bounds, True))
+
+
+def test_radix_tier_reports_an_outgrown_dictionary(dev):
+    """Every row its own group and a unit far bigger than declared: partitions hold more keys than a dictionary has
+    slots -> the wrapper answers None (the engine then takes the hash-table path)."""
+    import torch
+
+    from minispark_amd import hipspark as hs
+    from minispark_amd.device import DCol
+
+    n = 100_000
+    key = DCol(hs.I32, torch.arange(n, dtype=torch.int32, device="cuda"), n)
+    bounds = torch.tensor([0, n], dtype=torch.int64, device="cuda")
+    assert dev.group_radix(key, None, n, bounds, 1, 2000, [(None, 1, True)], [hs.AGG_SUM], True) is None
+
+
+def test_engine_takes_the_radix_tier_for_integer_keys(tmp_path):
+    """Through the engine: the high-cardinality GROUP BY of test_gpu_q1_large runs on the radix tier and still equals
+    the Python oracle bit for bit; with HIPSPARK_RADIX=0 the hash-table tier gives the same rows."""
+    from minispark_amd import constants
+    from minispark_amd.constants import ColumnType as T
+    from minispark_amd.dataframe import DataFrame
+    from minispark_amd.execution import HipExecutionEngine
+    from minispark_amd.io import BlockFile
+    from minispark_amd.sql import Col, Functions as F
+    from oracle.py_engine import run_query
+    from tests.conftest import assert_rows_match
+
+    constants.SHUFFLE_FOLDER = tmp_path / "shuffle"
+    rng = np.random.default_rng(5)
+    n = 120_000
+    keys = rng.integers(-20_000, 20_000, n).astype(np.int32)
+    qty = rng.integers(1, 50, n).astype(np.int32)
+    price = (rng.integers(100, 100_000, n) / 7.0).astype(np.float32)
+    path = tmp_path / "t.bin"
+    schema = [("k", T.INTEGER), ("q", T.INTEGER), ("p", T.FLOAT)]
+    per = 50_000
+    BlockFile(path).write_raw_blocks(schema, [[keys[i: i + per], qty[i: i + per], price[i: i + per]] for i in range(0, n, per)])
+
+    def build(engine):
+        return (DataFrame(engine).table(str(path)).filter(Col("q") > 3).group_by(Col("k"))
+                .agg(F.sum(Col("q") * Col("p")).alias("rev"), F.count(), F.min(Col("p")).alias("lo"),
+                     F.avg(Col("p")).alias("mean"), F.max(Col("q")).alias("hi")))
+
+    want = run_query(build(object()).task)
+    with HipExecutionEngine(0) as engine:
+        rows = build(engine).collect()
+        assert engine.dev.last_global_tier == "radix"
+        assert_rows_match(rows, want, max_ulps=0)
+        assert_rows_match(build(engine).collect(), want, max_ulps=0)
+        engine.dev.radix_enabled = False
+        engine._version += 1
+        assert_rows_match(build(engine).collect(), want, max_ulps=0)
+        assert engine.dev.last_global_tier == "hash"

@@ -103,3 +103,12 @@ def global_agg():
 t0 = time.perf_counter(); global_agg(); torch.cuda.synchronize()
 ms = timed(global_agg, reps=3)
 report(f"A5 global tier build+fold ({N // 16} groups)", ms, N * (4 + 4), f"{N / ms / 1e3:.0f} M rows/s (bit-exact sequential fold)")
+
+# A5 the same through the radix tier (hs_group_radix_*: partition passes + one wave per partition, round 2)
+bounds1 = torch.tensor([0, N], dtype=torch.int64, device="cuda")
+def radix_agg():
+    return dev.group_radix(gcol, None, N, bounds1, 1, N, [(vals, 0, False)], [hs.AGG_SUM], True)
+out = radix_agg(); torch.cuda.synchronize()
+assert out is not None
+ms = timed(radix_agg, reps=3)
+report(f"A5 radix tier partition+fold ({N // 16} groups)", ms, N * (4 + 4), f"{N / ms / 1e3:.0f} M rows/s (bit-exact sequential fold; {out[0].n} groups)")
