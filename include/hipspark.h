@@ -357,6 +357,9 @@ int hs_group_radix_run(void* stream, const hs_radix_plan* plan, const hs_col* ke
                        const int64_t* unit_bounds, const hs_col* val_cols, const uint64_t* const_cells,
                        const hs_agg_spec* spec, void* ws, int64_t* out_unit_groups, uint32_t* flags);
 int hs_group_radix_emit(void* stream, const hs_radix_plan* plan, void* ws, void* out_key, void* const* out_acc);
+/* Debug aid: with HIPSPARK_RADIX_STAMPS=1 in the environment the fold kernel sums the cycles its waves spend per phase;
+ * out8 = {clear tables, wait for loads, slot lookup, ranking, fold, emit, waves, 0} since the last call. */
+int hs_group_radix_debug_stamps(uint64_t* out8);
 /* mask[s] = 1 for non-empty slots (compact it with hs_compact to get the dense slot list). */
 int hs_group_mask(void* stream, const int64_t* slot_start, int64_t table_cap, uint8_t* mask);
 /* One lane per group folds val_cols[a][position] over the group's positions front to back - the reference's

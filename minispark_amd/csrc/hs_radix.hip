@@ -21,6 +21,7 @@
 // (the caller takes the round-1 path).  Keys: INTEGER / TIMESTAMP (the key word is the value).
 #include "hs_device.h"
 
+#include <cstdlib>
 #include <cstring>
 
 extern thread_local char g_hs_err[256];
@@ -147,14 +148,20 @@ __global__ void __launch_bounds__(RX_THREADS) k_rx_scatter(const RxPass A_kernar
     const int64_t b = A.seg_start[seg] + t * RX_TILE;
     const int64_t seg_end = A.seg_start[seg + 1];
     const int64_t e = (b + RX_TILE) < seg_end ? (b + RX_TILE) : seg_end;
+    // all loads of a phase are issued before the first dependent use: the kernel would otherwise pay one global
+    // round trip per row step (the ranking's LDS updates and the scatter's stores fence the loads behind them)
     uint64_t word[RX_PER];
     uint32_t bin[RX_PER], local[RX_PER];
     const uint64_t below = (1ull << lane) - 1ull;
+    const int64_t first = b + (int64_t)w * RX_SUB + lane;
 #pragma unroll
     for (int j = 0; j < RX_PER; ++j) {
-        const int64_t i = b + (int64_t)w * RX_SUB + j * HS_WAVE + lane;
-        const bool valid = i < e;
-        word[j] = valid ? rx_key(A, i) : 0;
+        const int64_t i = first + j * HS_WAVE;
+        word[j] = i < e ? rx_key(A, i) : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < RX_PER; ++j) {
+        const bool valid = first + j * HS_WAVE < e;
         bin[j] = valid ? rx_bin(word[j], A.shift, A.bits) : 0u;
         uint64_t peers = __ballot(valid);
         for (int bit = 0; bit < A.bits; ++bit) {
@@ -180,14 +187,31 @@ __global__ void __launch_bounds__(RX_THREADS) k_rx_scatter(const RxPass A_kernar
         gbase[tid] = A.counters[(A.tile_base[seg] << A.bits) + (int64_t)tid * nt + t];
     }
     __syncthreads();
+    int64_t to[RX_PER];
 #pragma unroll
     for (int j = 0; j < RX_PER; ++j) {
-        const int64_t i = b + (int64_t)w * RX_SUB + j * HS_WAVE + lane;
-        if (i >= e) continue;
-        const int64_t to = gbase[bin[j]] + whist[w][bin[j]] + local[j];
-        if (A.esize[0] == 4) ((int32_t*)A.dst[0])[to] = (int32_t)word[j];
-        else ((uint64_t*)A.dst[0])[to] = word[j];
-        for (int c = 1; c < A.n_cols; ++c) rx_move(A.src[c], A.dst[c], A.esize[c], i, to);
+        to[j] = first + j * HS_WAVE < e ? gbase[bin[j]] + whist[w][bin[j]] + local[j] : -1;
+        if (to[j] < 0) continue;
+        if (A.esize[0] == 4) ((int32_t*)A.dst[0])[to[j]] = (int32_t)word[j];
+        else ((uint64_t*)A.dst[0])[to[j]] = word[j];
+    }
+    for (int c = 1; c < A.n_cols; ++c) {
+        const int es = A.esize[c];
+        const void* src = A.src[c];
+        void* dst = A.dst[c];
+        uint64_t v[RX_PER];
+#pragma unroll
+        for (int j = 0; j < RX_PER; ++j) {
+            const int64_t i = first + j * HS_WAVE;
+            v[j] = to[j] < 0 ? 0 : (es == 4 ? (uint64_t)((const uint32_t*)src)[i] : es == 8 ? ((const uint64_t*)src)[i] : (uint64_t)((const uint8_t*)src)[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < RX_PER; ++j) {
+            if (to[j] < 0) continue;
+            if (es == 4) ((uint32_t*)dst)[to[j]] = (uint32_t)v[j];
+            else if (es == 8) ((uint64_t*)dst)[to[j]] = v[j];
+            else ((uint8_t*)dst)[to[j]] = (uint8_t)v[j];
+        }
     }
 }
 
@@ -217,10 +241,15 @@ struct RxAgg {
     uint64_t const_cell[HS_MAX_ACC];
     hs_agg_spec spec;
     int32_t cap, quantise;
+    int32_t debug, last;           // last: no later launch takes what this one cannot hold
     uint64_t* prov_key;            // [n] a partition's groups, from the partition's own start
     void* prov_acc[HS_MAX_ACC];    // [n] each: f32 / i32 when quantising, f64 / i64 bits otherwise
     int64_t* pcount;               // [n_parts] groups of the partition
     uint32_t* flags;
+    const int64_t* list;           // second launch: the partitions the small table could not hold ...
+    const int64_t* list_count;     // ... and their number (device)
+    int64_t* overflow;             // first launch: where such partitions are noted
+    int64_t* overflow_count;
 };
 
 __device__ __forceinline__ uint64_t rx_cell(const void* src, int kind, int64_t i) {
@@ -232,99 +261,221 @@ __device__ __forceinline__ uint64_t rx_cell(const void* src, int kind, int64_t i
     }
 }
 
+__device__ __forceinline__ uint64_t rx_widen(uint64_t raw, int kind) {
+    switch (kind) {
+        case HS_I32: return (uint64_t)(int64_t)(int32_t)(uint32_t)raw;
+        case HS_F32: return hs_d2u((double)__uint_as_float((uint32_t)raw));
+        default: return raw;  // HS_I64 / HS_F64 cells, HS_U8 zero-extended
+    }
+}
+__device__ __forceinline__ uint64_t rx_raw(const void* src, int esize, int64_t i) {
+    return esize == 4 ? (uint64_t)((const uint32_t*)src)[i] : esize == 8 ? ((const uint64_t*)src)[i] : (uint64_t)((const uint8_t*)src)[i];
+}
+
+// HIPSPARK_RADIX_STAMPS=1: cycles (s_memtime) a wave spends per phase of k_rx_fold, summed over all waves
+__device__ unsigned long long rx_stamp_acc[8];
+#define RX_T(var) const long long var = A.debug ? (long long)clock64() : 0
+
+constexpr int RX_CHUNK = 4;  // 64-row steps loaded together; the next chunk is in flight while this one is folded
+
+// NC = value columns that travel with the rows (0 .. 4 specialised: the tuples of a chunk sit in registers;
+// -1: any number, one global round trip per step and column).
+//
+// A wave's tables: keys[cap], acc[NA][cap] and order[cap] - the slots in the order their keys first appeared, which is
+// also the order the partition's groups are written in.  The tables are cleared once per wave; after a partition only
+// the slots on its list are reset, so a partition costs its rows and its groups, not the table size.
+//
+// Two launches share the kernel: the first with a SMALL table (512 slots: many waves per CU), where a partition that
+// meets more keys than 3/4 of it is put on the overflow list instead of being finished; the second (A.list set) takes
+// the listed partitions with the big table the plan sized for the worst case (every row its own group).
+template <int NC>
 __global__ void __launch_bounds__(256) k_rx_fold(const RxAgg A_kernarg) {
     HS_KERNARG(RxAgg, A);
     extern __shared__ __align__(16) uint64_t rx_lds[];
     const int lane = threadIdx.x & (HS_WAVE - 1), w = threadIdx.x / HS_WAVE, wpb = blockDim.x / HS_WAVE;
     const int NA = A.spec.n_acc, cap = A.cap;
-    uint64_t* keys = rx_lds + (size_t)w * cap * (1 + NA);  // [cap]
-    uint64_t* acc = keys + cap;                             // [NA][cap]
+    const size_t per_wave = (size_t)cap * (1 + NA) + (size_t)cap / 4;  // in 8-byte words; order[] is u16
+    uint64_t* keys = rx_lds + (size_t)w * per_wave;  // [cap]
+    uint64_t* acc = keys + cap;                       // [NA][cap]
+    uint16_t* order = (uint16_t*)(acc + (size_t)NA * cap);
     const uint32_t mask = (uint32_t)cap - 1u;
+    const int limit = A.last ? cap : cap - cap / 4;   // groups a partition may hold in this launch
     const uint64_t below = (1ull << lane) - 1ull;
-    int slot_bits = 0;
-    while ((1 << slot_bits) < cap) ++slot_bits;
+    constexpr int NCR = NC > 0 ? NC : 1;
     uint32_t err = 0;
-    for (int64_t p = (int64_t)blockIdx.x * wpb + w; p < A.n_parts; p += (int64_t)gridDim.x * wpb) {
+    long long t_init = 0, t_slot = 0, t_rank = 0, t_fold = 0, t_emit = 0, t_wait = 0;
+    for (int s = lane; s < cap; s += HS_WAVE) keys[s] = HS_EMPTY_KEY;
+    for (int a = 0; a < NA; ++a) {
+        const uint64_t id = hs_acc_identity(A.spec.op[a], A.spec.is_int[a] != 0);
+        for (int s = lane; s < cap; s += HS_WAVE) acc[a * cap + s] = id;
+    }
+    const int64_t n_todo = A.list ? *A.list_count : A.n_parts;
+    for (int64_t q = (int64_t)blockIdx.x * wpb + w; q < n_todo; q += (int64_t)gridDim.x * wpb) {
+        const int64_t p = A.list ? A.list[q] : q;
         const int64_t b = A.seg_start[p], e = A.seg_start[p + 1];
         if (b >= e) {
             if (lane == 0) A.pcount[p] = 0;
             continue;
         }
-        for (int s = lane; s < cap; s += HS_WAVE) keys[s] = HS_EMPTY_KEY;
-        for (int a = 0; a < NA; ++a) {
-            const uint64_t id = hs_acc_identity(A.spec.op[a], A.spec.is_int[a] != 0);
-            for (int s = lane; s < cap; s += HS_WAVE) acc[a * cap + s] = id;
-        }
-        for (int64_t base = b; base < e; base += HS_WAVE) {
-            const int64_t i = base + lane;
-            bool valid = i < e;
-            int slot = 0;
-            if (valid) {
-                const uint64_t k = A.esize[0] == 4 ? (uint64_t)(int64_t)((const int32_t*)A.src[0])[i] : ((const uint64_t*)A.src[0])[i];
-                uint32_t h = (uint32_t)(hs_mix64(k) >> 36) & mask;
-                slot = -1;
-                for (uint32_t probe = 0; probe <= mask; ++probe) {
-                    uint64_t cur = __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (cur == HS_EMPTY_KEY) {
-                        cur = atomicCAS((unsigned long long*)&keys[h], (unsigned long long)HS_EMPTY_KEY, (unsigned long long)k);
-                        if (cur == HS_EMPTY_KEY) cur = k;
-                    }
-                    if (cur == k) {
-                        slot = (int)h;
-                        break;
-                    }
-                    h = (h + 1) & mask;
+        RX_T(c0);
+        uint64_t nk[RX_CHUNK], nx[RX_CHUNK][NCR];
+        auto load_chunk = [&](int64_t base) {
+#pragma unroll
+            for (int j = 0; j < RX_CHUNK; ++j) {
+                const int64_t i = base + j * HS_WAVE + lane;
+                const bool valid = i < e;
+                nk[j] = !valid ? 0 : (A.esize[0] == 4 ? (uint64_t)(int64_t)((const int32_t*)A.src[0])[i] : ((const uint64_t*)A.src[0])[i]);
+                if constexpr (NC > 0) {
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) nx[j][c] = valid ? rx_raw(A.src[1 + c], A.esize[1 + c], i) : 0;
                 }
             }
-            if (__ballot(valid && slot < 0) != 0ull) {  // more distinct keys than slots: the caller takes the other path
-                err |= HS_FLAG_DICT_FULL;
-                break;
+        };
+        load_chunk(b);
+        int ngroups = 0;
+        bool full = false;
+        RX_T(c1);
+        t_init += c1 - c0;
+        for (int64_t base = b; base < e && !full; base += RX_CHUNK * HS_WAVE) {
+            RX_T(w0);
+            uint64_t ck[RX_CHUNK], cx[RX_CHUNK][NCR];
+#pragma unroll
+            for (int j = 0; j < RX_CHUNK; ++j) {
+                ck[j] = nk[j];
+#pragma unroll
+                for (int c = 0; c < NCR; ++c) cx[j][c] = NC > 0 ? nx[j][c] : 0;
             }
-            // lanes of this step in the same group, and my rank among them (row order = lane order)
-            uint64_t peers = __ballot(valid);
-            for (int bit = 0; bit < slot_bits; ++bit) {
-                const bool on = (slot >> bit) & 1;
-                const uint64_t bal = __ballot(valid && on);
-                peers &= on ? bal : ~bal;
-            }
-            const int rank = __popcll(peers & below);
-            for (int a = 0; a < NA; ++a) {
-                const uint32_t op = A.spec.op[a];
-                const bool is_int = A.spec.is_int[a] != 0;
-                const int c = A.carried[a];
-                const uint64_t x = !valid ? 0 : (c ? rx_cell(A.src[c], A.val_kind[a], i) : A.const_cell[a]);
-                for (int r = 0; __ballot(valid && rank >= r) != 0ull; ++r)
-                    if (valid && rank == r) acc[a * cap + slot] = hs_acc_fold(op, is_int, acc[a * cap + slot], x);
-            }
-        }
-        // the partition's groups, in slot order, from the partition's own start
-        int64_t running = 0;
-        for (int s0 = 0; s0 < cap; s0 += HS_WAVE) {
-            const int s = s0 + lane;
-            const uint64_t k = keys[s];
-            const bool occ = k != HS_EMPTY_KEY;
-            const uint64_t bal = __ballot(occ);
-            if (occ) {
-                const int64_t at = b + running + __popcll(bal & below);
-                A.prov_key[at] = k;
+            if (A.debug) t_wait += (long long)(ck[0] & 1) * 0 + (long long)clock64() - w0;  // the chunk's loads have landed
+            if (base + RX_CHUNK * HS_WAVE < e) load_chunk(base + RX_CHUNK * HS_WAVE);
+#pragma unroll
+            for (int j = 0; j < RX_CHUNK; ++j) {
+                const int64_t i = base + j * HS_WAVE + lane;
+                if (base + j * HS_WAVE >= e || full) break;
+                const bool valid = i < e;
+                RX_T(s0);
+                int slot = 0;
+                bool inserted = false;
+                if (valid) {
+                    const uint64_t k = ck[j];
+                    uint32_t h = (uint32_t)(hs_mix64(k) >> 36) & mask;
+                    slot = -1;
+                    for (uint32_t probe = 0; probe <= mask; ++probe) {
+                        uint64_t cur = __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (cur == HS_EMPTY_KEY) {
+                            cur = atomicCAS((unsigned long long*)&keys[h], (unsigned long long)HS_EMPTY_KEY, (unsigned long long)k);
+                            if (cur == HS_EMPTY_KEY) {
+                                cur = k;
+                                inserted = true;
+                            }
+                        }
+                        if (cur == k) {
+                            slot = (int)h;
+                            break;
+                        }
+                        h = (h + 1) & mask;
+                    }
+                }
+                const uint64_t fresh = __ballot(inserted);
+                if (inserted) order[ngroups + __popcll(fresh & below)] = (uint16_t)slot;
+                ngroups += __popcll(fresh);
+                if (ngroups > limit || __ballot(valid && slot < 0) != 0ull) {  // too many keys for this table
+                    full = true;
+                    break;
+                }
+                // lanes of this step in the same group (one ballot per slot bit; bits the table does not use are 0
+                // everywhere and change nothing), my rank among them: row order = lane order
+                RX_T(s1);
+                t_slot += s1 - s0;
+                uint64_t peers = __ballot(valid);
+#pragma unroll
+                for (int bit = 0; bit < 12; ++bit) {
+                    const bool on = (slot >> bit) & 1;
+                    peers &= ~(__ballot(valid && on) ^ (on ? ~0ull : 0ull));
+                }
+                const int rank = __popcll(peers & below);
+                const int most = __popcll(peers);
+                uint64_t crowded = __ballot(valid && most > 1);
+                RX_T(s2);
+                t_rank += s2 - s1;
                 for (int a = 0; a < NA; ++a) {
+                    const uint32_t op = A.spec.op[a];
                     const bool is_int = A.spec.is_int[a] != 0;
-                    uint64_t v = acc[a * cap + s];
-                    if (hs_float_identity_left(A.spec.op[a], is_int, v)) err |= HS_FLAG_TYPE_ASSERT;
-                    if (A.quantise) {
-                        v = hs_quantise_cell(is_int, v, err);
-                        if (is_int) ((int32_t*)A.prov_acc[a])[at] = (int32_t)(int64_t)v;
-                        else ((float*)A.prov_acc[a])[at] = (float)hs_u2d(v);
-                    } else {
-                        ((uint64_t*)A.prov_acc[a])[at] = v;
+                    const int c = A.carried[a];
+                    uint64_t x = A.const_cell[a];
+                    if (c) {
+                        uint64_t raw = 0;
+                        if constexpr (NC > 0) {
+#pragma unroll
+                            for (int cc = 0; cc < NC; ++cc)
+                                if (c - 1 == cc) raw = cx[j][cc];
+                        } else {
+                            raw = valid ? rx_raw(A.src[c], A.esize[c], i) : 0;
+                        }
+                        x = rx_widen(raw, A.val_kind[a]);
                     }
+                    // a group's first lane of the step folds the values of all its lanes, in lane order, from registers
+                    uint64_t v = 0;
+                    const bool leader = valid && rank == 0;
+                    if (leader) v = hs_acc_fold(op, is_int, acc[a * cap + slot], x);
+                    if (crowded) {
+                        uint64_t rest = leader ? peers & ~(1ull << lane) : 0ull;
+                        while (__ballot(rest != 0ull) != 0ull) {
+                            const int from = rest ? __ffsll((long long)rest) - 1 : lane;
+                            const uint64_t xv = __shfl(x, from, HS_WAVE);
+                            if (rest) {
+                                v = hs_acc_fold(op, is_int, v, xv);
+                                rest &= rest - 1;
+                            }
+                        }
+                    }
+                    if (leader) acc[a * cap + slot] = v;
+                }
+                if (A.debug) t_fold += (long long)clock64() - s2;
+            }
+        }
+        RX_T(e0);
+        if (full) {
+            // leave the partition to the launch with the big table (or, from that one, to the caller's other path)
+            if (A.last) err |= HS_FLAG_DICT_FULL;
+            else if (lane == 0) A.overflow[atomicAdd((unsigned long long*)A.overflow_count, 1ull)] = p;
+            if (lane == 0) A.pcount[p] = 0;
+        }
+        // the partition's groups, in the order their keys first appeared, from the partition's own start
+        for (int g0 = 0; g0 < ngroups; g0 += HS_WAVE) {
+            const int g = g0 + lane;
+            if (g >= ngroups) continue;
+            const int s = order[g];
+            const int64_t at = b + g;
+            if (!full) A.prov_key[at] = keys[s];
+            keys[s] = HS_EMPTY_KEY;
+            for (int a = 0; a < NA; ++a) {
+                const bool is_int = A.spec.is_int[a] != 0;
+                uint64_t v = acc[a * cap + s];
+                acc[a * cap + s] = hs_acc_identity(A.spec.op[a], is_int);
+                if (full) continue;
+                if (hs_float_identity_left(A.spec.op[a], is_int, v)) err |= HS_FLAG_TYPE_ASSERT;
+                if (A.quantise) {
+                    v = hs_quantise_cell(is_int, v, err);
+                    if (is_int) ((int32_t*)A.prov_acc[a])[at] = (int32_t)(int64_t)v;
+                    else ((float*)A.prov_acc[a])[at] = (float)hs_u2d(v);
+                } else {
+                    ((uint64_t*)A.prov_acc[a])[at] = v;
                 }
             }
-            running += __popcll(bal);
         }
-        if (lane == 0) A.pcount[p] = running;
+        if (!full && lane == 0) A.pcount[p] = ngroups;
+        if (A.debug) t_emit += (long long)clock64() - e0;
     }
     if (err) atomicOr(A.flags, err);
+    if (A.debug && lane == 0) {
+        atomicAdd(&rx_stamp_acc[0], (unsigned long long)t_init);
+        atomicAdd(&rx_stamp_acc[1], (unsigned long long)t_wait);
+        atomicAdd(&rx_stamp_acc[2], (unsigned long long)t_slot);
+        atomicAdd(&rx_stamp_acc[3], (unsigned long long)t_rank);
+        atomicAdd(&rx_stamp_acc[4], (unsigned long long)t_fold);
+        atomicAdd(&rx_stamp_acc[5], (unsigned long long)t_emit);
+        atomicAdd(&rx_stamp_acc[6], 1ull);
+    }
 }
 
 // ---- dense output -----------------------------------------------------------------------------------------------
@@ -375,7 +526,7 @@ static size_t rx_align(size_t x) { return (x + 255) & ~(size_t)255; }
 enum {
     PL_N, PL_UNITS, PL_BITS1, PL_BITS2, PL_CAP, PL_NA, PL_NCARRIED, PL_QUANTISE, PL_KEYKIND, PL_NSEG1, PL_PARTS, PL_TILES1,
     PL_TILES2, PL_COUNTERS, PL_OSIZE, PL_WS, PL_OFF_BUF_A, PL_OFF_BUF_B, PL_OFF_SEG1, PL_OFF_SEG2, PL_OFF_TB0, PL_OFF_TB1,
-    PL_OFF_CNT, PL_OFF_SCAN, PL_OFF_SCANWS, PL_OFF_PKEY, PL_OFF_PACC, PL_OFF_PCOUNT, PL_OFF_PSCAN, PL_TUPLE, PL_ESIZE0 /* .. +16 */
+    PL_OFF_CNT, PL_OFF_SCAN, PL_OFF_SCANWS, PL_OFF_PKEY, PL_OFF_PACC, PL_OFF_PCOUNT, PL_OFF_PSCAN, PL_OFF_OVERFLOW, PL_TUPLE, PL_ESIZE0 /* .. +16 */
 };
 
 extern "C" int hs_group_radix_plan(int32_t key_kind, int64_t n, int32_t n_units, int64_t max_unit_rows, const int32_t* val_kinds,
@@ -389,7 +540,7 @@ extern "C" int hs_group_radix_plan(int32_t key_kind, int64_t n, int32_t n_units,
     for (int i = 0; i < 48; ++i) f[i] = 0;
     const int NA = spec->n_acc;
     int cap = 2048;
-    while (cap > 64 && (size_t)cap * 8 * (1 + NA) > 65536) cap >>= 1;
+    while (cap > 64 && ((size_t)cap * (1 + NA) + (size_t)cap / 4) * 8 > 65536) cap >>= 1;
     int bits = 0;
     while (bits < 2 * RX_MAX_BITS && ((int64_t)(cap / 2) << bits) < max_unit_rows) ++bits;
     const int bits1 = bits <= RX_MAX_BITS ? bits : (bits + 1) / 2, bits2 = bits - bits1;
@@ -446,6 +597,7 @@ extern "C" int hs_group_radix_plan(int32_t key_kind, int64_t n, int32_t n_units,
     take(PL_OFF_PACC, (size_t)NA * rx_align((size_t)n * f[PL_OSIZE]));
     take(PL_OFF_PCOUNT, (size_t)f[PL_PARTS] * 8);
     take(PL_OFF_PSCAN, (size_t)(f[PL_PARTS] + 1) * 8);
+    take(PL_OFF_OVERFLOW, (size_t)(f[PL_PARTS] + 1) * 8);
     f[PL_WS] = (int64_t)off;
     return HS_OK;
 }
@@ -567,12 +719,41 @@ extern "C" int hs_group_radix_run(void* stream_, const hs_radix_plan* plan, cons
     for (int a = 0; a < NA; ++a) G.prov_acc[a] = ws + f[PL_OFF_PACC] + (size_t)a * rx_align((size_t)n * f[PL_OSIZE]);
     G.pcount = (int64_t*)(ws + f[PL_OFF_PCOUNT]);
     G.flags = flags;
-    const size_t per_wave = (size_t)G.cap * 8 * (1 + NA);
-    int wpb = (int)(65536 / per_wave);
-    wpb = wpb < 1 ? 1 : (wpb > 4 ? 4 : wpb);
-    int64_t grid = (parts + wpb - 1) / wpb;
-    if (grid > 256 * 64) grid = 256 * 64;
-    hipLaunchKernelGGL(k_rx_fold, dim3((unsigned)grid), dim3(HS_WAVE * wpb), per_wave * wpb, stream, G);
+    static const bool stamps = getenv("HIPSPARK_RADIX_STAMPS") != nullptr;
+    G.debug = stamps ? 1 : 0;
+    int64_t* overflow = (int64_t*)(ws + f[PL_OFF_OVERFLOW]);  // [0] = count, [1 ..] = partitions
+    hs_memset_async(overflow, 0, 8, stream);
+    auto fold = [&](int cap, bool listed) {
+        G.cap = cap;
+        G.last = cap == (int)f[PL_CAP] ? 1 : 0;
+        G.list = listed ? overflow + 1 : nullptr;
+        G.list_count = listed ? overflow : nullptr;
+        G.overflow = overflow + 1;
+        G.overflow_count = overflow;
+        const size_t per_wave = ((size_t)cap * (1 + NA) + (size_t)cap / 4) * 8;
+        int wpb = (int)(65536 / per_wave);
+        wpb = wpb < 1 ? 1 : (wpb > 4 ? 4 : wpb);
+        int64_t grid = (parts + wpb - 1) / wpb;
+        if (grid > 256 * 32) grid = 256 * 32;
+        const dim3 g((unsigned)grid), t(HS_WAVE * wpb);
+        switch ((int)f[PL_NCARRIED]) {
+            case 0: hipLaunchKernelGGL(k_rx_fold<0>, g, t, per_wave * wpb, stream, G); break;
+            case 1: hipLaunchKernelGGL(k_rx_fold<1>, g, t, per_wave * wpb, stream, G); break;
+            case 2: hipLaunchKernelGGL(k_rx_fold<2>, g, t, per_wave * wpb, stream, G); break;
+            case 3: hipLaunchKernelGGL(k_rx_fold<3>, g, t, per_wave * wpb, stream, G); break;
+            case 4: hipLaunchKernelGGL(k_rx_fold<4>, g, t, per_wave * wpb, stream, G); break;
+            default: hipLaunchKernelGGL(k_rx_fold<-1>, g, t, per_wave * wpb, stream, G); break;
+        }
+    };
+    const int big = (int)f[PL_CAP], small = big > 512 ? 512 : big;
+    static const bool one_table = getenv("HIPSPARK_RADIX_ONE_TABLE") != nullptr;
+    if (small < big && !one_table) {
+        fold(small, false);
+        RX_CHECK_LAUNCH("hs_group_radix_run (fold)");
+        fold(big, true);
+    } else {
+        fold(big, false);  // nothing can overflow into a list: a full table raises HS_FLAG_DICT_FULL ...
+    }
     RX_CHECK_LAUNCH("hs_group_radix_run (fold)");
     int64_t* pscan = (int64_t*)(ws + f[PL_OFF_PSCAN]);
     rc = hs_exclusive_scan_i64(stream, G.pcount, parts, pscan, scan_ws);
@@ -608,5 +789,18 @@ extern "C" int hs_group_radix_emit(void* stream_, const hs_radix_plan* plan, voi
     if (grid > 256 * 64) grid = 256 * 64;
     hipLaunchKernelGGL(k_rx_emit, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream_, E);
     RX_CHECK_LAUNCH("hs_group_radix_emit");
+    return HS_OK;
+}
+
+/* debug (HIPSPARK_RADIX_STAMPS=1): cycles per phase of the fold kernel summed over waves since the last call:
+ * [0] clear tables [1] wait for a chunk's loads [2] slot lookup [3] ranking [4] fold [5] emit [6] waves */
+extern "C" int hs_group_radix_debug_stamps(uint64_t* out8) {
+    unsigned long long zero[8] = {0};
+    if (!out8 || hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpyFromSymbol(out8, HIP_SYMBOL(rx_stamp_acc), sizeof(zero)) != hipSuccess ||
+        hipMemcpyToSymbol(HIP_SYMBOL(rx_stamp_acc), zero, sizeof(zero)) != hipSuccess) {
+        hs_set_error("hs_group_radix_debug_stamps failed");
+        return HS_E_ARG;
+    }
     return HS_OK;
 }

@@ -1,0 +1,36 @@
+"""Radix tier of GROUP BY alone (hs_group_radix_*): python tools/bench_radix.py [rows] [groups] [units] [reps]
+One SUM(f32) over `groups` random int32 keys - the A5 line of tools/bench_ops.py without the rest, for rocprofv3."""
+import os, sys, time
+from pathlib import Path
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", str(Path(__file__).resolve().parent.parent)))
+import torch
+from minispark_amd import hipspark as hs
+from minispark_amd.device import DCol
+from minispark_amd.execution import HipExecutionEngine
+
+N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1 << 26
+G = int(float(sys.argv[2])) if len(sys.argv) > 2 else N // 16
+U = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+engine = HipExecutionEngine(0)
+dev = engine.dev
+g = torch.Generator(device="cuda"); g.manual_seed(1)
+keys = DCol(hs.I32, torch.randint(0, G, (N,), dtype=torch.int32, device="cuda", generator=g), N)
+vals = DCol(hs.F32, torch.rand(N, dtype=torch.float32, device="cuda", generator=g), N)
+bounds = torch.tensor([N * u // U for u in range(U + 1)], dtype=torch.int64, device="cuda")
+biggest = max(N * (u + 1) // U - N * u // U for u in range(U))
+for r in range(reps):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    a.record(); out = dev.group_radix(keys, None, N, bounds, U, biggest, [(vals, 0, False)], [hs.AGG_SUM], True); b.record()
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(f"rows {N} groups {G} units {U}: run {r}: {a.elapsed_time(b):7.3f} ms (host {dt * 1e3:7.3f} ms) = "
+          f"{N / a.elapsed_time(b) / 1e6:6.2f} G rows/s, {out[0].n} groups", flush=True)
+    if os.environ.get("HIPSPARK_RADIX_STAMPS"):
+        import ctypes
+        st = (ctypes.c_uint64 * 8)()
+        hs.check(dev.lib.hs_group_radix_debug_stamps(st), "stamps")
+        names = ["clear", "wait", "slot", "rank", "fold", "emit"]
+        waves = max(int(st[6]), 1)
+        print("   fold kernel, cycles per wave: " + "  ".join(f"{nm} {int(st[k]) / waves:9.0f}" for k, nm in enumerate(names)) + f"  ({waves} waves)")
+engine.__exit__(None, None, None)
