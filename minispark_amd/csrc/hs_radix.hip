@@ -136,10 +136,17 @@ __global__ void __launch_bounds__(RX_THREADS) k_rx_hist(const RxPass A_kernarg) 
 // Stable scatter of a tile.  Wave w ranks rows [w * 512, (w + 1) * 512) of the tile, 64 at a time in order: a row's
 // rank among the rows of its bin = the wave's running count of the bin + its rank among this step's equal-bin lanes
 // (the AND of one ballot per bin bit).  A scan over the waves per bin and the tile's scanned counter finish the address.
-__global__ void __launch_bounds__(RX_THREADS) k_rx_scatter(const RxPass A_kernarg) {
+//
+// STAGED: the tile is first put in bin order in LDS, one column at a time, and written out by consecutive threads:
+// the rows of a bin (32 on average at fan-out 256) leave as one or two contiguous segments instead of one 4-8 B store
+// per row and bin - the store path of a CU takes a request per distinct line, not per byte.
+template <bool STAGED>
+__global__ void __launch_bounds__(RX_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) k_rx_scatter(const RxPass A_kernarg) {
     HS_KERNARG(RxPass, A);
     __shared__ uint32_t whist[RX_WAVES][1 << RX_MAX_BITS];
     __shared__ int64_t gbase[1 << RX_MAX_BITS];
+    __shared__ uint32_t s_wave_tot[4];
+    extern __shared__ __align__(16) uint8_t rx_stage[];  // STAGED: sbin[RX_TILE] u8, then stage[RX_TILE] of the widest column
     int64_t seg, t;
     if (!rx_find_tile(A.tile_base, A.n_seg, blockIdx.x, seg, t)) return;
     const int tid = threadIdx.x, lane = tid & (HS_WAVE - 1), w = tid / HS_WAVE, F = 1 << A.bits;
@@ -177,6 +184,7 @@ __global__ void __launch_bounds__(RX_THREADS) k_rx_scatter(const RxPass A_kernar
     }
     __syncthreads();
     const int64_t nt = A.tile_base[seg + 1] - A.tile_base[seg];
+    uint32_t bin_total = 0;
     if (tid < F) {
         uint32_t run = 0;
         for (int k = 0; k < RX_WAVES; ++k) {
@@ -184,7 +192,81 @@ __global__ void __launch_bounds__(RX_THREADS) k_rx_scatter(const RxPass A_kernar
             whist[k][tid] = run;
             run += c;
         }
+        bin_total = run;
         gbase[tid] = A.counters[(A.tile_base[seg] << A.bits) + (int64_t)tid * nt + t];
+    }
+    if constexpr (STAGED) {
+        // tile-local start of every bin: exclusive scan of the bin totals (threads 0 .. 255 = waves 0 .. 3);
+        // gbase becomes "global position minus tile-local position"
+        uint32_t x = bin_total;
+        for (int d = 1; d < HS_WAVE; d <<= 1) {
+            const uint32_t up = __shfl_up(x, d, HS_WAVE);
+            if (lane >= d) x += up;
+        }
+        if (w < 4 && lane == HS_WAVE - 1) s_wave_tot[w] = x;
+        __syncthreads();
+        if (tid < F) {
+            uint32_t before = 0;
+            for (int k = 0; k < w; ++k) before += s_wave_tot[k];
+            const uint32_t bin_start = before + x - bin_total;
+            gbase[tid] -= bin_start;
+            for (int k = 0; k < RX_WAVES; ++k) whist[k][tid] += bin_start;  // now: tile-local start of (wave, bin)
+        }
+        __syncthreads();
+        uint8_t* sbin = rx_stage;
+        uint8_t* stage = rx_stage + RX_TILE;
+        const int rows = (int)(e - b);
+        uint32_t lpos2[RX_PER / 2];  // two 16-bit tile-local positions per register; 0xffff: no row
+#pragma unroll
+        for (int j = 0; j < RX_PER; ++j) {
+            const bool valid = first + j * HS_WAVE < e;
+            const uint32_t at = valid ? whist[w][bin[j]] + local[j] : 0xffffu;
+            if (valid) sbin[at] = (uint8_t)bin[j];
+            lpos2[j / 2] = (j & 1) ? (lpos2[j / 2] | (at << 16)) : at;
+        }
+        auto lpos = [&](int j) -> uint32_t { return (lpos2[j / 2] >> ((j & 1) * 16)) & 0xffffu; };
+        auto write_out = [&](void* dst, int es) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < RX_PER; ++k) {
+                const int i = tid + k * RX_THREADS;
+                if (i >= rows) continue;
+                const int64_t to = gbase[sbin[i]] + i;
+                if (es == 4) ((uint32_t*)dst)[to] = ((const uint32_t*)stage)[i];
+                else if (es == 8) ((uint64_t*)dst)[to] = ((const uint64_t*)stage)[i];
+                else ((uint8_t*)dst)[to] = stage[i];
+            }
+            __syncthreads();
+        };
+        {   // the key column, from registers
+            const int es = A.esize[0];
+#pragma unroll
+            for (int j = 0; j < RX_PER; ++j) {
+                if (lpos(j) == 0xffffu) continue;
+                if (es == 4) ((uint32_t*)stage)[lpos(j)] = (uint32_t)word[j];
+                else ((uint64_t*)stage)[lpos(j)] = word[j];
+            }
+            write_out(A.dst[0], es);
+        }
+        for (int c = 1; c < A.n_cols; ++c) {
+            const int es = A.esize[c];
+            const void* src = A.src[c];
+            uint64_t v[RX_PER];
+#pragma unroll
+            for (int j = 0; j < RX_PER; ++j) {
+                const int64_t i = first + j * HS_WAVE;
+                v[j] = lpos(j) == 0xffffu ? 0 : (es == 4 ? (uint64_t)((const uint32_t*)src)[i] : es == 8 ? ((const uint64_t*)src)[i] : (uint64_t)((const uint8_t*)src)[i]);
+            }
+#pragma unroll
+            for (int j = 0; j < RX_PER; ++j) {
+                if (lpos(j) == 0xffffu) continue;
+                if (es == 4) ((uint32_t*)stage)[lpos(j)] = (uint32_t)v[j];
+                else if (es == 8) ((uint64_t*)stage)[lpos(j)] = v[j];
+                else stage[lpos(j)] = (uint8_t)v[j];
+            }
+            write_out(A.dst[c], es);
+        }
+        return;
     }
     __syncthreads();
     int64_t to[RX_PER];
@@ -688,7 +770,11 @@ extern "C" int hs_group_radix_run(void* stream_, const hs_radix_plan* plan, cons
         const int rc = hs_exclusive_scan_i64(stream, counters, ncnt, scanned, scan_ws);
         if (rc != HS_OK) return rc;
         P.counters = scanned;
-        hipLaunchKernelGGL(k_rx_scatter, dim3((unsigned)max_tiles), dim3(RX_THREADS), 0, stream, P);
+        static const bool direct = getenv("HIPSPARK_RADIX_DIRECT") != nullptr;
+        int widest = 1;
+        for (int c = 0; c < P.n_cols; ++c) widest = P.esize[c] > widest ? P.esize[c] : widest;
+        if (direct) hipLaunchKernelGGL(k_rx_scatter<false>, dim3((unsigned)max_tiles), dim3(RX_THREADS), 0, stream, P);
+        else hipLaunchKernelGGL(k_rx_scatter<true>, dim3((unsigned)max_tiles), dim3(RX_THREADS), (size_t)RX_TILE * (1 + widest), stream, P);
         RX_CHECK_LAUNCH("hs_group_radix_run (scatter)");
         const int64_t nout = (n_seg << bits) + 1;
         hipLaunchKernelGGL(k_rx_next, dim3((unsigned)((nout + 255) / 256 > 4096 ? 4096 : (nout + 255) / 256)), dim3(256), 0, stream,
