@@ -118,19 +118,31 @@ __device__ __forceinline__ void rx_move(const void* src, void* dst, int esize, i
 
 __global__ void __launch_bounds__(RX_THREADS) k_rx_hist(const RxPass A_kernarg) {
     HS_KERNARG(RxPass, A);
-    __shared__ uint32_t hist[1 << RX_MAX_BITS];
+    __shared__ uint32_t hist[RX_WAVES][1 << RX_MAX_BITS];  // one per wave: LDS atomics of different waves never meet
     int64_t seg, t;
     if (!rx_find_tile(A.tile_base, A.n_seg, blockIdx.x, seg, t)) return;
-    const int tid = threadIdx.x, F = 1 << A.bits;
-    if (tid < F) hist[tid] = 0;
+    const int tid = threadIdx.x, w = tid / HS_WAVE, F = 1 << A.bits;
+    for (int i = tid; i < RX_WAVES * F; i += RX_THREADS) hist[i / F][i % F] = 0;
     __syncthreads();
     const int64_t b = A.seg_start[seg] + t * RX_TILE;
     const int64_t seg_end = A.seg_start[seg + 1];
     const int64_t e = (b + RX_TILE) < seg_end ? (b + RX_TILE) : seg_end;
-    for (int64_t i = b + tid; i < e; i += RX_THREADS) atomicAdd(&hist[rx_bin(rx_key(A, i), A.shift, A.bits)], 1u);
+    uint64_t word[RX_PER];
+#pragma unroll
+    for (int j = 0; j < RX_PER; ++j) {
+        const int64_t i = b + tid + (int64_t)j * RX_THREADS;
+        word[j] = i < e ? rx_key(A, i) : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < RX_PER; ++j)
+        if (b + tid + (int64_t)j * RX_THREADS < e) atomicAdd(&hist[w][rx_bin(word[j], A.shift, A.bits)], 1u);
     __syncthreads();
     const int64_t nt = A.tile_base[seg + 1] - A.tile_base[seg];
-    if (tid < F) A.counters[(A.tile_base[seg] << A.bits) + (int64_t)tid * nt + t] = hist[tid];
+    if (tid < F) {
+        uint32_t total = 0;
+        for (int k = 0; k < RX_WAVES; ++k) total += hist[k][tid];
+        A.counters[(A.tile_base[seg] << A.bits) + (int64_t)tid * nt + t] = total;
+    }
 }
 
 // Stable scatter of a tile.  Wave w ranks rows [w * 512, (w + 1) * 512) of the tile, 64 at a time in order: a row's
@@ -141,6 +153,7 @@ __global__ void __launch_bounds__(RX_THREADS) k_rx_hist(const RxPass A_kernarg) 
 // the rows of a bin (32 on average at fan-out 256) leave as one or two contiguous segments instead of one 4-8 B store
 // per row and bin - the store path of a CU takes a request per distinct line, not per byte.
 template <bool STAGED>
+// two workgroups per CU (<= 64 VGPRs, a few spilled) beat one at 94 VGPRs: 560 us against 840 us per pass of 64 M rows
 __global__ void __launch_bounds__(RX_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) k_rx_scatter(const RxPass A_kernarg) {
     HS_KERNARG(RxPass, A);
     __shared__ uint32_t whist[RX_WAVES][1 << RX_MAX_BITS];
@@ -370,7 +383,7 @@ constexpr int RX_CHUNK = 4;  // 64-row steps loaded together; the next chunk is 
 // Two launches share the kernel: the first with a SMALL table (512 slots: many waves per CU), where a partition that
 // meets more keys than 3/4 of it is put on the overflow list instead of being finished; the second (A.list set) takes
 // the listed partitions with the big table the plan sized for the worst case (every row its own group).
-template <int NC>
+template <int NC, int SLOT_BITS>
 __global__ void __launch_bounds__(256) k_rx_fold(const RxAgg A_kernarg) {
     HS_KERNARG(RxAgg, A);
     extern __shared__ __align__(16) uint64_t rx_lds[];
@@ -464,13 +477,13 @@ __global__ void __launch_bounds__(256) k_rx_fold(const RxAgg A_kernarg) {
                     full = true;
                     break;
                 }
-                // lanes of this step in the same group (one ballot per slot bit; bits the table does not use are 0
-                // everywhere and change nothing), my rank among them: row order = lane order
+                // lanes of this step in the same group (one ballot per slot bit, SLOT_BITS >= log2(cap)), my rank among
+                // them: row order = lane order
                 RX_T(s1);
                 t_slot += s1 - s0;
                 uint64_t peers = __ballot(valid);
 #pragma unroll
-                for (int bit = 0; bit < 12; ++bit) {
+                for (int bit = 0; bit < SLOT_BITS; ++bit) {
                     const bool on = (slot >> bit) & 1;
                     peers &= ~(__ballot(valid && on) ^ (on ? ~0ull : 0ull));
                 }
@@ -822,14 +835,18 @@ extern "C" int hs_group_radix_run(void* stream_, const hs_radix_plan* plan, cons
         int64_t grid = (parts + wpb - 1) / wpb;
         if (grid > 256 * 32) grid = 256 * 32;
         const dim3 g((unsigned)grid), t(HS_WAVE * wpb);
+#define RX_FOLD(NC)                                                                                    \
+    if (cap <= 512) hipLaunchKernelGGL((k_rx_fold<NC, 9>), g, t, per_wave * wpb, stream, G);           \
+    else hipLaunchKernelGGL((k_rx_fold<NC, 12>), g, t, per_wave * wpb, stream, G)
         switch ((int)f[PL_NCARRIED]) {
-            case 0: hipLaunchKernelGGL(k_rx_fold<0>, g, t, per_wave * wpb, stream, G); break;
-            case 1: hipLaunchKernelGGL(k_rx_fold<1>, g, t, per_wave * wpb, stream, G); break;
-            case 2: hipLaunchKernelGGL(k_rx_fold<2>, g, t, per_wave * wpb, stream, G); break;
-            case 3: hipLaunchKernelGGL(k_rx_fold<3>, g, t, per_wave * wpb, stream, G); break;
-            case 4: hipLaunchKernelGGL(k_rx_fold<4>, g, t, per_wave * wpb, stream, G); break;
-            default: hipLaunchKernelGGL(k_rx_fold<-1>, g, t, per_wave * wpb, stream, G); break;
+            case 0: RX_FOLD(0); break;
+            case 1: RX_FOLD(1); break;
+            case 2: RX_FOLD(2); break;
+            case 3: RX_FOLD(3); break;
+            case 4: RX_FOLD(4); break;
+            default: RX_FOLD(-1); break;
         }
+#undef RX_FOLD
     };
     const int big = (int)f[PL_CAP], small = big > 512 ? 512 : big;
     static const bool one_table = getenv("HIPSPARK_RADIX_ONE_TABLE") != nullptr;
