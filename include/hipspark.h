@@ -357,6 +357,16 @@ int hs_group_radix_run(void* stream, const hs_radix_plan* plan, const hs_col* ke
                        const int64_t* unit_bounds, const hs_col* val_cols, const uint64_t* const_cells,
                        const hs_agg_spec* spec, void* ws, int64_t* out_unit_groups, uint32_t* flags);
 int hs_group_radix_emit(void* stream, const hs_radix_plan* plan, void* ws, void* out_key, void* const* out_acc);
+/* Merge order of a multi-rank final aggregate (the reference reads a partition's shuffle files in block order,
+ * tasks.py:117-133): STABLE sort of positions 0 .. n-1 by order[i] in [-1, n_order) (global block id; -1 = padding,
+ * sorted first) with the radix tier's partition passes, least significant byte first.  out_perm[j] = position of the
+ * j-th row in merge order, out_sorted[j] = its order key.  ws: hs_sort_by_order_ws_bytes(n). */
+size_t hs_sort_by_order_ws_bytes(int64_t n);
+int hs_sort_by_order(void* stream, const int64_t* order, int64_t n, int64_t n_order, int64_t* out_perm, int64_t* out_sorted,
+                     void* ws);
+/* out[i] = values[s] for bounds[s] <= i < bounds[s+1], i in [0, n) (device arrays; bounds has n_seg + 1 entries,
+ * bounds[0] = 0): the global block id of every partial row of a multi-rank partial aggregate. */
+int hs_expand_by_bounds(void* stream, const int64_t* bounds, const int64_t* values, int64_t n_seg, int64_t n, int64_t* out);
 /* Debug aid: with HIPSPARK_RADIX_STAMPS=1 in the environment the fold kernel sums the cycles its waves spend per phase;
  * out8 = {clear tables, wait for loads, slot lookup, ranking, fold, emit, waves, 0} since the last call. */
 int hs_group_radix_debug_stamps(uint64_t* out8);

@@ -92,8 +92,9 @@ struct RxPass {
     const int64_t* seg_start;  // [n_seg + 1] positions in the row list
     const int64_t* tile_base;  // [n_seg + 1]
     int64_t n_seg;
-    int32_t shift, bits;       // bin = (mix(key word) >> shift) & (2^bits - 1)
+    int32_t shift, bits;       // bin = (mix(key word) >> shift) & (2^bits - 1); raw: ((key + 1) >> shift) & ... (hs_sort_by_order)
     int32_t n_cols, first;     // columns that travel (0 = key); first pass reads the key through `key` / `sel`
+    int32_t raw, pad;
     hs_col key;
     const int64_t* sel;
     int64_t row0;
@@ -107,8 +108,8 @@ __device__ __forceinline__ uint64_t rx_key(const RxPass& A, int64_t i) {
     if (A.first) return hs_key_at(A.key, A.sel ? A.sel[i] : A.row0 + i);
     return A.esize[0] == 4 ? (uint64_t)(int64_t)((const int32_t*)A.src[0])[i] : ((const uint64_t*)A.src[0])[i];
 }
-__device__ __forceinline__ uint32_t rx_bin(uint64_t word, int shift, int bits) {
-    return (uint32_t)(hs_mix64(word) >> shift) & ((1u << bits) - 1u);
+__device__ __forceinline__ uint32_t rx_bin(uint64_t word, int shift, int bits, int raw) {
+    return (uint32_t)((raw ? word + 1 : hs_mix64(word)) >> shift) & ((1u << bits) - 1u);
 }
 __device__ __forceinline__ void rx_move(const void* src, void* dst, int esize, int64_t from, int64_t to) {
     if (esize == 4) ((uint32_t*)dst)[to] = ((const uint32_t*)src)[from];
@@ -135,7 +136,7 @@ __global__ void __launch_bounds__(RX_THREADS) k_rx_hist(const RxPass A_kernarg) 
     }
 #pragma unroll
     for (int j = 0; j < RX_PER; ++j)
-        if (b + tid + (int64_t)j * RX_THREADS < e) atomicAdd(&hist[w][rx_bin(word[j], A.shift, A.bits)], 1u);
+        if (b + tid + (int64_t)j * RX_THREADS < e) atomicAdd(&hist[w][rx_bin(word[j], A.shift, A.bits, A.raw)], 1u);
     __syncthreads();
     const int64_t nt = A.tile_base[seg + 1] - A.tile_base[seg];
     if (tid < F) {
@@ -182,7 +183,7 @@ __global__ void __launch_bounds__(RX_THREADS) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
     for (int j = 0; j < RX_PER; ++j) {
         const bool valid = first + j * HS_WAVE < e;
-        bin[j] = valid ? rx_bin(word[j], A.shift, A.bits) : 0u;
+        bin[j] = valid ? rx_bin(word[j], A.shift, A.bits, A.raw) : 0u;
         uint64_t peers = __ballot(valid);
         for (int bit = 0; bit < A.bits; ++bit) {
             const bool on = (bin[j] >> bit) & 1u;
@@ -624,6 +625,34 @@ enum {
     PL_OFF_CNT, PL_OFF_SCAN, PL_OFF_SCANWS, PL_OFF_PKEY, PL_OFF_PACC, PL_OFF_PCOUNT, PL_OFF_PSCAN, PL_OFF_OVERFLOW, PL_TUPLE, PL_ESIZE0 /* .. +16 */
 };
 
+// one partition pass over the segments of P: tiles, histogram, scan, scatter, the next level's segments
+static int rx_pass(hipStream_t stream, RxPass& P, int64_t max_tiles, int64_t* counters, int64_t* scanned, void* scan_ws, int64_t n,
+                   int64_t* next_seg) {
+    hipLaunchKernelGGL(k_rx_tiles, dim3(1), dim3(1024), 0, stream, P.seg_start, P.n_seg, (int64_t*)P.tile_base);
+    RX_CHECK_LAUNCH("radix pass (tiles)");
+    const int64_t ncnt = max_tiles << P.bits;
+    hs_memset_async(counters, 0, (size_t)ncnt * 8, stream);
+    P.counters = counters;
+    hipLaunchKernelGGL(k_rx_hist, dim3((unsigned)max_tiles), dim3(RX_THREADS), 0, stream, P);
+    RX_CHECK_LAUNCH("radix pass (histogram)");
+    const int rc = hs_exclusive_scan_i64(stream, counters, ncnt, scanned, scan_ws);
+    if (rc != HS_OK) return rc;
+    P.counters = scanned;
+    static const bool direct = getenv("HIPSPARK_RADIX_DIRECT") != nullptr;
+    int widest = 1;
+    for (int c = 0; c < P.n_cols; ++c) widest = P.esize[c] > widest ? P.esize[c] : widest;
+    if (direct) hipLaunchKernelGGL(k_rx_scatter<false>, dim3((unsigned)max_tiles), dim3(RX_THREADS), 0, stream, P);
+    else hipLaunchKernelGGL(k_rx_scatter<true>, dim3((unsigned)max_tiles), dim3(RX_THREADS), (size_t)RX_TILE * (1 + widest), stream, P);
+    RX_CHECK_LAUNCH("radix pass (scatter)");
+    if (next_seg) {
+        const int64_t nout = (P.n_seg << P.bits) + 1;
+        hipLaunchKernelGGL(k_rx_next, dim3((unsigned)((nout + 255) / 256 > 4096 ? 4096 : (nout + 255) / 256)), dim3(256), 0, stream,
+                           P.seg_start, P.tile_base, P.n_seg, (int32_t)P.bits, (const int64_t*)scanned, n, next_seg);
+        RX_CHECK_LAUNCH("radix pass (segments)");
+    }
+    return HS_OK;
+}
+
 extern "C" int hs_group_radix_plan(int32_t key_kind, int64_t n, int32_t n_units, int64_t max_unit_rows, const int32_t* val_kinds,
                                    const hs_agg_spec* spec, int32_t quantise, hs_radix_plan* plan) {
     if (!plan || !spec || n < 1 || n_units < 1 || max_unit_rows < 1 || spec->n_acc < 0 || spec->n_acc > HS_MAX_ACC ||
@@ -764,10 +793,6 @@ extern "C" int hs_group_radix_run(void* stream_, const hs_radix_plan* plan, cons
 
     auto pass = [&](const int64_t* seg_start, int64_t n_seg, int64_t* tile_base, int64_t max_tiles, int shift, int bits, bool first,
                     void* const* src, void* const* dst, int64_t* next_seg) -> int {
-        hipLaunchKernelGGL(k_rx_tiles, dim3(1), dim3(1024), 0, stream, seg_start, n_seg, tile_base);
-        RX_CHECK_LAUNCH("hs_group_radix_run (tiles)");
-        const int64_t ncnt = max_tiles << bits;
-        hs_memset_async(counters, 0, (size_t)ncnt * 8, stream);
         P.seg_start = seg_start;
         P.tile_base = tile_base;
         P.n_seg = n_seg;
@@ -777,23 +802,7 @@ extern "C" int hs_group_radix_run(void* stream_, const hs_radix_plan* plan, cons
         if (!first)
             for (int c = 0; c < P.n_cols; ++c) P.src[c] = src[c];
         for (int c = 0; c < P.n_cols; ++c) P.dst[c] = dst[c];
-        P.counters = counters;
-        hipLaunchKernelGGL(k_rx_hist, dim3((unsigned)max_tiles), dim3(RX_THREADS), 0, stream, P);
-        RX_CHECK_LAUNCH("hs_group_radix_run (histogram)");
-        const int rc = hs_exclusive_scan_i64(stream, counters, ncnt, scanned, scan_ws);
-        if (rc != HS_OK) return rc;
-        P.counters = scanned;
-        static const bool direct = getenv("HIPSPARK_RADIX_DIRECT") != nullptr;
-        int widest = 1;
-        for (int c = 0; c < P.n_cols; ++c) widest = P.esize[c] > widest ? P.esize[c] : widest;
-        if (direct) hipLaunchKernelGGL(k_rx_scatter<false>, dim3((unsigned)max_tiles), dim3(RX_THREADS), 0, stream, P);
-        else hipLaunchKernelGGL(k_rx_scatter<true>, dim3((unsigned)max_tiles), dim3(RX_THREADS), (size_t)RX_TILE * (1 + widest), stream, P);
-        RX_CHECK_LAUNCH("hs_group_radix_run (scatter)");
-        const int64_t nout = (n_seg << bits) + 1;
-        hipLaunchKernelGGL(k_rx_next, dim3((unsigned)((nout + 255) / 256 > 4096 ? 4096 : (nout + 255) / 256)), dim3(256), 0, stream,
-                           seg_start, (const int64_t*)tile_base, n_seg, (int32_t)bits, (const int64_t*)scanned, n, next_seg);
-        RX_CHECK_LAUNCH("hs_group_radix_run (segments)");
-        return HS_OK;
+        return rx_pass(stream, P, max_tiles, counters, scanned, scan_ws, n, next_seg);
     };
     int rc = pass(unit_bounds, n_units, tb0, f[PL_TILES1], 0, bits1, true, nullptr, buf_a, seg1);
     if (rc != HS_OK) return rc;
@@ -905,5 +914,104 @@ extern "C" int hs_group_radix_debug_stamps(uint64_t* out8) {
         hs_set_error("hs_group_radix_debug_stamps failed");
         return HS_E_ARG;
     }
+    return HS_OK;
+}
+
+// =====================================================================================================
+// Merge order of a multi-rank final aggregate (reference: the shuffle files of a partition are read in block order,
+// tasks.py:117-133): a STABLE sort of the partial rows by their order key (global block id, -1 = padding) with the
+// same partition passes, least significant byte first.  Replaces torch.argsort on this path.
+// =====================================================================================================
+__global__ void __launch_bounds__(256) k_rx_iota(int64_t* out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = i;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // the one segment of the passes: [0, n)
+        out[n] = 0;
+        out[n + 1] = n;
+    }
+}
+
+extern "C" size_t hs_sort_by_order_ws_bytes(int64_t n) {
+    const int64_t tiles = n / RX_TILE + 2;
+    return rx_align((size_t)n * 8) * 2 + rx_align((size_t)(n + 2) * 8) + 256 + rx_align((size_t)(tiles << 8) * 8) +
+           rx_align((size_t)((tiles << 8) + 1) * 8) + rx_align(hs_scan_ws_bytes(tiles << 8));
+}
+
+extern "C" int hs_sort_by_order(void* stream_, const int64_t* order, int64_t n, int64_t n_order, int64_t* out_perm,
+                                int64_t* out_sorted, void* ws_) {
+    if (n == 0) return HS_OK;
+    if (!order || !out_perm || !out_sorted || !ws_ || n < 0 || n_order < 0) {
+        hs_set_error("hs_sort_by_order: bad arguments");
+        return HS_E_ARG;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    uint8_t* ws = (uint8_t*)ws_;
+    const int64_t tiles = n / RX_TILE + 2;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        uint8_t* p = ws + off;
+        off += rx_align(bytes);
+        return p;
+    };
+    int64_t* key_b = (int64_t*)take((size_t)n * 8);
+    int64_t* perm_b = (int64_t*)take((size_t)n * 8);
+    int64_t* iota = (int64_t*)take((size_t)(n + 2) * 8);  // [n], then the segment bounds {0, n}
+    int64_t* tile_base = (int64_t*)take(256);
+    int64_t* counters = (int64_t*)take((size_t)(tiles << 8) * 8);
+    int64_t* scanned = (int64_t*)take((size_t)((tiles << 8) + 1) * 8);
+    void* scan_ws = take(hs_scan_ws_bytes(tiles << 8));
+    hipLaunchKernelGGL(k_rx_iota, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, stream, iota, n);
+    RX_CHECK_LAUNCH("hs_sort_by_order (iota)");
+    int bits = 1;
+    while (bits < 64 && ((int64_t)1 << bits) <= n_order) ++bits;  // values + 1 lie in [0, n_order]
+    const int passes = (bits + 7) / 8;
+    RxPass P;
+    std::memset(&P, 0, sizeof(P));
+    P.seg_start = iota + n;
+    P.tile_base = tile_base;
+    P.n_seg = 1;
+    P.n_cols = 2;
+    P.esize[0] = P.esize[1] = 8;
+    P.raw = 1;
+    for (int k = 0; k < passes; ++k) {
+        const bool to_out = ((passes - 1 - k) & 1) == 0;  // the last pass lands in the caller's arrays
+        P.first = k == 0 ? 1 : 0;
+        P.key = hs_col{HS_I64, -1, order, nullptr, nullptr};
+        P.sel = nullptr;
+        P.row0 = 0;
+        P.src[0] = k == 0 ? nullptr : (to_out ? (const void*)key_b : (const void*)out_sorted);
+        P.src[1] = k == 0 ? (const void*)iota : (to_out ? (const void*)perm_b : (const void*)out_perm);
+        P.dst[0] = to_out ? (void*)out_sorted : (void*)key_b;
+        P.dst[1] = to_out ? (void*)out_perm : (void*)perm_b;
+        P.shift = 8 * k;
+        P.bits = bits - 8 * k < 8 ? bits - 8 * k : 8;
+        const int rc = rx_pass(stream, P, tiles, counters, scanned, scan_ws, n, nullptr);
+        if (rc != HS_OK) return rc;
+    }
+    return HS_OK;
+}
+
+// out[i] = values[s] for bounds[s] <= i < bounds[s + 1]: a value per segment spread over the segment's rows (the global
+// block id of every partial row, multi-rank partial aggregate).  Replaces torch.repeat_interleave.
+__global__ void __launch_bounds__(256) k_expand_by_bounds(const int64_t* bounds, const int64_t* values, int64_t n_seg, int64_t n,
+                                                          int64_t* out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t lo = 0, hi = n_seg;  // last s with bounds[s] <= i
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (bounds[mid] <= i) lo = mid;
+            else hi = mid;
+        }
+        out[i] = values[lo];
+    }
+}
+extern "C" int hs_expand_by_bounds(void* stream, const int64_t* bounds, const int64_t* values, int64_t n_seg, int64_t n, int64_t* out) {
+    if (n == 0) return HS_OK;
+    if (!bounds || !values || !out || n_seg < 1 || n < 0) {
+        hs_set_error("hs_expand_by_bounds: bad arguments");
+        return HS_E_ARG;
+    }
+    hipLaunchKernelGGL(k_expand_by_bounds, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, bounds, values, n_seg, n, out);
+    RX_CHECK_LAUNCH("hs_expand_by_bounds");
     return HS_OK;
 }

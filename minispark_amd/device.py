@@ -1371,6 +1371,27 @@ class Device:
                 out[i] = (col, 0, tag in ("I", "B"))
         return out
 
+    def sort_by_order(self, order: torch.Tensor, n: int, n_order: int) -> tuple[torch.Tensor, int]:
+        """Stable sort of the partial rows by their order key (global block id, -1 = padding) -> (positions in merge
+        order with the padding rows dropped, number of rows left)."""
+        perm, srt = self.empty(max(n, 1), torch.int64), self.empty(max(n, 1), torch.int64)
+        ws = self.workspace(self.lib.hs_sort_by_order_ws_bytes(n))
+        hs.check(self.lib.hs_sort_by_order(self.stream, order.data_ptr(), n, max(int(n_order), 1), perm.data_ptr(),
+                                           srt.data_ptr(), ws.data_ptr()), "hs_sort_by_order")
+        zero = self.to_device(np.zeros(1, dtype=np.int64))
+        n_pad = self.host_int(self.lower_bound(srt, n, zero))  # rows with order < 0
+        return perm[n_pad:n], n - n_pad
+
+    def unit_ids_per_row(self, unit_rows: Sequence[int], unit_ids: Sequence[int]) -> torch.Tensor:
+        """Global block id of every partial row: unit_ids[u] for rows unit_rows[u] .. unit_rows[u + 1]."""
+        n = int(unit_rows[-1])
+        out = self.empty(max(n, 1), torch.int64)
+        bounds = self.to_device(np.asarray(unit_rows, dtype=np.int64))
+        ids = self.to_device(np.asarray(unit_ids, dtype=np.int64))
+        hs.check(self.lib.hs_expand_by_bounds(self.stream, bounds.data_ptr(), ids.data_ptr(), len(unit_ids), n, out.data_ptr()),
+                 "hs_expand_by_bounds")
+        return out[:n]
+
     def group_radix(self, key: DCol, sel: torch.Tensor | None, n: int, bounds: torch.Tensor, n_units: int,
                     max_unit_rows: int, values: Sequence[tuple], ops: Sequence[int], quantise: bool):
         """hs_group_radix_plan / run / emit -> (key column, accumulator columns, groups before every unit) or None when
@@ -1459,8 +1480,7 @@ class Device:
                 self.last_global_tier = "radix"
                 order = None
                 if batch.unit_ids is not None:  # multi-GPU: remember which global unit every partial row came from
-                    counts = torch.tensor([unit_rows[u + 1] - unit_rows[u] for u in range(n_units)], device=self.device)
-                    order = torch.repeat_interleave(torch.tensor(batch.unit_ids, dtype=torch.int64, device=self.device), counts)
+                    order = self.unit_ids_per_row(unit_rows, batch.unit_ids)
                 return DBatch(list(out_schema), [key_col] + [accs[a] for a in agg_to_acc], unit_rows[-1], unit_rows, order=order,
                               total_units=batch.total_units)
         self.last_global_tier = "hash"
@@ -1499,8 +1519,7 @@ class Device:
         unit_rows = [int(v) for v in self.lower_bound(slot_list, ng, d_region_base).tolist()]
         order = None
         if batch.unit_ids is not None:  # multi-GPU: remember which global unit every partial row came from
-            counts = torch.tensor([unit_rows[u + 1] - unit_rows[u] for u in range(n_units)], device=self.device)
-            order = torch.repeat_interleave(torch.tensor(batch.unit_ids, dtype=torch.int64, device=self.device), counts)
+            order = self.unit_ids_per_row(unit_rows, batch.unit_ids)
         return DBatch(list(out_schema), [key_col] + [accs[a] for a in agg_to_acc], ng, unit_rows, order=order,
                       total_units=batch.total_units)
 
@@ -1511,25 +1530,22 @@ class Device:
         n = batch.nrows
         sel = None
         if batch.order is not None:  # multi-GPU: visit rows by (block id, row); padding rows (order < 0) dropped
-            order = batch.order[:n]
-            perm = torch.argsort(order, stable=True)
-            n_pad = int((order < 0).sum().item())
-            sel = perm[n_pad:].contiguous()
-            n = n - n_pad
+            n_order = batch.total_units if batch.total_units else 1 << 31  # unknown: sort on all 32 bits
+            sel, n = self.sort_by_order(batch.order, n, n_order)
         ops = [{"sum": hs.AGG_SUM, "min": hs.AGG_MIN, "max": hs.AGG_MAX}[a.type] for a in agg_columns]
         vals = batch.cols[1: 1 + len(agg_columns)]
         is_int = [v.kind in (hs.I32, hs.I64) for v in vals]
         key = batch.cols[0]
-        if (self.radix_enabled and sel is None and n > 0 and key.kind in (hs.I32, hs.I64) and key.dict is None
+        if sel is not None:  # values are read by POSITION: bring them into visiting order
+            vals = [self.gather_col(v, sel, n) for v in vals]
+        if (self.radix_enabled and n > 0 and key.kind in (hs.I32, hs.I64) and key.dict is None
                 and all(v.kind in (hs.I32, hs.F32, hs.I64, hs.F64) and v.dict is None for v in vals)):
-            # single GPU: the partial rows already sit in unit order = the reference's merge order; ONE unit of n rows
+            # the partial rows in merge order (single GPU: as they are; multi-rank: through sel) are ONE unit of n rows
             bounds = self.to_device(np.asarray([0, n], dtype=np.int64))
-            done = self.group_radix(key, None, n, bounds, 1, n, [(v, 0, i) for v, i in zip(vals, is_int)], ops, quantise=False)
+            done = self.group_radix(key, sel, n, bounds, 1, n, [(v, 0, i) for v, i in zip(vals, is_int)], ops, quantise=False)
             if done is not None:
                 key_col, cols, unit_rows = done
                 return DBatch(list(out_schema), [key_col] + cols, unit_rows[-1], [0, unit_rows[-1]])
-        if sel is not None:  # fold reads values by POSITION: bring them into visiting order
-            vals = [self.gather_col(v, sel, n) for v in vals]
         slot_start, positions, slot_list, ng = self._group_build(batch.cols[0], sel, n)
         rep_row, cols = self._group_fold(vals, ops, is_int, slot_start, positions, slot_list, ng, sel, quantise=False)
         key_col = self.gather_col(batch.cols[0], rep_row, ng)

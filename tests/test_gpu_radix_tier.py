@@ -180,3 +180,25 @@ def test_engine_takes_the_radix_tier_for_integer_keys(tmp_path):
         engine._version += 1
         assert_rows_match(build(engine).collect(), want, max_ulps=0)
         assert engine.dev.last_global_tier == "hash"
+
+
+@pytest.mark.parametrize(("n", "n_order"), [(1, 1), (5000, 3), (300_000, 287), (1_000_000, 70_000)])
+def test_sort_by_order_is_a_stable_sort_with_padding_first(dev, n, n_order):
+    """hs_sort_by_order (the merge order of a multi-rank final aggregate) against numpy's stable argsort."""
+    import torch
+
+    rng = np.random.default_rng(n)
+    order = rng.integers(-1, n_order, n).astype(np.int64)
+    sel, left = dev.sort_by_order(torch.from_numpy(order).cuda(), n, n_order)
+    want = np.argsort(order, kind="stable")
+    n_pad = int((order < 0).sum())
+    assert left == n - n_pad
+    assert np.array_equal(sel[:left].cpu().numpy(), want[n_pad:])
+
+
+def test_unit_ids_per_row(dev):
+    unit_rows = [0, 3, 3, 10, 11, 4000]
+    ids = [7, 1, 300, 2, 9]
+    got = dev.unit_ids_per_row(unit_rows, ids).cpu().numpy()
+    want = np.repeat(np.asarray(ids), np.diff(unit_rows))
+    assert np.array_equal(got, want)
