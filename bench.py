@@ -40,11 +40,16 @@ def q1_frame(engine, table_path: str, cutoff: str = CUTOFF):
     return workloads.q1(workloads.engine_api(engine), table_path, cutoff)
 
 
+SCAN_KERNEL_SOURCES = ("hs_device.h", "hs_agg_kernel.h", "hs_capture.h", "hs_agg.hip", "hs_jit.hip")
+
+
 def kernel_sources_sha() -> str:
-    """Identity of the device code: PMC traffic figures under profiles/ are only quoted while it is unchanged."""
+    """Identity of the scan kernel's code: PMC traffic figures under profiles/ are only quoted while it is unchanged.
+    Covers what k_agg_jit is compiled from and launched by - the embedded headers, the code generator, the launch
+    geometry (csrc/hs_agg.hip) and the public header they all include; operators the Q1 step never launches (join,
+    radix tier, stage engine) are not part of it."""
     h = hashlib.sha256()
-    for p in sorted([*(ROOT / "minispark_amd" / "csrc").glob("*.h"), *(ROOT / "minispark_amd" / "csrc").glob("*.hip"),
-                     ROOT / "include" / "hipspark.h"]):
+    for p in [*(ROOT / "minispark_amd" / "csrc" / name for name in SCAN_KERNEL_SOURCES), ROOT / "include" / "hipspark.h"]:
         h.update(p.name.encode())
         h.update(p.read_bytes())
     return h.hexdigest()[:16]

@@ -33,4 +33,15 @@ for r in range(reps):
         names = ["clear", "wait", "slot", "rank", "fold", "emit"]
         waves = max(int(st[6]), 1)
         print("   fold kernel, cycles per wave: " + "  ".join(f"{nm} {int(st[k]) / waves:9.0f}" for k, nm in enumerate(names)) + f"  ({waves} waves)")
+# the timed result, checked over ALL rows (checker = plain torch, fp64: order-free, so a tolerance of a few f32 ulps)
+if U == 1:
+    key_col, accs, _ = out
+    got_k, got_s = key_col.data[: key_col.n].to(torch.int64), accs[0].data[: key_col.n].to(torch.float64)
+    uniq, inv = torch.unique(keys.data[:N].to(torch.int64), return_inverse=True)
+    want = torch.zeros(uniq.numel(), dtype=torch.float64, device="cuda").index_add_(0, inv, vals.data[:N].to(torch.float64))
+    o = torch.argsort(got_k)
+    assert torch.equal(got_k[o], uniq), "group keys differ"
+    rel = ((got_s[o] - want).abs() / want.abs().clamp_min(1e-30)).max().item()
+    assert rel < 4e-7, rel
+    print(f"check over all {N} rows: {uniq.numel()} groups, keys equal, max relative difference of the f32 sums {rel:.2e}")
 engine.__exit__(None, None, None)
