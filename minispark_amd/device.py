@@ -297,6 +297,8 @@ class Device:
             self.exchange_events = None
 
     def exchange_ms(self) -> float:
+        # a rank that does not receive the result returns from the query without waiting for its stream
+        self.exchange_events[1].synchronize()
         return self.exchange_events[0].elapsed_time(self.exchange_events[1])
 
     def time_join(self, enable: bool = True) -> None:
@@ -317,6 +319,7 @@ class Device:
         return None if ev is None else ev[i].cuda_event
 
     def scan_kernel_ms(self) -> float:
+        self.scan_events[1].synchronize()  # see exchange_ms
         return self.scan_events[0].elapsed_time(self.scan_events[1])
 
     @property

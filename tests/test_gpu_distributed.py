@@ -201,3 +201,22 @@ def test_bench_runs_over_rccl_world1(tmp_path):
     line = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["config"]["groups"] == 3
     assert "all_gather" in line["config"]["exchange"] and "nccl" in line["config"]["exchange"]
+
+
+def test_bench_runs_on_three_ranks_over_gloo(tmp_path):
+    """bench.py end to end with more than one rank (gloo, all ranks on this one GPU): every rank times its own scan and
+    exchange events - also the ranks that do not receive the result and therefore return from a step without waiting
+    for their stream (round 2: reading those events unsynchronised failed on rank 3 of 4) - the timings are reduced
+    with MAX, rank 0 prints one line whose timed result equals the oracle over the whole table."""
+    env = dict(os.environ, HIPSPARK_DIST_BACKEND="gloo", HIPSPARK_FORCE_DEVICE="0")
+    for var in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(var, None)
+    proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+                           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), str(ROOT / "bench.py"),
+                           "--gpus", "3", "--sf", "1.5", "--steps", "6", "--warmup", "1", "--no-cpu-baseline"],
+                          env=env, capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
+    line = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 3 and line["config"]["groups"] == 3 and line["scaling"] == "strong"
+    assert line["full_check"]["gpu_matches_oracle_full"] is True
+    assert line["time_split_ms"]["exchange"] > 0
