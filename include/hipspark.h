@@ -52,6 +52,10 @@ extern "C" {
                                      * then fails `assert type(val) is float` at the file write, io.py:93 */
 #define HS_FLAG_STR_TOO_LONG 0x20u /* a concatenated string exceeds 255 bytes (BlockFile length byte, io.py:18) */
 #define HS_FLAG_JOIN_DUP 0x80u     /* hs_join_build_unique met a key twice: the caller takes the general (CSR) join */
+#define HS_FLAG_MERGE_ROWS 0x200u /* hs_agg_merge_small was given an upper bound of rows that does not fit LDS and
+                                    ran with what fits; the device-side count turned out larger: use the HBM-tier merge */
+#define HS_FLAG_MERGE_FULL 0x100u /* the FINAL merge met more distinct keys than merge_cap (hs_agg_merge_small /
+                                    hs_agg_finish): grow that capacity, the per-unit one (HS_FLAG_DICT_FULL) is fine */
 
 /* ---- storage kinds of a device column ---- */
 #define HS_I32 0 /* INTEGER as stored in a BlockFile */
@@ -613,7 +617,8 @@ int hs_table_attach(hs_engine* engine, int32_t n_cols, const hs_col* cols, const
 int hs_stage_prepare(hs_engine* engine, hs_table* table, const hs_stage_plan* plan, size_t plan_bytes, int32_t world,
                      hs_stage** out);
 void hs_stage_destroy(hs_stage* stage);
-/* world 1: launches, waits for the result image, retries with larger dictionaries on HS_FLAG_DICT_FULL.  *flags_out:
+/* world 1: launches, waits for the result image, retries with larger dictionaries on HS_FLAG_DICT_FULL (per-unit
+ * tables) / HS_FLAG_MERGE_FULL (final merge).  *flags_out:
  * the remaining HS_FLAG_* bits (division by zero, overflow at a file write ...) for the host to raise. */
 int hs_stage_run(hs_stage* stage, void* stream, uint32_t* flags_out, int64_t* n_rows_out);
 /* world > 1: scan into this rank's slab | the caller all-gathers the slabs (RCCL) | finish over the gathered slabs. */

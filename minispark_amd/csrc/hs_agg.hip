@@ -258,7 +258,7 @@ struct AggMergeArgs {
     const int64_t* n_rows_dev; // optional exact row count on the device
     const int64_t* order;      // optional per-row order key (global unit id); rows with order < 0 are padding
     int32_t n_order;           // order keys lie in [0, n_order)
-    int32_t pad0;
+    int32_t limited;  // n_rows was cut down to what LDS holds: more rows on the device -> HS_FLAG_MERGE_ROWS
     int32_t cap;
     int32_t hashed;
     int64_t* out_rep;
@@ -506,7 +506,7 @@ __device__ __forceinline__ int hs_merge_small_core(const In& in, const hs_agg_sp
         const int64_t o = in.order(r);
         if (o >= 0) {
             sl = in.upsert(dkeys, dreps, mask, r);
-            if (sl < 0) err |= HS_FLAG_DICT_FULL;
+            if (sl < 0) err |= HS_FLAG_MERGE_FULL;  // the merge's own capacity, not the per-unit dictionaries'
             else atomicAdd(&cnt[sl], 1);
             if (ordered && sl >= 0) {
                 if (o >= nord) {
@@ -688,11 +688,12 @@ __global__ void __launch_bounds__(1024) k_agg_merge_small(const AggMergeArgs A_k
     HS_KERNARG(AggMergeArgs, A);
     extern __shared__ __align__(16) uint64_t lds[];
     int64_t n64 = A.n_rows;
+    uint32_t err = 0;
     if (A.n_rows_dev) {
         const int64_t nd = *A.n_rows_dev;
         n64 = nd < A.n_rows ? nd : A.n_rows;
+        if (A.limited && nd > A.n_rows) err |= HS_FLAG_MERGE_ROWS;
     }
-    uint32_t err = 0;
     const MergeFlatIn in{A};
     const int ngroups = hs_merge_small_core(in, A.spec, (int)n64, A.n_rows, A.n_order, A.cap, lds, A.out_rep, A.out_acc, err);
     if (threadIdx.x == 0) *A.out_ngroups = ngroups;
@@ -1277,12 +1278,22 @@ extern "C" int hs_agg_merge(void* stream, const hs_col* key, const hs_col* acc_c
         hs_set_error("hs_agg_merge: n_order=%lld out of range", (long long)n_order);
         return HS_E_ARG;
     }
-    const size_t lds = (size_t)cap * 16 + (size_t)n_rows * spec->n_acc * 8 + (size_t)n_rows * 12 + (size_t)cap * 16 +
-                       (order ? (size_t)n_order * 8 : 0) + 16;
+    const size_t fixed = (size_t)cap * 32 + (order ? (size_t)n_order * 8 : 0) + 16, per_row = (size_t)spec->n_acc * 8 + 12;
+    size_t lds = fixed + (size_t)n_rows * per_row;
+    int32_t limited = 0;
     if (lds > HS_MERGE_LDS_MAX) {
-        hs_set_error("hs_agg_merge: %lld partial rows x %d accumulators need %zu B LDS (> %zu): use the unit-stepped merge",
-                     (long long)n_rows, spec->n_acc, lds, HS_MERGE_LDS_MAX);
-        return HS_E_LIMIT;
+        // n_rows is an upper bound when the real count lives on the device (dense partial rows of the shared tier:
+        // units x table capacity): run with as many rows as LDS holds; the kernel raises HS_FLAG_MERGE_ROWS when the
+        // device count is larger, and the caller takes the HBM-tier merge from then on
+        const int64_t fit = fixed < HS_MERGE_LDS_MAX ? (int64_t)((HS_MERGE_LDS_MAX - fixed) / per_row) : 0;
+        if (!n_rows_dev || fit < 64) {
+            hs_set_error("hs_agg_merge: %lld partial rows x %d accumulators need %zu B LDS (> %zu): use the HBM-tier merge",
+                         (long long)n_rows, spec->n_acc, lds, HS_MERGE_LDS_MAX);
+            return HS_E_LIMIT;
+        }
+        n_rows = fit;
+        limited = 1;
+        lds = fixed + (size_t)n_rows * per_row;
     }
     AggMergeArgs A;
     A.key = *key;
@@ -1293,7 +1304,7 @@ extern "C" int hs_agg_merge(void* stream, const hs_col* key, const hs_col* acc_c
     A.n_rows_dev = n_rows_dev;
     A.order = order;
     A.n_order = order ? (int32_t)n_order : 0;
-    A.pad0 = 0;
+    A.limited = limited;
     A.cap = cap;
     A.hashed = hs_col_packs(*key) ? 0 : 1;
     A.out_rep = out_rep;

@@ -673,14 +673,17 @@ extern "C" int hs_stage_run(hs_stage* s, void* stream, uint32_t* flags_out, int6
         rc = wait_result(s, stream);
         if (rc) return rc;
         ++s->runs;
-        if (s->last_flags & HS_FLAG_DICT_FULL) {
-            // more groups than the dictionaries were sized for: x2 per workgroup while per-lane tables apply, x4 for the merge
-            if (s->group_cap >= 16 && s->merge_cap >= 4096) {
+        if (s->last_flags & (HS_FLAG_DICT_FULL | HS_FLAG_MERGE_FULL)) {
+            // more groups than a dictionary was sized for: x2 per workgroup (per-lane tables), x4 for the merge - each
+            // grows on its own flag; the merge also keeps up with the per-unit capacity (it holds at least as many keys)
+            const bool unit_full = s->last_flags & HS_FLAG_DICT_FULL, merge_full = s->last_flags & HS_FLAG_MERGE_FULL;
+            if ((unit_full && s->group_cap >= 16) || (merge_full && s->merge_cap >= 4096)) {
                 hs_set_error("hs_stage_run: GROUP BY cardinality exceeds the on-chip tiers of this path");
                 return HS_E_LIMIT;
             }
-            if (s->group_cap < 16) s->group_cap *= 2;
-            if (s->merge_cap < 4096) s->merge_cap *= 4;
+            if (unit_full) s->group_cap *= 2;
+            if (merge_full) s->merge_cap *= 4;
+            if (s->merge_cap < 4 * s->group_cap) s->merge_cap = 4 * s->group_cap;
             s->ready = false;
             s->runs = 0;
             ++s->grows;
@@ -721,12 +724,14 @@ extern "C" int hs_stage_wait(hs_stage* s, void* stream, uint32_t* flags_out, int
     if (n_rows_out) *n_rows_out = s->last_rows;
     return HS_OK;
 }
-// After HS_FLAG_DICT_FULL in the multi-rank form (every rank sees the same flags): grow and prepare again.
+// After HS_FLAG_DICT_FULL / HS_FLAG_MERGE_FULL in the multi-rank form (every rank sees the same flags): grow and prepare again.
 extern "C" int hs_stage_grow(hs_stage* s) {
     if (!s) return HS_E_ARG;
-    if (s->group_cap >= 16 && s->merge_cap >= 4096) return HS_E_LIMIT;
-    if (s->group_cap < 16) s->group_cap *= 2;
-    if (s->merge_cap < 4096) s->merge_cap *= 4;
+    const bool unit_full = s->last_flags & HS_FLAG_DICT_FULL, merge_full = s->last_flags & HS_FLAG_MERGE_FULL;
+    if ((unit_full && s->group_cap >= 16) || (merge_full && s->merge_cap >= 4096)) return HS_E_LIMIT;
+    if (unit_full) s->group_cap *= 2;
+    if (merge_full || !unit_full) s->merge_cap = s->merge_cap < 4096 ? s->merge_cap * 4 : s->merge_cap;
+    if (s->merge_cap < 4 * s->group_cap) s->merge_cap = 4 * s->group_cap;
     s->ready = false;
     ++s->grows;
     return stage_prepare(s);

@@ -147,7 +147,13 @@ class SlabUnsupported(NotImplementedError):
 
 class RetryWithLargerDictionary(Exception):
     """A launch met more distinct group keys than its dictionary capacity (noticed at the query's single
-    host round trip); the engine re-runs the query with larger capacities."""
+    host round trip); the engine re-runs the query with larger capacities.  ``flags`` says which: HS_FLAG_DICT_FULL =
+    the per-unit dictionaries of the partial aggregate, HS_FLAG_MERGE_FULL = the final merge's."""
+
+    def __init__(self, flags: int = hs.FLAG_DICT_FULL | hs.FLAG_MERGE_FULL) -> None:
+        super().__init__(f"dictionary capacity exceeded (flags {flags:#x})")
+        self.unit_full = bool(flags & hs.FLAG_DICT_FULL)
+        self.merge_full = bool(flags & hs.FLAG_MERGE_FULL)
 
 
 class DeviceError(RuntimeError):

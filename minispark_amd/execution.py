@@ -130,6 +130,7 @@ class HipExecutionEngine(ExecutionEngine):
         self.fused_join_enabled = os.environ.get("HIPSPARK_FUSED_JOIN", "1") != "0"
         self._no_fused_join: set[Any] = set()  # join task ids whose build side turned out to hold duplicate keys
         self._fused_join_tasks: set[Any] = set()  # join task ids the running query took the in-place path for
+        self._lds_merges: list[int] = []  # final-merge tasks the running query folded on chip (see HS_FLAG_MERGE_ROWS)
         budget = os.environ.get("HIPSPARK_HBM_BUDGET")
         self.hbm_budget: int | None = int(float(budget)) if budget else None  # bytes of referenced columns kept resident
         self.streamed_ranges = 0
@@ -338,6 +339,7 @@ class HipExecutionEngine(ExecutionEngine):
             self._version += 1  # a full run may load / re-code tables, grow capacities, replace recordings
             self.dev.reset_flags()
             self._fused_join_tasks.clear()
+            self._lds_merges: list[int] = []
             outputs: dict[int, Any] = {}
             results: list[JobResult] = []
             # record the second (cache-warm) run of a plan: by then every buffer it needs is prepared
@@ -364,15 +366,21 @@ class HipExecutionEngine(ExecutionEngine):
                 return results
             except RestartQuery:
                 self.dev.stop_recording()
-            except RetryWithLargerDictionary:
+            except RetryWithLargerDictionary as grow:
                 self.dev.stop_recording()
-                # more distinct GROUP BY keys than the dictionaries were sized for: grow and re-run; past the
-                # on-chip limits the stages switch to the global-memory tier (TierExceeded in _run_stage)
-                # x2 while the private-table tier applies, x4 beyond (every step re-runs the scan)
-                self.group_cap_hint *= 2 if self.group_cap_hint < PRIVATE_TIER_MAX else 4
-                if self.merge_cap_hint >= 4096:
-                    self._merge_overflowed = True
-                self.merge_cap_hint = min(self.merge_cap_hint * 4, 4096)
+                # more distinct GROUP BY keys than a dictionary was sized for: grow and re-run; past the on-chip
+                # limits the stages switch to the global-memory tier (TierExceeded in _run_stage).  The per-unit
+                # capacity (x2 while the private-table tier applies, x4 beyond; every step re-runs the scan) and the
+                # final merge's (x4, on-chip up to 4096 slots) grow on their own flags: a query with 50 groups in 29
+                # units climbs 4 -> 64 per unit and must not end up with an "overflowed" merge of 1 450 rows
+                if grow.unit_full:
+                    self.group_cap_hint *= 2 if self.group_cap_hint < PRIVATE_TIER_MAX else 4
+                if grow.merge_full:
+                    if self.merge_cap_hint >= 4096:
+                        self._merge_overflowed = True
+                    self.merge_cap_hint = min(self.merge_cap_hint * 4, 4096)
+                # the merge sees at least the keys of one unit
+                self.merge_cap_hint = min(max(self.merge_cap_hint, 4 * self.group_cap_hint), 4096)
             except (HipSparkError, DeviceError) as e:
                 self.dev.stop_recording()
                 raise ExecutionError(str(e)) from e
@@ -635,6 +643,7 @@ class HipExecutionEngine(ExecutionEngine):
                         try:
                             batch = self.dev.aggregate_merge(batch, task.agg_columns, task.inferred_schema,
                                                              self.merge_cap_hint)
+                            self._lds_merges.append(_uid(task))  # HS_FLAG_MERGE_ROWS sends them to the HBM tier
                         except TierExceeded:
                             use_global = True
                     if use_global:
@@ -1278,8 +1287,12 @@ class HipExecutionEngine(ExecutionEngine):
             # the in-place join met a build key twice: every join of this query takes the general path from now on
             self._no_fused_join.update(self._fused_join_tasks)
             raise RestartQuery
-        if flags & hs.FLAG_DICT_FULL:
-            raise RetryWithLargerDictionary
+        if flags & hs.FLAG_MERGE_ROWS:
+            # an on-chip merge ran on an upper bound of rows that did not fit and the real count was larger
+            self._global_merge.update(self._lds_merges)
+            raise RestartQuery
+        if flags & (hs.FLAG_DICT_FULL | hs.FLAG_MERGE_FULL):
+            raise RetryWithLargerDictionary(flags)
         self.dev.raise_for_flags(flags)
         return self._emit_result(raw, nrows, schema, stage_id)
 
@@ -1324,8 +1337,8 @@ class HipExecutionEngine(ExecutionEngine):
 
             flags = or_flags(self.dist, flags, self.dev.device, self.group)
             self._generic_exchange_used = False
-        if flags & hs.FLAG_DICT_FULL:
-            raise RetryWithLargerDictionary
+        if flags & (hs.FLAG_DICT_FULL | hs.FLAG_MERGE_FULL):
+            raise RetryWithLargerDictionary(flags)
         self.dev.raise_for_flags(flags)
         return self._emit_result(raw, nrows, schema, stage_id)
 

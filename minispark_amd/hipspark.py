@@ -29,6 +29,8 @@ FLAG_DIV_ZERO = 0x1
 FLAG_INT_OVERFLOW = 0x2
 FLAG_FLT_OVERFLOW = 0x4
 FLAG_DICT_FULL = 0x8
+FLAG_MERGE_FULL = 0x100
+FLAG_MERGE_ROWS = 0x200
 FLAG_BAD_PROGRAM = 0x10
 FLAG_STR_TOO_LONG = 0x20
 FLAG_TYPE_ASSERT = 0x40

@@ -358,7 +358,7 @@ def test_ordered_merge_survives_invalid_rows_and_full_dictionaries(dev, cap, hol
     dictionary leave holes inside a block's row range.  The visiting sequence must still be a permutation of the
     valid rows (it once assumed position = row - first row of the block: with holes the representatives of some
     groups were never written and stale indices reached the gathers).  With a dictionary large enough the result
-    equals a sequential fold in (block, row) order; with a small one only HS_FLAG_DICT_FULL may be raised."""
+    equals a sequential fold in (block, row) order; with a small one only HS_FLAG_MERGE_FULL may be raised."""
     import torch
 
     from minispark_amd import hipspark as hs
@@ -389,7 +389,7 @@ def test_ordered_merge_survives_invalid_rows_and_full_dictionaries(dev, cap, hol
     ng = int(out.nrows_dev[0].item())
     got_keys = out.cols[0].data[:ng].cpu().numpy()
     if n_groups > cap:
-        assert flags & hs.FLAG_DICT_FULL and ng <= cap and set(got_keys.tolist()) <= set(keys[valid].tolist())
+        assert flags == hs.FLAG_MERGE_FULL and ng <= cap and set(got_keys.tolist()) <= set(keys[valid].tolist())
         dev.reset_flags()
         return
     assert flags == 0 and ng == n_groups

@@ -172,3 +172,48 @@ def test_random_many_group_queries_match_the_oracle(engine, tmp_path, seed):
     for _ in range(2):
         flips = assert_rows_match(frame.collect(), want, max_ulps=1)
         assert flips <= 3
+
+
+def _blocks_table(path, blocks, rows_per_block, groups, seed):
+    from minispark_amd.constants import ColumnType as T
+    from minispark_amd.io import BlockFile
+
+    rng = np.random.default_rng(seed)
+    n = blocks * rows_per_block
+    k = rng.integers(0, groups, n).astype(np.int32)
+    f = rng.normal(0, 1e3, n).astype(np.float32)
+    BlockFile(path).write_raw_blocks([("k", T.INTEGER), ("f", T.FLOAT)],
+                                     [[k[b * rows_per_block:(b + 1) * rows_per_block], f[b * rows_per_block:(b + 1) * rows_per_block]]
+                                      for b in range(blocks)])
+
+
+@pytest.mark.parametrize(("groups", "on_chip"), [(50, True), (3000, False)])
+def test_final_merge_tier_follows_the_real_number_of_partial_rows(tmp_path, groups, on_chip):
+    """The shared tier hands its partial rows over densely with only an UPPER BOUND of their number on the host (units x
+    table capacity).  The on-chip merge runs with as many rows as LDS holds: 30 units x 50 groups = 1 500 rows fit (the
+    query is then recorded and replayed), 30 x 3 000 = 90 000 raise HS_FLAG_MERGE_ROWS and the query moves to the HBM-tier
+    merge - never because of the bound alone, and never because the PER-UNIT dictionaries had to grow on the way."""
+    from minispark_amd import constants
+    from minispark_amd.dataframe import DataFrame
+    from minispark_amd.execution import HipExecutionEngine
+    from minispark_amd.sql import Col, Functions as F
+    from oracle.py_engine import run_query
+
+    constants.SHUFFLE_FOLDER = tmp_path / "shuffle"
+    path = tmp_path / "b.bin"
+    _blocks_table(path, 30, 4000, groups, groups)
+
+    def build(engine):
+        return DataFrame(engine).table(str(path)).group_by(Col("k")).agg(F.sum(Col("f")).alias("s"), F.count(), F.max(Col("f")).alias("m"))
+
+    want = run_query(build(object()).task)
+    with HipExecutionEngine(0) as engine:
+        frame = build(engine)
+        for _ in range(5):
+            flips = assert_rows_match(frame.collect(), want, max_ulps=1)
+            assert flips <= 3
+        assert engine.dev.last_scan["tier"] == "shared"
+        assert bool(engine._global_merge) != on_chip
+        assert not engine._caps["merge_overflowed"]
+        if on_chip:
+            assert engine.replays >= 1
