@@ -285,7 +285,10 @@ int hs_agg_pack(void* stream, const int64_t* rep, const uint64_t* acc, const int
  * Outputs are DENSE (group i = i-th occupied dictionary slot) and column-major: out_rep[i] = first input
  * row of group i, out_acc[a * cap + i] = un-rounded 64-bit cell of aggregate a, *out_ngroups = number of
  * groups (<= cap).  n_rows is an upper bound when n_rows_dev != NULL (then *n_rows_dev, a device int64, is
- * the exact count): lets a whole query run without a host round trip between its kernels. */
+ * the exact count): lets a whole query run without a host round trip between its kernels.  Everything is staged in
+ * LDS: when n_rows does not fit (HS_E_LIMIT without n_rows_dev) but the count is on the device, the merge runs with as
+ * many rows as fit and raises HS_FLAG_MERGE_ROWS if *n_rows_dev is larger (the caller then takes the HBM-tier merge);
+ * more distinct keys than `cap` raise HS_FLAG_MERGE_FULL. */
 int hs_agg_merge(void* stream, const hs_col* key, const hs_col* acc_cols, const hs_agg_spec* spec,
                  const int64_t* order, int64_t n_order, int64_t n_rows, const int64_t* n_rows_dev, int32_t cap,
                  int64_t* out_rep, uint64_t* out_acc, int64_t* out_ngroups, uint32_t* flags);
