@@ -26,6 +26,7 @@ from __future__ import annotations
 
 import os
 import struct
+import time
 from dataclasses import dataclass, field
 from datetime import datetime
 from pathlib import Path
@@ -105,6 +106,18 @@ def datetime_to_timestamp(dt: datetime) -> int:
 def timestamp_to_datetime(microseconds_since_epoch: int) -> datetime:
     """Inverse of :func:`datetime_to_timestamp` with the reference's float division (io.py:38-39)."""
     return datetime.fromtimestamp(microseconds_since_epoch / 1_000_000)
+
+
+def timestamps_to_datetimes(us: np.ndarray) -> list[datetime]:
+    """:func:`timestamp_to_datetime` for a whole column.  When the local time zone is UTC (``TZ=UTC``: the only setting
+    under which the reference compares TIMESTAMPs consistently) the conversion is one vectorised step:
+    ``fromtimestamp(v / 1e6)`` rounds the float seconds back to the same integer microseconds for every |v| < 4e15
+    (year 2096), so the naive datetime is epoch + v.  Any other zone, or values out of that range: value by value."""
+    if time.timezone == 0 and time.daylight == 0 and us.size and int(np.abs(us).max()) < 4_000_000_000_000_000:
+        out = us.astype("datetime64[us]").tolist()
+        if not out or isinstance(out[0], datetime):
+            return out
+    return [timestamp_to_datetime(v) for v in us.tolist()]
 
 
 # --------------------------------------------------------------------------------------------------
@@ -544,7 +557,7 @@ def rows_from_raw(schema: Schema, cols: Sequence[RawColumn]) -> Iterator[Row]:
                 p += ln
             values.append(vals)
         elif col_type == ColumnType.TIMESTAMP:
-            values.append([timestamp_to_datetime(v) for v in c.tolist()])
+            values.append(timestamps_to_datetimes(np.asarray(c, dtype=np.int64)))
         else:
             values.append(c.tolist())
     for row in zip(*values, strict=True):

@@ -130,3 +130,19 @@ def test_result_file_rows_equal_the_rows_of_the_file_it_writes(tmp_path):
     assert direct == from_file
     assert [type(v) for v in direct[1].values()] == [type(v) for v in from_file[1].values()]
     assert isinstance(direct[0]["t"], datetime) and isinstance(direct[0]["f"], float) and isinstance(direct[0]["i"], int)
+
+
+def test_vectorised_timestamp_column_equals_the_value_by_value_conversion():
+    """rows_from_raw turns a TIMESTAMP column into datetimes in one numpy step when the local zone is UTC; it must give
+    exactly what the reference's ``datetime.fromtimestamp(us / 1_000_000)`` gives value by value (io.py:38-39)."""
+    import numpy as np
+
+    from minispark_amd import io
+
+    rng = np.random.default_rng(3)
+    us = rng.integers(-10**15, 3 * 10**15, 50_000).astype(np.int64)
+    us[:6] = [0, 1, -1, 999_999, 10**15 + 1, 883_612_800_000_000]
+    assert io.timestamps_to_datetimes(us) == [io.timestamp_to_datetime(int(v)) for v in us.tolist()]
+    assert io.timestamps_to_datetimes(np.zeros(0, np.int64)) == []
+    far = np.asarray([5 * 10**15], dtype=np.int64)  # beyond the range the shortcut is proven for: value by value
+    assert io.timestamps_to_datetimes(far) == [io.timestamp_to_datetime(int(far[0]))]
