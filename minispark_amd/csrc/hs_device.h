@@ -206,12 +206,17 @@ __device__ __forceinline__ bool hs_like(HsStr s, const uint8_t* pat, uint32_t pl
 }
 
 // ---- Python arithmetic -----------------------------------------------------------------------------
+// b == -1 is answered without dividing: the compiler narrows a 64-bit division whose operands are sign-extended 32-bit
+// values to a 32-bit one (so GROUP BY k % 97 costs no 64-bit division), and that narrowing turns INT32_MIN // -1 into
+// INT32_MIN - Python's answer is 2147483648 (which then fails the i32 write with OverflowError, io.py:90).
 __device__ __forceinline__ int64_t hs_floordiv_i(int64_t a, int64_t b) {
+    if (b == -1) return -a;
     int64_t q = a / b;
     if ((a % b != 0) && ((a < 0) != (b < 0))) --q;
     return q;
 }
 __device__ __forceinline__ int64_t hs_mod_i(int64_t a, int64_t b) {
+    if (b == -1) return 0;
     int64_t m = a % b;
     if (m != 0 && ((m < 0) != (b < 0))) m += b;
     return m;

@@ -222,6 +222,38 @@ def test_expression_evaluator_against_python_semantics(dev, n, jit):
     assert (stats[1] > launched_before) == jit, "the compiled / interpreted route was not the one exercised"
 
 
+@pytest.mark.parametrize("jit", [True, False])
+def test_integer_floor_division_and_modulo_on_both_widths(dev, jit):
+    """Integers are 64-bit in flight; the compiler narrows // and % of sign-extended 32-bit operands to a 32-bit division
+    and keeps the wide one otherwise (products beyond 32 bits) - both must give Python's floor semantics, divisors of
+    either sign, and INT32_MIN // -1 = 2147483648 (hs_floordiv_i / hs_mod_i in csrc/hs_device.h answer b == -1 without
+    dividing: the narrowed division would return INT32_MIN)."""
+    from minispark_amd.constants import ColumnType as T
+    from minispark_amd.device import DBatch
+    from minispark_amd.sql import Col, Lit
+
+    dev.lib.hs_jit_set_enabled(1 if jit else 0)
+    r = _rng(23)
+    n = 3001
+    i = r.integers(-2**31, 2**31, n).astype(np.int32)
+    i[:6] = [-2**31, 2**31 - 1, 0, -1, 1, -2**31 + 1]
+    j = np.where(r.random(n) < 0.5, r.integers(1, 50_000, n), -r.integers(1, 50_000, n)).astype(np.int32)
+    j[:6] = [-1, -1, 7, -1, -7, 2**31 - 1]
+    t = (r.integers(-10**6, 10**6, n).astype(np.int64) * 86_400_000_123)
+    schema = [("i", T.INTEGER), ("j", T.INTEGER), ("t", T.TIMESTAMP)]
+    batch = DBatch(schema, [dev.upload_raw(i, T.INTEGER), dev.upload_raw(j, T.INTEGER), dev.upload_raw(t, T.TIMESTAMP)], n)
+    exprs = [(Col("i") // Col("j"), lambda a, b, c: a // b), (Col("i") % Col("j"), lambda a, b, c: a % b),
+             (Col("i") // Lit(-1), lambda a, b, c: a // -1), (Col("i") % Lit(-1), lambda a, b, c: a % -1),
+             (Col("i") % Lit(97), lambda a, b, c: a % 97), (Col("i") // Lit(-97), lambda a, b, c: a // -97),
+             (Col("i") * Col("j") // Col("j"), lambda a, b, c: a * b // b), ((Col("i") * 100_000 + Col("j")) % Col("j"), lambda a, b, c: (a * 100_000 + b) % b)]
+    out = dev.eval_numeric(batch, [e for e, _ in exprs])
+    rows = list(zip(i.tolist(), j.tolist(), t.tolist()))
+    for (expr, fn), (col, _) in zip(exprs, out):
+        assert col.data[:n].cpu().numpy().tolist() == [fn(*row) for row in rows], str(expr)
+    assert dev.read_flags() == 0
+    dev.lib.hs_jit_set_enabled(1)
+
+
 def test_quantise_flags_overflow(dev):
     import torch
 
