@@ -732,9 +732,10 @@ class Device:
         if any(batch.cols[v].data.data_ptr() % 16 for _, v in col_parts):
             return None  # the combine reads 16 code bytes per lane
         out = self.empty(n, torch.uint8)
-        ptrs = (C.c_void_p * len(col_parts))(*[batch.cols[v].data.data_ptr() for _, v in col_parts])
-        strd = (C.c_int32 * len(col_parts))(*strides)
-        hs.check(self.lib.hs_dict_combine(self.stream, len(col_parts), ptrs, strd, n, out.data_ptr()), "hs_dict_combine")
+        if n > 0:  # an empty batch (every row filtered out) has no buffers to hand over
+            ptrs = (C.c_void_p * len(col_parts))(*[batch.cols[v].data.data_ptr() for _, v in col_parts])
+            strd = (C.c_int32 * len(col_parts))(*strides)
+            hs.check(self.lib.hs_dict_combine(self.stream, len(col_parts), ptrs, strd, n, out.data_ptr()), "hs_dict_combine")
         return DCol(hs.STR, out, n, lens=self.const_lens(1, n), offs=None, fixed_len=1, dict=tuple(entries))
 
     # ---- string concat -------------------------------------------------------------------------------

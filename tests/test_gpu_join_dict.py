@@ -111,6 +111,9 @@ DICT_QUERIES = {
         .select(api.Col("s"), (api.Col("s") + "/" + api.Col("v") + "/" + api.Col("w")).alias("c"), api.Col("i")),
     "like_underscore_and_literal_prefix": lambda api, p: api.DataFrame().table(p).filter(api.Col("s").like("x_y") | api.Col("s").like("100%"))
         .select(api.Col("s"), api.Col("v")),
+    "concat_key_after_a_filter_nothing_passes": lambda api, p: api.DataFrame().table(p).filter(api.Col("i") > 1000)
+        .select((api.Col("w") + "-" + api.Col("v")).alias("k"), api.Col("f"))
+        .group_by(api.Col("k")).agg(api.F.sum(api.Col("f")).alias("sf"), api.F.count()),
     "long_concat_falls_back": lambda api, p: api.DataFrame().table(p)
         .select((api.Col("s") + api.Col("s") + api.Col("v") + api.Col("w")).alias("k"), api.Col("i"))
         .group_by(api.Col("k")).agg(api.F.sum(api.Col("i")).alias("t")),
