@@ -19,10 +19,13 @@ keys = DCol(hs.I32, torch.randint(0, G, (N,), dtype=torch.int32, device="cuda", 
 vals = DCol(hs.F32, torch.rand(N, dtype=torch.float32, device="cuda", generator=g), N)
 bounds = torch.tensor([N * u // U for u in range(U + 1)], dtype=torch.int64, device="cuda")
 biggest = max(N * (u + 1) // U - N * u // U for u in range(U))
+COUNT = os.environ.get("RADIX_BENCH_COUNT") == "1"  # a second aggregate: COUNT (a constant 1 that does not travel)
+VALUES = [(vals, 0, False)] + ([(None, 1, True)] if COUNT else [])
+OPS = [hs.AGG_SUM] * len(VALUES)
 for r in range(reps):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    a.record(); out = dev.group_radix(keys, None, N, bounds, U, biggest, [(vals, 0, False)], [hs.AGG_SUM], True); b.record()
+    a.record(); out = dev.group_radix(keys, None, N, bounds, U, biggest, VALUES, OPS, True); b.record()
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f"rows {N} groups {G} units {U}: run {r}: {a.elapsed_time(b):7.3f} ms (host {dt * 1e3:7.3f} ms) = "
           f"{N / a.elapsed_time(b) / 1e6:6.2f} G rows/s, {out[0].n} groups", flush=True)
@@ -44,4 +47,16 @@ if U == 1:
     rel = ((got_s[o] - want).abs() / want.abs().clamp_min(1e-30)).max().item()
     assert rel < 4e-7, rel
     print(f"check over all {N} rows: {uniq.numel()} groups, keys equal, max relative difference of the f32 sums {rel:.2e}")
+# size-independent properties of the timed result, any number of units: the groups' counts add up to the row count and
+# their sums to the column's sum (fp64 of f32-rounded group sums: relative 1e-6)
+key_col, accs, unit_rows = out
+total = accs[0].data[: key_col.n].to(torch.float64).sum().item()
+want_total = vals.data[:N].to(torch.float64).sum().item()
+assert abs(total - want_total) <= 1e-6 * abs(want_total), (total, want_total)
+line = f"properties over all {N} rows / {U} units: {key_col.n} groups, sum of group sums {total:.6e} vs column sum {want_total:.6e}"
+if COUNT:
+    n_counted = int(accs[1].data[: key_col.n].to(torch.int64).sum().item())
+    assert n_counted == N, (n_counted, N)
+    line += f", counts add up to {n_counted}"
+print(line)
 engine.__exit__(None, None, None)
