@@ -543,6 +543,10 @@ void hs_jit_set_enabled(int enabled);
 int hs_jit_get_enabled(void);
 /* counters[0] = programs compiled, [1] = launches of compiled programs, [2] = compile failures */
 void hs_jit_stats(int32_t* counters);
+/* Compiled code objects are kept on disk between processes: $HIPSPARK_JIT_CACHE (default $TMPDIR/hipspark-jit-<uid>,
+ * "0" = off), one file per program named by a hash of everything the compiler sees; -> programs of this process that
+ * were loaded from there instead of being compiled. */
+int hs_jit_disk_hits(void);
 const char* hs_jit_last_log(void);
 /* Translate + compile only (needs no GPU): proves the generated source builds for `arch`
  * (NULL = "gfx950"); optionally returns the generated source text. */

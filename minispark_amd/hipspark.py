@@ -240,6 +240,7 @@ SIGNATURES: dict[str, tuple] = {
     "hs_jit_set_enabled": (None, [C.c_int]),
     "hs_jit_get_enabled": (C.c_int, []),
     "hs_jit_stats": (None, [C.POINTER(_I32)]),
+    "hs_jit_disk_hits": (C.c_int, []),
     "hs_jit_last_log": (C.c_char_p, []),
     "hs_jit_compile_check": (C.c_int, [_COLP, _I32, _I32, _PROGP, _SPECP, C.c_char_p, C.POINTER(_I64), C.c_char_p, _I64]),
     "hs_jit_compile_check_shared": (C.c_int, [_COLP, _I32, _I32, _I32, _PROGP, _SPECP, C.c_char_p, C.POINTER(_I64),

@@ -232,3 +232,48 @@ def test_capacity_hints_are_per_query_shape(tmp_path):
         assert len(rows) == 3
         assert engine.dev.last_scan["group_cap"] == 4 and engine.dev.last_scan["wg_threads"] == 256
         assert len(many.collect()) == 50 and engine.dev.last_group_cap >= 64  # and its own hint is remembered
+
+
+def test_compiled_programs_are_kept_on_disk_between_processes(tmp_path):
+    """A second process asking for the same programs loads their code objects from $HIPSPARK_JIT_CACHE instead of
+    compiling them again (hs_jit_disk_hits), gives the same rows, and a damaged cache file is ignored and rewritten."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    script = (
+        "import json, sys, time\n"
+        f"sys.path.insert(0, {str(root)!r})\n"
+        "from minispark_amd import hipspark as hs, synth, workloads\n"
+        "from minispark_amd.execution import HipExecutionEngine\n"
+        "with HipExecutionEngine(0) as e:\n"
+        "    path = sys.argv[1]\n"
+        "    e.attach_device_table(path, synth.make_lineitem(e.dev, path, 300_000))\n"
+        "    t0 = time.perf_counter()\n"
+        "    rows = workloads.q1(workloads.engine_api(e), path).collect()\n"
+        "    dt = time.perf_counter() - t0\n"
+        "    c = (hs.C.c_int32 * 3)()\n"
+        "    e.dev.lib.hs_jit_stats(c)\n"
+        "    print(json.dumps({'rows': [[str(v) for v in r.values()] for r in rows], 'hits': e.dev.lib.hs_jit_disk_hits(),\n"
+        "                      'compiled': c[0], 'failures': c[2], 'first_query_s': dt}))\n")
+    cache = tmp_path / "jit"
+    env = dict(os.environ, HIPSPARK_JIT_CACHE=str(cache), TZ="UTC")
+
+    def run():
+        proc = subprocess.run([sys.executable, "-c", script, str(tmp_path / "li.bin")], env=env, capture_output=True, text=True,
+                              timeout=600)
+        assert proc.returncode == 0, proc.stdout[-1500:] + proc.stderr[-3000:]
+        return json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
+
+    cold = run()
+    files = sorted(cache.glob("*.hsaco"))
+    assert cold["hits"] == 0 and cold["compiled"] >= 1 and cold["failures"] == 0 and len(files) == cold["compiled"]
+    warm = run()
+    assert warm["hits"] == cold["compiled"] and warm["failures"] == 0 and warm["rows"] == cold["rows"]
+    assert warm["first_query_s"] < cold["first_query_s"]
+    files[0].write_bytes(files[0].read_bytes()[:-7] + b"damaged")  # checksum no longer matches: compiled again
+    again = run()
+    assert again["hits"] == cold["compiled"] - 1 and again["failures"] == 0 and again["rows"] == cold["rows"]
