@@ -1,3 +1,4 @@
+"""Host profile of the 2 526-group GROUP BY (60 M rows): python tools/probes/prof_mid.py"""
 import os, sys, tempfile, time, cProfile, pstats
 from pathlib import Path
 os.environ.setdefault("TZ", "UTC"); time.tzset()
