@@ -189,3 +189,28 @@ def test_stage_plan_blob_lowers_without_a_gpu_and_matches_the_library_mirror():
     assert blob.fin_prog.n_ins > 0  # the three AVG = sum / count projections
     assert [blob.out_names[o].value.decode() for o in range(9)] == [n for n, _ in schema]
     assert blob.out_types[0] == 1 and blob.out_types[8] == 0  # STRING key ... INTEGER count
+
+
+def test_radix_tier_plan_is_host_only_and_sizes_its_workspace():
+    """hs_group_radix_plan (csrc/hs_radix.hip) touches no GPU: the workspace grows with the row count, a unit that fits
+    one table needs no partition fan-out to speak of, unsupported key kinds and empty inputs are refused."""
+    lib = hs.load_library()
+    spec = hs.hs_agg_spec()
+    spec.n_acc = 2
+    spec.op[0], spec.op[1] = hs.AGG_SUM, hs.AGG_SUM
+    spec.is_int[0], spec.is_int[1] = 0, 1
+    kinds = (C.c_int32 * 2)(hs.F32, -1)  # SUM(f32 column), COUNT (a constant that does not travel)
+
+    def ws(n, units, biggest, key_kind=hs.I32):
+        plan = hs.hs_radix_plan()
+        rc = lib.hs_group_radix_plan(key_kind, n, units, biggest, kinds, C.byref(spec), 1, C.byref(plan))
+        return rc, (lib.hs_group_radix_ws_bytes(C.byref(plan)) if rc == 0 else 0)
+
+    rc_small, small = ws(1000, 1, 1000)
+    rc_mid, mid = ws(60_000_000, 29, 2_097_152)
+    rc_big, big = ws(600_037_902, 287, 2_097_152)
+    assert (rc_small, rc_mid, rc_big) == (0, 0, 0) and 0 < small < mid < big
+    # two buffer sets of (4 B key + 4 B value) per row + provisional groups (8 B key + 2 x 4 B) + bookkeeping
+    assert 32 * 60_000_000 <= mid <= 48 * 60_000_000
+    assert ws(1000, 1, 1000, key_kind=hs.STR)[0] != 0 and ws(0, 1, 1)[0] != 0 and ws(10, 0, 10)[0] != 0
+    assert b"hs_group_radix_plan" in lib.hs_last_error()
