@@ -641,6 +641,9 @@ static int rx_pass(hipStream_t stream, RxPass& P, int64_t max_tiles, int64_t* co
     static const bool direct = getenv("HIPSPARK_RADIX_DIRECT") != nullptr;
     int widest = 1;
     for (int c = 0; c < P.n_cols; ++c) widest = P.esize[c] > widest ? P.esize[c] : widest;
+    static unsigned long long attr_set = 0;
+    if (hs_first_on_device(attr_set))  // 8-byte columns stage 72 KB + 18 KB static: above the 64 KB a launch gets unasked
+        (void)hipFuncSetAttribute((const void*)k_rx_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, RX_TILE * 9);
     if (direct) hipLaunchKernelGGL(k_rx_scatter<false>, dim3((unsigned)max_tiles), dim3(RX_THREADS), 0, stream, P);
     else hipLaunchKernelGGL(k_rx_scatter<true>, dim3((unsigned)max_tiles), dim3(RX_THREADS), (size_t)RX_TILE * (1 + widest), stream, P);
     RX_CHECK_LAUNCH("radix pass (scatter)");
