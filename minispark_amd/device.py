@@ -1201,6 +1201,7 @@ class Device:
         hs.check(rc, "hs_agg_finish")
         self.last_merge_cap = cap
         result, columns, mapped = p["result"], p["columns"], p["host_image"]
+        image_bytes = max((off + cap * width for off, _, width in columns), default=16)
         key_dict = tail.get("key_dict")
         stream = torch.cuda.current_stream(self.device)
 
@@ -1215,9 +1216,12 @@ class Device:
                         stream.synchronize()
                         if done[0] == 0:
                             raise DeviceError("hs_agg_finish completed without handing its result over")
-                host = mapped
+                # a small image (the usual few groups) is copied out whole - the columns below are then views of that
+                # one private copy; a large one (thousands of slots) column by column, only the rows that are there
+                host = mapped[:image_bytes].copy() if image_bytes <= 8192 else mapped
             else:
                 host = result.cpu().numpy()  # the single synchronising copy
+            private = host is not mapped
             flags = int(host[0:4].view(np.uint32)[0])
             n = min(int(host[8:16].view(np.int64)[0]), cap)
             raw: list[Any] = []
@@ -1226,9 +1230,11 @@ class Device:
                     if key_dict is not None:
                         raw.append(_decode_codes(host[off: off + n], key_dict))
                     else:
-                        raw.append(StrCol(np.full(n, width, dtype=np.uint8), host[off: off + n * width].copy()))
+                        data = host[off: off + n * width]
+                        raw.append(StrCol(np.full(n, width, dtype=np.uint8), data if private else data.copy()))
                 else:
-                    raw.append(host[off: off + n * width].view(_NP_DTYPE[kind]).copy())
+                    data = host[off: off + n * width].view(_NP_DTYPE[kind])
+                    raw.append(data if private else data.copy())
             if mapped is not None:
                 done[0] = 0  # ready for the next launch into this image
             return raw, n, flags
