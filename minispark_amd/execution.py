@@ -67,6 +67,9 @@ class ExecutionEngine(AbstractContextManager, ABC):
         output_files = {file for result in results for file in result.output_files}
         for file in output_files:
             rows = file.rows() if isinstance(file, ResultFile) else BlockFile(file.file_path).read_data_rows()
+            if limit == math.inf:
+                yield from rows
+                continue
             for row in rows:
                 yield row
                 limit -= 1
