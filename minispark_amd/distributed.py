@@ -27,6 +27,7 @@ from typing import Any
 import torch
 
 HEADER_BYTES = 16  # [flags: u32][pad: u32][row count: i64]
+FLAG_BITS = 32     # width of the status word or_flags() reduces (every HS_FLAG_* bit)
 
 
 @dataclass
@@ -195,9 +196,12 @@ def agree_string_width(dist: Any, fixed_len: int, nrows: int, device: torch.devi
 
 
 def or_flags(dist: Any, flags: int, device: torch.device, group: Any = None) -> int:
-    """Bitwise OR of a status word over all ranks (so every rank takes the same retry / error decision)."""
+    """Bitwise OR of a 32-bit status word over all ranks (so every rank takes the same retry / error decision).
+    RCCL has no BOR reduction: the word travels as one element per bit under MAX.  All 32 bits - round 2 reduced only
+    the low byte and dropped HS_FLAG_MERGE_FULL / HS_FLAG_MERGE_ROWS (bits 8-9), see tests/test_distributed_cpu.py."""
     backend = dist.get_backend(group)
     dev = torch.device("cpu") if backend == "gloo" else device
-    bits = torch.tensor([(flags >> b) & 1 for b in range(8)], dtype=torch.int32, device=dev)
+    flags = int(flags) & 0xFFFFFFFF
+    bits = torch.tensor([(flags >> b) & 1 for b in range(FLAG_BITS)], dtype=torch.int32, device=dev)
     dist.all_reduce(bits, op=dist.ReduceOp.MAX, group=group)
     return sum(int(v) << b for b, v in enumerate(bits.tolist()))

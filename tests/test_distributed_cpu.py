@@ -111,3 +111,30 @@ def test_size_matrix_and_single_data_collective_world3():
         assert theirs == [[10 * s + r, 100 * s + r] for s in range(world)]
         want = [v for s in range(world) for v in [16 * s + r] * (10 * s + r)]
         assert got == want
+
+
+def _flags_worker(rank: int, world: int, port: int, result):
+    from minispark_amd.distributed import or_flags
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cpu = torch.device("cpu")
+    mine = [0x300, 0x100 if rank == 0 else 0x0, 0x308 if rank == 1 else 0x1, 0x80000000 if rank == 0 else 0x0, 0]
+    result[rank] = [or_flags(dist, f, cpu) for f in mine]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_or_flags_reduces_the_whole_status_word_world2():
+    """Round 2 reduced bits 0-7 only: HS_FLAG_MERGE_FULL (0x100) / HS_FLAG_MERGE_ROWS (0x200) - tested by the engine
+    AFTER or_flags - were erased on every multi-rank generic-exchange query (even the rank's own bits), so an
+    overflowed final merge came back short, silently."""
+    from minispark_amd import hipspark as hs
+
+    assert hs.FLAG_MERGE_FULL == 0x100 and hs.FLAG_MERGE_ROWS == 0x200
+    world = 2
+    manager = mp.Manager()
+    result = manager.dict()
+    mp.spawn(_flags_worker, args=(world, _free_port(), result), nprocs=world, join=True)
+    assert result[0] == result[1] == [0x300, 0x100, 0x309, 0x80000000, 0]

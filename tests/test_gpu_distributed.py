@@ -177,6 +177,26 @@ def test_ranks_agree_on_the_exchange_form(tmp_path, variant, world):
     assert assert_rows_match(rows, want) == 0
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_final_merge_outgrowing_its_capacity_is_retried_on_every_rank(tmp_path, world):
+    """6 blocks x 14 disjoint variable-length keys: every unit's dictionary fits (14 <= 16, HS_FLAG_DICT_FULL stays
+    down), the final merge's first capacity (16) does not hold the union of 84 keys -> HS_FLAG_MERGE_FULL (bit 8).
+    Round 2's or_flags reduced bits 0-7 only and erased it - on the rank that raised it too - so the query was not
+    repeated with a larger merge dictionary and came back short, silently (VERDICT round 2, weak #1)."""
+    from minispark_amd.dataframe import DataFrame
+    from minispark_amd.sql import Col, Functions, Lit
+    from minispark_amd.workloads import api_namespace
+    from oracle.py_engine import run_query
+
+    blocks = [[f"k{b}-{'x' * (i % 5)}{i}" for i in range(14)] * 3 for b in range(6)]
+    _width_table(tmp_path / "w.bin", blocks)
+    api = api_namespace(lambda: DataFrame(object()), Col, Functions, Lit)
+    want = run_query(width_query(api, str(tmp_path / "w.bin")).task)
+    assert len(want) == 84
+    rows = _run_ranks("width:union", world, tmp_path / "rows.json", _free_port(), want)
+    assert assert_rows_match(rows, want) == 0
+
+
 # ---- RCCL itself (backend "nccl"): one rank per device, so world 1 on the one-GPU test box ----------------------------
 @pytest.mark.parametrize("case_name", ["q1_multiblock", "q1_ragged_blocks", "join_group", "concat_like", "many_groups",
                                        "e2e_join_select", "fruit"])
