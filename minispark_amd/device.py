@@ -729,6 +729,10 @@ class Device:
             if len(text) > 255:
                 return None  # the reference fails at the file write; the generic path reports it per row
             entries.append(text)
+        if len(set(entries)) != len(entries):
+            # two code combinations spell the same string ({'a','ab'} + {'bc','c'}: 'a'+'bc' == 'ab'+'c'): a GROUP BY
+            # on the code byte would return that string twice; the reference groups on the string.  Plain strings then.
+            return None
         if any(batch.cols[v].data.data_ptr() % 16 for _, v in col_parts):
             return None  # the combine reads 16 code bytes per lane
         out = self.empty(n, torch.uint8)

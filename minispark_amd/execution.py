@@ -673,6 +673,12 @@ class HipExecutionEngine(ExecutionEngine):
         the free device memory; a range holds as many consecutive blocks as fit half of it."""
         from . import table as tbl  # noqa: PLC0415
 
+        if self.dist is not None:
+            # Streaming is a per-rank decision (local free memory, local blocks) while the resident path's width
+            # agreements and the result gather are collectives: ranks deciding differently would issue mismatched
+            # collectives, and a streamed to-file stage would keep every rank's rows in its own file.  On N ranks a
+            # rank holds 1/N of the table and stays resident (ADVICE round 2).
+            return None
         key = str(Path(producer.file_path).resolve())
         cached = self._tables.get(key)
         if cached is not None and cached.stamp == ():
@@ -736,7 +742,7 @@ class HipExecutionEngine(ExecutionEngine):
                 parts.append(quantised)
                 continue
             raw, nrows, flags = self.dev.download_batch(quantised, schema, None)
-            self.dev.raise_for_flags(flags & ~0x8)
+            self._act_on_flags(flags)  # also HS_FLAG_DICT_FULL: the query is repeated with larger dictionaries
             if nrows:
                 if out_path is None:
                     out_path = self._result_path(stage.stage_id)
@@ -1286,6 +1292,18 @@ class HipExecutionEngine(ExecutionEngine):
             self._generic_exchange_used = False
         if os.environ.get("HIPSPARK_DEBUG_FLAGS"):
             print(f"[hipspark] result flags {flags:#x} nrows {nrows} caps {self._caps}", flush=True)
+        self._act_on_flags(flags)
+        return self._emit_result(raw, nrows, schema, stage_id)
+
+    def _act_on_flags(self, flags: int) -> None:
+        """The one place a query's status word is turned into a decision - every result path (general write, short
+        tail, streamed ranges) ends here, so no bit is handled on one path and ignored on another:
+        restart without a fused path, retry with larger dictionaries, or the exception the reference raises."""
+        from . import hipspark as hs  # noqa: PLC0415
+        from .device import DeviceError, RetryWithLargerDictionary  # noqa: PLC0415
+
+        if not flags:
+            return
         if flags & hs.FLAG_JOIN_DUP:
             # the in-place join met a build key twice: every join of this query takes the general path from now on
             self._no_fused_join.update(self._fused_join_tasks)
@@ -1297,7 +1315,8 @@ class HipExecutionEngine(ExecutionEngine):
         if flags & (hs.FLAG_DICT_FULL | hs.FLAG_MERGE_FULL):
             raise RetryWithLargerDictionary(flags)
         self.dev.raise_for_flags(flags)
-        return self._emit_result(raw, nrows, schema, stage_id)
+        if flags & ~hs.FLAG_KNOWN:
+            raise DeviceError(f"status word {flags:#x} holds bits no result path handles")
 
     def _finish_short_tail(self, batch: Any, consumers: Sequence[Any], writer: Any, stage_id: str) -> JobResult:
         """[all-gather of the slabs] + ONE launch: final merge, projection, stored kinds, result image."""
@@ -1340,9 +1359,7 @@ class HipExecutionEngine(ExecutionEngine):
 
             flags = or_flags(self.dist, flags, self.dev.device, self.group)
             self._generic_exchange_used = False
-        if flags & (hs.FLAG_DICT_FULL | hs.FLAG_MERGE_FULL):
-            raise RetryWithLargerDictionary(flags)
-        self.dev.raise_for_flags(flags)
+        self._act_on_flags(flags)
         return self._emit_result(raw, nrows, schema, stage_id)
 
     def _emit_result(self, raw: list, nrows: int, schema: Schema, stage_id: str) -> JobResult:

@@ -35,6 +35,7 @@ FLAG_BAD_PROGRAM = 0x10
 FLAG_STR_TOO_LONG = 0x20
 FLAG_TYPE_ASSERT = 0x40
 FLAG_JOIN_DUP = 0x80
+FLAG_KNOWN = 0x3FF  # every HS_FLAG_* bit include/hipspark.h defines
 
 AGG_SUM, AGG_MIN, AGG_MAX = 0, 1, 2
 

@@ -114,11 +114,18 @@ def timestamps_to_datetimes(us: np.ndarray) -> list[datetime]:
     under which the reference compares TIMESTAMPs consistently) the conversion is one vectorised step:
     ``fromtimestamp(v / 1e6)`` rounds the float seconds back to the same integer microseconds for every |v| < 4e15
     (year 2096), so the naive datetime is epoch + v.  Any other zone, or values out of that range: value by value."""
-    if time.timezone == 0 and time.daylight == 0 and us.size and int(np.abs(us).max()) < 4_000_000_000_000_000:
+    if _zone_is_utc() and us.size and int(np.abs(us).max()) < 4_000_000_000_000_000:
         out = us.astype("datetime64[us]").tolist()
         if not out or isinstance(out[0], datetime):
             return out
     return [timestamp_to_datetime(v) for v in us.tolist()]
+
+
+def _zone_is_utc() -> bool:
+    """The process zone is UTC by NAME.  ``time.timezone == 0`` describes a zone's current standard offset only:
+    Africa/Monrovia passes that test but was at -0:44:30 until 1972, and ``datetime.fromtimestamp`` applies the
+    historical offset."""
+    return time.tzname == ("UTC", "UTC") and time.timezone == 0 and time.daylight == 0
 
 
 # --------------------------------------------------------------------------------------------------

@@ -149,6 +149,38 @@ def test_dictionary_off_gives_the_same_rows(tmp_path):
         assert all(c.dict is None for c in e._table(path).columns.values())
 
 
+def test_concatenation_of_dictionaries_that_spell_one_string_twice(engine, tmp_path):
+    """dict(a) = {'a', 'ab'}, dict(b) = {'bc', 'c'}: codes (0, 0) and (1, 1) both decode to 'abc'.  A GROUP BY on the
+    product code would return 'abc' twice; the reference groups on the string.  Device.dict_concat
+    refuses such a product, the plain-string path runs."""
+    from minispark_amd.constants import ColumnType as T
+    from minispark_amd.io import BlockFile, StrCol
+    from oracle.py_engine import run_query
+
+    rng = random.Random(3)
+    n = 4000
+    a = [rng.choice(["a", "ab"]) for _ in range(n)]
+    b = [rng.choice(["bc", "c"]) for _ in range(n)]
+    i = np.arange(n, dtype=np.int32)
+    path = tmp_path / "c.bin"
+    BlockFile(path).write_raw_blocks([("a", T.STRING), ("b", T.STRING), ("i", T.INTEGER)],
+                                     [[StrCol.from_strings(a[:1500]), StrCol.from_strings(b[:1500]), i[:1500]],
+                                      [StrCol.from_strings(a[1500:]), StrCol.from_strings(b[1500:]), i[1500:]]])
+
+    def query(api):
+        C, F = api.Col, api.F
+        return (api.DataFrame().table(str(path)).filter(C("i") >= 10).select((C("a") + C("b")).alias("k"), C("i"))
+                .group_by(C("k")).agg(F.sum(C("i")).alias("t"), F.count()))
+
+    want = run_query(query(_oracle_api()).task)
+    assert sorted(r["k"] for r in want) == ["abbc", "abc", "ac"]
+    frame = query(_api(engine))
+    for _ in range(3):
+        assert_rows_match(frame.collect(), want)
+    table = engine._table(path)
+    assert all(table.columns[c].dict is not None for c in (0, 1)), "both columns are dictionary-coded at table open"
+
+
 # ---- the unique-key join --------------------------------------------------------------------------------------
 @pytest.mark.parametrize("mode", ["direct", "hashed"])
 def test_join_probe_unique_against_numpy(engine, mode):
