@@ -246,6 +246,7 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_avg_ms, exchange_avg_ms = (float(v) for v in t.tolist())
 
+    extra_split = wl.extra_split_ms() if hasattr(wl, "extra_split_ms") else {}
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         out = {
@@ -258,8 +259,9 @@ def main() -> None:
             # where a step goes (SURVEY.md 8d "Scaling report"): scan + partial aggregate (the dominant kernel with the
             # per-unit combine fused into its epilogue; HIP events), the exchange collective (events around it on the
             # launch stream; 0 without ranks), and the final merge + projection + hand-over + host time (the rest)
-            "time_split_ms": {"scan_partial": kernel_avg_ms, "exchange": exchange_avg_ms,
-                              "final": ms_per_step - kernel_avg_ms - exchange_avg_ms},
+            "time_split_ms": dict({"scan_partial": kernel_avg_ms, "exchange": exchange_avg_ms,
+                                   "final": ms_per_step - kernel_avg_ms - exchange_avg_ms - sum(extra_split.values())},
+                                  **extra_split),
             "whole_step_GBps_per_gpu": wl.algorithmic_bytes_per_launch() / (elapsed / args.steps) / 1e9,
         }
         if not args.no_full_check:

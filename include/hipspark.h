@@ -64,6 +64,17 @@ extern "C" {
 #define HS_F64 3 /* in-flight FLOAT (the reference computes in Python floats) */
 #define HS_STR 4 /* STRING: lens[nrows] + payload bytes + (offs[nrows+1] unless fixed_len >= 0) */
 #define HS_U8 5  /* boolean mask */
+/* Virtual columns of the fused join + aggregate (hs_agg_shared_join8, round 3): `data` = the probe side's INTEGER key
+ * column; the value of row i is looked up in the hs_join8 byte table while the aggregate scans - never stored. */
+#define HS_JOIN8_CODE 16 /* the table byte of the row's key: the build side's 1-byte payload (a dictionary code) */
+#define HS_JOIN8_UNIT 17 /* python_hash(key) % n_parts (the row's shuffle partition), 0xff = the key has no match */
+/* the byte table those lookups read (built by hs_join8_build, see the join section below) */
+typedef struct hs_join8 {
+    const uint8_t* table; /* hs_join8_table_bytes(slots) bytes */
+    int64_t slots;        /* key range covered: keys key_min .. key_min + slots - 1 */
+    int32_t key_min;
+    int32_t n_parts;      /* shuffle partitions (the reference's SHUFFLE_PARTITIONS): unit = python_hash(key) % n_parts */
+} hs_join8;
 
 typedef struct hs_col {
     int32_t kind;        /* HS_I32 ... HS_U8 */
@@ -131,7 +142,7 @@ typedef struct hs_agg_spec {
 const char* hs_last_error(void);
 int hs_version(void);
 /* sizeof() of ABI structure `which` as compiled: 0 hs_col, 1 hs_program, 2 hs_agg_spec, 3 hs_agg_geom, 4 hs_chunk,
- * 5 hs_slab_desc, 6 hs_finish_out, 7 hs_finish_spec, 8 hs_stage_plan, 9 hs_result_col (0 for anything else) - lets a
+ * 5 hs_slab_desc, 6 hs_finish_out, 7 hs_finish_spec, 8 hs_stage_plan, 9 hs_result_col, 10 hs_join8 (0 for anything else) - lets a
  * binding verify its mirror. */
 size_t hs_sizeof(int32_t which);
 
@@ -262,6 +273,33 @@ int hs_agg_shared_units(void* stream, const hs_col* cols, int32_t n_cols, int32_
                         int32_t n_unit_tables, const hs_program* prog, const hs_agg_spec* spec, const hs_chunk* chunks,
                         const hs_agg_geom* geom, int64_t* out_rep, uint64_t* out_acc, int32_t* out_ngroups, void* ws,
                         uint32_t* flags, void* ev_begin, void* ev_end);
+
+/* Round 3: hs_agg_shared_units with the join's probe INSIDE the scan.  cols[unit_col] is a
+ * HS_JOIN8_UNIT column and the GROUP BY key may be a HS_JOIN8_CODE column (both virtual: `data` = the probe side's key
+ * column, looked up in join->table per row; a lane's four consecutive keys share a lookup when equal); nothing is
+ * written per row.  Needs the run-time compiler (HS_E_LIMIT without it: the caller materialises unit / payload bytes
+ * with hs_join_probe_unique instead).  Leaves the units' tables RAW - key words unit_keys[n_unit_tables * geom->pad]
+ * (HS_EMPTY = free slot; the unit id in the top byte) and un-rounded 64-bit cells unit_acc[n_unit_tables * geom->pad *
+ * n_acc] - so that the shares of N ranks can be added up BEFORE the rounding the reference applies once per JoinJob
+ * (tasks.py:373 -> io.py:87-94).  ws: geom->n_chunks * n_unit_tables * geom->pad * n_acc * 8 bytes; out_rep scratch
+ * [n_unit_tables * geom->pad]. */
+int hs_agg_shared_join8(void* stream, const hs_col* cols, int32_t n_cols, int32_t key_col, int32_t unit_col,
+                        const hs_join8* join, int32_t n_unit_tables, const hs_program* prog, const hs_agg_spec* spec,
+                        const hs_chunk* chunks, const hs_agg_geom* geom, int64_t* out_rep, uint64_t* unit_keys,
+                        uint64_t* unit_acc, void* ws, uint32_t* flags, void* ev_begin, void* ev_end);
+/* N ranks hold raw unit tables of the same shape over DIFFERENT rows of the same units (each rank probed its own
+ * blocks): gathered = world x [16-byte header: flags u32, 12 pad][keys: slots x 8][cells: slots x n_acc x 8] with
+ * slots = n_units * unit_cap.  Merges them in rank order (deterministic given the inputs) into out_keys / out_acc of
+ * the same shape; header flags are OR-ed into *flags; a unit whose keys do not fit unit_cap raises HS_FLAG_DICT_FULL. */
+int hs_agg_units_merge(void* stream, const uint8_t* gathered, int32_t world, int32_t n_units, int32_t unit_cap,
+                       const hs_agg_spec* spec, uint64_t* out_keys, uint64_t* out_acc, uint32_t* flags);
+/* Raw unit tables -> the exchange slab hs_agg_finish reads (hs_slab_desc below): row u * unit_cap + s <- slot s of unit
+ * u: order key = u (or -1: free slot), key element from the low bytes of the key word, cells rounded to the stored
+ * kinds exactly like a shuffle-file write (overflow / type flags into *flags).  desc->slab_rows >= n_units * unit_cap. */
+struct hs_slab_desc;
+int hs_agg_units_to_slab(void* stream, const uint64_t* unit_keys, const uint64_t* unit_acc, int32_t n_units,
+                         int32_t unit_cap, const hs_agg_spec* spec, uint8_t* slab, const struct hs_slab_desc* desc,
+                         uint32_t* flags);
 
 /* Dense pack of the slot arrays: rows of unit u go to [pack_start[u], pack_start[u+1]).
  * out_cols[a] receives accumulator a as HS_F32 / HS_I32 storage (acc_kinds[a]) = the reference's
@@ -419,6 +457,32 @@ int hs_join_build_unique(void* stream, const int32_t* build_keys, int64_t n_buil
 int hs_join_probe_unique(void* stream, const int32_t* probe_keys, int64_t n_probe, const int32_t* build_keys,
                          int32_t key_min, int64_t slots, int32_t direct, const uint32_t* table, int32_t n_parts,
                          int64_t* out_build_row, uint8_t* out_unit, const uint8_t* build_payload, uint8_t* out_payload);
+
+/* ---- the same join with the PAYLOAD IN THE TABLE and the probe inside the aggregate (round 3) ----------------------
+ * Reference loops replaced: BroadcastHashJoinTask.generate_chunks tasks.py:201-240 (build the left side's hash map,
+ * probe with every right row, emit joined rows) feeding AggregateTask tasks.py:284-289 per JoinJob (plan.py:99-109).
+ * Table: ONE BYTE per slot, slot = key - key_min, value = the build row's 1-byte payload (the dictionary code of the
+ * one build-side column the aggregate reads; 0 when it reads none) or 0xff = no such key.  sf=10 orders: 60 MB instead
+ * of 240 MB of row numbers + a second dependent read of the payload column; it stays in the Infinity Cache.
+ *
+ * hs_join8_build: the build rows arrive in any order, so byte stores into the table would each cost a 32-byte HBM
+ * sector (round 2 measured 7.8x write amplification).  Instead: (1) per workgroup a histogram of the rows' WINDOWS
+ * (HS_JOIN8_WINDOW consecutive slots), (2) a scan, (3) the rows are partitioned by window as 4-byte (offset, payload)
+ * tuples, (4) one workgroup per window assembles its slice of the table in LDS and writes it out with 16-byte
+ * stores - the table is written exactly once, coalesced, and never read back: two tuples meeting in one byte
+ * (= a duplicate key -> HS_FLAG_JOIN_DUP) show up as fewer occupied bytes than tuples, counted while writing.
+ * Build rows may be the concatenation of equally long SEGMENTS (the all-gathered shares of N ranks): seg_len rows
+ * each (a multiple of 4), of which the first seg_counts[s] (device, optional) are valid; n_build = segments * seg_len.
+ * payload NULL: every present key gets byte 0.  payload bytes must be < 0xff.  A key outside [key_min, key_min +
+ * slots) raises HS_FLAG_BAD_PROGRAM and is left out.  table: hs_join8_table_bytes(slots) bytes, 16-byte aligned;
+ * ws: hs_join8_ws_bytes(n_build, slots).  slots <= 2^30. */
+#define HS_JOIN8_WINDOW 65536
+size_t hs_join8_table_bytes(int64_t slots);
+size_t hs_join8_ws_bytes(int64_t n_build, int64_t slots);
+int hs_join8_build(void* stream, const int32_t* build_keys, const uint8_t* payload, int64_t n_build, int64_t seg_len,
+                   const int64_t* seg_counts, int32_t key_min, int64_t slots, uint8_t* table, void* ws, uint32_t* flags);
+/* out[i] = lut[codes[i]] (re-coding a dictionary-coded column after the ranks agreed on one dictionary). */
+int hs_remap_u8(void* stream, const uint8_t* codes, int64_t n, const uint8_t* lut256, uint8_t* out);
 
 /* ---- dictionary-coded STRING columns (round 2; csrc/hs_join.hip) ------------------------------------------------
  * A STRING column with at most 256 distinct values is re-coded at table open as one byte per row + its dictionary

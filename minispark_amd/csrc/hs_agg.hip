@@ -1574,7 +1574,8 @@ extern "C" int hs_agg_shared_geom(const int64_t* host_unit_rows, int64_t n_units
 static int agg_shared_impl(void* stream, const hs_col* cols, int32_t n_cols, int32_t key_col, int32_t unit_col,
                            const hs_program* prog, const hs_agg_spec* spec, const hs_chunk* chunks, int64_t n_units,
                            const hs_agg_geom* geom, int64_t* out_rep, uint64_t* out_acc, int32_t* out_ngroups, void* ws,
-                           uint32_t* flags, void* ev_begin, void* ev_end);
+                           uint32_t* flags, void* ev_begin, void* ev_end, const hs_join8* join = nullptr,
+                           uint64_t* unit_keys = nullptr);
 
 extern "C" int hs_agg_shared(void* stream, const hs_col* cols, int32_t n_cols, int32_t key_col, const hs_program* prog,
                              const hs_agg_spec* spec, const hs_chunk* chunks, int64_t n_units, const hs_agg_geom* geom,
@@ -1606,8 +1607,9 @@ extern "C" int hs_agg_shared_units(void* stream, const hs_col* cols, int32_t n_c
 static int agg_shared_impl(void* stream, const hs_col* cols, int32_t n_cols, int32_t key_col, int32_t unit_col,
                            const hs_program* prog, const hs_agg_spec* spec, const hs_chunk* chunks, int64_t n_units,
                            const hs_agg_geom* geom, int64_t* out_rep, uint64_t* out_acc, int32_t* out_ngroups, void* ws,
-                           uint32_t* flags, void* ev_begin, void* ev_end) {
-    if (!cols || !prog || !spec || !chunks || !geom || !out_rep || !out_acc || !out_ngroups || !ws || !flags ||
+                           uint32_t* flags, void* ev_begin, void* ev_end, const hs_join8* join, uint64_t* unit_keys) {
+    // join != NULL: the fused probe (hs_agg_shared_join8) - unit tables stay raw (no rounding pass, no group counts)
+    if (!cols || !prog || !spec || !chunks || !geom || !out_rep || !out_acc || (!out_ngroups && !join) || !ws || !flags ||
         key_col < 0 || key_col >= n_cols) {
         hs_set_error("hs_agg_shared: null or out-of-range argument");
         return HS_E_ARG;
@@ -1623,7 +1625,7 @@ static int agg_shared_impl(void* stream, const hs_col* cols, int32_t n_cols, int
         hs_set_error("hs_agg_shared: geometry not made by hs_agg_shared_geom");
         return HS_E_ARG;
     }
-    if (n_units == 0 || geom->n_chunks == 0) return HS_OK;
+    if (n_units == 0 || (geom->n_chunks == 0 && !join)) return HS_OK;  // (a rank without probe rows still clears its tables)
     AggMainArgs A;
     int rc = fill_cols(A.cols, cols, n_cols);
     if (rc) return rc;
@@ -1631,6 +1633,12 @@ static int agg_shared_impl(void* stream, const hs_col* cols, int32_t n_cols, int
         if (cols[i].kind != HS_STR || i == key_col) {
             hs_set_error("hs_agg_shared: more than %d numeric column slots", HS_FUSED_COLS);
             return HS_E_LIMIT;
+        }
+    }
+    for (int i = 0; i < n_cols; ++i) {
+        if ((cols[i].kind == HS_JOIN8_CODE || cols[i].kind == HS_JOIN8_UNIT) && !join) {
+            hs_set_error("hs_agg_shared: HS_JOIN8_* columns belong to hs_agg_shared_join8");
+            return HS_E_ARG;
         }
     }
     const int depth = program_depth(prog);
@@ -1651,7 +1659,7 @@ static int agg_shared_impl(void* stream, const hs_col* cols, int32_t n_cols, int
     A.chunks = chunks;
     A.unit_chunk0 = nullptr;
     A.n_units = n_units;
-    A.part_keys = (uint64_t*)ws;
+    A.part_keys = unit_keys ? unit_keys : (uint64_t*)ws;
     A.part_rep = out_rep;
     A.part_acc = out_acc;
     A.flags = flags;
@@ -1659,8 +1667,12 @@ static int agg_shared_impl(void* stream, const hs_col* cols, int32_t n_cols, int
     memset(&A.unit, 0, sizeof(A.unit));
     A.unit_col = unit_col;  // -1: units are the chunks' row ranges; else n_units = number of unit tables
     A.pad3 = 0;
-    // computed units: per-chunk cells behind the unit tables' key words in `ws` (hs_agg_shared_units documents the size)
-    A.chunk_acc = unit_col >= 0 ? (uint64_t*)((char*)ws + (((size_t)n_units * (size_t)geom->pad * 8 + 256 + 15) & ~(size_t)15)) : nullptr;
+    // computed units: per-chunk cells behind the unit tables' key words in `ws` (hs_agg_shared_units documents the size);
+    // with caller-owned key words (hs_agg_shared_join8) `ws` holds the per-chunk cells only
+    A.chunk_acc = unit_col < 0 ? nullptr : unit_keys ? (uint64_t*)ws
+                : (uint64_t*)((char*)ws + (((size_t)n_units * (size_t)geom->pad * 8 + 256 + 15) & ~(size_t)15));
+    if (join) A.join = *join;
+    else memset(&A.join, 0, sizeof(A.join));
     {  // the replica count the geometry sized the LDS block for
         const size_t per_replica = (size_t)geom->group_cap * (size_t)(spec->n_acc > 0 ? spec->n_acc : 1) * 8;
         const size_t r = (geom->lds_bytes - (size_t)geom->group_cap * 16) / per_replica;
@@ -1685,6 +1697,11 @@ static int agg_shared_impl(void* stream, const hs_col* cols, int32_t n_cols, int
     int64_t init_blocks = (I.n_slots + 255) / 256;
     if (init_blocks > 4096) init_blocks = 4096;
     hipLaunchKernelGGL(k_agg_shared_init, dim3((unsigned)init_blocks), dim3(256), 0, s, I);
+    if (geom->n_chunks == 0) {  // join mode, no rows on this rank: empty tables are its share
+        if (ev_begin) hs_event_record((hipEvent_t)ev_begin, s);
+        if (ev_end) hs_event_record((hipEvent_t)ev_end, s);
+        return hipGetLastError() == hipSuccess ? HS_OK : HS_E_LAUNCH;
+    }
     const bool hashed = !hs_col_packs(cols[key_col]);
     static unsigned long long attrs_set = 0;
     if (hs_first_on_device(attrs_set)) {
@@ -1697,6 +1714,10 @@ static int agg_shared_impl(void* stream, const hs_col* cols, int32_t n_cols, int
     const int jit_rc = hs_jit_launch_agg_shared(&A, hashed, grid.x, block.x, geom->lds_bytes, s);
     if (jit_rc == HS_OK) {
         // launched the program compiled for exactly this bytecode
+    } else if (join) {
+        // the interpreter kernels do not know the virtual columns; the init launch above is harmless
+        hs_set_error("hs_agg_shared_join8: needs the run-time compiler (hiprtc): %s", hs_jit_last_log());
+        return HS_E_LIMIT;
     } else if (hashed) {
         hipLaunchKernelGGL((k_agg_shared<true, 8>), grid, block, geom->lds_bytes, s, A);
     } else if (depth <= 4) {
@@ -1717,6 +1738,13 @@ static int agg_shared_impl(void* stream, const hs_col* cols, int32_t n_cols, int
         hipLaunchKernelGGL(k_agg_shared_fold_chunks, dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, s, G);
     }
     if (ev_end) hs_event_record((hipEvent_t)ev_end, s);
+    if (join) {
+        if (hipGetLastError() != hipSuccess) {
+            hs_set_error("hs_agg_shared_join8: kernel launch failed");
+            return HS_E_LAUNCH;
+        }
+        return HS_OK;  // raw tables: hs_agg_units_merge (N ranks) / hs_agg_units_to_slab round and emit them
+    }
     SharedFinishArgs F;
     F.reps = out_rep;
     F.acc = out_acc;
@@ -1728,6 +1756,206 @@ static int agg_shared_impl(void* stream, const hs_col* cols, int32_t n_cols, int
     hipLaunchKernelGGL(k_agg_shared_finish, dim3((unsigned)n_units), dim3(256), 0, s, F);
     if (hipGetLastError() != hipSuccess) {
         hs_set_error("hs_agg_shared: kernel launch failed");
+        return HS_E_LAUNCH;
+    }
+    return HS_OK;
+}
+
+// ---- round 3: the join's probe inside the scan; raw unit tables -> [merge over ranks] -> exchange slab ----------------
+extern "C" const char* hs_jit_last_log(void);
+
+extern "C" int hs_agg_shared_join8(void* stream, const hs_col* cols, int32_t n_cols, int32_t key_col, int32_t unit_col,
+                                   const hs_join8* join, int32_t n_unit_tables, const hs_program* prog, const hs_agg_spec* spec,
+                                   const hs_chunk* chunks, const hs_agg_geom* geom, int64_t* out_rep, uint64_t* unit_keys,
+                                   uint64_t* unit_acc, void* ws, uint32_t* flags, void* ev_begin, void* ev_end) {
+    if (!cols || !join || !join->table || join->slots < 1 || join->n_parts < 1 || join->n_parts > 127 || !unit_keys ||
+        unit_col < 0 || unit_col >= n_cols || unit_col >= HS_FUSED_COLS || cols[unit_col].kind != HS_JOIN8_UNIT ||
+        n_unit_tables != join->n_parts || key_col < 0 || key_col >= n_cols) {
+        hs_set_error("hs_agg_shared_join8: the unit column must be a HS_JOIN8_UNIT column in a preloaded slot, one unit "
+                     "table per shuffle partition (1..127)");
+        return HS_E_ARG;
+    }
+    const void* probe_keys = cols[unit_col].data;
+    for (int i = 0; i < n_cols; ++i) {
+        const bool virt = cols[i].kind == HS_JOIN8_CODE || cols[i].kind == HS_JOIN8_UNIT;
+        if (virt && (i >= HS_FUSED_COLS || cols[i].data != probe_keys || !probe_keys || ((uintptr_t)probe_keys & 15))) {
+            hs_set_error("hs_agg_shared_join8: virtual columns sit in preloaded slots and share one 16-byte aligned key column");
+            return HS_E_ARG;
+        }
+    }
+    const hs_col& kc = cols[key_col];
+    const bool key_ok = kc.kind == HS_I32 || kc.kind == HS_U8 || kc.kind == HS_JOIN8_CODE ||
+                        (kc.kind == HS_STR && kc.fixed_len >= 1 && kc.fixed_len <= 6);
+    if (!key_ok) {
+        hs_set_error("hs_agg_shared_join8: the key must fit 56 bits (INTEGER, the table byte, or a string of fixed length <= 6)");
+        return HS_E_LIMIT;
+    }
+    return agg_shared_impl(stream, cols, n_cols, key_col, unit_col, prog, spec, chunks, n_unit_tables, geom, out_rep,
+                           unit_acc, nullptr, ws, flags, ev_begin, ev_end, join, unit_keys);
+}
+
+// One workgroup per unit.  Rank after rank: every occupied slot of the rank's table is upserted into the unit's
+// output table (a rank holds a key at most once, so no two lanes meet in one output slot within a step) and its cells
+// are folded in - additions in rank order.  Output accesses are agent-scope atomics (they bypass the CU's vector
+// cache: lanes of LATER steps read what other lanes of this workgroup wrote).
+struct UnitsMergeArgs {
+    const uint8_t* gathered;
+    int64_t stride;  // bytes per rank
+    int32_t world, n_units, unit_cap, pad;
+    hs_agg_spec spec;
+    uint64_t* out_keys;
+    uint64_t* out_acc;
+    uint32_t* flags;
+};
+__global__ void __launch_bounds__(256) k_agg_units_merge(const UnitsMergeArgs A) {
+    const int NA = A.spec.n_acc, UC = A.unit_cap, tid = threadIdx.x, nthr = blockDim.x;
+    const int64_t u = blockIdx.x, slots = (int64_t)A.n_units * UC;
+    uint64_t* okeys = A.out_keys + u * UC;
+    uint64_t* oacc = A.out_acc + u * (int64_t)UC * NA;
+    for (int sl = tid; sl < UC; sl += nthr) {
+        __hip_atomic_store(&okeys[sl], HS_EMPTY_KEY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int a = 0; a < NA; ++a)
+            __hip_atomic_store(&oacc[(int64_t)sl * NA + a], hs_acc_identity(A.spec.op[a], A.spec.is_int[a] != 0), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    uint32_t err = 0;
+    const uint32_t mask = (uint32_t)UC - 1;
+    for (int r = 0; r < A.world; ++r) {
+        const uint8_t* base = A.gathered + (int64_t)r * A.stride;
+        if (u == 0 && tid == 0) err |= *(const uint32_t*)base;  // the rank's status word travels in the header
+        const uint64_t* rkeys = (const uint64_t*)(base + 16) + u * UC;
+        const uint64_t* racc = (const uint64_t*)(base + 16) + slots + u * (int64_t)UC * NA;
+        for (int sl = tid; sl < UC; sl += nthr) {
+            const uint64_t k = rkeys[sl];
+            if (k == HS_EMPTY_KEY) continue;
+            uint32_t h = hs_slot_hash_strong(k) & mask;
+            int found = -1;
+            for (uint32_t probe = 0; probe <= mask; ++probe) {
+                uint64_t cur = __hip_atomic_load(&okeys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur == HS_EMPTY_KEY) {
+                    cur = atomicCAS((unsigned long long*)&okeys[h], (unsigned long long)HS_EMPTY_KEY, (unsigned long long)k);
+                    if (cur == HS_EMPTY_KEY) cur = k;
+                }
+                if (cur == k) {
+                    found = (int)h;
+                    break;
+                }
+                h = (h + 1) & mask;
+            }
+            if (found < 0) {
+                err |= HS_FLAG_DICT_FULL;
+                continue;
+            }
+            for (int a = 0; a < NA; ++a) {
+                uint64_t* cell = &oacc[(int64_t)found * NA + a];
+                const uint64_t v = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(cell, hs_acc_fold(A.spec.op[a], A.spec.is_int[a] != 0, v, racc[(int64_t)sl * NA + a]),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();  // the next rank's rows may land in slots this step filled
+    }
+    if (err) atomicOr(A.flags, err);
+}
+
+extern "C" int hs_agg_units_merge(void* stream, const uint8_t* gathered, int32_t world, int32_t n_units, int32_t unit_cap,
+                                  const hs_agg_spec* spec, uint64_t* out_keys, uint64_t* out_acc, uint32_t* flags) {
+    if (!gathered || !spec || !out_keys || !out_acc || !flags || world < 1 || n_units < 1 || n_units > 127 || unit_cap < 1 ||
+        (unit_cap & (unit_cap - 1)) || spec->n_acc < 0 || spec->n_acc > HS_MAX_ACC || ((uintptr_t)gathered & 7)) {
+        hs_set_error("hs_agg_units_merge: bad arguments");
+        return HS_E_ARG;
+    }
+    UnitsMergeArgs A;
+    A.gathered = gathered;
+    A.stride = 16 + (int64_t)n_units * unit_cap * 8 * (1 + spec->n_acc);
+    A.world = world;
+    A.n_units = n_units;
+    A.unit_cap = unit_cap;
+    A.pad = 0;
+    A.spec = *spec;
+    A.out_keys = out_keys;
+    A.out_acc = out_acc;
+    A.flags = flags;
+    hipLaunchKernelGGL(k_agg_units_merge, dim3((unsigned)n_units), dim3(256), 0, (hipStream_t)stream, A);
+    if (hipGetLastError() != hipSuccess) {
+        hs_set_error("hs_agg_units_merge: kernel launch failed");
+        return HS_E_LAUNCH;
+    }
+    return HS_OK;
+}
+
+struct UnitsSlabArgs {
+    const uint64_t* keys;
+    const uint64_t* acc;
+    int32_t n_units, unit_cap;
+    hs_agg_spec spec;
+    uint8_t* slab;
+    hs_slab_desc desc;
+    uint32_t* flags;
+};
+__global__ void __launch_bounds__(256) k_agg_units_to_slab(const UnitsSlabArgs A) {
+    const int NA = A.spec.n_acc;
+    const int64_t n = (int64_t)A.n_units * A.unit_cap;
+    int64_t* order = (int64_t*)(A.slab + A.desc.order_off);
+    const int kb = A.desc.key_kind == HS_STR ? A.desc.key_len : (A.desc.key_kind == HS_U8 ? 1 : 4);
+    uint32_t err = 0;
+    for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < A.desc.slab_rows; row += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t k = row < n ? A.keys[row] : HS_EMPTY_KEY;
+        if (k == HS_EMPTY_KEY) {
+            order[row] = -1;
+            continue;
+        }
+        order[row] = row / A.unit_cap;
+        uint8_t* kp = A.slab + A.desc.key_off + row * kb;
+        for (int b = 0; b < kb; ++b) kp[b] = (uint8_t)(k >> (8 * b));  // packed strings and INTEGER keys: little-endian low bytes
+        for (int a = 0; a < NA; ++a) {
+            uint64_t cell = A.acc[row * NA + a];
+            const bool is_int = A.spec.is_int[a] != 0;
+            if (hs_float_identity_left(A.spec.op[a], is_int, cell)) err |= HS_FLAG_TYPE_ASSERT;
+            cell = hs_quantise_cell(is_int, cell, err);
+            uint8_t* col = A.slab + A.desc.acc_off[a];
+            if (A.desc.acc_kind[a] == HS_I32) ((int32_t*)col)[row] = (int32_t)(int64_t)cell;
+            else ((float*)col)[row] = (float)hs_u2d(cell);
+        }
+    }
+    if (err) atomicOr(A.flags, err);
+}
+
+extern "C" int hs_agg_units_to_slab(void* stream, const uint64_t* unit_keys, const uint64_t* unit_acc, int32_t n_units,
+                                    int32_t unit_cap, const hs_agg_spec* spec, uint8_t* slab, const hs_slab_desc* desc,
+                                    uint32_t* flags) {
+    if (!unit_keys || !unit_acc || !spec || !slab || !desc || !flags || n_units < 1 || unit_cap < 1 ||
+        desc->slab_rows < (int64_t)n_units * unit_cap || desc->n_acc != spec->n_acc || spec->n_acc > HS_MAX_ACC) {
+        hs_set_error("hs_agg_units_to_slab: bad arguments (the slab must hold n_units * unit_cap rows)");
+        return HS_E_ARG;
+    }
+    const bool key_ok = desc->key_kind == HS_I32 || desc->key_kind == HS_U8 ||
+                        (desc->key_kind == HS_STR && (desc->key_len == 1 || desc->key_len == 2 || desc->key_len == 4));
+    if (!key_ok) {
+        hs_set_error("hs_agg_units_to_slab: key kind %d cannot be rebuilt from a key word", desc->key_kind);
+        return HS_E_LIMIT;
+    }
+    for (int a = 0; a < spec->n_acc; ++a) {
+        if (desc->acc_kind[a] != (spec->is_int[a] ? HS_I32 : HS_F32)) {
+            hs_set_error("hs_agg_units_to_slab: slab column %d does not hold the aggregate's stored kind", a);
+            return HS_E_ARG;
+        }
+    }
+    UnitsSlabArgs A;
+    A.keys = unit_keys;
+    A.acc = unit_acc;
+    A.n_units = n_units;
+    A.unit_cap = unit_cap;
+    A.spec = *spec;
+    A.slab = slab;
+    A.desc = *desc;
+    A.flags = flags;
+    int64_t blocks = (desc->slab_rows + 255) / 256;
+    if (blocks > 64) blocks = 64;
+    hipLaunchKernelGGL(k_agg_units_to_slab, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, A);
+    if (hipGetLastError() != hipSuccess) {
+        hs_set_error("hs_agg_units_to_slab: kernel launch failed");
         return HS_E_LAUNCH;
     }
     return HS_OK;

@@ -225,6 +225,9 @@ struct AggMainArgs {
     // a small kernel folds them per (unit, slot): with ONE row range every chunk holds the same few (unit, key)
     // groups, and ~900 workgroups adding into the same 200 global cells at the end of the scan serialised to 3 ms
     uint64_t* chunk_acc;
+    // round 3: the join's byte table when cols hold HS_JOIN8_CODE / HS_JOIN8_UNIT columns (the probe runs inside the
+    // scan: include/hipspark.h hs_agg_shared_join8); table NULL otherwise
+    hs_join8 join;
 };
 
 // key word of (unit, key): valid for key words that carry their information in the low 56 bits - INTEGER keys

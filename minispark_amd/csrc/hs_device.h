@@ -705,3 +705,18 @@ __device__ __forceinline__ uint64_t hs_quantise_cell(bool is_int, uint64_t cell,
     if (isinf(f) && !isinf(d)) err |= HS_FLAG_FLT_OVERFLOW;
     return hs_d2u((double)f);
 }
+
+// ---- the join's byte table (include/hipspark.h hs_join8): used by the build kernels and by the fused probe that the
+// run-time compiler splices into the aggregate scan -----------------------------------------------------------------
+// Python: hash(int) % n (hash(-1) = -2, floor-mod) - the reference's shuffle partition of a row, tasks.py:362
+__device__ __forceinline__ uint32_t hs_py_partition(int32_t key, int32_t n_parts) {
+    const int32_t h = key == -1 ? -2 : key;
+    int32_t m = h % n_parts;
+    if (m < 0) m += n_parts;
+    return (uint32_t)m;
+}
+// table byte of `key`: the build side's payload, 0xff = no build row has this key
+__device__ __forceinline__ uint32_t hs_join8_lookup(const hs_join8& J, int32_t key) {
+    const int64_t off = (int64_t)key - (int64_t)J.key_min;
+    return (uint64_t)off < (uint64_t)J.slots ? (uint32_t)J.table[off] : 0xffu;
+}

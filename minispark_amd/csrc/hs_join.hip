@@ -241,12 +241,12 @@ extern "C" int hs_minmax_i32(void* stream, const int32_t* values, int64_t n, int
         hs_set_error("hs_minmax_i32: bad arguments");
         return HS_E_ARG;
     }
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_minmax_i32_init, dim3(1), dim3(1), 0, s, minmax);
     if ((uintptr_t)values & 15) {
         hs_set_error("hs_minmax_i32: values must be 16-byte aligned");
         return HS_E_ARG;
     }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_minmax_i32_init, dim3(1), dim3(1), 0, s, minmax);
     if (n > 0) hipLaunchKernelGGL(k_minmax_i32, dim3(hsj_grid(n, 256 * 16, 1024)), dim3(256), 0, s, values, n, minmax);
     HSJ_CHECK_LAUNCH("hs_minmax_i32");
     return HS_OK;
@@ -256,14 +256,6 @@ static constexpr uint32_t HSJ_EMPTY = 0xffffffffu;
 
 __device__ __forceinline__ uint64_t hsj_hash_slot(int32_t key, uint64_t mask) {
     return (hs_mix64((uint64_t)(uint32_t)key) >> 7) & mask;
-}
-
-// Python: hash(int) % n (hash(-1) = -2, floor-mod) - the reference's shuffle partition of a row, tasks.py:362
-__device__ __forceinline__ uint32_t hsj_py_partition(int32_t key, int32_t n_parts) {
-    int64_t h = key == -1 ? -2 : (int64_t)key;
-    int64_t m = h % n_parts;
-    if (m < 0) m += n_parts;
-    return (uint32_t)m;
 }
 
 struct JoinUniqueArgs {
@@ -288,8 +280,17 @@ __global__ void __launch_bounds__(256) k_fill_u32(uint32_t* p, int64_t n, uint32
 
 // direct addressing: plain stores (a duplicate key makes two rows race for one slot: one of them wins) ...
 __global__ void __launch_bounds__(256) k_join_scatter_direct(const JoinUniqueArgs A) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * blockDim.x)
-        A.table[(int64_t)A.keys[i] - (int64_t)A.key_min] = (uint32_t)i;
+    uint32_t err = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += (int64_t)gridDim.x * blockDim.x) {
+        // key_min / slots come from the caller (a cached column range): a key outside them must not become a store
+        const int64_t off = (int64_t)A.keys[i] - (int64_t)A.key_min;
+        if ((uint64_t)off >= (uint64_t)A.slots) {
+            err |= HS_FLAG_BAD_PROGRAM;
+            continue;
+        }
+        A.table[off] = (uint32_t)i;
+    }
+    if (err) atomicOr(A.flags, err);
 }
 // ... and a streaming pass over the table counts the occupied slots: fewer than build rows = two rows met in one
 // slot = duplicate keys (sequential 16-byte reads of the table instead of one random read per build row)
@@ -416,7 +417,7 @@ __global__ void __launch_bounds__(256) k_join_probe_unique(const JoinProbeUnique
         uint32_t units = 0, pays = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t u = r[j] != HSJ_EMPTY ? hsj_py_partition(k[j], A.n_parts) : 0xffu;
+            const uint32_t u = r[j] != HSJ_EMPTY ? hs_py_partition(k[j], A.n_parts) : 0xffu;
             units |= u << (8 * j);
             pays |= (uint32_t)pay[j] << (8 * j);
         }
@@ -459,6 +460,267 @@ extern "C" int hs_join_probe_unique(void* stream, const int32_t* probe_keys, int
     if (n_probe > 0)
         hipLaunchKernelGGL(k_join_probe_unique, dim3(hsj_grid((n_probe + 3) / 4, 256, 1 << 15)), dim3(256), 0, (hipStream_t)stream, A);
     HSJ_CHECK_LAUNCH("hs_join_probe_unique");
+    return HS_OK;
+}
+
+// =====================================================================================================
+// The byte table of the fused join (include/hipspark.h hs_join8): window partition + assembly in LDS
+// =====================================================================================================
+// Build rows arrive in any key order.  Workgroup g owns the contiguous row range [g * per, (g + 1) * per) in BOTH
+// passes over the rows, so the per-(workgroup, window) counts of the histogram pass are exactly the segment sizes the
+// scatter pass fills.  All counts are 32-bit (n_build < 2^32).
+static constexpr int HSJ8_WSHIFT = 16;                       // log2(HS_JOIN8_WINDOW)
+static constexpr int HSJ8_MAX_WINDOWS = 16384;               // the window histogram lives in LDS (64 KiB)
+static_assert((1 << HSJ8_WSHIFT) == HS_JOIN8_WINDOW, "window size");
+
+struct Join8Args {
+    const int32_t* keys;
+    const uint8_t* payload;     // optional
+    int64_t n, seg_len;         // rows; rows per segment (valid: the first seg_counts[s] of a segment)
+    const int64_t* seg_counts;  // optional (device)
+    int64_t slots;
+    int32_t key_min;
+    int32_t n_win;
+    int64_t per;                // rows per workgroup (a multiple of 4)
+    uint32_t* hist;             // [n_groups][n_win]: counts, then offsets inside the window's segment
+    uint32_t* win_start;        // [n_win + 1]
+    uint32_t* tuples;           // [n]: (offset in window) | payload << 24
+    uint8_t* table;
+    uint32_t* flags;
+};
+
+// window of row i's key, or -1 (padding row of a segment / key outside the table: flagged)
+__device__ __forceinline__ int hsj8_window(const Join8Args& A, int64_t i, int32_t key, uint32_t& off, uint32_t& err) {
+    if (A.seg_counts) {
+        const uint32_t seg = (uint32_t)((uint64_t)i / (uint64_t)A.seg_len);
+        if (i - (int64_t)seg * A.seg_len >= A.seg_counts[seg]) return -1;
+    }
+    const int64_t o = (int64_t)key - (int64_t)A.key_min;
+    if ((uint64_t)o >= (uint64_t)A.slots) {
+        err |= HS_FLAG_BAD_PROGRAM;
+        return -1;
+    }
+    off = (uint32_t)o & (HS_JOIN8_WINDOW - 1);
+    return (int)(o >> HSJ8_WSHIFT);
+}
+
+__global__ void __launch_bounds__(512) k_join8_hist(const Join8Args A) {
+    extern __shared__ __align__(16) uint32_t s_hist[];
+    for (int w = threadIdx.x; w < A.n_win; w += blockDim.x) s_hist[w] = 0;
+    __syncthreads();
+    const int64_t r0 = (int64_t)blockIdx.x * A.per, r1 = r0 + A.per < A.n ? r0 + A.per : A.n;
+    uint32_t err = 0;
+    for (int64_t q = r0 + (int64_t)threadIdx.x * 4; q < r1; q += (int64_t)blockDim.x * 4) {
+        const int4 kv = *reinterpret_cast<const int4*>(A.keys + q);  // buffers carry slack past the last row
+        const int32_t k[4] = {kv.x, kv.y, kv.z, kv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (q + j >= r1) break;
+            uint32_t off;
+            const int w = hsj8_window(A, q + j, k[j], off, err);
+            if (w >= 0) atomicAdd(&s_hist[w], 1u);
+        }
+    }
+    __syncthreads();
+    uint32_t* mine = A.hist + (int64_t)blockIdx.x * A.n_win;
+    for (int w = threadIdx.x; w < A.n_win; w += blockDim.x) mine[w] = s_hist[w];
+    if (err) atomicOr(A.flags, err);
+}
+
+// per window: counts of the workgroups -> their offsets inside the window's segment (in workgroup order), total
+__global__ void __launch_bounds__(256) k_join8_scan_groups(uint32_t* hist, int32_t n_groups, int32_t n_win, uint32_t* win_total) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_win) return;
+    uint32_t run = 0;
+    for (int g = 0; g < n_groups; ++g) {  // lanes read consecutive windows of one workgroup's row: coalesced
+        const uint32_t c = hist[(int64_t)g * n_win + w];
+        hist[(int64_t)g * n_win + w] = run;
+        run += c;
+    }
+    win_total[w] = run;
+}
+// exclusive scan of the window totals in place (one workgroup; n_win <= 16384): win_start[n_win] = all rows
+__global__ void __launch_bounds__(1024) k_join8_scan_windows(uint32_t* win_start, int32_t n_win) {
+    __shared__ uint32_t s_part[16];
+    __shared__ uint32_t s_base;
+    const int tid = threadIdx.x, lane = tid & (HS_WAVE - 1), wv = tid / HS_WAVE;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int w0 = 0; w0 < n_win; w0 += 1024) {
+        const int w = w0 + tid;
+        const uint32_t c = w < n_win ? win_start[w] : 0;
+        uint32_t x = c;
+        for (int d = 1; d < HS_WAVE; d <<= 1) {
+            const uint32_t t = __shfl_up(x, d, HS_WAVE);
+            if (lane >= d) x += t;
+        }
+        if (lane == HS_WAVE - 1) s_part[wv] = x;
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+        for (int k = 0; k < 16; ++k) {
+            if (k < wv) before += s_part[k];
+            all += s_part[k];
+        }
+        if (w < n_win) win_start[w] = s_base + before + x - c;
+        __syncthreads();
+        if (tid == 0) s_base += all;
+        __syncthreads();
+    }
+    if (tid == 0) win_start[n_win] = s_base;
+}
+
+__global__ void __launch_bounds__(512) k_join8_scatter(const Join8Args A) {
+    extern __shared__ __align__(16) uint32_t s_cur[];  // next free tuple position per window, for this workgroup
+    const uint32_t* mine = A.hist + (int64_t)blockIdx.x * A.n_win;
+    for (int w = threadIdx.x; w < A.n_win; w += blockDim.x) s_cur[w] = A.win_start[w] + mine[w];
+    __syncthreads();
+    const int64_t r0 = (int64_t)blockIdx.x * A.per, r1 = r0 + A.per < A.n ? r0 + A.per : A.n;
+    uint32_t err = 0;
+    for (int64_t q = r0 + (int64_t)threadIdx.x * 4; q < r1; q += (int64_t)blockDim.x * 4) {
+        const int4 kv = *reinterpret_cast<const int4*>(A.keys + q);
+        const int32_t k[4] = {kv.x, kv.y, kv.z, kv.w};
+        uint32_t pv = 0;
+        if (A.payload) pv = *reinterpret_cast<const uint32_t*>(A.payload + q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (q + j >= r1) break;
+            uint32_t off;
+            const int w = hsj8_window(A, q + j, k[j], off, err);
+            if (w < 0) continue;
+            const uint32_t code = (pv >> (8 * j)) & 0xffu;
+            if (code == 0xffu) err |= HS_FLAG_BAD_PROGRAM;  // 0xff is the table's "no such key"
+            const uint32_t pos = atomicAdd(&s_cur[w], 1u);
+            A.tuples[pos] = off | (code << 24);
+        }
+    }
+    if (err) atomicOr(A.flags, err);
+}
+
+// one workgroup per window: the window's slice of the table is assembled in LDS and leaves with 16-byte stores
+__global__ void __launch_bounds__(512) k_join8_fill(const Join8Args A) {
+    extern __shared__ __align__(16) uint32_t s_win[];  // HS_JOIN8_WINDOW bytes
+    __shared__ uint32_t s_occupied;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    uint4* w4 = reinterpret_cast<uint4*>(s_win);
+    for (int i = tid; i < HS_JOIN8_WINDOW / 16; i += nthr) w4[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    if (tid == 0) s_occupied = 0;
+    __syncthreads();
+    const uint32_t t0 = A.win_start[blockIdx.x], t1 = A.win_start[blockIdx.x + 1];
+    uint8_t* bytes = reinterpret_cast<uint8_t*>(s_win);
+    for (uint32_t t = t0 + tid; t < t1; t += nthr) {
+        const uint32_t v = A.tuples[t];
+        bytes[v & (HS_JOIN8_WINDOW - 1)] = (uint8_t)(v >> 24);
+    }
+    __syncthreads();
+    uint4* out = reinterpret_cast<uint4*>(A.table + (int64_t)blockIdx.x * HS_JOIN8_WINDOW);
+    uint32_t occ = 0;
+    for (int i = tid; i < HS_JOIN8_WINDOW / 16; i += nthr) {
+        const uint4 v = w4[i];
+        out[i] = v;
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            // occupied bytes (!= 0xff) = non-zero bytes of ~x; exact SWAR: per byte ((b & 0x7f) + 0x7f) | b has its top
+            // bit set iff b != 0, and no carry crosses a byte
+            const uint32_t x = ~w[k];
+            occ += __popc((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u);
+        }
+    }
+    for (int d = HS_WAVE / 2; d >= 1; d >>= 1) occ += __shfl_down(occ, d, HS_WAVE);
+    if ((tid & (HS_WAVE - 1)) == 0 && occ) atomicAdd(&s_occupied, occ);
+    __syncthreads();
+    // two tuples in one byte = one key twice on the build side
+    if (tid == 0 && s_occupied != t1 - t0) atomicOr(A.flags, HS_FLAG_JOIN_DUP);
+}
+
+static int64_t hsj8_windows(int64_t slots) { return (slots + HS_JOIN8_WINDOW - 1) >> HSJ8_WSHIFT; }
+static void hsj8_geometry(int64_t n, int64_t& per, int64_t& groups) {
+    per = (n + 1023) / 1024;
+    if (per < 8192) per = 8192;
+    per = (per + 3) & ~(int64_t)3;
+    groups = n > 0 ? (n + per - 1) / per : 0;
+}
+extern "C" size_t hs_join8_table_bytes(int64_t slots) {
+    return slots < 1 ? 0 : (size_t)hsj8_windows(slots) * HS_JOIN8_WINDOW;
+}
+extern "C" size_t hs_join8_ws_bytes(int64_t n_build, int64_t slots) {
+    if (n_build < 0 || slots < 1) return 0;
+    int64_t per, groups;
+    hsj8_geometry(n_build, per, groups);
+    const int64_t n_win = hsj8_windows(slots);
+    return (size_t)(groups * n_win + n_win + 1 + n_build) * 4 + 64;
+}
+extern "C" int hs_join8_build(void* stream, const int32_t* build_keys, const uint8_t* payload, int64_t n_build,
+                              int64_t seg_len, const int64_t* seg_counts, int32_t key_min, int64_t slots, uint8_t* table,
+                              void* ws, uint32_t* flags) {
+    if (!build_keys || !table || !ws || !flags || n_build < 0 || n_build >= 0xffffffffll || slots < 1 ||
+        slots > (1ll << 30) || ((uintptr_t)build_keys & 15) || ((uintptr_t)table & 15) || (payload && ((uintptr_t)payload & 3)) ||
+        ((uintptr_t)ws & 3)) {
+        hs_set_error("hs_join8_build: bad arguments (aligned buffers, n_build < 2^32, slots <= 2^30)");
+        return HS_E_ARG;
+    }
+    if (seg_counts && (seg_len < 4 || (seg_len & 3) || n_build % seg_len)) {
+        hs_set_error("hs_join8_build: segments must be equally long, a multiple of 4 rows");
+        return HS_E_ARG;
+    }
+    const int64_t n_win = hsj8_windows(slots);
+    if (n_win > HSJ8_MAX_WINDOWS) {
+        hs_set_error("hs_join8_build: key range too wide");
+        return HS_E_LIMIT;
+    }
+    int64_t per, groups;
+    hsj8_geometry(n_build, per, groups);
+    Join8Args A;
+    A.keys = build_keys;
+    A.payload = payload;
+    A.n = n_build;
+    A.seg_len = seg_counts ? seg_len : (n_build > 0 ? n_build : 1);
+    A.seg_counts = seg_counts;
+    A.slots = slots;
+    A.key_min = key_min;
+    A.n_win = (int32_t)n_win;
+    A.per = per;
+    A.hist = (uint32_t*)ws;
+    A.win_start = A.hist + groups * n_win;
+    A.tuples = A.win_start + n_win + 1;
+    A.table = table;
+    A.flags = flags;
+    hipStream_t s = (hipStream_t)stream;
+    static unsigned long long attr_set = 0;
+    if (hs_first_on_device(attr_set)) {
+        hipFuncSetAttribute((const void*)k_join8_fill, hipFuncAttributeMaxDynamicSharedMemorySize, HS_JOIN8_WINDOW);
+        hipFuncSetAttribute((const void*)k_join8_hist, hipFuncAttributeMaxDynamicSharedMemorySize, HSJ8_MAX_WINDOWS * 4);
+        hipFuncSetAttribute((const void*)k_join8_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, HSJ8_MAX_WINDOWS * 4);
+    }
+    const size_t hist_lds = (size_t)n_win * 4;
+    if (groups > 0) {
+        hipLaunchKernelGGL(k_join8_hist, dim3((unsigned)groups), dim3(512), hist_lds, s, A);
+        hipLaunchKernelGGL(k_join8_scan_groups, dim3((unsigned)((n_win + 255) / 256)), dim3(256), 0, s, A.hist, (int32_t)groups,
+                           (int32_t)n_win, A.win_start);
+    } else {
+        hs_memset_async(A.win_start, 0, (size_t)(n_win + 1) * 4, s);
+    }
+    hipLaunchKernelGGL(k_join8_scan_windows, dim3(1), dim3(1024), 0, s, A.win_start, (int32_t)n_win);
+    if (groups > 0) hipLaunchKernelGGL(k_join8_scatter, dim3((unsigned)groups), dim3(512), hist_lds, s, A);
+    hipLaunchKernelGGL(k_join8_fill, dim3((unsigned)n_win), dim3(512), HS_JOIN8_WINDOW, s, A);
+    HSJ_CHECK_LAUNCH("hs_join8_build");
+    return HS_OK;
+}
+
+__global__ void __launch_bounds__(256) k_remap_u8(const uint8_t* codes, int64_t n, const uint8_t* lut, uint8_t* out) {
+    __shared__ uint8_t s_lut[256];
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = s_lut[codes[i]];
+}
+extern "C" int hs_remap_u8(void* stream, const uint8_t* codes, int64_t n, const uint8_t* lut256, uint8_t* out) {
+    if (!codes || !lut256 || !out || n < 0) {
+        hs_set_error("hs_remap_u8: bad arguments");
+        return HS_E_ARG;
+    }
+    if (n > 0) hipLaunchKernelGGL(k_remap_u8, dim3(hsj_grid(n, 256 * 8, 4096)), dim3(256), 0, (hipStream_t)stream, codes, n, lut256, out);
+    HSJ_CHECK_LAUNCH("hs_remap_u8");
     return HS_OK;
 }
 

@@ -34,6 +34,7 @@ extern "C" size_t hs_sizeof(int32_t which) {
         case 7: return sizeof(hs_finish_spec);
         case 8: return sizeof(hs_stage_plan);
         case 9: return sizeof(hs_result_col);
+        case 10: return sizeof(hs_join8);
         default: return 0;
     }
 }

@@ -63,10 +63,14 @@ class DCol:
     # partition key, the result hand-over) goes through the lowering's dictionary forms or decodes first.
     dict: tuple | None = None
     plain: "DCol | None" = None  # the same rows as real strings, where they exist anyway (table columns)
+    # hs.JOIN8_CODE / hs.JOIN8_UNIT: a VIRTUAL column of the fused join + aggregate - `data` is the probe
+    # side's key column and the row's value is looked up in the join's byte table while the aggregate scans; only
+    # Device.aggregate_join8 understands it
+    virtual: int = 0
 
     def as_hs(self) -> hs.hs_col:
         c = hs.hs_col()
-        c.kind = self.kind
+        c.kind = self.virtual or self.kind
         c.fixed_len = self.fixed_len
         c.data = self.data.data_ptr()
         c.lens = self.lens.data_ptr() if self.lens is not None else None
@@ -104,6 +108,9 @@ class DBatch:
     unit_col: torch.Tensor | None = None  # COMPUTED units (probe side of a join, rows left in place): u8 unit id per
     n_unit_ids: int = 0                   # row (0xff = dropped) and the number of units; unit_rows is then [0, nrows]
     join_task_id: Any = None              # the join that produced the computed units (for the fall-back decision)
+    join8: dict | None = None             # the join's byte table + probe key column (Device.join8_table): the probe runs
+                                          # INSIDE the partial aggregate (Device.aggregate_join8); such a batch carries
+                                          # virtual columns and can feed nothing else
 
     def __post_init__(self) -> None:
         if self.nrows_dev is None and not self.unit_rows:
@@ -296,7 +303,9 @@ class Device:
         """Bracket the exchange collective of every following query with events on the launch stream (bench.py's
         time split); read with exchange_ms() after a synchronise."""
         if enable:
-            self.exchange_events = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+            # [0], [1]: around the query's first exchange (slabs / the join's build side); [2], [3]: around a second one
+            # (the unit tables of the fused join)
+            self.exchange_events = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             for ev in self.exchange_events:
                 ev.record()
         else:
@@ -304,8 +313,10 @@ class Device:
 
     def exchange_ms(self) -> float:
         # a rank that does not receive the result returns from the query without waiting for its stream
-        self.exchange_events[1].synchronize()
-        return self.exchange_events[0].elapsed_time(self.exchange_events[1])
+        for ev in self.exchange_events:
+            ev.synchronize()
+        ev = self.exchange_events
+        return ev[0].elapsed_time(ev[1]) + ev[2].elapsed_time(ev[3])
 
     def time_join(self, enable: bool = True) -> None:
         """Bracket the in-place join operator (table build + probe) of every following query with events on the
@@ -660,6 +671,22 @@ class Device:
             return None
         return DCol(hs.STR, codes, col.n, lens=self.const_lens(1, col.n), offs=None, fixed_len=1,
                     dict=tuple(entries), plain=col)
+
+    def dict_recode(self, plain: DCol, coded: DCol | None, entries: tuple) -> DCol:
+        """The coded column re-expressed in another (larger) dictionary `entries` that holds every string of its own:
+        code bytes through a 256-entry table (hs_remap_u8).  `coded` None = a column without rows."""
+        n = plain.n
+        out = self.empty(n, torch.uint8)
+        if coded is not None and n > 0:
+            index = {text: code for code, text in enumerate(entries)}
+            lut = np.zeros(256, dtype=np.uint8)
+            for old, text in enumerate(coded.dict):
+                lut[old] = index[text]
+            d_lut = torch.from_numpy(lut).to(self.device)
+            hs.check(self._raw_lib.hs_remap_u8(self.stream, coded.data.data_ptr(), n, d_lut.data_ptr(), out.data_ptr()),
+                     "hs_remap_u8")
+            torch.cuda.current_stream(self.device).synchronize()  # d_lut goes out of scope: table open, not a query
+        return DCol(hs.STR, out, n, lens=self.const_lens(1, n), offs=None, fixed_len=1, dict=tuple(entries), plain=plain)
 
     def dict_column(self, entries: tuple) -> DCol:
         """The dictionary's strings as a device STRING column (row = code): the source of decoding gathers."""
@@ -1651,6 +1678,226 @@ class Device:
             self.op(self.join_events[1].record)
         self.last_join = {"mode": "direct" if direct else "hashed", "slots": slots, "n_build": n_build, "n_probe": n_probe}
         return rows, unit, pay
+
+    # ---- the join's probe inside the aggregate scan (round 3) -----------------------------------------
+    JOIN8_MAX_SPREAD = 32      # the byte table is used while the build side's key range holds <= this many slots per key
+    JOIN8_MAX_SLOTS = 1 << 30
+
+    def key_range(self, col: DCol) -> tuple[int, int, int]:
+        """(min, max, rows) of an INTEGER column, learnt once per column object (one small read-back)."""
+        span = col.__dict__.get("_hs_minmax")
+        if span is None:
+            if col.n == 0:
+                span = (2**31 - 1, -(2**31))
+            else:
+                minmax = self.empty(2, torch.int32)
+                hs.check(self._raw_lib.hs_minmax_i32(self.stream, col.data.data_ptr(), col.n, minmax.data_ptr()), "hs_minmax_i32")
+                if self.rec is not None:
+                    self.rec.poisoned = True  # this run learnt the range on the way; the next one finds it cached
+                span = tuple(int(v) for v in minmax.tolist())
+            col.__dict__["_hs_minmax"] = span
+        return span[0], span[1], col.n
+
+    def join8_plan(self, build_key: DCol, dist_ctx: tuple | None = None) -> dict | None:
+        """Shape of the byte table for this build key column - or None when the key range is too sparse / wide for direct
+        addressing.  N ranks: every rank's (min, max, rows) travel once per column (cached), so that all ranks take the
+        same decision and know the segment length of the gathered build side."""
+        plan = build_key.__dict__.get("_hs_join8_plan")
+        if plan is not None and plan["world"] == (dist_ctx[2] if dist_ctx else 1):
+            return plan["shape"]
+        lo, hi, n = self.key_range(build_key)
+        rows = [n]
+        if dist_ctx is not None:
+            dist, group, world = dist_ctx
+            mine = torch.tensor([lo, hi, n], dtype=torch.int64)
+            everyone = [torch.zeros(3, dtype=torch.int64) for _ in range(world)]
+            if dist.get_backend(group) == "gloo":
+                dist.all_gather(everyone, mine, group=group)
+            else:
+                dev_all = [t.to(self.device) for t in everyone]
+                dist.all_gather(dev_all, mine.to(self.device), group=group)
+                everyone = [t.cpu() for t in dev_all]
+            if self.rec is not None:
+                self.rec.poisoned = True
+            triples = [[int(v) for v in t.tolist()] for t in everyone]
+            lo, hi = min(t[0] for t in triples), max(t[1] for t in triples)
+            rows = [t[2] for t in triples]
+        total = sum(rows)
+        slots = hi - lo + 1 if total else 1
+        shape = None
+        if 0 < total < 0xFFFFFFFF and 0 < slots <= min(self.JOIN8_MAX_SLOTS, self.JOIN8_MAX_SPREAD * total) and lo >= -(2**31):
+            seg_len = (max(rows) + 15) & ~15
+            shape = {"key_min": lo, "slots": slots, "rows": rows, "seg_len": seg_len, "total": total}
+        build_key.__dict__["_hs_join8_plan"] = {"world": dist_ctx[2] if dist_ctx else 1, "shape": shape}
+        return shape
+
+    def join8_table(self, shape: dict, build_key: DCol, payload: DCol | None, n_parts: int,
+                    dist_ctx: tuple | None = None) -> dict:
+        """Build the join's byte table (hs_join8_build: window partition + assembly in LDS, the table is written once,
+        coalesced).  N ranks: the build side is small next to the probe side (orders : lineitem = 1 : 4 rows, 5 : 12
+        referenced bytes) - every rank all-gathers key + payload code columns (padded to one segment length, valid
+        counts alongside) and builds the WHOLE table; its probe rows then never leave the rank.  Duplicate keys raise
+        HS_FLAG_JOIN_DUP in the status word."""
+        slots, key_min = shape["slots"], shape["key_min"]
+        table = self.workspace(self.lib.hs_join8_table_bytes(slots))
+        keys, codes, n, seg_len, counts = build_key.data, payload.data if payload is not None else None, build_key.n, 0, None
+        if self.join_events is not None:
+            self.op(self.join_events[0].record)
+        if dist_ctx is not None:
+            from .distributed import all_gather_into  # noqa: PLC0415
+
+            dist, group, world = dist_ctx
+            seg_len = shape["seg_len"]
+            timed = self.exchange_events
+            if timed is not None:
+                self.op(timed[0].record)
+            kpad = self.empty(seg_len, torch.int32)
+            self.op(kpad[:n].copy_, keys[:n])
+            keys = self.empty(world * seg_len, torch.int32)
+            self.op(all_gather_into, dist, kpad, keys, group)
+            if codes is not None:
+                cpad = self.empty(seg_len, torch.uint8)
+                self.op(cpad[:n].copy_, codes[:n])
+                codes = self.empty(world * seg_len, torch.uint8)
+                self.op(all_gather_into, dist, cpad, codes, group)
+            if timed is not None:
+                self.op(timed[1].record)
+            # valid rows per segment: known from the plan's exchange (a table column's row count does not change)
+            counts = self.to_device_const(np.asarray(shape["rows"], dtype=np.int64))
+            n = world * seg_len
+        ws = self.workspace(self.lib.hs_join8_ws_bytes(n, slots))
+        hs.check(self.lib.hs_join8_build(self.stream, keys.data_ptr(), codes.data_ptr() if codes is not None else None, n,
+                                         seg_len, counts.data_ptr() if counts is not None else None, key_min, slots,
+                                         table.data_ptr(), ws.data_ptr(), self.flags.data_ptr()), "hs_join8_build")
+        if self.join_events is not None:
+            self.op(self.join_events[1].record)
+        self.last_join = {"mode": "byte table", "slots": slots, "n_build": shape["total"], "table_bytes": int(table.numel())}
+        return {"table": table, "key_min": key_min, "slots": slots, "n_parts": n_parts, "keep": (keys, codes, counts, ws)}
+
+    def to_device_const(self, arr: np.ndarray) -> torch.Tensor:
+        """A small constant of the query SHAPE (not of this run's data): uploading it does not poison a recording."""
+        recording, self.rec = self.rec, None
+        try:
+            t = self.to_device(arr)
+        finally:
+            self.rec = recording
+        if self.rec is not None:
+            self.rec.keep.append(t)
+        return t
+
+    def aggregate_join8(self, batch: DBatch, filters: Sequence[Any], group_by: Any, agg_columns: Sequence[Any],
+                        out_schema: Schema, group_cap_hint: int, cache_key: Any = None,
+                        dist_ctx: tuple | None = None) -> DBatch:
+        """Partial aggregate per JoinJob (plan.py:99-109) of a join whose rows were never produced: the scan looks every
+        probe key up in the join's byte table (`batch.join8`), takes the unit from python_hash(key) % partitions and
+        the GROUP BY key / nothing from the table byte, and folds the probe side's columns into per-(unit, key) cells
+        (shared-dictionary tier with computed units).  The units' RAW tables - on N ranks added up over the ranks first
+        (one small all-gather), because the reference rounds a JoinJob's sums once, over all of its rows - are rounded
+        into an exchange slab, which the short tail's finish launch turns into the result.  Raises TierExceeded for
+        shapes this path does not hold."""
+        j = batch.join8
+        low = lower_aggregate(batch.schema, batch.kinds, filters, group_by, agg_columns, batch.dicts)
+        n_cols = len(low.program.columns)
+        if low.numeric_slots >= hs.HS_FUSED_COLS or n_cols >= hs.HS_FUSED_COLS:
+            raise TierExceeded("no preloaded column slot left for the unit ids")
+        if low.program.code_columns:
+            raise TierExceeded("predicates on dictionary codes next to the fused probe")
+        key_idx = low.program.columns[low.key_slot]
+        kc = batch.cols[key_idx]
+        key_ok = kc.virtual == hs.JOIN8_CODE or (kc.virtual == 0 and (kc.kind == hs.I32 or (kc.kind == hs.STR and kc.fixed_len in (1, 2, 4))))
+        if not key_ok or any(batch.cols[c].virtual and c != key_idx for c in low.program.columns):
+            raise TierExceeded("the fused probe needs a GROUP BY key of at most 4 bytes and no other use of the build side")
+        n_acc = len(low.acc_ops)
+        n_units = int(j["n_parts"])
+        cap = 16
+        while cap < max(int(group_cap_hint), 4) * n_units:
+            cap *= 2
+        cap = min(cap, 4096)
+        world = dist_ctx[2] if dist_ctx else 1
+        key = (cache_key, cap, batch.nrows, j["table"].data_ptr(), j["key_min"], j["slots"], world,
+               tuple((c.kind, c.virtual, c.fixed_len, c.data.data_ptr(), c.n) for c in batch.cols))
+        preps = self.__dict__.setdefault("_join8_prepared", {})
+        p = preps.get(key) if cache_key is not None else None
+        if p is None:
+            host_units = (C.c_int64 * 2)(0, batch.nrows)
+            geom = hs.hs_agg_geom()
+            rc = self.lib.hs_agg_shared_geom(host_units, 1, n_acc, cap, C.byref(geom))
+            if rc == 2:
+                raise TierExceeded("fused probe: " + self.lib.hs_last_error().decode())
+            hs.check(rc, "hs_agg_shared_geom")
+            chunks = np.zeros((max(int(geom.n_chunks), 1), 4), dtype=np.int64)
+            chunk0 = np.zeros(2, dtype=np.int64)
+            hs.check(self.lib.hs_agg_partial_chunks(host_units, 1, C.byref(geom), chunks.ctypes.data_as(C.POINTER(hs.hs_chunk)),
+                                                    chunk0.ctypes.data_as(C.POINTER(C.c_int64))), "hs_agg_partial_chunks")
+            per_unit, small = max(4, cap // n_units), 16
+            while small < 4 * per_unit:
+                small *= 2
+            geom.pad = min(int(geom.pad), small)  # slots of ONE unit's table (x4: open addressing)
+            unit_cap = int(geom.pad)
+            slots = n_units * unit_cap
+            acc_kinds = [hs.I32 if is_int else hs.F32 for is_int in low.acc_is_int]
+            key_stored = DCol(hs.STR, kc.data, kc.n, fixed_len=1, dict=kc.dict) if kc.virtual else kc
+            layout, slab, desc = self._tail_slab(key_stored, out_schema, acc_kinds, slots)
+            cols_arr = (hs.hs_col * (n_cols + 1))()
+            base_arr = self._cols_array(batch, low.program.columns)
+            for slot in range(n_cols):
+                cols_arr[slot] = base_arr[slot]
+            cols_arr[n_cols] = DCol(hs.U8, j["probe_key"].data, batch.nrows, virtual=hs.JOIN8_UNIT).as_hs()
+            table_bytes = 16 + slots * 8 * (1 + n_acc)
+            xbuf = torch.zeros(table_bytes + PAD, dtype=torch.uint8, device=self.device)
+            join = hs.hs_join8(j["table"].data_ptr(), j["slots"], j["key_min"], n_units)
+            p = {"geom": geom, "d_units": self.to_device_const(chunks.reshape(-1)), "cols": cols_arr, "n_cols": n_cols + 1,
+                 "unit_slot": n_cols, "key_slot": low.key_slot, "prog": low.program.to_struct(), "spec": low.spec(),
+                 "join": join, "n_units": n_units, "unit_cap": unit_cap, "slots": slots, "xbuf": xbuf,
+                 "table_bytes": table_bytes, "out_rep": self.empty(slots, torch.int64),
+                 "ws": self.workspace(max(int(geom.n_chunks), 1) * slots * max(n_acc, 1) * 8),
+                 "slab": slab, "layout": layout, "desc": desc, "keep": (batch, j),
+                 "tail": {"desc": desc, "layout": layout, "slab": slab, "agg_to_acc": list(low.agg_to_acc),
+                          "acc_kinds": acc_kinds, "key_kind": key_stored.kind, "key_len": key_stored.fixed_len,
+                          "n_units": n_units, "key_dict": key_stored.dict, "replicated": True},
+                 "info": {"rows": batch.nrows, "chunks": int(geom.n_chunks), "chunk_rows": int(geom.chunk_rows),
+                          "wg_threads": int(geom.wg_threads), "group_cap": cap, "lds_bytes": int(geom.lds_bytes),
+                          "tier": "shared, probe fused"}}
+            if world > 1:
+                p["gathered"] = torch.zeros(world * table_bytes + PAD, dtype=torch.uint8, device=self.device)
+                p["merged"] = torch.zeros(table_bytes + PAD, dtype=torch.uint8, device=self.device)
+            if cache_key is not None:
+                if len(preps) >= 8:
+                    preps.pop(next(iter(preps)))
+                preps[key] = p
+        if self.rec is not None:
+            self.rec.keep.append(p)
+        xbuf, slots = p["xbuf"], p["slots"]
+        keys_ptr, acc_ptr = xbuf.data_ptr() + 16, xbuf.data_ptr() + 16 + slots * 8
+        hs.check(self.lib.hs_agg_shared_join8(self.stream, p["cols"], p["n_cols"], p["key_slot"], p["unit_slot"],
+                                              C.byref(p["join"]), p["n_units"], C.byref(p["prog"]), C.byref(p["spec"]),
+                                              p["d_units"].data_ptr(), C.byref(p["geom"]), p["out_rep"].data_ptr(), keys_ptr,
+                                              acc_ptr, p["ws"].data_ptr(), self.flags.data_ptr(), self._event_handle(0),
+                                              self._event_handle(1)), "hs_agg_shared_join8")
+        self.last_scan = p["info"]
+        self.last_group_cap = cap
+        if world > 1:
+            from .distributed import all_gather_into  # noqa: PLC0415
+
+            dist, group, _ = dist_ctx
+            nb = p["table_bytes"]
+            self.op(xbuf[:4].view(torch.int32).copy_, self.flags[:1])  # this rank's status travels in the header
+            timed = self.exchange_events
+            if timed is not None:
+                self.op(timed[2].record)
+            self.op(all_gather_into, dist, xbuf[:nb], p["gathered"][: world * nb], group)
+            if timed is not None:
+                self.op(timed[3].record)
+            merged = p["merged"]
+            keys_ptr, acc_ptr = merged.data_ptr() + 16, merged.data_ptr() + 16 + slots * 8
+            hs.check(self.lib.hs_agg_units_merge(self.stream, p["gathered"].data_ptr(), world, p["n_units"], p["unit_cap"],
+                                                 C.byref(p["spec"]), keys_ptr, acc_ptr, self.flags.data_ptr()),
+                     "hs_agg_units_merge")
+        hs.check(self.lib.hs_agg_units_to_slab(self.stream, keys_ptr, acc_ptr, p["n_units"], p["unit_cap"], C.byref(p["spec"]),
+                                               p["slab"].data_ptr(), C.byref(p["desc"]), self.flags.data_ptr()),
+                 "hs_agg_units_to_slab")
+        return DBatch(list(out_schema), [], slots, [0, slots], None, total_units=p["n_units"], slab=p["slab"],
+                      slab_layout=p["layout"], tail=p["tail"])
 
     # ---- hash join (A8) --------------------------------------------------------------------------------
     def join_indices(self, left_key: DCol, right_key: DCol) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, int]:

@@ -100,6 +100,18 @@ def all_gather_slabs_into(dist: Any, slab: torch.Tensor, out: torch.Tensor, grou
         dist.all_gather_into_tensor(out, slab, group=group)
 
 
+def all_gather_into(dist: Any, inp: torch.Tensor, out: torch.Tensor, group: Any = None) -> None:
+    """all_gather_into_tensor of any dtype into a caller-owned buffer (out.numel() == world * inp.numel()); device
+    tensors are staged through the host under gloo (CPU tests, single-GPU rehearsal)."""
+    backend = dist.get_backend(group)
+    if backend == "gloo" and inp.device.type != "cpu":
+        host_out = torch.empty(out.numel(), dtype=out.dtype)
+        dist.all_gather_into_tensor(host_out, inp.cpu(), group=group)
+        out.copy_(host_out)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+
+
 def unpack_gathered(gathered: torch.Tensor, layout: SlabLayout) -> tuple[torch.Tensor, torch.Tensor, list[torch.Tensor]]:
     """[world, slab_bytes] -> (flags int32[world], order int64[world*M] with -1 on padding rows,
     columns, each contiguous over all world*M rows in rank-major order)."""

@@ -131,6 +131,9 @@ class HipExecutionEngine(ExecutionEngine):
         # round 2: dictionary-coded string columns and the in-place unique-key join (4.6)
         self.dict_enabled = os.environ.get("HIPSPARK_DICT", "1") != "0"
         self.fused_join_enabled = os.environ.get("HIPSPARK_FUSED_JOIN", "1") != "0"
+        self.fused_probe_enabled = os.environ.get("HIPSPARK_FUSED_PROBE", "1") != "0"  # round 3: probe inside the aggregate
+        self.fused_probes = 0
+        self._no_join8: set[Any] = set()  # join task ids the fused probe turned out not to hold
         self._no_fused_join: set[Any] = set()  # join task ids whose build side turned out to hold duplicate keys
         self._fused_join_tasks: set[Any] = set()  # join task ids the running query took the in-place path for
         self._lds_merges: list[int] = []  # final-merge tasks the running query folded on chip (see HS_FLAG_MERGE_ROWS)
@@ -395,7 +398,7 @@ class HipExecutionEngine(ExecutionEngine):
     def _switches(self) -> tuple:
         """The run-time switches a recording was made under (tests flip them between runs of one query)."""
         return (self.replay_enabled, self.short_tail_enabled, self.shared_tier_enabled, self.dict_enabled,
-                self.fused_join_enabled, self.dev.zero_copy_results)
+                self.fused_join_enabled, self.fused_probe_enabled, self.dev.zero_copy_results)
 
     @staticmethod
     def _stamp_of(path: str) -> tuple:
@@ -522,7 +525,7 @@ class HipExecutionEngine(ExecutionEngine):
             first_real = next((t for t in consumers if _cls(t) != "FilterTask"), None)
             feeds_aggregate = first_real is not None and _cls(first_real) == "AggregateTask" and first_real.before_shuffle
             batch = self._join(producer, outputs[id(stage.dependencies[0])], outputs[id(stage.dependencies[1])],
-                               self._needed_names(consumers), feeds_aggregate)
+                               self._needed_names(consumers), feeds_aggregate, consumers)
         else:
             raise NotImplementedError(f"Job creation not implemented for {type(producer)}")
 
@@ -544,6 +547,7 @@ class HipExecutionEngine(ExecutionEngine):
     def _consume(self, batch: Any, consumers: Sequence[Any]) -> Any:
         """Run a stage's consumer tasks (filters, projections, aggregates) over one batch."""
         from .device import SlabUnsupported, TierExceeded  # noqa: PLC0415
+        from .hipspark import HipSparkLimit  # noqa: PLC0415
 
         pending: list[Any] = []  # WHERE conditions not yet applied to `batch`
         for position, task in enumerate(consumers):
@@ -561,6 +565,19 @@ class HipExecutionEngine(ExecutionEngine):
                 batch = self._project(batch, pending, task)
                 pending = []
             elif tname == "AggregateTask":
+                if task.before_shuffle and batch.join8 is not None:
+                    # the join's probe runs inside this aggregate's scan; what it cannot hold sends the
+                    # query back through the materialising joins
+                    try:
+                        batch = self.dev.aggregate_join8(batch, pending, task.group_by_column, task.agg_columns,
+                                                         task.inferred_schema, self.group_cap_hint,
+                                                         cache_key=(_uid(task), "join8"), dist_ctx=self._dist_ctx())
+                    except (TierExceeded, SlabUnsupported, HipSparkLimit):
+                        self._no_join8.add(batch.join_task_id)
+                        raise RestartQuery from None
+                    batch.tail["task_id"] = _uid(task)
+                    pending = []
+                    continue
                 if task.before_shuffle and self.dist is not None:
                     batch = self._agree_key_width(batch, task)  # the exchange form must not depend on local rows
                 if task.before_shuffle and batch.unit_col is not None:
@@ -809,6 +826,8 @@ class HipExecutionEngine(ExecutionEngine):
         tbl.load_columns(self.dev, table, col_ids)
         if self.dist is not None:
             self._agree_table_widths(table, col_ids)
+            if self.dict_enabled:
+                self._encode_string_columns_on_ranks(table, col_ids)
         elif self.dict_enabled:
             self._encode_string_columns(table, col_ids)
         batch = tbl.table_batch(table, col_ids, producer.alias)
@@ -830,6 +849,33 @@ class HipExecutionEngine(ExecutionEngine):
             coded = self.dev.dict_encode(col)
             if coded is not None:
                 table.columns[cid] = coded
+
+    def _encode_string_columns_on_ranks(self, table: Any, col_ids: Sequence[int]) -> None:
+        """_encode_string_columns when every rank holds other blocks of the table: the ranks code their own rows, then
+        AGREE on one dictionary per column - all-gather of the (at most 256) distinct strings, union, sorted - and
+        re-code their bytes through a 256-entry table.  Equal codes then mean equal strings on every rank: code bytes
+        may travel (the join's gathered build side, exchange slabs) and per-dictionary predicate bits are the same
+        everywhere.  A column that any rank cannot code, or whose union outgrows a code byte, stays plain on ALL ranks
+        (once per table and column; every rank scans the same tables with the same column lists, so the collectives
+        match)."""
+        from . import hipspark as hs  # noqa: PLC0415
+
+        tried = table.__dict__.setdefault("_hs_dict_tried", set())
+        for cid in sorted(col_ids):
+            col = table.columns[cid]
+            if cid in tried or col.kind != hs.STR:
+                continue
+            tried.add(cid)
+            coded = self.dev.dict_encode(col) if col.n > 0 else None
+            mine = [] if col.n == 0 else (list(coded.dict) if coded is not None else None)
+            everyone: list = [None] * self.world
+            self.dist.all_gather_object(everyone, mine, group=self.group)
+            if any(entries is None for entries in everyone):
+                continue
+            union = sorted(set().union(*map(set, everyone)))
+            if not union or len(union) > 256:
+                continue
+            table.columns[cid] = self.dev.dict_recode(col, coded, tuple(union))
 
     def _agree_table_widths(self, table: Any, col_ids: Sequence[int]) -> None:
         """fixed_len of a stored STRING column becomes a FILE-global property (once per table and column): see
@@ -866,8 +912,68 @@ class HipExecutionEngine(ExecutionEngine):
                 return needed
         return None
 
+    def _dist_ctx(self) -> tuple | None:
+        return (self.dist, self.group, self.world) if self.dist is not None else None
+
+    def _join_fused_probe(self, task: Any, left: Any, right: Any, lkey: int, rkey: int, needed: set[str],
+                          consumers: Sequence[Any]) -> Any:
+        """Primary-key / foreign-key join feeding a partial aggregate, round 3 (BASELINE config 4 on 1..N GPUs; DESIGN.md
+        4.6): the build side becomes a BYTE table (slot = key - key_min, value = the dictionary code of the one
+        build-side column the aggregate reads) and the probe happens inside the aggregate's scan - per probe row nothing
+        is written at all.  On N ranks the (small) build side is all-gathered and every rank builds the whole table;
+        probe rows never cross xGMI.  -> a batch of virtual columns for Device.aggregate_join8, or None when the shape
+        does not qualify (decided from plan structure and GLOBAL table properties only, so every rank decides alike)."""
+        from . import hipspark as hs  # noqa: PLC0415
+        from .device import DBatch, DCol  # noqa: PLC0415
+
+        agg = next((t for t in consumers if _cls(t) != "FilterTask"), None)
+        if (agg is None or not getattr(agg, "_hs_short_tail", False) or _uid(agg) in self._no_short_tail
+                or not self.short_tail_enabled or not self.shared_tier_enabled or left.lazy or right.lazy):
+            return None
+        if left.cols[lkey].kind != hs.I32 or right.cols[rkey].kind != hs.I32 or constants.SHUFFLE_PARTITIONS > 127:
+            return None
+        left_names = {name for name, _ in left.schema}
+        for t in consumers:  # a WHERE between join and aggregate may look at the probe side only
+            if _cls(t) == "FilterTask" and any(name in left_names for name in _plain_names(t.condition)):
+                return None
+        wanted_left = [i for i, (name, _) in enumerate(left.schema) if name in needed]
+        if len(wanted_left) > 1:
+            return None
+        payload = left.cols[wanted_left[0]] if wanted_left else None
+        if payload is not None and (payload.dict is None or len(payload.dict) > 255):
+            return None
+        dev = self.dev
+        shape = dev.join8_plan(left.cols[lkey], self._dist_ctx())
+        if shape is None or right.nrows >= 0xFFFFFFFF:
+            return None
+        if right.cols[rkey].data.data_ptr() % 16 or left.cols[lkey].data.data_ptr() % 16:
+            raise ExecutionError("join key columns must be 16-byte aligned")
+        j = dev.join8_table(shape, left.cols[lkey], payload, constants.SHUFFLE_PARTITIONS, self._dist_ctx())
+        j["probe_key"] = right.cols[rkey]
+        n = right.nrows
+        schema, cols = [], []
+        if payload is not None:
+            schema.append(left.schema[wanted_left[0]])
+            cols.append(DCol(hs.STR, right.cols[rkey].data, n, lens=dev.const_lens(1, n), offs=None, fixed_len=1,
+                             dict=payload.dict, virtual=hs.JOIN8_CODE))
+        for (name, ctype), col in zip(right.schema, right.cols):
+            if name in needed:
+                schema.append((name, ctype))
+                cols.append(col)
+        if len(cols) == (1 if payload is not None else 0):  # e.g. COUNT only: a row count carrier
+            schema.append(right.schema[rkey])
+            cols.append(right.cols[rkey])
+        joined = DBatch(schema, cols, n, [0, n])
+        joined.join8 = j
+        joined.join_task_id = _uid(task)
+        joined.total_units = constants.SHUFFLE_PARTITIONS
+        self._fused_join_tasks.add(_uid(task))
+        self.fused_joins += 1
+        self.fused_probes += 1
+        return joined
+
     def _join(self, task: Any, left: Any, right: Any, needed: set[str] | None = None,
-              feeds_aggregate: bool = False) -> Any:
+              feeds_aggregate: bool = False, consumers: Sequence[Any] = ()) -> Any:
         """Partitioned inner hash join; output rows grouped by ``hash(key) % SHUFFLE_PARTITIONS`` so
         that a following partial aggregate sees the reference's JoinJob units (plan.py:99-109)."""
         from . import hipspark as hs  # noqa: PLC0415
@@ -878,11 +984,16 @@ class HipExecutionEngine(ExecutionEngine):
         rkey = right.column_index(task.right_key.name)
         # codes of two dictionaries do not compare: join keys are matched on the strings themselves
         left, right = self.dev.decoded_batch(left, [lkey]), self.dev.decoded_batch(right, [rkey])
+        if (feeds_aggregate and self.fused_join_enabled and self.fused_probe_enabled and needed is not None
+                and _uid(task) not in self._no_fused_join and _uid(task) not in self._no_join8):
+            fused = self._join_fused_probe(task, left, right, lkey, rkey, needed, consumers)
+            if fused is not None:
+                return fused
         if (feeds_aggregate and self.fused_join_enabled and self.dist is None and needed is not None
                 and _uid(task) not in self._no_fused_join and left.nrows > 0 and right.nrows > 0
                 and left.cols[lkey].kind == hs.I32 and right.cols[rkey].kind == hs.I32
                 and left.nrows < 0xFFFFFFFF and constants.SHUFFLE_PARTITIONS <= 127
-                and right.cols[rkey].data.data_ptr() % 16 == 0):
+                and right.cols[rkey].data.data_ptr() % 16 == 0 and left.cols[lkey].data.data_ptr() % 16 == 0):
             return self._join_in_place(task, left, right, lkey, rkey, needed)
         if self.dist is not None:
             # both inputs travel to the owner of their key's partition (p % world), then a local join
@@ -1031,7 +1142,7 @@ class HipExecutionEngine(ExecutionEngine):
             data = cols[slab_col]
             if src.kind == hs.STR:
                 out.append(DCol(hs.STR, data, n, lens=self.dev.const_lens(src.fixed_len, n), offs=None,
-                                fixed_len=src.fixed_len))
+                                fixed_len=src.fixed_len, dict=src.dict))
             else:
                 out.append(DCol(src.kind, data, n))
         return DBatch(list(batch.schema), out, n, [0, n], None, order=order, total_units=batch.total_units)
@@ -1330,7 +1441,11 @@ class HipExecutionEngine(ExecutionEngine):
         project = list(consumers[1].columns) if len(consumers) == 2 else None
         schema = writer.inferred_schema
         slab = tail["slab"]
-        if self.dist is not None:
+        if tail.get("replicated"):
+            # the fused join's unit tables were added up over the ranks before they were rounded into the slab: every
+            # rank holds the same, complete partial rows
+            gathered, world, n_order = slab, 1, max(tail["n_units"], 1)
+        elif self.dist is not None:
             from .distributed import all_gather_slabs_into  # noqa: PLC0415
 
             gathered = torch.empty(self.world * tail["layout"].nbytes, dtype=torch.uint8, device=slab.device)

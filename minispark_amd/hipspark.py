@@ -22,6 +22,8 @@ HS_FUSED_COLS = 8
 
 # storage kinds
 I32, F32, I64, F64, STR, U8 = 0, 1, 2, 3, 4, 5
+JOIN8_CODE, JOIN8_UNIT = 16, 17  # virtual columns of the fused join + aggregate (hs_agg_shared_join8)
+JOIN8_WINDOW = 65536
 KIND_BYTES = {I32: 4, F32: 4, I64: 8, F64: 8, U8: 1}
 
 # flags
@@ -54,6 +56,11 @@ class HipSparkError(RuntimeError):
     pass
 
 
+class HipSparkLimit(HipSparkError):
+    """An entry point returned HS_E_LIMIT: the call exceeds one of its documented limits (the caller may take another
+    path; nothing ran wrong)."""
+
+
 class hs_col(C.Structure):
     _fields_ = [
         ("kind", C.c_int32),
@@ -80,6 +87,10 @@ class hs_agg_spec(C.Structure):
         ("op", C.c_uint8 * HS_MAX_ACC),
         ("is_int", C.c_uint8 * HS_MAX_ACC),
     ]
+
+
+class hs_join8(C.Structure):
+    _fields_ = [("table", C.c_void_p), ("slots", C.c_int64), ("key_min", C.c_int32), ("n_parts", C.c_int32)]
 
 
 class hs_chunk(C.Structure):
@@ -195,6 +206,10 @@ SIGNATURES: dict[str, tuple] = {
     "hs_agg_shared": (C.c_int, [_P, _COLP, _I32, _I32, _PROGP, _SPECP, _P, _I64, _GEOMP, _P, _P, _P, _P, _P, _P, _P]),
     "hs_agg_shared_units": (C.c_int, [_P, _COLP, _I32, _I32, _I32, _I32, _PROGP, _SPECP, _P, _GEOMP, _P, _P, _P, _P, _P,
                                       _P, _P]),
+    "hs_agg_shared_join8": (C.c_int, [_P, _COLP, _I32, _I32, _I32, C.POINTER(hs_join8), _I32, _PROGP, _SPECP, _P, _GEOMP,
+                                      _P, _P, _P, _P, _P, _P, _P]),
+    "hs_agg_units_merge": (C.c_int, [_P, _P, _I32, _I32, _I32, _SPECP, _P, _P, _P]),
+    "hs_agg_units_to_slab": (C.c_int, [_P, _P, _P, _I32, _I32, _SPECP, _P, C.POINTER(hs_slab_desc), _P]),
     "hs_agg_partial_slab": (
         C.c_int,
         [_P, _COLP, _I32, _I32, _PROGP, _SPECP, _P, _P, _I64, _GEOMP, _P, _P, C.POINTER(hs_slab_desc), _P, _P, _P, _P],
@@ -231,6 +246,10 @@ SIGNATURES: dict[str, tuple] = {
     "hs_minmax_i32": (C.c_int, [_P, _P, _I64, _P]),
     "hs_join_build_unique": (C.c_int, [_P, _P, _I64, _I32, _I64, _I32, _P, _P]),
     "hs_join_probe_unique": (C.c_int, [_P, _P, _I64, _P, _I32, _I64, _I32, _P, _I32, _P, _P, _P, _P]),
+    "hs_join8_table_bytes": (C.c_size_t, [_I64]),
+    "hs_join8_ws_bytes": (C.c_size_t, [_I64, _I64]),
+    "hs_join8_build": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _I32, _I64, _P, _P, _P]),
+    "hs_remap_u8": (C.c_int, [_P, _P, _I64, _P, _P]),
     "hs_dict_build": (C.c_int, [_P, _COLP, _I64, _I32, _P, _P, _P, _P]),
     "hs_dict_assign": (C.c_int, [_P, _COLP, _I64, _I32, _P, _P, _P, _P, _P]),
     "hs_dict_combine": (C.c_int, [_P, _I32, C.POINTER(_P), C.POINTER(_I32), _I64, _P]),
@@ -314,4 +333,4 @@ def load_library(build_if_missing: bool = True) -> C.CDLL:
 def check(rc: int, what: str = "") -> None:
     if rc != 0:
         msg = load_library().hs_last_error()
-        raise HipSparkError(f"{what or 'libhipspark'} failed (code {rc}): {msg.decode() if msg else ''}")
+        raise (HipSparkLimit if rc == 2 else HipSparkError)(f"{what or 'libhipspark'} failed (code {rc}): {msg.decode() if msg else ''}")

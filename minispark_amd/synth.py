@@ -65,20 +65,32 @@ def strings_from_codes(dev: Device, codes: torch.Tensor, n: int, entries: list[s
     return dev.gather_col(dev.dict_column(tuple(e.encode() for e in entries)), idx, n)
 
 
-def make_orders(dev: Device, path: Path, n_orders: int, seed: int = SEED) -> DeviceTable:
+def make_orders(dev: Device, path: Path, n_orders: int, seed: int = SEED, rank: int = 0, world: int = 1,
+                rows_per_block: int | None = None) -> DeviceTable:
     """Synthetic orders of BASELINE config 4: o_orderkey = key(perm(row)) (every key once, build order != key order),
-    o_orderpriority one of the five TPC-H strings (5-15 bytes).  CPU twin: oracle/q45_oracle.c q4_gen_orders."""
+    o_orderpriority one of the five TPC-H strings (5-15 bytes); this rank's blocks (block b belongs to rank b % world).
+    CPU twin: oracle/q45_oracle.c q4_gen_orders."""
     from .workloads import PRIORITIES  # noqa: PLC0415
 
-    okey = dev.empty(n_orders, torch.int32)
-    code = dev.empty(n_orders, torch.uint8)
-    hs.check(dev.lib.hs_gen_orders(dev.stream, seed, 0, n_orders, n_orders, okey.data_ptr(), code.data_ptr()), "hs_gen_orders")
+    per = rows_per_block or constants.ROWS_PER_BLOCK
+    sizes = block_sizes(n_orders, per)
+    mine = [(b, n) for b, n in enumerate(sizes) if b % world == rank]
+    n_local = sum(n for _, n in mine)
+    okey = dev.empty(n_local, torch.int32)
+    code = dev.empty(n_local, torch.uint8)
+    off = 0
+    for b, n in mine:
+        hs.check(dev.lib.hs_gen_orders(dev.stream, seed, b * per, n, n_orders, okey[off:].data_ptr(), code[off:].data_ptr()),
+                 "hs_gen_orders")
+        off += n
     path = Path(path)
     path.parent.mkdir(parents=True, exist_ok=True)
     BlockFile(path, list(ORDERS_SCHEMA)).write_rows([])  # header only
-    table = DeviceTable(path, list(ORDERS_SCHEMA), block_sizes(n_orders), {}, ())
-    table.columns[0] = DCol(hs.I32, okey, n_orders)
-    table.columns[1] = strings_from_codes(dev, code, n_orders, PRIORITIES)
+    table = DeviceTable(path, list(ORDERS_SCHEMA), [n for _, n in mine], {}, ())
+    table.global_blocks = [b for b, _ in mine]
+    table.total_blocks = len(sizes)
+    table.columns[0] = DCol(hs.I32, okey, n_local)
+    table.columns[1] = strings_from_codes(dev, code, n_local, PRIORITIES)
     return table
 
 

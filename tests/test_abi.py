@@ -37,7 +37,7 @@ def test_struct_layouts_match_the_header():
     # and the sizes the library was compiled with
     lib = hs.load_library()
     mirrors = [hs.hs_col, hs.hs_program, hs.hs_agg_spec, hs.hs_agg_geom, hs.hs_chunk, hs.hs_slab_desc, hs.hs_finish_out,
-               hs.hs_finish_spec, hs.hs_stage_plan, hs.hs_result_col]
+               hs.hs_finish_spec, hs.hs_stage_plan, hs.hs_result_col, hs.hs_join8]
     for which, mirror in enumerate(mirrors):
         assert lib.hs_sizeof(which) == C.sizeof(mirror), mirror.__name__
     assert lib.hs_sizeof(len(mirrors)) == 0
@@ -169,6 +169,45 @@ def test_shared_tier_programs_with_computed_units_and_dictionary_predicates_comp
         text = src.value.decode()
         assert "hs_agg_shared_body<JitProg>" in text and "hs_dictbit(" in text and "run_slot" in text
         assert ("hs_unit_key(" in text) == (unit_col >= 0)
+
+
+def test_the_fused_probe_translates_and_compiles_for_gfx950_without_a_gpu():
+    """Round 3: BASELINE config 4's kernel - the join's probe spliced into the shared-dictionary scan.  The GROUP BY key
+    is a HS_JOIN8_CODE column, the unit a HS_JOIN8_UNIT column (both virtual: the probe side's key column looked up in
+    the byte table while the keys are loaded); the interpreter kernels do not know them."""
+    from minispark_amd.constants import ColumnType as T
+    from minispark_amd.lowering import lower_aggregate
+    from minispark_amd.sql import Col, Functions as F
+
+    lib = hs.load_library()
+    schema = [("o_orderpriority", T.STRING), ("l_quantity", T.FLOAT), ("l_extendedprice", T.FLOAT)]
+    kinds = [hs.STR, hs.F32, hs.F32]
+    dicts = [(b"1-URGENT", b"2-HIGH", b"3-MEDIUM"), None, None]
+    low = lower_aggregate(schema, kinds, [Col("l_quantity") > 10], Col("o_orderpriority"),
+                          [F.count().alias("n"), F.sum(Col("l_quantity")).alias("q"), F.max(Col("l_extendedprice")).alias("m")],
+                          dicts)
+    assert not low.program.code_columns
+    n = len(low.program.columns)
+    cols = (hs.hs_col * (n + 1))()
+    for slot, ci in enumerate(low.program.columns):
+        cols[slot].kind, cols[slot].fixed_len = (hs.JOIN8_CODE, 1) if kinds[ci] == hs.STR else (kinds[ci], -1)
+    cols[n].kind, cols[n].fixed_len = hs.JOIN8_UNIT, -1
+    prog, spec = low.program.to_struct(), low.spec()
+    src = C.create_string_buffer(1 << 16)
+    nbytes = C.c_int64(0)
+    rc = lib.hs_jit_compile_check_shared(cols, n + 1, low.key_slot, n, C.byref(prog), C.byref(spec), b"gfx950",
+                                         C.byref(nbytes), src, len(src))
+    assert rc == 0, (lib.hs_last_error(), lib.hs_jit_last_log()[:3000])
+    text = src.value.decode()
+    assert "hs_agg_shared_body<JitProg>" in text and text.count("hs_join8_lookup(A.join") == 4
+    assert text.count("hs_py_partition(") == 4 and "hs_unit_key(" in text and "k1 == k0 ? b0" in text
+    # outside the shared tier with that unit column the translator refuses (the caller then materialises the probe)
+    rc = lib.hs_jit_compile_check_shared(cols, n + 1, low.key_slot, -1, C.byref(prog), C.byref(spec), b"gfx950",
+                                         C.byref(nbytes), src, len(src))
+    assert rc == 2 and b"HS_JOIN8" in lib.hs_last_error()
+    assert lib.hs_join8_table_bytes(1) == hs.JOIN8_WINDOW and lib.hs_join8_table_bytes(hs.JOIN8_WINDOW + 1) == 2 * hs.JOIN8_WINDOW
+    assert lib.hs_join8_ws_bytes(15_000_000, 60_000_000) > 4 * 15_000_000
+    assert lib.hs_join8_build(None, None, None, 0, 0, None, 0, 1, None, None, None) == 1  # null arguments are refused
 
 
 def test_stage_plan_blob_lowers_without_a_gpu_and_matches_the_library_mirror():

@@ -271,20 +271,85 @@ def _join_queries(api, orders, lineitem):
         "filtered_with_build_side_argument": both().filter(C("l_quantity") > 10).group_by(C("o_orderpriority")).agg(
             F.sum(C("o_totalprice") * C("l_quantity")).alias("w"), F.min(C("l_extendedprice")).alias("lo"), F.count()),
         "probe_side_int_key": both().group_by(C("l_orderkey")).agg(F.count(), F.sum(C("l_quantity")).alias("q")),
+        "filtered_on_the_probe_side": both().filter((C("l_quantity") > 10) & (C("l_extendedprice") < 60000.0))
+            .group_by(C("o_orderpriority")).agg(F.sum(C("l_extendedprice")).alias("rev"), F.avg(C("l_quantity")).alias("aq"), F.count()),
+        "count_only": both().group_by(C("o_orderpriority")).agg(F.count()),
     }
 
 
-@pytest.mark.parametrize("name", ["config4", "filtered_with_build_side_argument", "probe_side_int_key"])
-def test_in_place_join_matches_the_oracle(engine, tmp_path, name):
+JOIN_NAMES = ["config4", "filtered_with_build_side_argument", "probe_side_int_key", "filtered_on_the_probe_side", "count_only"]
+# which of them the fused probe (round 3: byte table, probe inside the aggregate) holds; the others - a second build-side
+# column - take round 2's materialising in-place join
+FUSED_PROBE = {"config4", "probe_side_int_key", "filtered_on_the_probe_side", "count_only"}
+
+
+@pytest.mark.parametrize("probe", ["fused", "materialised"])
+@pytest.mark.parametrize("name", JOIN_NAMES)
+def test_in_place_join_matches_the_oracle(engine, tmp_path, name, probe):
     from oracle.py_engine import run_query
 
+    engine.fused_probe_enabled = probe == "fused"
     orders, lineitem = _join_tables(tmp_path, 3000 if name != "probe_side_int_key" else 300, 20_000, seed=21)
     want = run_query(_join_queries(_oracle_api(), orders, lineitem)[name].task)
     frame = _join_queries(_api(engine), orders, lineitem)[name]
-    for _ in range(3):
+    for _ in range(4):  # first run, second (recorded), replays
         flips = assert_rows_match(frame.collect(), want, max_ulps=1)
         assert flips <= 2  # the shared-dictionary tier adds in hardware order
     assert engine.fused_joins >= 1, "the in-place join must have run"
+    if probe == "fused" and name in FUSED_PROBE:
+        assert engine.fused_probes >= 1 and engine.dev.last_join["mode"] == "byte table" and not engine._no_join8
+        assert engine.replays >= 1, "the fused join is recorded and replayed like any query"
+    else:
+        assert engine.fused_probes == 0 or engine._no_join8 or name not in FUSED_PROBE
+
+
+@pytest.mark.parametrize("variant", ["plain", "segments", "duplicate", "out_of_range", "no_payload"])
+def test_join8_build_against_numpy(engine, variant):
+    """hs_join8_build: window histogram -> scan -> (offset, payload) tuples by window -> windows assembled in LDS.
+    The table must equal a plain scatter; duplicate keys, keys outside the table and padded segments are reported /
+    skipped."""
+    import torch
+
+    from minispark_amd import hipspark as hs
+
+    dev = engine.dev
+    rng = np.random.default_rng(11)
+    n, key_min = 200_000, -7000
+    slots = 5 * hs.JOIN8_WINDOW + 1234  # six windows, the last one partial
+    keys = (rng.permutation(slots)[:n] + key_min).astype(np.int32)
+    payload = rng.integers(0, 255, n).astype(np.uint8)
+    seg_len, counts = 0, None
+    valid = np.ones(n, dtype=bool)
+    if variant == "segments":  # three segments of 70 000 rows, the valid prefixes differ
+        seg_len, per = 70_000, [70_000, 12_345, 0]
+        keys, payload = keys[: 3 * seg_len].copy(), payload[: 3 * seg_len].copy()
+        valid = np.concatenate([np.arange(seg_len) < c for c in per])
+        keys[~valid] = rng.integers(-(2**31), 2**31 - 1, int((~valid).sum()), dtype=np.int64).astype(np.int32)  # garbage padding
+        counts = dev.to_device(np.asarray(per, dtype=np.int64))
+        n = 3 * seg_len
+    if variant == "duplicate":
+        keys[777] = keys[123_456]
+    if variant == "out_of_range":
+        keys[5] = key_min + slots
+        keys[6] = key_min - 1
+        valid[5] = valid[6] = False
+    d_keys = dev.to_device(keys)
+    d_pay = dev.to_device(payload) if variant != "no_payload" else None
+    table = torch.zeros(dev.lib.hs_join8_table_bytes(slots) + 64, dtype=torch.uint8, device=dev.device)
+    ws = dev.workspace(dev.lib.hs_join8_ws_bytes(n, slots))
+    dev.reset_flags()
+    hs.check(dev.lib.hs_join8_build(dev.stream, d_keys.data_ptr(), d_pay.data_ptr() if d_pay is not None else None, n, seg_len,
+                                    counts.data_ptr() if counts is not None else None, key_min, slots, table.data_ptr(),
+                                    ws.data_ptr(), dev.flags.data_ptr()), "hs_join8_build")
+    flags = dev.read_flags()
+    got = table.cpu().numpy()[: 6 * hs.JOIN8_WINDOW]
+    want = np.full(6 * hs.JOIN8_WINDOW, 0xFF, dtype=np.uint8)
+    want[(keys[valid].astype(np.int64) - key_min)] = payload[valid] if variant != "no_payload" else 0
+    if variant == "duplicate":
+        assert flags & hs.FLAG_JOIN_DUP
+        return
+    assert flags == (hs.FLAG_BAD_PROGRAM if variant == "out_of_range" else 0)
+    assert np.array_equal(got, want)
 
 
 def test_duplicate_build_keys_fall_back_to_the_general_join(engine, tmp_path):
@@ -297,6 +362,7 @@ def test_duplicate_build_keys_fall_back_to_the_general_join(engine, tmp_path):
     for _ in range(2):
         assert_rows_match(frame.collect(), want, max_ulps=1)
     assert engine._no_fused_join, "duplicate keys must have sent the query through the general join"
+    assert engine.fused_probes >= 1, "the byte table's build is what noticed them (HS_FLAG_JOIN_DUP)"
 
 
 # ---- BASELINE configs 4 and 5 at size -------------------------------------------------------------------------
@@ -313,8 +379,27 @@ def test_config4_join_group_matches_the_c_port(engine, tmp_path, sf):
     check = wl.full_check(rows)
     assert check["gpu_matches_oracle_full"], check
     assert check["f32_ulp_flips_full"] <= 2
-    assert engine.fused_joins >= 1 and engine.dev.last_join["mode"] == "direct"
+    assert engine.fused_joins >= 1 and engine.dev.last_join["mode"] == "byte table" and engine.replays >= 1
     assert sum(r["n"] for r in rows) == wl.n_li  # every lineitem finds its order
+
+
+def test_config4_through_the_materialising_probe(tmp_path):
+    """Round 2's form of the in-place join (32-bit row table, unit / payload bytes written per row) stays the path for
+    joins the byte table does not hold: kept green at sf=1."""
+    from types import SimpleNamespace
+
+    from minispark_amd.execution import HipExecutionEngine
+    from tools.bench_configs import JoinWorkload
+
+    with HipExecutionEngine(device=0) as e:
+        e.fused_probe_enabled = False
+        wl = JoinWorkload(e, tmp_path, SimpleNamespace(sf=1.0, config="join"), 0, 1)
+        rows = None
+        for _ in range(3):
+            rows = wl.frame.collect()
+        check = wl.full_check(rows)
+        assert check["gpu_matches_oracle_full"], check
+        assert e.fused_joins >= 1 and e.fused_probes == 0 and e.dev.last_join["mode"] == "direct"
 
 
 @pytest.mark.parametrize("sf", [1, 10])

@@ -41,18 +41,19 @@ class _Workload:
     def __init__(self, engine, scratch: Path, args, rank: int, world: int) -> None:
         from minispark_amd import synth
 
-        if world != 1:
-            raise SystemExit(f"--config {args.config} is a single-GPU bench line (the multi-GPU line is Q1)")
-        self.engine, self.scratch, self.args = engine, scratch, args
+        self.engine, self.scratch, self.args, self.rank, self.world = engine, scratch, args, rank, world
         self.n_li = synth.lineitem_rows(args.sf)
         self.total_units = self.n_li
         self.timer = None
 
     def exchange_ms(self) -> float:
-        return 0.0
+        return self.engine.dev.exchange_ms() if self.engine.dist is not None else 0.0
 
     def exchange_text(self, backend: str) -> str:
         return "none"
+
+    def extra_split_ms(self) -> dict:
+        return {}
 
     def dominant_kernel_ms(self) -> float:
         return self.engine.dev.scan_kernel_ms()
@@ -74,8 +75,10 @@ class _Workload:
 
 
 class JoinWorkload(_Workload):
-    """Config 4.  Byte accounting: orders (4 + 1 + len(priority)) + lineitem (4 + 4 + 4 referenced payload),
-    read once, + one 64-byte random access per probe row."""
+    """Config 4 on 1..N GPUs.  Every rank holds its blocks (b % N) of BOTH tables; the build side (orders: key + priority
+    code) is all-gathered, every rank builds the whole byte table and probes its own lineitem blocks inside the aggregate
+    scan; the units' raw tables meet through one small all-gather.  Byte accounting: orders
+    (4 + 1 + len(priority)) + lineitem (4 + 4 + 4 referenced payload), read once, + one random access per probe row."""
 
     metric = "orders JOIN lineitem GROUP BY o_orderpriority (BASELINE config 4): lineitem probe rows/sec"
 
@@ -85,16 +88,28 @@ class JoinWorkload(_Workload):
 
         self.n_ord = synth.orders_rows(self.n_li)
         self.li_path, self.ord_path = scratch / "lineitem.bin", scratch / "orders.bin"
-        li = synth.make_lineitem(engine.dev, self.li_path, self.n_li, with_orderkey=True)
-        engine.attach_device_table(self.li_path, li)
-        orders = synth.make_orders(engine.dev, self.ord_path, self.n_ord)
+        self.li = synth.make_lineitem(engine.dev, self.li_path, self.n_li, with_orderkey=True, rank=rank, world=world)
+        engine.attach_device_table(self.li_path, self.li)
+        orders = synth.make_orders(engine.dev, self.ord_path, self.n_ord, rank=rank, world=world)
         engine.attach_device_table(self.ord_path, orders)
         self.prio_bytes = sum(len(p) for p in workloads.PRIORITIES) / len(workloads.PRIORITIES)
         self.frame = workloads.join_group(workloads.engine_api(engine), str(self.ord_path), str(self.li_path))
-        engine.dev.time_join(True)  # events around table build + probe, part of the recorded run
+        engine.dev.time_join(True)  # events around the table build, part of the recorded run
+
+    def fused(self) -> bool:
+        return (getattr(self.engine.dev, "last_join", None) or {}).get("mode") == "byte table"
 
     def dominant_kernel_ms(self) -> float:
-        return self.engine.dev.join_ms()
+        # fused probe: the aggregate scan with the probe inside (the library's event pair around it); the materialising
+        # form of round 2: table build + probe kernels (events around the operator)
+        return self.engine.dev.scan_kernel_ms() if self.fused() else self.engine.dev.join_ms()
+
+    def extra_split_ms(self) -> dict:
+        return {"join_build": self.engine.dev.join_ms()} if self.fused() else {}
+
+    def exchange_text(self, backend: str) -> str:
+        return (f"all_gather of the build side's key + code columns, one all_gather of the raw unit tables per query ({backend}); "
+                "probe rows never leave their rank")
 
     def algorithmic_bytes_per_launch(self) -> float:
         return self.n_ord * (4 + 1 + self.prio_bytes) + self.n_li * (4 + 4 + 4) + self.n_li * 64.0
@@ -103,26 +118,44 @@ class JoinWorkload(_Workload):
         return {"workload": f"SELECT o_orderpriority, COUNT(), SUM(l_quantity), SUM(l_extendedprice), MAX(l_extendedprice) "
                             f"FROM orders JOIN lineitem ON o_orderkey = l_orderkey GROUP BY o_orderpriority, synthetic sf={self.args.sf:g}",
                 "rows": self.n_li, "orders": self.n_ord, "groups": len(rows or []),
-                "join": getattr(self.engine.dev, "last_join", None), "fused_joins": self.engine.fused_joins}
+                "join": getattr(self.engine.dev, "last_join", None), "fused_joins": self.engine.fused_joins,
+                "probe_inside_the_aggregate": self.engine.fused_probes > 0}
 
     def roofline(self, kernel_avg_ms: float) -> dict:
-        # the join operator (table fill + scatter + occupied-slot count + probe), priced on the bytes it must move when
-        # every access were perfectly coalesced: orders key + code read (5 B), one 4-byte table word written per order,
-        # the table filled and counted (2 x 4 B per slot), lineitem key read (4 B) + one table word + unit and code
-        # bytes written (2 B) per probe row
-        slots = (self.engine.dev.last_join or {}).get("slots", 4 * self.n_ord)
+        last = self.engine.dev.last_join or {}
+        if self.fused():
+            # The scan reads the rank's probe-side columns once (key + the two aggregated f32 columns) and one table byte
+            # per probe key; lineitem is clustered on the order key, so the table is in effect streamed: its bytes once.
+            n_local = self.li.nrows
+            table_bytes = last.get("slots", 4 * self.n_ord)
+            algo = n_local * 12 + table_bytes
+            achieved = algo / (kernel_avg_ms * 1e-3) / 1e9
+            build_ms = self.engine.dev.join_ms()
+            build_algo = self.n_ord * 5 + self.n_ord * 4 * 2 + table_bytes  # keys + codes read, tuples written + read, table written
+            return {"bound": "hbm", "kernel": "k_agg_shared_jit with the join's probe inside (byte table lookup per key, unit = "
+                                              "python_hash(key) % 10, LDS dictionary of (unit, code) cells)",
+                    "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                    "kernel_ms": kernel_avg_ms, "rows_per_launch": n_local, "algorithmic_bytes_per_launch": algo,
+                    "launch": self.engine.dev.last_scan,
+                    "build": {"kernels": "k_join8_hist + scans + k_join8_scatter + k_join8_fill", "ms": build_ms,
+                              "algorithmic_bytes": build_algo, "GBps": build_algo / (build_ms * 1e-3) / 1e9 if build_ms > 0 else None},
+                    "sector_accounting_GBps": (n_local * (12 + 64.0)) / (kernel_avg_ms * 1e-3) / 1e9,
+                    "accounting": "achieved = 12 B per local lineitem row (key + quantity + extendedprice) + the byte table once "
+                                  "(probe keys arrive clustered: the table is streamed, not sampled); SURVEY 8d's own accounting "
+                                  "(64 B per probe as a random access) is the sector_accounting figure; build: keys + codes in, "
+                                  "4-byte tuples out and in, table out"}
+        # round 2's materialising form (table fill + scatter + occupied-slot count + probe), priced on the bytes it must
+        # move when every access were perfectly coalesced
+        slots = last.get("slots", 4 * self.n_ord)
         algo = self.n_ord * (5 + 4) + slots * 8 + self.n_li * (4 + 4 + 2)
         achieved = algo / (kernel_avg_ms * 1e-3) / 1e9
         sector = self.n_ord * (5 + 64.0) + slots * 8 + self.n_li * (4 + 64.0 + 2)
         return {"bound": "hbm", "kernel": "in-place join: k_fill_u32 + k_join_scatter_direct + k_join_count_occupied + k_join_probe_unique",
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                 "kernel_ms": kernel_avg_ms, "rows_per_launch": self.n_li, "algorithmic_bytes_per_launch": algo,
-                # SURVEY 8d's own accounting counts every random table access as a 64-byte sector:
                 "sector_accounting_GBps": sector / (kernel_avg_ms * 1e-3) / 1e9,
                 "accounting": "achieved = coalesced-minimum bytes (5 B per order + 4 B table word per order and per probe + 8 B per "
-                              "table slot for fill and count + 4 B key and 2 B out per lineitem); the table accesses are random "
-                              "(orders arrive in permuted key order), so sectors, not bytes, bound the scatter: with 64 B per random "
-                              "access (SURVEY 8d) the same time is the sector_accounting figure"}
+                              "table slot for fill and count + 4 B key and 2 B out per lineitem)"}
 
     def _host_columns(self):
         from minispark_amd import synth
