@@ -156,6 +156,76 @@ def q1_full_check(rows, total_rows: int, cutoff: str) -> dict:
     return out
 
 
+def timed_steps(wl, engine, steps: int, warmup: int, dist):
+    """W untimed + exactly K timed steps of one workload, bracketed by synchronise (+ barrier) on both sides; the MAX
+    over the ranks.  -> (seconds for the K steps, dominant kernel ms per step, exchange ms per step, last rows)."""
+    import torch
+
+    frame = wl.frame
+    engine.dev.time_scan_kernel(True)
+    if dist is not None:
+        engine.dev.time_exchange(True)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # setup, not warm-up: the first runs of a query compile its kernels (hiprtc), fill the plan / launch caches and
+    # record the replayable launch sequence; whatever --warmup says, the timed steps are steady-state steps
+    for _ in range(3):
+        frame.collect()
+    rows = None
+    for _ in range(warmup):
+        rows = frame.collect()
+    fence()
+    kernel_ms, exchange_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rows = frame.collect()
+        kernel_ms.append(wl.dominant_kernel_ms())  # the step ended with the result on the host: events are complete
+        if dist is not None:
+            exchange_ms.append(wl.exchange_ms())
+    fence()
+    elapsed = time.perf_counter() - t0
+    kernel_avg_ms = sum(kernel_ms) / len(kernel_ms)
+    exchange_avg_ms = sum(exchange_ms) / len(exchange_ms) if exchange_ms else 0.0
+    if dist is not None:
+        t = torch.tensor([elapsed, kernel_avg_ms, exchange_avg_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_avg_ms, exchange_avg_ms = (float(v) for v in t.tolist())
+    return elapsed, kernel_avg_ms, exchange_avg_ms, rows
+
+
+def other_configs(local_rank: int, scratch: Path, steps: int, warmup: int) -> dict:
+    """BASELINE configs 4 and 5 (sf=10) in the same process, AFTER the headline's timed region: the driver runs the
+    default command only, and these lines must not exist as builder-run files alone.  Each: its own engine and tables,
+    `steps` timed steps like the headline, the timed result checked against the C port over the whole tables."""
+    from types import SimpleNamespace
+
+    from minispark_amd.execution import HipExecutionEngine
+    from tools.bench_configs import JoinWorkload, StrKeyWorkload
+
+    out = {}
+    for name, cls in (("join", JoinWorkload), ("strkey", StrKeyWorkload)):
+        engine = HipExecutionEngine(device=local_rank)
+        try:
+            wl = cls(engine, scratch / f"other_{name}", SimpleNamespace(sf=10.0, config=name), 0, 1)
+            elapsed, kernel_avg_ms, _, rows = timed_steps(wl, engine, steps, warmup, None)
+            ms = elapsed / steps * 1e3
+            extra = wl.extra_split_ms()
+            out[name] = {"metric": wl.metric, "value": wl.total_units / (elapsed / steps), "unit": "rows/s", "steps": steps,
+                         "ms_per_step": ms, "config": wl.config(rows), "roofline": wl.roofline(kernel_avg_ms),
+                         "time_split_ms": dict({"scan_partial": kernel_avg_ms, "exchange": 0.0,
+                                                "final": ms - kernel_avg_ms - sum(extra.values())}, **extra),
+                         "full_check": wl.full_check(rows)}
+        finally:
+            engine.__exit__(None, None, None)
+            del engine
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,6 +236,8 @@ def main() -> None:
     ap.add_argument("--sample-blocks", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-check", action="store_true", help="skip the whole-table oracle check of the timed result")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="q1 on one GPU: do not run BASELINE configs 4 / 5 (sf=10) after the timed region")
     ap.add_argument("--cutoff", default=CUTOFF, help="q1: WHERE l_shipdate <= CUTOFF")
     args = ap.parse_args()
     if args.sf is None:
@@ -208,44 +280,7 @@ def main() -> None:
         from tools.bench_configs import JoinWorkload, StrKeyWorkload  # noqa: PLC0415
 
         wl = (JoinWorkload if args.config == "join" else StrKeyWorkload)(engine, scratch, args, rank, world)
-    frame = wl.frame
-    engine.dev.time_scan_kernel(True)
-    if dist is not None:
-        engine.dev.time_exchange(True)
-
-    def step():
-        return frame.collect()
-
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    # setup, not warm-up: the first runs of a query compile its kernels (hiprtc), fill the plan / launch caches and
-    # record the replayable launch sequence; whatever --warmup says, the timed steps are steady-state steps
-    for _ in range(3):
-        step()
-    rows = None
-    for _ in range(args.warmup):
-        rows = step()
-    fence()
-    kernel_ms, exchange_ms = [], []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rows = step()
-        kernel_ms.append(wl.dominant_kernel_ms())  # the step ended with the result on the host: events are complete
-        if dist is not None:
-            exchange_ms.append(wl.exchange_ms())
-    fence()
-    elapsed = time.perf_counter() - t0
-    kernel_avg_ms = sum(kernel_ms) / len(kernel_ms)
-    exchange_avg_ms = sum(exchange_ms) / len(exchange_ms) if exchange_ms else 0.0
-    if dist is not None:
-        t = torch.tensor([elapsed, kernel_avg_ms, exchange_avg_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_avg_ms, exchange_avg_ms = (float(v) for v in t.tolist())
-
+    elapsed, kernel_avg_ms, exchange_avg_ms, rows = timed_steps(wl, engine, args.steps, args.warmup, dist)
     extra_split = wl.extra_split_ms() if hasattr(wl, "extra_split_ms") else {}
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -268,6 +303,8 @@ def main() -> None:
             out["full_check"] = wl.full_check(rows)
         if world == 1 and dist is None and not args.no_cpu_baseline:
             out["cpu_baseline"] = wl.cpu_baseline()
+        if world == 1 and dist is None and args.config == "q1" and not args.no_other_configs and not args.no_full_check:
+            out["other_configs"] = other_configs(local_rank, scratch, args.steps, args.warmup)
         print(json.dumps(out), flush=True)
     engine.__exit__(None, None, None)
     if dist is not None:

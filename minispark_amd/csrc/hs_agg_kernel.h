@@ -394,6 +394,7 @@ struct AggCtx {
 template <bool HASHED_, int D>
 struct InterpProg {
     static constexpr bool HASHED = HASHED_;
+    static constexpr bool TWO_STAGE = false;  // (compiled programs with the join's probe inside load in two stages)
     struct Cells {
         uint64_t cell[HS_FUSED_COLS][HS_V];
     };
@@ -809,7 +810,14 @@ __device__ __forceinline__ void hs_agg_shared_body(const AggMainArgs& A) {
 
     const int64_t stride = (int64_t)nthr * HS_V;
     int64_t base = c0 + (int64_t)tid * HS_V;
-    typename Prog::Cells cur, nxt;
+    typename Prog::Cells cur, nxt, far;
+    if constexpr (Prog::TWO_STAGE) {
+        // The join's probe is a DEPENDENT load (probe key -> table byte).  Keys travel two steps ahead of the rows being
+        // folded, table bytes (with the step's other columns) one step ahead: no wave waits for a load it has just
+        // issued.  (One stage - keys and bytes in the same prefetch - left the waves parked 60 % of their cycles.)
+        if (base < c1) Prog::load_keys(A, base, nxt);
+        if (base + stride < c1) Prog::load_keys(A, base + stride, far);
+    }
     if (base < c1) Prog::load(A, base, nxt);
     for (int i = tid; i < GC; i += nthr) {
         dkeys[i] = HS_EMPTY_KEY;
@@ -839,7 +847,15 @@ __device__ __forceinline__ void hs_agg_shared_body(const AggMainArgs& A) {
     while (base < c1) {
         cur = nxt;
         const int64_t next_base = base + stride;
-        if (next_base < c1) Prog::load(A, next_base, nxt);
+        if constexpr (Prog::TWO_STAGE) {
+            if (next_base < c1) {
+                Prog::take_keys(nxt, far);
+                Prog::load(A, next_base, nxt);
+                if (next_base + stride < c1) Prog::load_keys(A, next_base + stride, far);
+            }
+        } else {
+            if (next_base < c1) Prog::load(A, next_base, nxt);
+        }
         ctx.row0 = base;
 #pragma unroll
         for (int j = 0; j < HS_V; ++j) {

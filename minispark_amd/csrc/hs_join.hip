@@ -16,6 +16,8 @@
 // Reference loops replaced: BroadcastHashJoinTask.generate_chunks tasks.py:201-240 (zig-src/src/tasks.zig:70-194),
 // WriteToShufflePartitions.write tasks.py:347-375 for the two join inputs, LikeColumn / BinaryOperatorColumn on
 // strings sql.py:166-212, 262-266.  All HBM-bound integer / byte work.
+#include <stdlib.h>
+
 #include "hs_device.h"
 
 extern thread_local char g_hs_err[256];
@@ -482,7 +484,9 @@ struct Join8Args {
     int32_t key_min;
     int32_t n_win;
     int64_t per;                // rows per workgroup (a multiple of 4)
-    uint32_t* hist;             // [n_groups][n_win]: counts, then offsets inside the window's segment
+    int32_t staged, pad;        // the scatter stages a workgroup's tuples in LDS in window order (per <= HSJ8_STAGE_ROWS)
+    uint32_t* hist;             // [n_groups][n_win]: tuples of workgroup g in window w
+    uint32_t* offs;             // [n_groups][n_win]: where they start inside the window's segment (workgroup order)
     uint32_t* win_start;        // [n_win + 1]
     uint32_t* tuples;           // [n]: (offset in window) | payload << 24
     uint8_t* table;
@@ -527,17 +531,45 @@ __global__ void __launch_bounds__(512) k_join8_hist(const Join8Args A) {
     if (err) atomicOr(A.flags, err);
 }
 
-// per window: counts of the workgroups -> their offsets inside the window's segment (in workgroup order), total
-__global__ void __launch_bounds__(256) k_join8_scan_groups(uint32_t* hist, int32_t n_groups, int32_t n_win, uint32_t* win_total) {
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= n_win) return;
-    uint32_t run = 0;
-    for (int g = 0; g < n_groups; ++g) {  // lanes read consecutive windows of one workgroup's row: coalesced
-        const uint32_t c = hist[(int64_t)g * n_win + w];
-        hist[(int64_t)g * n_win + w] = run;
-        run += c;
+// per window: counts of the workgroups -> their offsets inside the window's segment (in workgroup order), total.
+// A workgroup takes 16 consecutive windows; its 64 lane groups take 16 workgroup rows each (a row's load is 64
+// contiguous bytes, all 16 of a lane in flight together), sums meet in LDS, a carry runs over chunks of 1024 rows.
+// (First version: one lane per window walking all rows with a dependent store in between - 4 workgroups, latency-bound.)
+__global__ void __launch_bounds__(1024) k_join8_scan_groups(const uint32_t* hist, uint32_t* offs, int32_t n_groups, int32_t n_win,
+                                                            uint32_t* win_total) {
+    constexpr int WPB = 16, SEGS = 1024 / WPB, RPS = 16;  // windows per workgroup, lane groups, rows per lane group and chunk
+    __shared__ uint32_t s_sum[SEGS][WPB];
+    __shared__ uint32_t s_carry[WPB];
+    const int wl = threadIdx.x & (WPB - 1), seg = threadIdx.x / WPB;
+    const int w = blockIdx.x * WPB + wl;
+    const bool on = w < n_win;
+    if (seg == 0) s_carry[wl] = 0;
+    __syncthreads();
+    for (int g0 = 0; g0 < n_groups; g0 += SEGS * RPS) {
+        uint32_t c[RPS];
+        uint32_t sum = 0;
+        const int gs = g0 + seg * RPS;
+#pragma unroll
+        for (int k = 0; k < RPS; ++k) {
+            const int g = gs + k;
+            c[k] = (on && g < n_groups) ? hist[(int64_t)g * n_win + w] : 0u;
+            sum += c[k];
+        }
+        s_sum[seg][wl] = sum;
+        __syncthreads();
+        uint32_t base = s_carry[wl];
+        for (int k = 0; k < seg; ++k) base += s_sum[k][wl];
+#pragma unroll
+        for (int k = 0; k < RPS; ++k) {
+            const int g = gs + k;
+            if (on && g < n_groups) offs[(int64_t)g * n_win + w] = base;
+            base += c[k];
+        }
+        __syncthreads();
+        if (seg == SEGS - 1) s_carry[wl] = base;
+        __syncthreads();
     }
-    win_total[w] = run;
+    if (seg == 0 && on) win_total[w] = s_carry[wl];
 }
 // exclusive scan of the window totals in place (one workgroup; n_win <= 16384): win_start[n_win] = all rows
 __global__ void __launch_bounds__(1024) k_join8_scan_windows(uint32_t* win_start, int32_t n_win) {
@@ -569,9 +601,10 @@ __global__ void __launch_bounds__(1024) k_join8_scan_windows(uint32_t* win_start
     if (tid == 0) win_start[n_win] = s_base;
 }
 
+// Direct form: tuples go straight to their place (4-byte stores, a (workgroup, window) segment fills up piecemeal).
 __global__ void __launch_bounds__(512) k_join8_scatter(const Join8Args A) {
     extern __shared__ __align__(16) uint32_t s_cur[];  // next free tuple position per window, for this workgroup
-    const uint32_t* mine = A.hist + (int64_t)blockIdx.x * A.n_win;
+    const uint32_t* mine = A.offs + (int64_t)blockIdx.x * A.n_win;
     for (int w = threadIdx.x; w < A.n_win; w += blockDim.x) s_cur[w] = A.win_start[w] + mine[w];
     __syncthreads();
     const int64_t r0 = (int64_t)blockIdx.x * A.per, r1 = r0 + A.per < A.n ? r0 + A.per : A.n;
@@ -592,6 +625,77 @@ __global__ void __launch_bounds__(512) k_join8_scatter(const Join8Args A) {
             const uint32_t pos = atomicAdd(&s_cur[w], 1u);
             A.tuples[pos] = off | (code << 24);
         }
+    }
+    if (err) atomicOr(A.flags, err);
+}
+
+// Staged form (a workgroup's rows fit LDS): the tuples are first laid out in LDS in window order - the workgroup's own
+// counts give every window its run - and then each run leaves as ONE contiguous store of a wave, so a (workgroup,
+// window) segment (64 bytes on average at sf=10) is written by one instruction instead of 16 stores spread over the
+// workgroup's lifetime (partial sectors evicted from L2 in between were the build's write amplification).
+static constexpr int HSJ8_STAGE_ROWS = 12288;   // 48 KiB of tuples
+static constexpr int HSJ8_STAGE_WINDOWS = 4096; // + 2 x 16 KiB of run starts / cursors
+__global__ void __launch_bounds__(512) k_join8_scatter_staged(const Join8Args A) {
+    extern __shared__ __align__(16) uint32_t s_lds[];
+    __shared__ uint32_t s_part[8];
+    const int NW = A.n_win, tid = threadIdx.x, nthr = blockDim.x, lane = tid & (HS_WAVE - 1), wv = tid / HS_WAVE;
+    uint32_t* s_base = s_lds;            // [NW + 1] start of every window's run in s_tup
+    uint32_t* s_cur = s_lds + NW + 1;    // [NW] fill cursors, later the runs' global positions
+    uint32_t* s_tup = s_cur + NW;        // [per]
+    const uint32_t* cnt = A.hist + (int64_t)blockIdx.x * NW;
+    for (int w = tid; w < NW; w += nthr) s_base[w] = cnt[w];
+    __syncthreads();
+    {   // exclusive scan of the counts in place: per-thread ranges, wave shuffles, one hop through LDS
+        const int per_t = (NW + nthr - 1) / nthr;
+        const int lo = tid * per_t < NW ? tid * per_t : NW, hi = lo + per_t < NW ? lo + per_t : NW;
+        uint32_t sum = 0;
+        for (int i = lo; i < hi; ++i) sum += s_base[i];
+        uint32_t x = sum;
+        for (int d = 1; d < HS_WAVE; d <<= 1) {
+            const uint32_t t = __shfl_up(x, d, HS_WAVE);
+            if (lane >= d) x += t;
+        }
+        if (lane == HS_WAVE - 1) s_part[wv] = x;
+        __syncthreads();
+        uint32_t run = x - sum;
+        for (int k = 0; k < wv; ++k) run += s_part[k];
+        for (int i = lo; i < hi; ++i) {
+            const uint32_t c = s_base[i];
+            s_base[i] = run;
+            run += c;
+        }
+        if (tid == nthr - 1) s_base[NW] = run;  // the last thread's range ends the table (or is empty: run = total)
+    }
+    __syncthreads();
+    for (int w = tid; w < NW; w += nthr) s_cur[w] = s_base[w];
+    __syncthreads();
+    const int64_t r0 = (int64_t)blockIdx.x * A.per, r1 = r0 + A.per < A.n ? r0 + A.per : A.n;
+    uint32_t err = 0;
+    for (int64_t q = r0 + (int64_t)tid * 4; q < r1; q += (int64_t)nthr * 4) {
+        const int4 kv = *reinterpret_cast<const int4*>(A.keys + q);
+        const int32_t k[4] = {kv.x, kv.y, kv.z, kv.w};
+        uint32_t pv = 0;
+        if (A.payload) pv = *reinterpret_cast<const uint32_t*>(A.payload + q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (q + j >= r1) break;
+            uint32_t off;
+            const int w = hsj8_window(A, q + j, k[j], off, err);
+            if (w < 0) continue;
+            const uint32_t code = (pv >> (8 * j)) & 0xffu;
+            if (code == 0xffu) err |= HS_FLAG_BAD_PROGRAM;
+            s_tup[atomicAdd(&s_cur[w], 1u)] = off | (code << 24);
+        }
+    }
+    __syncthreads();
+    const uint32_t* off_g = A.offs + (int64_t)blockIdx.x * NW;
+    for (int w = tid; w < NW; w += nthr) s_cur[w] = A.win_start[w] + off_g[w];
+    __syncthreads();
+    // a quarter wave per window (a run holds ~13 tuples at sf=10): four runs leave per wave instruction
+    for (int w = tid >> 4; w < NW; w += nthr >> 4) {
+        const uint32_t b = s_base[w], e = s_base[w + 1];
+        uint32_t* dst = A.tuples + s_cur[w];
+        for (uint32_t i = b + (lane & 15); i < e; i += 16) dst[i - b] = s_tup[i];
     }
     if (err) atomicOr(A.flags, err);
 }
@@ -634,11 +738,18 @@ __global__ void __launch_bounds__(512) k_join8_fill(const Join8Args A) {
 }
 
 static int64_t hsj8_windows(int64_t slots) { return (slots + HS_JOIN8_WINDOW - 1) >> HSJ8_WSHIFT; }
-static void hsj8_geometry(int64_t n, int64_t& per, int64_t& groups) {
-    per = (n + 1023) / 1024;
-    if (per < 8192) per = 8192;
-    per = (per + 3) & ~(int64_t)3;
+// rows per workgroup of the two passes over the build rows; staged = the scatter's LDS form applies
+static void hsj8_geometry(int64_t n, int64_t n_win, int64_t& per, int64_t& groups, bool& staged) {
+    static const bool allow = !(getenv("HIPSPARK_JOIN8_STAGED") && getenv("HIPSPARK_JOIN8_STAGED")[0] == '0');
+    per = HSJ8_STAGE_ROWS;
     groups = n > 0 ? (n + per - 1) / per : 0;
+    staged = allow && n_win <= HSJ8_STAGE_WINDOWS && (size_t)groups * (size_t)n_win * 8 <= ((size_t)256 << 20);
+    if (!staged) {  // big inputs: at most 1024 workgroups, tuples go straight to their place
+        per = (n + 1023) / 1024;
+        if (per < 8192) per = 8192;
+        per = (per + 3) & ~(int64_t)3;
+        groups = n > 0 ? (n + per - 1) / per : 0;
+    }
 }
 extern "C" size_t hs_join8_table_bytes(int64_t slots) {
     return slots < 1 ? 0 : (size_t)hsj8_windows(slots) * HS_JOIN8_WINDOW;
@@ -646,9 +757,10 @@ extern "C" size_t hs_join8_table_bytes(int64_t slots) {
 extern "C" size_t hs_join8_ws_bytes(int64_t n_build, int64_t slots) {
     if (n_build < 0 || slots < 1) return 0;
     int64_t per, groups;
-    hsj8_geometry(n_build, per, groups);
+    bool staged;
     const int64_t n_win = hsj8_windows(slots);
-    return (size_t)(groups * n_win + n_win + 1 + n_build) * 4 + 64;
+    hsj8_geometry(n_build, n_win, per, groups, staged);
+    return (size_t)(2 * groups * n_win + n_win + 1 + n_build) * 4 + 64;
 }
 extern "C" int hs_join8_build(void* stream, const int32_t* build_keys, const uint8_t* payload, int64_t n_build,
                               int64_t seg_len, const int64_t* seg_counts, int32_t key_min, int64_t slots, uint8_t* table,
@@ -669,7 +781,8 @@ extern "C" int hs_join8_build(void* stream, const int32_t* build_keys, const uin
         return HS_E_LIMIT;
     }
     int64_t per, groups;
-    hsj8_geometry(n_build, per, groups);
+    bool staged;
+    hsj8_geometry(n_build, n_win, per, groups, staged);
     Join8Args A;
     A.keys = build_keys;
     A.payload = payload;
@@ -680,28 +793,37 @@ extern "C" int hs_join8_build(void* stream, const int32_t* build_keys, const uin
     A.key_min = key_min;
     A.n_win = (int32_t)n_win;
     A.per = per;
+    A.staged = staged ? 1 : 0;
+    A.pad = 0;
     A.hist = (uint32_t*)ws;
-    A.win_start = A.hist + groups * n_win;
+    A.offs = A.hist + groups * n_win;
+    A.win_start = A.offs + groups * n_win;
     A.tuples = A.win_start + n_win + 1;
     A.table = table;
     A.flags = flags;
     hipStream_t s = (hipStream_t)stream;
+    const size_t stage_lds = (size_t)(2 * n_win + 1 + HSJ8_STAGE_ROWS) * 4;
     static unsigned long long attr_set = 0;
     if (hs_first_on_device(attr_set)) {
         hipFuncSetAttribute((const void*)k_join8_fill, hipFuncAttributeMaxDynamicSharedMemorySize, HS_JOIN8_WINDOW);
         hipFuncSetAttribute((const void*)k_join8_hist, hipFuncAttributeMaxDynamicSharedMemorySize, HSJ8_MAX_WINDOWS * 4);
         hipFuncSetAttribute((const void*)k_join8_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, HSJ8_MAX_WINDOWS * 4);
+        hipFuncSetAttribute((const void*)k_join8_scatter_staged, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (2 * HSJ8_STAGE_WINDOWS + 1 + HSJ8_STAGE_ROWS) * 4);
     }
     const size_t hist_lds = (size_t)n_win * 4;
     if (groups > 0) {
         hipLaunchKernelGGL(k_join8_hist, dim3((unsigned)groups), dim3(512), hist_lds, s, A);
-        hipLaunchKernelGGL(k_join8_scan_groups, dim3((unsigned)((n_win + 255) / 256)), dim3(256), 0, s, A.hist, (int32_t)groups,
-                           (int32_t)n_win, A.win_start);
+        hipLaunchKernelGGL(k_join8_scan_groups, dim3((unsigned)((n_win + 15) / 16)), dim3(1024), 0, s, A.hist, A.offs,
+                           (int32_t)groups, (int32_t)n_win, A.win_start);
     } else {
         hs_memset_async(A.win_start, 0, (size_t)(n_win + 1) * 4, s);
     }
     hipLaunchKernelGGL(k_join8_scan_windows, dim3(1), dim3(1024), 0, s, A.win_start, (int32_t)n_win);
-    if (groups > 0) hipLaunchKernelGGL(k_join8_scatter, dim3((unsigned)groups), dim3(512), hist_lds, s, A);
+    if (groups > 0) {
+        if (staged) hipLaunchKernelGGL(k_join8_scatter_staged, dim3((unsigned)groups), dim3(512), stage_lds, s, A);
+        else hipLaunchKernelGGL(k_join8_scatter, dim3((unsigned)groups), dim3(512), hist_lds, s, A);
+    }
     hipLaunchKernelGGL(k_join8_fill, dim3((unsigned)n_win), dim3(512), HS_JOIN8_WINDOW, s, A);
     HSJ_CHECK_LAUNCH("hs_join8_build");
     return HS_OK;

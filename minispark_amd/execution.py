@@ -361,7 +361,10 @@ class HipExecutionEngine(ExecutionEngine):
                         if self.tracer is not None:
                             self.tracer.end()
                     stage.job_results.extend(results)
-                self._plan_runs[rec_key] = self._plan_runs.get(rec_key, 0) + 1
+                # counted under the key the NEXT run will compute: a first run may re-code table columns (dictionaries)
+                # or learn capacities, which are part of the key
+                done_key = self._recording_key(plan)
+                self._plan_runs[done_key] = self._plan_runs.get(done_key, 0) + 1
                 if recording is not None:
                     self.dev.stop_recording()
                     recording.scan_info = getattr(self.dev, "last_scan", None)

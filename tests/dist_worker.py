@@ -54,6 +54,32 @@ def main() -> None:
 
         seed = int(case_name.split(":")[1])
         build = lambda api: _wide_query(random.Random(seed), api, str(Path(out_path).parent / "w.bin"))  # noqa: E731
+    elif case_name.startswith(("config4:", "config5:")):
+        # BASELINE configs 4 / 5 at size (tools/bench_configs.py): every rank generates its blocks (b % world) of the
+        # synthetic tables, rank 0 checks the rows against the C port of the reference's algorithm over the WHOLE tables
+        from types import SimpleNamespace
+
+        from tools.bench_configs import JoinWorkload, StrKeyWorkload
+
+        sf = float(case_name.split(":")[1])
+        with HipExecutionEngine(device=int(os.environ.get("LOCAL_RANK", "0"))) as engine:
+            engine.enable_distributed(dist)
+            cls, name = (JoinWorkload, "join") if case_name.startswith("config4:") else (StrKeyWorkload, "strkey")
+            wl = cls(engine, Path(out_path).parent / f"tables_r{rank}", SimpleNamespace(sf=sf, config=name), rank, world)
+            rows = None
+            for _ in range(5):
+                rows = wl.frame.collect()
+            report = {"replays": engine.replays, "fused_probes": engine.fused_probes, "rows": len(rows),
+                      "join": getattr(engine.dev, "last_join", None)}
+            if rank == 0:
+                report["check"] = wl.full_check(rows)
+                report["n"] = sum(r.get("n", r.get("count", 0)) for r in rows)
+                Path(out_path).write_text(json.dumps(report))
+            else:
+                assert rows == [], f"rank {rank} must not own result rows"
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     elif case_name.startswith("width:"):
         # GROUP BY a string key whose fixed width the ranks see differently (tests/test_gpu_distributed.py)
         from tests.test_gpu_distributed import width_query

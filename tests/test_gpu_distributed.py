@@ -197,6 +197,46 @@ def test_final_merge_outgrowing_its_capacity_is_retried_on_every_rank(tmp_path, 
     assert assert_rows_match(rows, want) == 0
 
 
+# ---- BASELINE config 4 as stated: hash-join + GROUP BY on N GPUs, at size ---------------------------------------------
+def _run_config_ranks(case: str, world: int, out, backend: str = "gloo") -> dict:
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(ROOT / "tests" / "dist_worker.py"), case, str(out), backend],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    if any(p.returncode != 0 for p in procs):
+        report = "\n".join(f"--- rank {r} (exit {p.returncode}) ---\n{log[-2500:]}" for r, (p, log) in enumerate(zip(procs, logs)))
+        raise AssertionError(report)
+    return json.loads(out.read_text())
+
+
+@pytest.mark.parametrize("world,backend,sf", [(2, "gloo", 10), (3, "gloo", 10), (1, "nccl", 10), (4, "gloo", 1)])
+def test_config4_on_n_ranks_matches_the_c_port(tmp_path, world, backend, sf):
+    """orders JOIN lineitem GROUP BY o_orderpriority with both tables spread over the ranks (block b on rank b % N):
+    dictionaries agreed across ranks, the build side all-gathered (key + code bytes), the byte table built on every
+    rank, the probe inside each rank's aggregate scan over its OWN lineitem blocks, raw unit tables added up over the
+    ranks before the one rounding per JoinJob, finish launch on every rank - equal to q4_run (the C port of the
+    reference's algorithm, pinned to its goldens) over the whole sf=10 tables.  RCCL itself at world 1."""
+    report = _run_config_ranks(f"config4:{sf}", world, tmp_path / "report.json", backend)
+    assert report["check"]["gpu_matches_oracle_full"], report
+    assert report["check"]["f32_ulp_flips_full"] <= 2
+    assert report["fused_probes"] >= 1 and report["join"]["mode"] == "byte table", "N ranks must not fall back to the general join"
+    assert report["replays"] >= 1, "recorded and replayed, collectives included"
+    assert report["rows"] == 5 and report["n"] > 0
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_config5_on_n_ranks_matches_the_c_port(tmp_path, world):
+    """LIKE + CONCAT-key GROUP BY with l_shipmode / l_returnflag dictionary-coded on every rank in ONE agreed dictionary
+    per column: predicate bits, product dictionary and the coded key in the exchange slabs mean the same on all ranks."""
+    report = _run_config_ranks("config5:1", world, tmp_path / "report.json")
+    assert report["check"]["gpu_matches_oracle_full"], report
+    assert report["rows"] == 6 and report["replays"] >= 1
+
+
 # ---- RCCL itself (backend "nccl"): one rank per device, so world 1 on the one-GPU test box ----------------------------
 @pytest.mark.parametrize("case_name", ["q1_multiblock", "q1_ragged_blocks", "join_group", "concat_like", "many_groups",
                                        "e2e_join_select", "fruit"])

@@ -303,7 +303,7 @@ def test_in_place_join_matches_the_oracle(engine, tmp_path, name, probe):
         assert engine.fused_probes == 0 or engine._no_join8 or name not in FUSED_PROBE
 
 
-@pytest.mark.parametrize("variant", ["plain", "segments", "duplicate", "out_of_range", "no_payload"])
+@pytest.mark.parametrize("variant", ["plain", "segments", "duplicate", "out_of_range", "no_payload", "wide"])
 def test_join8_build_against_numpy(engine, variant):
     """hs_join8_build: window histogram -> scan -> (offset, payload) tuples by window -> windows assembled in LDS.
     The table must equal a plain scatter; duplicate keys, keys outside the table and padded segments are reported /
@@ -316,12 +316,17 @@ def test_join8_build_against_numpy(engine, variant):
     rng = np.random.default_rng(11)
     n, key_min = 200_000, -7000
     slots = 5 * hs.JOIN8_WINDOW + 1234  # six windows, the last one partial
-    keys = (rng.permutation(slots)[:n] + key_min).astype(np.int32)
+    if variant == "wide":  # more windows than the staged scatter's LDS tables hold: tuples go straight to their place
+        slots = 4100 * hs.JOIN8_WINDOW + 77
+        keys = (rng.choice(slots, n, replace=False) + key_min).astype(np.int32)
+    else:
+        keys = (rng.permutation(slots)[:n] + key_min).astype(np.int32)
+    n_win = -(-slots // hs.JOIN8_WINDOW)
     payload = rng.integers(0, 255, n).astype(np.uint8)
     seg_len, counts = 0, None
     valid = np.ones(n, dtype=bool)
-    if variant == "segments":  # three segments of 70 000 rows, the valid prefixes differ
-        seg_len, per = 70_000, [70_000, 12_345, 0]
+    if variant == "segments":  # three segments of 60 000 rows, the valid prefixes differ
+        seg_len, per = 60_000, [60_000, 12_345, 0]
         keys, payload = keys[: 3 * seg_len].copy(), payload[: 3 * seg_len].copy()
         valid = np.concatenate([np.arange(seg_len) < c for c in per])
         keys[~valid] = rng.integers(-(2**31), 2**31 - 1, int((~valid).sum()), dtype=np.int64).astype(np.int32)  # garbage padding
@@ -342,8 +347,8 @@ def test_join8_build_against_numpy(engine, variant):
                                     counts.data_ptr() if counts is not None else None, key_min, slots, table.data_ptr(),
                                     ws.data_ptr(), dev.flags.data_ptr()), "hs_join8_build")
     flags = dev.read_flags()
-    got = table.cpu().numpy()[: 6 * hs.JOIN8_WINDOW]
-    want = np.full(6 * hs.JOIN8_WINDOW, 0xFF, dtype=np.uint8)
+    got = table.cpu().numpy()[: n_win * hs.JOIN8_WINDOW]
+    want = np.full(n_win * hs.JOIN8_WINDOW, 0xFF, dtype=np.uint8)
     want[(keys[valid].astype(np.int64) - key_min)] = payload[valid] if variant != "no_payload" else 0
     if variant == "duplicate":
         assert flags & hs.FLAG_JOIN_DUP

@@ -211,12 +211,15 @@ class StrKeyWorkload(_Workload):
         from minispark_amd import synth, workloads
 
         self.li_path = scratch / "lineitem.bin"
-        self.table = synth.make_lineitem(engine.dev, self.li_path, self.n_li, with_shipmode=True)
+        self.table = synth.make_lineitem(engine.dev, self.li_path, self.n_li, with_shipmode=True, rank=rank, world=world)
         engine.attach_device_table(self.li_path, self.table)
         self.mode_bytes = sum(len(m) for m in workloads.SHIPMODES) / len(workloads.SHIPMODES)
         self.frame = workloads.strkey_like(workloads.engine_api(engine), str(self.li_path))
         # dominant kernel = the fused scan (WHERE on the code column + GROUP BY the coded key): the library's own event
         # pair around it (Device.scan_kernel_ms), like Q1
+
+    def exchange_text(self, backend: str) -> str:
+        return f"one all_gather of partial-row slabs per query ({backend}); string columns coded in one dictionary agreed by all ranks"
 
     def algorithmic_bytes_per_launch(self) -> float:
         return self.n_li * (4 + 4 + 2 + 1 + self.mode_bytes)
@@ -229,14 +232,15 @@ class StrKeyWorkload(_Workload):
                 "rows": self.n_li, "groups": len(rows or []), "dictionary_coded": coded}
 
     def roofline(self, kernel_avg_ms: float) -> dict:
-        algo = self.algorithmic_bytes_per_launch()
+        n_local = self.table.nrows
+        algo = n_local * (4 + 4 + 2 + 1 + self.mode_bytes)
         achieved = algo / (kernel_avg_ms * 1e-3) / 1e9
-        moved = self.n_li * (4 + 4 + 1 + 1)
+        moved = n_local * (4 + 4 + 1 + 1)
         return {"bound": "hbm", "kernel": "k_agg_jit: fused scan + WHERE (bit test on the l_shipmode code) + GROUP BY the coded "
                                           "CONCAT key + partial aggregate (after one pass over code bytes that builds the key)",
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                "kernel_ms": kernel_avg_ms, "rows_per_launch": self.n_li,
-                "algorithmic_bytes_per_row": algo / self.n_li, "moved_bytes_per_row": moved / self.n_li,
+                "kernel_ms": kernel_avg_ms, "rows_per_launch": n_local,
+                "algorithmic_bytes_per_row": algo / max(n_local, 1), "moved_bytes_per_row": moved / max(n_local, 1),
                 "moved_GBps": moved / (kernel_avg_ms * 1e-3) / 1e9, "launch": self.engine.dev.last_scan,
                 "accounting": "algorithmic (SURVEY 8d) = 4 (qty) + 4 (discount) + (1 + len) of l_returnflag and l_shipmode; moved = "
                               "the two f32 columns + one key-code byte + one shipmode-code byte (both string columns are "
