@@ -301,6 +301,10 @@ struct MergeFlatIn {
         return A.hashed ? hs_dict_upsert_rows(dreps, mask, A.key, k, r) : hs_dict_upsert_word(dkeys, dreps, mask, k, r);
     }
     __device__ __forceinline__ uint64_t cell(int a, int r) const { return hs_load_cell(A.acc_cols[a], r); }
+    // handle of a row = what the sort-free merge keeps per (unit, group): here the row itself
+    __device__ __forceinline__ int handle(int r) const { return r; }
+    __device__ __forceinline__ int row_of(int h) const { return h; }
+    __device__ __forceinline__ uint64_t cell_h(int a, int h) const { return cell(a, h); }
 };
 
 struct AggFinishArgs {
@@ -367,6 +371,22 @@ struct MergeSlabIn {
         const uint8_t* base = s + A.desc.acc_off[src];
         if (A.desc.acc_kind[src] == HS_I32) return (uint64_t)(int64_t)((const int32_t*)base)[i];
         return hs_d2u((double)((const float*)base)[i]);
+    }
+    // handle = the row's element index relative to ANY 4-byte column of slab 0 (slabs are stride bytes apart, stride a
+    // multiple of 16): the fold reads cells without dividing by the slab length again
+    __device__ __forceinline__ int handle(int r) const {
+        const int k = r / (int)A.desc.slab_rows;
+        return k * (int)(A.desc.stride >> 2) + (r - k * (int)A.desc.slab_rows);
+    }
+    __device__ __forceinline__ int row_of(int h) const {
+        const int k = h / (int)(A.desc.stride >> 2);
+        return k * (int)A.desc.slab_rows + (h - k * (int)(A.desc.stride >> 2));
+    }
+    __device__ __forceinline__ uint64_t cell_h(int a, int h) const {
+        const int src = A.fin.fold_src[a];
+        const uint8_t* base = V.slabs + A.desc.acc_off[src];
+        if (A.desc.acc_kind[src] == HS_I32) return (uint64_t)(int64_t)((const int32_t*)base)[h];
+        return hs_d2u((double)((const float*)base)[h]);
     }
 };
 
@@ -453,37 +473,56 @@ __device__ __forceinline__ uint64_t hs_fold_bucket_wave(uint32_t op, bool is_int
     return hs_d2u(__shfl(incl, HS_WAVE - 1, HS_WAVE));
 }
 
-// The same fold over a sequence given by a functor: get(i) = cell i of the sequence, or the aggregate's identity for
-// a position that holds nothing (SUM: adding +0.0 / 0 changes neither the value - the accumulator starts from the
-// identity and so is never -0.0 - nor the exactness bookkeeping; MIN / MAX: folding the identity in again is a no-op,
-// the reference's accumulators start from it, tasks.py:303-310).
+// The same fold over a sequence given by a functor, by a GROUP of `width` lanes (16, 32 or 64: several folds share a
+// wave when there are more (group, aggregate) pairs than waves, or few positions per fold).  get(i) = cell i of the
+// sequence, or the aggregate's identity for a position that holds nothing (SUM: adding +0.0 / 0 changes neither the
+// value - the accumulator starts from the identity and so is never -0.0 - nor the exactness bookkeeping; MIN / MAX:
+// folding the identity in again is a no-op, the reference's accumulators start from it, tasks.py:303-310).  Every lane
+// of the wave must call this (m = 0 for a group without work); the result is valid on all lanes of the group.
 template <class Get>
-__device__ __forceinline__ uint64_t hs_fold_wave_indexed(uint32_t op, bool is_int, const Get& get, int m, int lane, bool& exact) {
-    const int c = (m + HS_WAVE - 1) / HS_WAVE;
-    const int lo = lane * c < m ? lane * c : m, hi = (lo + c) < m ? (lo + c) : m;
+__device__ __forceinline__ uint64_t hs_fold_group_indexed(uint32_t op, bool is_int, const Get& get, int m, int lane, int width,
+                                                          bool& exact) {
+    const int ln = lane & (width - 1), first_lane = lane - ln;
+    const int c = (m + width - 1) / width;
+    const int lo = ln * c < m ? ln * c : m, hi = (lo + c) < m ? (lo + c) : m;
     exact = true;
     if (is_int || op != HS_AGG_SUM) {
         uint64_t v = hs_acc_identity(op, is_int);
         for (int i = lo; i < hi; ++i) v = hs_acc_fold(op, is_int, v, get(i));
-        for (int d = 1; d < HS_WAVE; d <<= 1) {
-            const uint64_t other = __shfl_down(v, d, HS_WAVE);
-            if (lane + d < HS_WAVE) v = hs_acc_fold(op, is_int, v, other);
+        for (int d = 1; d < width; d <<= 1) {  // lane L holds lanes L .. L+2d-1 after the step; the group's lane 0 ends with all
+            const uint64_t other = __shfl_down(v, d, width);
+            if (ln + d < width) v = hs_acc_fold(op, is_int, v, other);
         }
-        return __shfl(v, 0, HS_WAVE);
+        return __shfl(v, first_lane, HS_WAVE);
     }
     bool ok = true;
     double s = 0.0;
-    for (int i = lo; i < hi; ++i) ok &= hs_add_exact(s, hs_u2d(get(i)), s);
-    double incl = s;
-    for (int d = 1; d < HS_WAVE; d <<= 1) {
-        const double before = __shfl_up(incl, d, HS_WAVE);
-        if (lane >= d) ok &= hs_add_exact(before, incl, incl);
+    constexpr int KEEP = 12;  // a lane's cells stay in registers for the second pass
+    double kept[KEEP];
+    if (c <= KEEP) {
+#pragma unroll
+        for (int j = 0; j < KEEP; ++j) kept[j] = lo + j < hi ? hs_u2d(get(lo + j)) : 0.0;
+#pragma unroll
+        for (int j = 0; j < KEEP; ++j) ok &= hs_add_exact(s, kept[j], s);
+    } else {
+        for (int i = lo; i < hi; ++i) ok &= hs_add_exact(s, hs_u2d(get(i)), s);
     }
-    double q = __shfl_up(incl, 1, HS_WAVE);
-    if (lane == 0) q = 0.0;
-    for (int i = lo; i < hi; ++i) ok &= hs_add_exact(q, hs_u2d(get(i)), q);
-    exact = __all(ok);
-    return hs_d2u(__shfl(incl, HS_WAVE - 1, HS_WAVE));
+    double incl = s;
+    for (int d = 1; d < width; d <<= 1) {
+        const double before = __shfl_up(incl, d, width);
+        if (ln >= d) ok &= hs_add_exact(before, incl, incl);
+    }
+    double q = __shfl_up(incl, 1, width);
+    if (ln == 0) q = 0.0;
+    if (c <= KEEP) {
+#pragma unroll
+        for (int j = 0; j < KEEP; ++j) ok &= hs_add_exact(q, kept[j], q);
+    } else {
+        for (int i = lo; i < hi; ++i) ok &= hs_add_exact(q, hs_u2d(get(i)), q);
+    }
+    const unsigned long long mine = width == HS_WAVE ? ~0ull : (((1ull << width) - 1) << first_lane);
+    exact = (__ballot(ok) & mine) == mine;
+    return hs_d2u(__shfl(incl, first_lane + width - 1, HS_WAVE));
 }
 
 // Final merge, everything staged in LDS.  The partials of a group must be folded in the reference's
@@ -557,80 +596,82 @@ __device__ __forceinline__ int hs_merge_small_core(const In& in, const hs_agg_sp
                 ferr |= HS_FLAG_BAD_PROGRAM;
             } else {
                 atomicAdd(&cnt[sl], 1);
-                if (atomicCAS(&M[(int)o * cap + sl], -1, r) != -1) s_dup = 1;
+                if (atomicCAS(&M[(int)o * cap + sl], -1, in.handle(r)) != -1) s_dup = 1;
             }
         }
         __syncthreads();
         HS_STAMP(2);
         if (!s_dup) {
             err |= ferr;
-            const int per = (cap + nthr - 1) / nthr;
-            const int s0 = tid * per, s1 = (s0 + per) < cap ? (s0 + per) : cap;
-            int mine = 0;
-            for (int sl = s0; sl < s1; ++sl) mine += cnt[sl] > 0;
             int ngroups;
-            int drun = hs_block_scan_incl(mine, s_part, ngroups) - mine;
-            for (int sl = s0; sl < s1; ++sl) {
-                if (cnt[sl] > 0) run[drun++] = sl;  // dense output row -> slot
+            if (cap <= HS_WAVE) {  // the usual few groups: one ballot numbers them
+                if (tid < HS_WAVE) {
+                    const bool has = tid < cap && cnt[tid] > 0;
+                    const unsigned long long m = __ballot(has);
+                    if (has) run[__popcll(m & ((1ull << tid) - 1))] = tid;  // dense output row -> slot
+                    if (tid == 0) s_part[0] = __popcll(m);
+                }
+                __syncthreads();
+                ngroups = s_part[0];
+                __syncthreads();  // (s_part is reused by later scans)
+            } else {
+                const int per = (cap + nthr - 1) / nthr;
+                const int s0 = tid * per, s1 = (s0 + per) < cap ? (s0 + per) : cap;
+                int mine = 0;
+                for (int sl = s0; sl < s1; ++sl) mine += cnt[sl] > 0;
+                int drun = hs_block_scan_incl(mine, s_part, ngroups) - mine;
+                for (int sl = s0; sl < s1; ++sl) {
+                    if (cnt[sl] > 0) run[drun++] = sl;
+                }
+                __syncthreads();
             }
-            __syncthreads();
             HS_STAMP(3);
             HS_STAMP(4);
             HS_STAMP(5);
             HS_STAMP(6);
             const int lane = tid & (HS_WAVE - 1), wv = tid / HS_WAVE, nwv = nthr / HS_WAVE;
-            if (nord >= 96) {
-                // a wave per (group, aggregate); its first task per group also finds the group's first row
-                for (int c = wv; c < ngroups * (NA > 0 ? NA : 1); c += nwv) {
-                    const int g = NA > 0 ? c / NA : c, a = NA > 0 ? c - g * NA : 0;
-                    const int sl = run[g];
-                    if (a == 0) {
-                        int first = 0x7fffffff;
-                        for (int o = lane; o < nord; o += HS_WAVE)
+            // One fold per (group, aggregate), by a lane group of 16 / 32 / 64 lanes: as wide as possible while all folds
+            // still fit one round of the workgroup's waves, and no wider than the sequence is long.  A further task per
+            // group finds its first row (the representative the key is copied from).
+            const int per_group = NA + 1, ntasks = ngroups * per_group;
+            int width = HS_WAVE;
+            while (width > 16 && (ntasks > nwv * (HS_WAVE / width) || nord <= width / 2)) width >>= 1;
+            const int per_wave = HS_WAVE / width, nslots = nwv * per_wave, ln = lane & (width - 1);
+            for (int c0 = 0; c0 < ntasks; c0 += nslots) {  // uniform trip count: every lane reaches the shuffles
+                const int c = c0 + wv * per_wave + lane / width;
+                const bool valid = c < ntasks;
+                const int g = valid ? c / per_group : 0, a = valid ? c - g * per_group - 1 : 0;  // a == -1: the first row
+                const int sl = valid ? run[g] : 0;
+                if (a < 0) {
+                    int first = 0x7fffffff;
+                    if (valid)
+                        for (int o = ln; o < nord; o += width)
                             if (M[o * cap + sl] >= 0) { first = o; break; }
-                        for (int d = HS_WAVE / 2; d >= 1; d >>= 1) {
-                            const int other = __shfl_down(first, d, HS_WAVE);
-                            first = other < first ? other : first;
-                        }
-                        if (lane == 0) out_rep[g] = M[first * cap + sl];
+                    for (int d = width / 2; d >= 1; d >>= 1) {
+                        const int other = __shfl_down(first, d, width);
+                        first = other < first ? other : first;
                     }
-                    if (NA == 0) continue;
-                    const uint32_t op = spec.op[a];
-                    const bool is_int = spec.is_int[a] != 0;
-                    const uint64_t ident = hs_acc_identity(op, is_int);
-                    auto get = [&](int o) -> uint64_t {
-                        const int r = M[o * cap + sl];
-                        return r >= 0 ? in.cell(a, r) : ident;
-                    };
-                    bool exact;
-                    uint64_t v = hs_fold_wave_indexed(op, is_int, get, nord, lane, exact);
-                    if (!exact && lane == 0) {  // the reference's own chain (fp64 additions in unit order)
+                    if (valid && ln == 0) out_rep[g] = first < nord ? in.row_of(M[first * cap + sl]) : -1;
+                }
+                // (groups of a wave may differ in `a`: the fold below is executed by all of them, a < 0 folds nothing)
+                const int aa = a < 0 ? 0 : a;
+                const uint32_t op = NA > 0 ? spec.op[aa] : HS_AGG_SUM;
+                const bool is_int = NA > 0 ? spec.is_int[aa] != 0 : true;
+                const uint64_t ident = hs_acc_identity(op, is_int);
+                auto get = [&](int o) -> uint64_t {
+                    const int h = M[o * cap + sl];
+                    return h >= 0 ? in.cell_h(aa, h) : ident;
+                };
+                bool exact;
+                uint64_t v = hs_fold_group_indexed(op, is_int, get, (valid && a >= 0) ? nord : 0, lane, width, exact);
+                if (valid && a >= 0 && ln == 0) {
+                    if (!exact) {  // the reference's own chain (fp64 additions in unit order)
                         double acc = 0.0;
                         for (int o = 0; o < nord; ++o) {
-                            const int r = M[o * cap + sl];
-                            if (r >= 0) acc = acc + hs_u2d(in.cell(a, r));
+                            const int h = M[o * cap + sl];
+                            if (h >= 0) acc = acc + hs_u2d(in.cell_h(a, h));
                         }
                         v = hs_d2u(acc);
-                    }
-                    if (lane == 0) out_acc[(int64_t)a * cap + g] = v;
-                }
-            } else {
-                // few units: a lane per (group, aggregate) walks them in order
-                for (int c = tid; c < ngroups * (NA + 1); c += nthr) {
-                    const int g = c / (NA + 1), a = c - g * (NA + 1) - 1;  // a == -1: the group's first row
-                    const int sl = run[g];
-                    if (a < 0) {
-                        int first = -1;
-                        for (int o = 0; o < nord && first < 0; ++o) first = M[o * cap + sl];
-                        out_rep[g] = first;
-                        continue;
-                    }
-                    const uint32_t op = spec.op[a];
-                    const bool is_int = spec.is_int[a] != 0;
-                    uint64_t v = hs_acc_identity(op, is_int);
-                    for (int o = 0; o < nord; ++o) {
-                        const int r = M[o * cap + sl];
-                        if (r >= 0) v = hs_acc_fold(op, is_int, v, in.cell(a, r));
                     }
                     out_acc[(int64_t)a * cap + g] = v;
                 }
