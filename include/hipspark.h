@@ -598,6 +598,21 @@ int hs_slab_unpack(void* stream, const uint8_t* gathered, int32_t world, int64_t
                    void* const* col_dsts, int32_t* flags_out, int64_t* order_out);
 
 /* =================================================================================================
+ * Multi-GPU: pack / unpack of the generic row exchange (round 3; csrc/hs_exchange.hip).  A rank's rows for all
+ * peers travel in ONE byte buffer (all_to_all_single): destination-major, inside a destination's share one slice per
+ * column piece (fixed-width values; length bytes and payload bytes of a STRING column).  Replaces the reference's
+ * per-partition shuffle files, written row by row (tasks.py:347-375) and concatenated by the reader
+ * (tasks.py:144-150).  Both directions are one launch over a device-resident list of segments:
+ * dst[0 .. bytes) = src[0 .. bytes) for every segment; max_bytes = the largest segment (sizes the launch).
+ * ===============================================================================================*/
+typedef struct hs_segment {
+    const void* src;
+    void* dst;
+    int64_t bytes;
+} hs_segment;
+int hs_copy_segments(void* stream, const hs_segment* segments_dev, int32_t n_segments, int64_t max_bytes);
+
+/* =================================================================================================
  * Run-time specialisation (reference: codegen.py:230-247 compiles every query with `zig build`).
  * hs_agg_partial translates its bytecode to straight-line code inside the hand-written kernel skeleton,
  * compiles it with hiprtc for the running GPU and caches it per program; on any failure it launches the

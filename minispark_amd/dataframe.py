@@ -83,6 +83,11 @@ class DataFrame:
     def collect(self) -> list:
         return self._rows()
 
+    def collect_columns(self) -> dict:
+        """The result column-wise: name -> numpy array (or list of str) - see ExecutionEngine.collect_columns."""
+        engine = self.engine
+        return engine.collect_columns(engine.execute_full_task(self.task))
+
     def show(self, n: int = 10) -> int:
         import tabulate  # noqa: PLC0415
 

@@ -1626,6 +1626,75 @@ class Device:
             self.rec.poisoned = True
         return perm, [int(v) for v in part_start.tolist()]
 
+    # ---- device-side packing of the row exchange between ranks ---------------------------------------------------
+    torch = torch  # (the engine's exchange code names dtypes without importing torch itself)
+
+    @staticmethod
+    def torch_dtype(kind: int) -> torch.dtype:
+        return _TORCH_DTYPE[kind]
+
+    def partition_by_ids_dev(self, ids: torch.Tensor, n: int, n_parts: int) -> tuple[torch.Tensor, torch.Tensor]:
+        """partition_by_ids without the read-back: -> (perm, start int64[n_parts + 1] on the device)."""
+        perm = self.empty(max(n, 1), torch.int64)
+        part_start = self.empty(n_parts + 1, torch.int64)
+        ws = self.workspace(self.lib.hs_partition_ws_bytes(n, n_parts))
+        hs.check(self.lib.hs_partition_perm(self.stream, ids.data_ptr() if n > 0 else None, n, n_parts, perm.data_ptr(),
+                                            part_start.data_ptr(), ws.data_ptr()), "hs_partition_perm")
+        return perm, part_start
+
+    def permute_col(self, col: DCol, perm: torch.Tensor, n: int) -> DCol:
+        """col[perm[i]] for a permutation of ALL n rows.  Unlike gather_col the host learns nothing: the payload of a
+        variable-length STRING column is exactly as long as the source's, so its buffer is sized from that."""
+        if col.kind != hs.STR or col.fixed_len in (1, 2, 4, 8):
+            return self.gather_col(col, perm, n)
+        src = col.as_hs()
+        lens = self.empty(n, torch.uint8)
+        hs.check(self.lib.hs_gather_str_lens(self.stream, C.byref(src), col.n, perm.data_ptr(), n, lens.data_ptr(),
+                                             self.flags.data_ptr()), "hs_gather_str_lens")
+        offs = self.empty(n + 1, torch.int64)
+        minmax = self.empty(2, torch.int32)
+        ws = self.workspace(self.lib.hs_scan_ws_bytes(n))
+        hs.check(self.lib.hs_str_offsets(self.stream, lens.data_ptr(), n, offs.data_ptr(), minmax.data_ptr(), ws.data_ptr()),
+                 "hs_str_offsets")
+        data = self.empty(int(col.data.numel()), torch.uint8)
+        hs.check(self.lib.hs_gather_str_bytes(self.stream, C.byref(src), col.n, perm.data_ptr(), n, offs.data_ptr(),
+                                              data.data_ptr()), "hs_gather_str_bytes")
+        if col.fixed_len >= 0:  # every row has that length: the payload is n x fixed_len bytes, no offsets needed
+            return DCol(hs.STR, data, n, lens=lens, offs=None, fixed_len=col.fixed_len)
+        return DCol(hs.STR, data, n, lens=lens, offs=offs, fixed_len=-1)
+
+    def exchange_boundaries(self, start_dev: torch.Tensor, world: int, offs_list: Sequence[torch.Tensor]):
+        """The sizes the host needs to lay out an exchange, in ONE device->host copy: the destination boundaries
+        start[0 .. world] and, per variable-length payload, its byte offsets at those boundaries."""
+        k = len(offs_list)
+        out = self.empty((world + 1) * (1 + k), torch.int64)
+        out[: world + 1].copy_(start_dev[: world + 1])
+        for j, offs in enumerate(offs_list):
+            dst = out[(world + 1) * (1 + j): (world + 1) * (2 + j)]
+            hs.check(self.lib.hs_gather_fixed(self.stream, offs.data_ptr(), 8, offs.numel(), start_dev.data_ptr(), world + 1,
+                                              None, dst.data_ptr(), self.flags.data_ptr()), "hs_gather_fixed")
+        if self.rec is not None:
+            self.rec.poisoned = True  # sizes reach the host
+        flat = out.tolist()
+        start = [int(v) for v in flat[: world + 1]]
+        var = [[int(v) for v in flat[(world + 1) * (1 + j): (world + 1) * (2 + j)]] for j in range(k)]
+        return start, var
+
+    def copy_segments(self, segs: Sequence[tuple[int, int, int]]) -> None:
+        """dst <- src for a list of (source address, destination address, bytes): one launch (hs_copy_segments)."""
+        if not segs:
+            return
+        arr = np.zeros((len(segs), 3), dtype=np.int64)
+        arr[:] = segs
+        recording, self.rec = self.rec, None  # (an exchange is never part of a recording: its sizes reached the host)
+        try:
+            d_segs = self.to_device(arr.reshape(-1))
+        finally:
+            self.rec = recording
+        hs.check(self.lib.hs_copy_segments(self.stream, d_segs.data_ptr(), len(segs), int(arr[:, 2].max())), "hs_copy_segments")
+        if self.rec is not None:
+            self.rec.keep.append(d_segs)
+
     def partition_ids(self, batch: DBatch, key_index: int, n_parts: int) -> torch.Tensor:
         part = self.empty(batch.nrows, torch.uint8)
         key = batch.cols[key_index].as_hs()
@@ -1741,8 +1810,6 @@ class Device:
         slots, key_min = shape["slots"], shape["key_min"]
         table = self.workspace(self.lib.hs_join8_table_bytes(slots))
         keys, codes, n, seg_len, counts = build_key.data, payload.data if payload is not None else None, build_key.n, 0, None
-        if self.join_events is not None:
-            self.op(self.join_events[0].record)
         if dist_ctx is not None:
             from .distributed import all_gather_into  # noqa: PLC0415
 
@@ -1766,6 +1833,8 @@ class Device:
             counts = self.to_device_const(np.asarray(shape["rows"], dtype=np.int64))
             n = world * seg_len
         ws = self.workspace(self.lib.hs_join8_ws_bytes(n, slots))
+        if self.join_events is not None:  # the build kernels alone (the gather above is timed as exchange)
+            self.op(self.join_events[0].record)
         hs.check(self.lib.hs_join8_build(self.stream, keys.data_ptr(), codes.data_ptr() if codes is not None else None, n,
                                          seg_len, counts.data_ptr() if counts is not None else None, key_min, slots,
                                          table.data_ptr(), ws.data_ptr(), self.flags.data_ptr()), "hs_join8_build")

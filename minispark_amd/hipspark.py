@@ -93,6 +93,10 @@ class hs_join8(C.Structure):
     _fields_ = [("table", C.c_void_p), ("slots", C.c_int64), ("key_min", C.c_int32), ("n_parts", C.c_int32)]
 
 
+class hs_segment(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("bytes", C.c_int64)]
+
+
 class hs_chunk(C.Structure):
     _fields_ = [("row_begin", C.c_int64), ("row_end", C.c_int64), ("unit_begin", C.c_int64), ("unit", C.c_int64)]
 
@@ -257,6 +261,7 @@ SIGNATURES: dict[str, tuple] = {
     "hs_quantise_many": (C.c_int, [_P, _I32, C.POINTER(_P), C.POINTER(_I32), _I64, _P, C.POINTER(_P), _P]),
     "hs_slab_unpack": (C.c_int, [_P, _P, _I32, _I64, _I64, _I64, _I32, C.POINTER(_I64), C.POINTER(_I32),
                                  C.POINTER(_P), _P, _P]),
+    "hs_copy_segments": (C.c_int, [_P, _P, _I32, _I64]),
     "hs_jit_set_enabled": (None, [C.c_int]),
     "hs_jit_get_enabled": (C.c_int, []),
     "hs_jit_stats": (None, [C.POINTER(_I32)]),

@@ -551,10 +551,9 @@ def _rows_from_bytes(buf: bytes) -> Iterator[Row]:
             yield dict(zip(names, row, strict=True))
 
 
-def rows_from_raw(schema: Schema, cols: Sequence[RawColumn]) -> Iterator[Row]:
-    """Rows (dicts of Python values) straight from raw columns: the values a reader of the BlockFile
-    holding these columns would produce (f32 widened to float, TIMESTAMP as datetime, STRING as str)."""
-    names = [n for n, _ in schema]
+def python_columns(schema: Schema, cols: Sequence[RawColumn]) -> list[list]:
+    """Raw columns -> lists of the Python values a reader of the BlockFile holding them would produce (f32 widened to
+    float, TIMESTAMP as datetime, STRING as str): the column-wise form of rows_from_raw."""
     values = []
     for (_, col_type), c in zip(schema, cols, strict=True):
         if isinstance(c, StrCol):
@@ -568,8 +567,56 @@ def rows_from_raw(schema: Schema, cols: Sequence[RawColumn]) -> Iterator[Row]:
             values.append(timestamps_to_datetimes(np.asarray(c, dtype=np.int64)))
         else:
             values.append(c.tolist())
-    # dict(zip(names, row)) per row without a Python-level loop: result sets of thousands of groups spend their time here
-    yield from map(dict, map(zip, itertools.repeat(names), zip(*values, strict=True)))
+    return values
+
+
+_ROW_BUILDERS: dict[int, Any] = {}
+
+
+def _row_builder(width: int) -> Any:
+    """names, columns -> [{name: value, ...} per row] as ONE list comprehension over a dict display of `width`
+    entries: ~2x the speed of dict(zip(names, row)) per row - result sets of 10^5 groups spend their time here."""
+    fn = _ROW_BUILDERS.get(width)
+    if fn is None:
+        keys = ", ".join(f"k{i}" for i in range(width))
+        vals = ", ".join(f"v{i}" for i in range(width))
+        cols = ", ".join(f"c{i}" for i in range(width))
+        body = ", ".join(f"k{i}: v{i}" for i in range(width))
+        comma = "," if width == 1 else ""
+        src = (f"def build(names, columns):\n    {keys}{comma} = names\n    {cols}{comma} = columns\n"
+               f"    return [{{{body}}} for {vals}{comma} in zip({cols})]\n")
+        scope: dict[str, Any] = {}
+        exec(src, scope)  # noqa: S102 - generated from an integer only
+        fn = _ROW_BUILDERS[width] = scope["build"]
+    return fn
+
+
+def rows_list_from_raw(schema: Schema, cols: Sequence[RawColumn]) -> list[Row]:
+    """rows_from_raw as a list, built without a generator in between."""
+    names = [n for n, _ in schema]
+    values = python_columns(schema, cols)
+    if not names:
+        return []
+    if len({len(v) for v in values}) != 1:
+        raise ValueError("columns of one result differ in length")
+    # 10^5 new dicts would trigger a dozen passes of the cyclic collector over objects that cannot be garbage yet
+    # (a third of the construction time): paused for the one comprehension
+    import gc  # noqa: PLC0415
+
+    paused = len(values[0]) >= 4096 and gc.isenabled()
+    if paused:
+        gc.disable()
+    try:
+        return _row_builder(len(names))(names, values)
+    finally:
+        if paused:
+            gc.enable()
+
+
+def rows_from_raw(schema: Schema, cols: Sequence[RawColumn]) -> Iterator[Row]:
+    """Rows (dicts of Python values) straight from raw columns: the values a reader of the BlockFile
+    holding these columns would produce (f32 widened to float, TIMESTAMP as datetime, STRING as str)."""
+    yield from rows_list_from_raw(schema, cols)
 
 
 def _split_rows(cols: Sequence[RawColumn], rows_per_block: int) -> Iterator[list[RawColumn]]:

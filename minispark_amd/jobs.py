@@ -46,9 +46,16 @@ class ResultFile:
         return self._path
 
     def rows(self):  # noqa: ANN201
-        from .io import rows_from_raw  # noqa: PLC0415
+        from .io import rows_list_from_raw  # noqa: PLC0415
 
-        return rows_from_raw(self.schema, self.raw)
+        return rows_list_from_raw(self.schema, self.raw)
+
+    def columns(self) -> dict:
+        """The result column-wise, as it arrived from the device: name -> numpy array (INTEGER i4, FLOAT f4, TIMESTAMP i8
+        microseconds) or list of str.  No per-row Python objects: what a caller with 10^5 result rows wants."""
+        from .io import StrCol  # noqa: PLC0415
+
+        return {name: (c.to_list() if isinstance(c, StrCol) else c) for (name, _), c in zip(self.schema, self.raw)}
 
 
 @dataclass

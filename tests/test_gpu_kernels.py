@@ -432,3 +432,22 @@ def test_ordered_merge_survives_invalid_rows_and_full_dictionaries(dev, cap, hol
         for r in rows:
             acc += float(vals[r])
         assert got[int(key)] == acc, key
+
+
+def test_copy_segments_packs_and_unpacks_byte_ranges(dev):
+    """hs_copy_segments (the exchange's pack / unpack launch): aligned, misaligned, tiny, empty and large segments."""
+    import torch
+
+    rng = np.random.default_rng(5)
+    src = rng.integers(0, 256, 3_000_000, dtype=np.uint8)
+    d_src = dev.to_device(src)
+    d_dst = torch.zeros(3_100_000, dtype=torch.uint8, device=dev.device)
+    #        (source offset, destination offset, bytes)
+    plan = [(0, 0, 1_000_000), (1_000_000, 1_000_016, 999_983), (1_999_983, 2_000_003, 17), (2_000_000, 2_000_100, 0),
+            (2_000_000, 2_000_033, 5), (2_100_000, 2_100_007, 700_001), (2_999_999, 3_099_999, 1)]
+    dev.copy_segments([(d_src.data_ptr() + s, d_dst.data_ptr() + d, n) for s, d, n in plan])
+    want = np.zeros(3_100_000, dtype=np.uint8)
+    for s, d, n in plan:
+        want[d: d + n] = src[s: s + n]
+    assert np.array_equal(d_dst.cpu().numpy(), want)
+    dev.copy_segments([])  # nothing to do

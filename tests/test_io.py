@@ -146,3 +146,29 @@ def test_vectorised_timestamp_column_equals_the_value_by_value_conversion():
     assert io.timestamps_to_datetimes(np.zeros(0, np.int64)) == []
     far = np.asarray([5 * 10**15], dtype=np.int64)  # beyond the range the shortcut is proven for: value by value
     assert io.timestamps_to_datetimes(far) == [io.timestamp_to_datetime(int(far[0]))]
+
+
+def test_rows_from_raw_columns_as_a_list_and_column_wise():
+    """The row builder (one generated list comprehension per column count) gives the rows a BlockFile reader gives;
+    ResultFile.columns hands the same result over without building a dict per row."""
+    from datetime import datetime
+
+    import numpy as np
+
+    from minispark_amd.constants import ColumnType as T
+    from minispark_amd.io import StrCol, datetime_to_timestamp, rows_from_raw, rows_list_from_raw
+    from minispark_amd.jobs import ResultFile
+
+    schema = [("s", T.STRING), ("i", T.INTEGER), ("f", T.FLOAT), ("t", T.TIMESTAMP)]
+    when = [datetime(1998, 9, 2), datetime(1970, 1, 1, 0, 0, 1), datetime(2024, 2, 29, 12, 30)]
+    raw = [StrCol.from_strings(["a", "", "long string"]), np.array([1, -2, 3], np.int32), np.array([0.5, 1.25, -3.0], np.float32),
+           np.array([datetime_to_timestamp(w) for w in when], np.int64)]
+    want = [{"s": "a", "i": 1, "f": 0.5, "t": when[0]}, {"s": "", "i": -2, "f": 1.25, "t": when[1]},
+            {"s": "long string", "i": 3, "f": -3.0, "t": when[2]}]
+    assert rows_list_from_raw(schema, raw) == want == list(rows_from_raw(schema, raw))
+    assert rows_list_from_raw(schema[1:2], raw[1:2]) == [{"i": 1}, {"i": -2}, {"i": 3}]
+    assert rows_list_from_raw([], []) == []
+    big = rows_list_from_raw(schema[1:3], [np.arange(10_000, dtype=np.int32), np.arange(10_000, dtype=np.float32)])
+    assert len(big) == 10_000 and big[9_999] == {"i": 9_999, "f": 9_999.0}
+    cols = ResultFile(None, schema, raw, 3).columns()
+    assert cols["s"] == ["a", "", "long string"] and cols["i"].tolist() == [1, -2, 3] and cols["t"].dtype == np.int64

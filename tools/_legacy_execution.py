@@ -65,34 +65,6 @@ class ExecutionEngine(AbstractContextManager, ABC):
 
     def collect_results(self, results: list[JobResult], limit: float = math.inf) -> Iterator[Row]:
         output_files = {file for result in results for file in result.output_files}
-        if limit == math.inf and len(output_files) == 1:
-            (file,) = output_files
-            if isinstance(file, ResultFile):  # rows already in host memory: hand the list over, no generator per row
-                return iter(file.rows())
-        return self._collect_results(output_files, limit)
-
-    def collect_columns(self, results: list[JobResult]) -> dict:
-        """The result column-wise (name -> numpy array / list of str) - no row dicts are built.  An addition to the
-        reference's surface for large result sets: 125 000 groups cost 40 ms as dicts, none as columns."""
-        output_files = [file for result in results for file in result.output_files]
-        if not output_files:
-            return {}
-        if len(output_files) == 1 and isinstance(output_files[0], ResultFile):
-            return output_files[0].columns()
-        import numpy as np  # noqa: PLC0415
-
-        from .io import StrCol  # noqa: PLC0415
-
-        merged: dict = {}
-        for file in output_files:
-            bf = BlockFile(file.file_path)
-            for block_id in range(len(bf.block_starts)):
-                for (name, _), raw in zip(bf.file_schema, bf.read_block_raw(block_id)):
-                    merged.setdefault(name, []).append(raw.to_list() if isinstance(raw, StrCol) else raw)
-        return {name: (np.concatenate(parts) if isinstance(parts[0], np.ndarray) else [v for p in parts for v in p])
-                for name, parts in merged.items()}
-
-    def _collect_results(self, output_files: Any, limit: float) -> Iterator[Row]:
         for file in output_files:
             rows = file.rows() if isinstance(file, ResultFile) else BlockFile(file.file_path).read_data_rows()
             if limit == math.inf:
@@ -1184,11 +1156,9 @@ class HipExecutionEngine(ExecutionEngine):
         of columns: one small all-to-all of a size matrix (rows and string-payload bytes per peer - the split sizes
         of the data collective must be host integers), then ONE all_to_all_single of a byte buffer in which every
         destination's share holds its slice of every column back to back (RCCL: direct peer-to-peer transfers on the
-        xGMI mesh).  Round 3: the byte buffer is packed and unpacked ON THE DEVICE - stable counting sort by
-        destination, one gather per column, then ONE launch that copies the world x pieces slices into place
-        (hs_copy_segments; round 2 sliced and concatenated torch tensors in Python loops) - and the sizes the host needs
-        (rows and payload bytes per destination) come back in a single read.  Returns (batch of received rows grouped
-        by source rank, received extras)."""
+        xGMI mesh).  Returns (batch of received rows grouped by source rank, received extras)."""
+        import torch  # noqa: PLC0415
+
         from . import hipspark as hs  # noqa: PLC0415
         from .device import DBatch, DCol  # noqa: PLC0415
         from .distributed import all_to_all_rows, exchange_size_matrix  # noqa: PLC0415
@@ -1197,104 +1167,92 @@ class HipExecutionEngine(ExecutionEngine):
         batch = dev.decoded_batch(dev.resolve(batch))  # codes of per-rank dictionaries do not travel
         n = batch.nrows
         self._generic_exchange_used = True
-        perm, start_dev = dev.partition_by_ids_dev(dest, n, world)
-        # every column (and extra) permuted into destination order; pieces = (bytes tensor, bytes per row or None for a
-        # variable-length payload whose per-destination sizes come from its offsets)
-        pieces: list[tuple[Any, int | None, Any]] = []
+        perm, start = dev.partition_by_ids(dest, n, world)
+        rows_to = [start[d + 1] - start[d] for d in range(world)]
+        # every column (and extra) as byte pieces in destination order: (tensor of bytes, bytes per destination)
+        pieces: list[tuple[Any, list[int]]] = []
         layout: list[tuple[str, Any]] = []  # how to rebuild the columns on the receiving side
+        str_cols = 0
         for col in batch.cols:
-            g = dev.permute_col(col, perm, n)
+            g = dev.gather_col(col, perm, n)
             if g.kind == hs.STR:
-                pieces.append((g.lens, 1, None))
-                pieces.append((g.data, g.fixed_len if g.fixed_len >= 0 else None, g.offs))
-                layout.append(("str", None))
+                # length bytes + payload; the payload's bytes per destination travel in the size matrix for EVERY
+                # string column (whether a column looks fixed-width is a property of the local rows only)
+                pieces.append((g.lens[:n], list(rows_to)))
+                if g.fixed_len >= 0:
+                    pieces.append((g.data[: n * g.fixed_len], [c * g.fixed_len for c in rows_to]))
+                else:
+                    offs = g.offs[torch.tensor(start, dtype=torch.int64, device=dev.device)].tolist()
+                    pieces.append((g.data[: int(offs[-1])], [int(offs[d + 1] - offs[d]) for d in range(world)]))
+                layout.append(("str", str_cols))
+                str_cols += 1
             else:
-                pieces.append((g.data, hs.KIND_BYTES[g.kind], None))
+                width = hs.KIND_BYTES[g.kind]
+                pieces.append((g.data[:n].view(torch.uint8), [c * width for c in rows_to]))
                 layout.append(("fixed", g.kind))
         for t in extras:
-            kind = hs.U8 if t.dtype == dev.torch.uint8 else hs.I64
-            g = dev.permute_col(DCol(kind, t, n), perm, n)
-            pieces.append((g.data, hs.KIND_BYTES[kind], None))
+            kind = hs.U8 if t.dtype == torch.uint8 else hs.I64
+            g = dev.gather_col(DCol(kind, t, n), perm, n)
+            pieces.append((g.data[:n].view(torch.uint8), [c * hs.KIND_BYTES[kind] for c in rows_to]))
             layout.append(("extra", kind))
-        # ONE read-back: destination boundaries + the payload offsets of every variable-length piece at them
-        start, var_offs = dev.exchange_boundaries(start_dev, world, [p[2] for p in pieces if p[1] is None])
-        rows_to = [start[d + 1] - start[d] for d in range(world)]
-        piece_bytes: list[list[int]] = []  # [piece][destination]
-        piece_base: list[list[int]] = []   # byte offset of the destination's slice inside the piece
-        v = 0
-        for _data, width, _offs in pieces:
-            if width is None:
-                bounds = var_offs[v]
-                v += 1
-                piece_base.append([int(bounds[d]) for d in range(world)])
-                piece_bytes.append([int(bounds[d + 1] - bounds[d]) for d in range(world)])
-            else:
-                piece_base.append([start[d] * width for d in range(world)])
-                piece_bytes.append([rows_to[d] * width for d in range(world)])
-        # sizes: per peer [rows, payload bytes of every string column] (a column looks fixed-width from local rows only)
-        str_payload = [i for i, (tag, _) in enumerate(self._piece_tags(layout)) if tag == "payload"]
-        mine = [[rows_to[d]] + [piece_bytes[i][d] for i in str_payload] for d in range(world)]
+        # sizes: per peer [rows, payload bytes of every variable-length string column]
+        mine = [[rows_to[d]] for d in range(world)]
+        i = 0
+        for tag, _ in layout:
+            if tag == "str":
+                for d in range(world):
+                    mine[d].append(pieces[i + 1][1][d])
+            i += 2 if tag == "str" else 1
         theirs = exchange_size_matrix(dist, mine, dev.device, group)
         rows_from = [row[0] for row in theirs]
         n_in = sum(rows_from)
-        recv_piece_bytes: list[list[int]] = []  # [piece][source]
-        k = 0
-        for tag, arg in self._piece_tags(layout):
-            if tag == "payload":
-                recv_piece_bytes.append([row[1 + k] for row in theirs])
-                k += 1
+        # bytes every piece contributes per SOURCE on the receiving side
+        recv_piece_bytes: list[list[int]] = []
+        for tag, arg in layout:
+            if tag == "str":
+                recv_piece_bytes += [list(rows_from), [row[1 + arg] for row in theirs]]
             else:
-                recv_piece_bytes.append([c * arg for c in rows_from])
-        send_splits = [sum(pb[d] for pb in piece_bytes) for d in range(world)]
+                recv_piece_bytes.append([c * hs.KIND_BYTES[arg] for c in rows_from])
+        send_splits = [sum(p[1][d] for p in pieces) for d in range(world)]
         recv_splits = [sum(pb[s] for pb in recv_piece_bytes) for s in range(world)]
-        # pack: destination-major, piece-minor - one launch
-        send_buf = dev.empty(sum(send_splits), dev.torch.uint8)
-        segs, pos = [], 0
+        # pack: destination-major, piece-minor (one concatenation)
+        parts = []
         for d in range(world):
-            for i, (data, _w, _o) in enumerate(pieces):
-                if piece_bytes[i][d]:
-                    segs.append((data.data_ptr() + piece_base[i][d], send_buf.data_ptr() + pos, piece_bytes[i][d]))
-                pos += piece_bytes[i][d]
-        dev.copy_segments(segs)
+            for data, per_dest in pieces:
+                lo = sum(per_dest[:d])
+                parts.append(data[lo: lo + per_dest[d]])
+        send_buf = torch.cat(parts) if parts else torch.empty(0, dtype=torch.uint8, device=dev.device)
         recv_buf = all_to_all_rows(dist, send_buf, send_splits, recv_splits, 1, group)
-        # unpack: per piece, the slices of every source end to end - one launch
-        got = [dev.empty(sum(pb), dev.torch.uint8) for pb in recv_piece_bytes]
-        segs, pos = [], 0
-        filled = [0] * len(got)
-        for s_rank in range(world):
-            for i, pb in enumerate(recv_piece_bytes):
-                if pb[s_rank]:
-                    segs.append((recv_buf.data_ptr() + pos, got[i].data_ptr() + filled[i], pb[s_rank]))
-                pos += pb[s_rank]
-                filled[i] += pb[s_rank]
-        dev.copy_segments(segs)
+        # unpack: per piece, the slices of every source in source order
+        got: list[Any] = []
+        base = [sum(recv_splits[:s]) for s in range(world)]
+        used = [0] * world
+        for pb in recv_piece_bytes:
+            slices = []
+            for s_rank in range(world):
+                lo = base[s_rank] + used[s_rank]
+                slices.append(recv_buf[lo: lo + pb[s_rank]])
+                used[s_rank] += pb[s_rank]
+            total = sum(pb)
+            out = dev.empty(total, torch.uint8)
+            if total:
+                out.copy_(torch.cat(slices))
+            got.append(out)
         out_cols, out_extras, i = [], [], 0
+        np_dtype = {hs.I32: torch.int32, hs.F32: torch.float32, hs.I64: torch.int64, hs.F64: torch.float64, hs.U8: torch.uint8}
         for tag, arg in layout:
             if tag == "str":
                 out_cols.append(dev.string_col(got[i], got[i + 1], n_in))
                 i += 2
             elif tag == "fixed":
-                out_cols.append(DCol(arg, got[i].view(dev.torch_dtype(arg)), n_in))
+                out_cols.append(DCol(arg, got[i].view(np_dtype[arg]), n_in))
                 i += 1
             else:
-                out_extras.append(got[i].view(dev.torch_dtype(arg)))
+                out_extras.append(got[i].view(np_dtype[arg]))
                 i += 1
         received = DBatch(list(batch.schema), out_cols, n_in, [0, n_in], total_units=batch.total_units)
         received.partitioned = True
         return received, out_extras
-
-    @staticmethod
-    def _piece_tags(layout: Sequence[tuple[str, Any]]) -> list[tuple[str, Any]]:
-        """Pieces of the exchange buffer in order: ("rows", bytes per row) or ("payload", None) for string bytes."""
-        from . import hipspark as hs  # noqa: PLC0415
-
-        out: list[tuple[str, Any]] = []
-        for tag, arg in layout:
-            if tag == "str":
-                out += [("rows", 1), ("payload", None)]
-            else:
-                out.append(("rows", hs.KIND_BYTES[arg]))
-        return out
 
     def _exchange_by_key(self, batch: Any, key_index: int) -> tuple[Any, Any]:
         """Route rows to the rank owning hash(key) % SHUFFLE_PARTITIONS (owner = partition % world); the

@@ -1,7 +1,8 @@
 """HBM tier of GROUP BY (any cardinality; bit-exact sequential fold) on a multi-block table:
     python tools/bench_hbm_tier.py [lineitem_rows] [groups_per_block ...]
 GROUP BY a key with ~g distinct values per file block (beyond the 4096-slot LDS tier), SUM + COUNT, timing the partial
-aggregate (Device.aggregate_partial_global: one pass over all blocks since round 2) and the whole query."""
+aggregate (Device.aggregate_partial_global: one pass over all blocks since round 2), the whole query with its rows as
+dicts (DataFrame.collect) and with its result column-wise (DataFrame.collect_columns, round 3)."""
 import os, sys, tempfile, time
 from pathlib import Path
 os.environ.setdefault("TZ", "UTC"); time.tzset()
@@ -43,5 +44,14 @@ for g in gs:
         torch.cuda.synchronize()
         print(f"{g} groups/block x {len(t.block_rows)} blocks: run {i}: query {dt*1e3:8.2f} ms  partial aggregate {ev[0].elapsed_time(ev[1]):8.2f} ms "
               f"= {rows/ev[0].elapsed_time(ev[1])/1e6:.2f} G rows/s  result groups {len(out)}", flush=True)
+    # the same query with the result handed over column-wise (no row dicts): what the engine itself costs end to end
+    for i in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); cols = q.collect_columns(); dt = time.perf_counter() - t0
+        print(f"{g} groups/block: columns run {i}: query {dt*1e3:8.2f} ms  ({len(cols['k'])} groups, numpy columns {sorted(cols)})", flush=True)
+    import numpy as np
+    order = np.argsort(cols["k"], kind="stable")
+    by_key = sorted(out, key=lambda r: r["k"])
+    assert [int(v) for v in cols["k"][order]] == [r["k"] for r in by_key]
+    assert [float(v) for v in cols["s"][order]] == [r["s"] for r in by_key] and [int(v) for v in cols["count"][order]] == [r["count"] for r in by_key]
     dev.aggregate_partial_global = inner
 engine.__exit__(None, None, None)
