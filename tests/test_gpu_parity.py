@@ -72,8 +72,10 @@ def test_library_loaded_is_in_tree():
 def test_the_result_column_wise_equals_the_rows(name):
     """DataFrame.collect_columns (round 3: large results without a Python object per row) hands over the same result
     as collect(): numpy columns in the file's storage kinds, strings as a list."""
-    from minispark_amd.io import rows_list_from_raw
+    from minispark_amd.dataframe import DataFrame
     from minispark_amd.execution import HipExecutionEngine
+    from minispark_amd.sql import Col, Functions, Lit
+    from tests.queries import case_by_name
 
     case, g = case_by_name(name), load_golden(name)
     with HipExecutionEngine(device=0) as engine:
