@@ -688,6 +688,18 @@ typedef struct hs_result_col {
 
 int hs_engine_create(int32_t device, hs_engine** out);
 void hs_engine_destroy(hs_engine* engine);
+/* Wall time and bytes of the last hs_table_load's read + host-to-device pipeline on this engine (the ingest bench's
+ * figure: page cache -> pinned staging -> HBM, against the PCIe link's peak). */
+int hs_engine_load_stats(const hs_engine* engine, double* seconds, int64_t* bytes);
+/* The reader's pipeline with caller-owned destinations: n_spans byte ranges of the file at `path` -> device addresses
+ * (reader threads pread chunks into the engine's pinned staging pool while earlier chunks' H2D copies are in flight).
+ * Returns when every byte has arrived.  Replaces the reference's per-block decode loop (io.py:112-163) for a host that
+ * keeps its own device buffers. */
+typedef struct hs_span {
+    int64_t file_offset, bytes;
+    void* dst; /* device address */
+} hs_span;
+int hs_read_spans(hs_engine* engine, const char* path, const hs_span* spans, int32_t n_spans);
 /* Parses header, footer and the column spans of the blocks this rank owns (block b -> rank b % world). */
 int hs_table_open(hs_engine* engine, const char* path, int32_t rank, int32_t world, hs_table** out);
 void hs_table_close(hs_table* table);

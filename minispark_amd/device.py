@@ -247,6 +247,15 @@ class Device:
         self.exchange_events = None
         self.join_events = None
 
+    def native_engine(self) -> Any:
+        """The library's engine handle for this GPU (hs_engine_create): owner of the reader's pinned staging pool."""
+        handle = self.__dict__.get("_native_engine")
+        if handle is None:
+            handle = C.c_void_p()
+            hs.check(self._raw_lib.hs_engine_create(self.index, C.byref(handle)), "hs_engine_create")
+            self.__dict__["_native_engine"] = handle
+        return handle
+
     # ---- recording ------------------------------------------------------------------------------------
     def start_recording(self) -> Recording:
         self.rec = Recording()

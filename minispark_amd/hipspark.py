@@ -93,6 +93,10 @@ class hs_join8(C.Structure):
     _fields_ = [("table", C.c_void_p), ("slots", C.c_int64), ("key_min", C.c_int32), ("n_parts", C.c_int32)]
 
 
+class hs_span(C.Structure):
+    _fields_ = [("file_offset", C.c_int64), ("bytes", C.c_int64), ("dst", C.c_void_p)]
+
+
 class hs_segment(C.Structure):
     _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("bytes", C.c_int64)]
 
@@ -274,6 +278,8 @@ SIGNATURES: dict[str, tuple] = {
                                             C.c_char_p, _I64]),
     "hs_engine_create": (C.c_int, [_I32, C.POINTER(_P)]),
     "hs_engine_destroy": (None, [_P]),
+    "hs_read_spans": (C.c_int, [_P, C.c_char_p, C.POINTER(hs_span), _I32]),
+    "hs_engine_load_stats": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(_I64)]),
     "hs_table_open": (C.c_int, [_P, C.c_char_p, _I32, _I32, C.POINTER(_P)]),
     "hs_table_close": (None, [_P]),
     "hs_table_info": (C.c_int, [_P, C.POINTER(_I32), C.POINTER(_I64), C.POINTER(_I32), C.POINTER(_I32)]),

@@ -92,28 +92,11 @@ def sub_table(table: DeviceTable, local_blocks: list[int]) -> DeviceTable:
 
 
 # ---- BlockFile -> HBM ingest ---------------------------------------------------------
-# Column pruning first (only the referenced columns' byte spans are read), then a pipeline: reader threads
-# preadv() every (block, column) span straight into pinned staging slots (the GIL is released during the read),
-# the caller's thread issues the H2D copies asynchronously on a side stream and recycles a slot once its copy's
-# event has fired.  Disk / page cache and PCIe run concurrently; nothing is copied twice on the host.
-import os as _os
-
-INGEST_READERS = int(_os.environ.get("HIPSPARK_INGEST_READERS", "8"))
-INGEST_SLOTS = 2 * INGEST_READERS
-
-
-class _Staging:
-    def __init__(self, nbytes: int) -> None:
-        self.buf = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
-        self.view = self.buf.numpy()
-        self.event: torch.cuda.Event | None = None
-
-
+# Column pruning first (only the referenced columns' byte spans are read), then the library's reader pipeline
+# (hs_read_spans): reader threads pread chunks straight into pinned staging slots while the H2D copies of earlier chunks
+# are in flight.  Disk / page cache and PCIe run concurrently; nothing is copied twice on the host.
 def load_columns(dev: Device, table: DeviceTable, col_ids: list[int]) -> None:
     """Read the byte spans of ``col_ids`` block by block and place them in per-column device buffers."""
-    import os
-    from concurrent.futures import ThreadPoolExecutor
-
     missing = [c for c in col_ids if c not in table.columns]
     if not missing:
         return
@@ -159,52 +142,20 @@ def load_columns(dev: Device, table: DeviceTable, col_ids: list[int]) -> None:
             finish.append((cid, out, None))
 
     if pieces:
-        slot_bytes = max(p[1] for p in pieces)
-        cached = getattr(dev, "_ingest_slots", None)  # pinning host memory is slow: keep the slots per device
-        if cached is None or cached[0].buf.numel() < slot_bytes:
-            cached = [_Staging(max(slot_bytes, 16 << 20)) for _ in range(INGEST_SLOTS)]
-            dev._ingest_slots = cached
-        slots = cached[: min(INGEST_SLOTS, len(pieces))]
-        for slot in slots:
-            slot.event = None
-        copy_stream = torch.cuda.Stream(device=dev.device)
-        fd = os.open(table.path, os.O_RDONLY)
+        # the read + host-to-device pipeline is the library's (csrc/hs_engine.hip hs_read_spans: reader threads pread
+        # chunks into pinned staging while earlier chunks' copies are in flight) - round 2 ran its own copy of that
+        # pipeline here, in Python threads, at 27 GB/s
+        import ctypes as C  # noqa: PLC0415
 
-        def read_into(slot: _Staging, off: int, nbytes: int) -> None:
-            done = 0
-            while done < nbytes:
-                got = os.preadv(fd, [memoryview(slot.view[done:nbytes])], off + done)
-                if got <= 0:
-                    raise OSError(f"{table.path}: short read at offset {off + done}")
-                done += got
+        from . import hipspark as hs  # noqa: PLC0415
 
-        try:
-            with ThreadPoolExecutor(max_workers=INGEST_READERS) as pool:
-                inflight: list[tuple[Any, _Staging, int, torch.Tensor]] = []
-                free = list(slots)
-                it = iter(pieces)
-                exhausted = False
-                while inflight or not exhausted:
-                    while free and not exhausted:
-                        nxt = next(it, None)
-                        if nxt is None:
-                            exhausted = True
-                            break
-                        slot = free.pop()
-                        if slot.event is not None:
-                            slot.event.synchronize()  # the previous H2D out of this slot has finished
-                        inflight.append((pool.submit(read_into, slot, nxt[0], nxt[1]), slot, nxt[1], nxt[2]))
-                    if inflight:
-                        fut, slot, nbytes, dst = inflight.pop(0)
-                        fut.result()
-                        with torch.cuda.stream(copy_stream):
-                            dst.copy_(slot.buf[:nbytes], non_blocking=True)
-                            slot.event = torch.cuda.Event()
-                            slot.event.record(copy_stream)
-                        free.append(slot)
-            copy_stream.synchronize()
-        finally:
-            os.close(fd)
+        spans = (hs.hs_span * len(pieces))()
+        for i, (off, nbytes, dst) in enumerate(pieces):
+            spans[i].file_offset, spans[i].bytes, spans[i].dst = off, nbytes, dst.data_ptr()
+        torch.cuda.current_stream(dev.device).synchronize()  # the destinations were allocated on this stream
+        if dev.rec is not None:
+            dev.rec.poisoned = True  # file contents flow in: not a run to replay
+        hs.check(dev._raw_lib.hs_read_spans(dev.native_engine(), str(table.path).encode(), spans, len(pieces)), "hs_read_spans")
 
     for cid, data, lens in finish:
         if lens is not None:

@@ -44,4 +44,50 @@ c = q1_native.gen(synth.SEED, 0, min(rows, 100000))
 assert np.array_equal(t.columns[1].data[:100000].cpu().numpy(), c["l_extendedprice"][:100000])
 assert t.columns[4].fixed_len == 1 and np.array_equal(t.columns[5].data[:100000].cpu().numpy(), c["l_shipdate"][:100000])
 print("ingested columns verified against the generator")
+
+# ---- the native reader (csrc/hs_engine.hip hs_table_open / hs_table_load): what a non-Python host gets ---------------------
+import ctypes as C, json
+from minispark_amd import hipspark as hs
+lib = hs.load_library()
+hip = C.CDLL("libamdhip64.so")
+eng = C.c_void_p()
+hs.check(lib.hs_engine_create(0, C.byref(eng)), "hs_engine_create")
+ids = (C.c_int32 * len(q1_cols))(*q1_cols)
+best = None
+for rep in range(4):
+    tab = C.c_void_p()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    hs.check(lib.hs_table_open(eng, str(path).encode(), 0, 1, C.byref(tab)), "hs_table_open")
+    hs.check(lib.hs_table_load(eng, tab, ids, len(q1_cols)), "hs_table_load")
+    dt = time.perf_counter() - t0
+    sec, nbytes = C.c_double(0), C.c_int64(0)
+    lib.hs_engine_load_stats(eng, C.byref(sec), C.byref(nbytes))
+    print(f"native ingest rep {rep}: open + load {dt*1e3:.0f} ms -> {want_bytes/dt/1e9:.2f} GB/s of referenced bytes; read + copy pipeline alone "
+          f"{sec.value*1e3:.0f} ms = {nbytes.value/sec.value/1e9:.2f} GB/s ({nbytes.value} bytes moved)", flush=True)
+    if best is None or dt < best[0]:
+        best = (dt, sec.value, nbytes.value)
+    if rep == 3:  # verify what landed in HBM against the generator
+        col, n_rows = hs.hs_col(), C.c_int64(0)
+        for cid, name, dtype in ((1, "l_extendedprice", np.float32), (5, "l_shipdate", np.int64)):
+            hs.check(lib.hs_table_column(tab, cid, C.byref(col), C.byref(n_rows)), "hs_table_column")
+            assert n_rows.value == rows
+            host = np.empty(100000, dtype=dtype)
+            assert hip.hipMemcpy(C.c_void_p(host.ctypes.data), C.c_void_p(col.data), C.c_size_t(host.nbytes), 2) == 0
+            assert np.array_equal(host, c[name][:100000]), name
+        tail = np.empty(1000, dtype=np.float32)
+        hs.check(lib.hs_table_column(tab, 0, C.byref(col), C.byref(n_rows)), "hs_table_column")
+        assert hip.hipMemcpy(C.c_void_p(tail.ctypes.data), C.c_void_p(col.data + 4 * (rows - 1000)), C.c_size_t(4000), 2) == 0
+        assert np.array_equal(tail, q1_native.gen(synth.SEED, rows - 1000, 1000)["l_quantity"])
+        print("native reader: columns verified against the generator (head and tail)")
+    lib.hs_table_close(tab)
+lib.hs_engine_destroy(eng)
+PCIE_PEAK = 63.0  # GB/s, PCIe Gen5 x16 per direction (spec)
+dt, sec, nbytes = best
+print(json.dumps({"metric": "BlockFile -> HBM ingest through the native reader (hs_table_open + hs_table_load), referenced bytes/sec",
+                  "value": want_bytes / dt / 1e9, "unit": "GB/s", "sf": sf, "rows": rows, "file_bytes": path.stat().st_size,
+                  "referenced_bytes": want_bytes, "pruned_fraction": 1 - want_bytes / path.stat().st_size,
+                  "open_plus_load_ms": dt * 1e3, "pipeline_ms": sec * 1e3,
+                  "roofline": {"bound": "pcie", "achieved": nbytes / sec / 1e9, "peak": PCIE_PEAK, "unit": "GB/s",
+                               "frac": nbytes / sec / 1e9 / PCIE_PEAK,
+                               "accounting": "bytes moved host -> device by the read + copy pipeline over its wall time (file in page cache)"}}))
 import shutil; shutil.rmtree(scratch)
