@@ -25,6 +25,8 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -102,7 +104,7 @@ struct PinnedPool {
         if (base && slot_bytes >= bytes_per_slot && n_slots >= slots) return true;
         if (base) (void)hipHostFree(base);
         base = nullptr;
-        if (hipHostMalloc(&base, bytes_per_slot * (size_t)slots, hipHostMallocDefault) != hipSuccess) {
+        if (hipHostMalloc(&base, bytes_per_slot * (size_t)slots, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
             base = nullptr;
             return false;
         }
@@ -113,12 +115,19 @@ struct PinnedPool {
     char* slot(int i) const { return (char*)base + (size_t)i * slot_bytes; }
 };
 
+struct ReaderPool;
+void hs_reader_pool_free(ReaderPool* p);
+
 struct hs_engine {
     int device = 0;
     DevBuf flags;  // one status word
     PinnedPool staging;
+    ReaderPool* readers = nullptr;   // persistent reader threads (created by the first load)
     double last_load_seconds = 0.0;  // wall time of the last hs_table_load's read + copy pipeline
     int64_t last_load_bytes = 0;
+    ~hs_engine() {
+        if (readers) hs_reader_pool_free(readers);
+    }
 };
 
 struct hs_table {
@@ -357,12 +366,141 @@ constexpr int HS_READ_SLOTS = 4;
 constexpr int HS_READ_THREADS_MAX = 16;
 
 int reader_threads() {
-    int n = HS_READ_THREADS_MAX;
+    // 8 by default: measured on the test box (16 host threads granted) 6-10 readers all reach 42-45 GB/s at sf=10,
+    // 16 fall back to 37-41 (they contend for the page cache / memory bandwidth, not for the link)
+    int n = 8;
     if (const char* env = getenv("HIPSPARK_INGEST_READERS")) n = atoi(env);
     const unsigned hw = std::thread::hardware_concurrency();
     if (hw && n > (int)hw) n = (int)hw;
-    return n < 1 ? 1 : (n > 64 ? 64 : n);
+    return n < 1 ? 1 : (n > HS_READ_THREADS_MAX ? HS_READ_THREADS_MAX : n);
 }
+
+// Host-to-device copy of one staged chunk by a KERNEL that reads the pinned slot over PCIe (the slot is mapped into
+// the device's address space): 16-byte loads from host memory, 16-byte stores to HBM.  HIPSPARK_INGEST_COPY=sdma uses
+// hipMemcpyAsync (the DMA engines) instead; the two measure alike (42-45 GB/s at sf=10, ~50 GB/s at sf=30).
+__global__ void __launch_bounds__(256) k_pull_chunk(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16,
+                                                    const uint8_t* __restrict__ src_tail, uint8_t* __restrict__ dst_tail, int tail) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = src[i];
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+
+bool copy_by_kernel() {
+    static const bool k = !(getenv("HIPSPARK_INGEST_COPY") && getenv("HIPSPARK_INGEST_COPY")[0] == 's');
+    return k;
+}
+
+}  // namespace
+
+// The engine's reader threads live as long as the engine: a thread's first HIP call, its stream and its events cost
+// milliseconds - at sf=10 (1.56 GB, ~31 ms at the link's practical rate) that was 5 ms of every load.
+struct ReaderPool {
+    struct Job {
+        const std::string* path = nullptr;
+        const std::vector<Piece>* pieces = nullptr;
+        char* pool_dev = nullptr;
+        bool by_kernel = false;
+        std::atomic<size_t> next{0};
+        std::atomic<bool> failed{false};
+    };
+    hs_engine* engine = nullptr;
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable cv_job, cv_done;
+    Job* job = nullptr;
+    uint64_t job_id = 0;
+    int working = 0;
+    bool stop = false;
+
+    ~ReaderPool() {
+        {
+            std::lock_guard<std::mutex> lock(m);
+            stop = true;
+        }
+        cv_job.notify_all();
+        for (std::thread& th : threads) th.join();
+    }
+
+    void worker(int w) {
+        const bool dev_ok = hipSetDevice(engine->device) == hipSuccess;
+        hipStream_t stream = nullptr;
+        hipEvent_t ev[HS_READ_SLOTS] = {};
+        bool ok_setup = dev_ok && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess;
+        for (int k = 0; ok_setup && k < HS_READ_SLOTS; ++k) ok_setup = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) == hipSuccess;
+        uint64_t seen = 0;
+        for (;;) {
+            Job* j = nullptr;
+            {
+                std::unique_lock<std::mutex> lock(m);
+                cv_job.wait(lock, [&] { return stop || job_id != seen; });
+                if (stop) break;
+                seen = job_id;
+                j = job;
+            }
+            bool ok = ok_setup;
+            const int fd = ok ? open(j->path->c_str(), O_RDONLY) : -1;
+            ok = ok && fd >= 0;
+            bool used[HS_READ_SLOTS] = {};
+            const std::vector<Piece>& pieces = *j->pieces;
+            for (int turn = 0; ok && !j->failed; turn = (turn + 1) % HS_READ_SLOTS) {
+                const size_t i = j->next.fetch_add(1);
+                if (i >= pieces.size()) break;
+                const Piece& p = pieces[i];
+                char* slot = engine->staging.slot(w * HS_READ_SLOTS + turn);
+                if (used[turn]) ok = hipEventSynchronize(ev[turn]) == hipSuccess;  // the slot's previous copy has left it
+                ok = ok && read_exact(fd, slot, (size_t)p.bytes, p.file_off);
+                if (ok && j->by_kernel && (((uintptr_t)p.dst) & 15) == 0) {
+                    // (a destination inside a column buffer is 16-byte aligned whenever the span starts on a multiple of
+                    // 16 bytes of the column: always for the fixed-width columns of 2 Mi-row blocks)
+                    char* mapped = j->pool_dev + (slot - (char*)engine->staging.base);
+                    const int64_t n16 = p.bytes / 16;
+                    const int tail = (int)(p.bytes - n16 * 16);
+                    hipLaunchKernelGGL(k_pull_chunk, dim3(64), dim3(256), 0, stream, (const uint4*)mapped, (uint4*)p.dst, n16,
+                                       (const uint8_t*)mapped + n16 * 16, (uint8_t*)p.dst + n16 * 16, tail);
+                    ok = hipGetLastError() == hipSuccess;
+                } else {
+                    ok = ok && hipMemcpyAsync(p.dst, slot, (size_t)p.bytes, hipMemcpyHostToDevice, stream) == hipSuccess;
+                }
+                ok = ok && hipEventRecord(ev[turn], stream) == hipSuccess;
+                used[turn] = true;
+            }
+            if (stream) ok = (hipStreamSynchronize(stream) == hipSuccess) && ok;
+            if (fd >= 0) close(fd);
+            if (!ok) j->failed = true;
+            {
+                std::lock_guard<std::mutex> lock(m);
+                --working;
+            }
+            cv_done.notify_all();
+        }
+        for (int k = 0; k < HS_READ_SLOTS; ++k)
+            if (ev[k]) (void)hipEventDestroy(ev[k]);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+
+    bool run(hs_engine* e, Job& j, int n_threads) {
+        engine = e;
+        while ((int)threads.size() < n_threads) {
+            const int w = (int)threads.size();
+            threads.emplace_back([this, w] { worker(w); });
+        }
+        {
+            std::lock_guard<std::mutex> lock(m);
+            job = &j;
+            ++job_id;
+            working = (int)threads.size();
+        }
+        cv_job.notify_all();
+        std::unique_lock<std::mutex> lock(m);
+        cv_done.wait(lock, [&] { return working == 0; });
+        job = nullptr;
+        return !j.failed;
+    }
+};
+
+void hs_reader_pool_free(ReaderPool* p) { delete p; }
+
+namespace {
 
 bool run_pieces(hs_engine* e, const std::string& path, const std::vector<Piece>& spans, std::string& err) {
     if (spans.empty()) return true;
@@ -375,53 +513,21 @@ bool run_pieces(hs_engine* e, const std::string& path, const std::vector<Piece>&
         }
         total += p.bytes;
     }
-    int n_threads = reader_threads();
-    if ((size_t)n_threads > pieces.size()) n_threads = (int)pieces.size();
     if (!e->staging.ensure((size_t)HS_READ_CHUNK, HS_READ_THREADS_MAX * HS_READ_SLOTS)) {
         err = "cannot pin host staging memory";
         return false;
     }
-    const int device = e->device;
-    std::atomic<size_t> next{0};
-    std::atomic<bool> failed{false};
-    std::vector<std::thread> threads;
+    if (!e->readers) e->readers = new ReaderPool();
+    ReaderPool::Job job;
+    job.path = &path;
+    job.pieces = &pieces;
+    job.by_kernel = copy_by_kernel() && hipHostGetDevicePointer((void**)&job.pool_dev, e->staging.base, 0) == hipSuccess && job.pool_dev;
     const auto t0 = std::chrono::steady_clock::now();
-    for (int w = 0; w < n_threads; ++w) {
-        threads.emplace_back([&, w]() {
-            if (hipSetDevice(device) != hipSuccess) {
-                failed = true;
-                return;
-            }
-            const int fd = open(path.c_str(), O_RDONLY);
-            hipStream_t stream = nullptr;
-            hipEvent_t ev[HS_READ_SLOTS] = {};
-            bool used[HS_READ_SLOTS] = {};
-            bool ok = fd >= 0 && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess;
-            for (int k = 0; ok && k < HS_READ_SLOTS; ++k) ok = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) == hipSuccess;
-            for (int turn = 0; ok && !failed; turn = (turn + 1) % HS_READ_SLOTS) {
-                const size_t i = next.fetch_add(1);
-                if (i >= pieces.size()) break;
-                const Piece& p = pieces[i];
-                char* slot = e->staging.slot(w * HS_READ_SLOTS + turn);
-                if (used[turn]) ok = hipEventSynchronize(ev[turn]) == hipSuccess;  // the slot's previous copy has left it
-                ok = ok && read_exact(fd, slot, (size_t)p.bytes, p.file_off);
-                ok = ok && hipMemcpyAsync(p.dst, slot, (size_t)p.bytes, hipMemcpyHostToDevice, stream) == hipSuccess;
-                ok = ok && hipEventRecord(ev[turn], stream) == hipSuccess;
-                used[turn] = true;
-            }
-            if (stream) ok = (hipStreamSynchronize(stream) == hipSuccess) && ok;
-            if (!ok) failed = true;
-            for (int k = 0; k < HS_READ_SLOTS; ++k)
-                if (ev[k]) (void)hipEventDestroy(ev[k]);
-            if (stream) (void)hipStreamDestroy(stream);
-            if (fd >= 0) close(fd);
-        });
-    }
-    for (std::thread& th : threads) th.join();
+    const bool ok = e->readers->run(e, job, reader_threads());
     e->last_load_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     e->last_load_bytes = total;
-    if (failed) err = "read or host-to-device copy failed";
-    return !failed;
+    if (!ok) err = "read or host-to-device copy failed";
+    return ok;
 }
 
 }  // namespace
