@@ -61,19 +61,21 @@ struct SharedFoldArgs {
     hs_agg_spec spec;
 };
 __global__ void __launch_bounds__(256) k_agg_shared_fold_chunks(const SharedFoldArgs A) {
+    // one wave per (unit, slot, aggregate): the aggregates of a cell are independent folds (round 2 walked them one
+    // after the other in one wave: 4 x 14 dependent loads for config 4's 916 chunks)
     const int NA = A.spec.n_acc;
     const int lane = threadIdx.x & (HS_WAVE - 1);
-    const int64_t cell = (int64_t)blockIdx.x * (blockDim.x / HS_WAVE) + threadIdx.x / HS_WAVE;  // (unit, slot)
+    const int64_t task = (int64_t)blockIdx.x * (blockDim.x / HS_WAVE) + threadIdx.x / HS_WAVE;
+    const int64_t cell = task / NA;  // (unit, slot)
+    const int a = (int)(task - cell * NA);
     if (cell >= (int64_t)A.n_units * A.unit_cap || A.reps[cell] < 0) return;  // wave-uniform
     const int64_t stride = (int64_t)A.n_units * A.unit_cap * NA;
-    for (int a = 0; a < NA; ++a) {
-        const uint32_t op = A.spec.op[a];
-        const bool is_int = A.spec.is_int[a] != 0;
-        uint64_t v = hs_acc_identity(op, is_int);
-        for (int64_t c = lane; c < A.n_chunks; c += HS_WAVE) v = hs_acc_fold(op, is_int, v, A.chunk_acc[c * stride + cell * NA + a]);
-        for (int d = HS_WAVE / 2; d >= 1; d >>= 1) v = hs_acc_fold(op, is_int, v, hs_shfl_down64(v, d));
-        if (lane == 0) A.acc[cell * NA + a] = v;
-    }
+    const uint32_t op = A.spec.op[a];
+    const bool is_int = A.spec.is_int[a] != 0;
+    uint64_t v = hs_acc_identity(op, is_int);
+    for (int64_t c = lane; c < A.n_chunks; c += HS_WAVE) v = hs_acc_fold(op, is_int, v, A.chunk_acc[c * stride + cell * NA + a]);
+    for (int d = HS_WAVE / 2; d >= 1; d >>= 1) v = hs_acc_fold(op, is_int, v, hs_shfl_down64(v, d));
+    if (lane == 0) A.acc[cell * NA + a] = v;
 }
 
 // after the scan: cells -> what the reference's shuffle file holds (f32 / i32 rounding, overflow and type flags),
@@ -1912,7 +1914,7 @@ static int agg_shared_impl(void* stream, const hs_col* cols, int32_t n_cols, int
     } else {
         hipLaunchKernelGGL((k_agg_shared<false, 8>), grid, block, geom->lds_bytes, s, A);
     }
-    if (A.chunk_acc) {
+    if (A.chunk_acc && spec->n_acc > 0) {
         SharedFoldArgs G;
         G.chunk_acc = A.chunk_acc;
         G.reps = out_rep;
@@ -1921,8 +1923,8 @@ static int agg_shared_impl(void* stream, const hs_col* cols, int32_t n_cols, int
         G.n_units = (int32_t)n_units;
         G.unit_cap = geom->pad;
         G.spec = *spec;
-        const int64_t cells = n_units * (int64_t)geom->pad;
-        hipLaunchKernelGGL(k_agg_shared_fold_chunks, dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, s, G);
+        const int64_t tasks = n_units * (int64_t)geom->pad * (spec->n_acc > 0 ? spec->n_acc : 1);
+        hipLaunchKernelGGL(k_agg_shared_fold_chunks, dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, s, G);
     }
     if (ev_end) hs_event_record((hipEvent_t)ev_end, s);
     if (join) {

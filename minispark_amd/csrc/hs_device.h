@@ -715,6 +715,19 @@ __device__ __forceinline__ uint32_t hs_py_partition(int32_t key, int32_t n_parts
     if (m < 0) m += n_parts;
     return (uint32_t)m;
 }
+// The same without an integer division (a 32-bit signed % by a run-time divisor is ~40 instructions, several of them
+// quarter-rate multiplies; the fused probe computes a partition per distinct key of every lane): the quotient comes from
+// a double-precision multiply by inv = 1.0 / n_parts - |h| < 2^32 and a relative error of 2^-52 leave it off by at most
+// one, which the remainder shows.
+__device__ __forceinline__ uint32_t hs_py_partition_inv(int32_t key, int32_t n_parts, double inv) {
+    const int32_t h = key == -1 ? -2 : key;
+    const uint32_t a = h < 0 ? 0u - (uint32_t)h : (uint32_t)h;
+    const uint32_t q = (uint32_t)((double)a * inv);
+    uint32_t r = a - q * (uint32_t)n_parts;
+    if ((int32_t)r < 0) r += (uint32_t)n_parts;
+    else if (r >= (uint32_t)n_parts) r -= (uint32_t)n_parts;
+    return (h < 0 && r != 0) ? (uint32_t)n_parts - r : r;  // Python's % takes the divisor's sign
+}
 // table byte of `key`: the build side's payload, 0xff = no build row has this key
 __device__ __forceinline__ uint32_t hs_join8_lookup(const hs_join8& J, int32_t key) {
     const int64_t off = (int64_t)key - (int64_t)J.key_min;

@@ -875,12 +875,37 @@ __global__ void __launch_bounds__(256) k_partition_ids(const hs_col key, const i
         part[i] = (uint8_t)p;
     }
 }
+// INTEGER keys, every row (the shuffle of a table column): four keys per lane in one 16-byte load, the partition
+// without an integer division (hs_py_partition_inv), four ids in one 4-byte store - 5 B/row at the HBM rate instead of
+// 18 % of it (one key per lane, a 64-bit % per row, byte stores).
+__global__ void __launch_bounds__(256) k_partition_ids_i32(const int32_t* keys, int64_t n, int32_t n_parts, uint8_t* part) {
+    const double inv = 1.0 / (double)n_parts;
+    const int64_t nquads = (n + 3) / 4;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nquads; q += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t base = q * 4;
+        const int4 kv = *reinterpret_cast<const int4*>(keys + base);  // buffers carry slack past the last row
+        const uint32_t p0 = hs_py_partition_inv(kv.x, n_parts, inv), p1 = hs_py_partition_inv(kv.y, n_parts, inv),
+                       p2 = hs_py_partition_inv(kv.z, n_parts, inv), p3 = hs_py_partition_inv(kv.w, n_parts, inv);
+        if (base + 4 <= n) {
+            *reinterpret_cast<uint32_t*>(part + base) = p0 | (p1 << 8) | (p2 << 16) | (p3 << 24);
+        } else {
+            const uint32_t p[4] = {p0, p1, p2, p3};
+            for (int j = 0; base + j < n; ++j) part[base + j] = (uint8_t)p[j];
+        }
+    }
+}
 extern "C" int hs_partition_ids(void* stream, const hs_col* key, const int64_t* sel, int64_t nrows, int32_t n_parts,
                                 uint8_t* part) {
     if (nrows == 0) return HS_OK;
     if (!key || !part || nrows < 0 || n_parts < 1 || n_parts > 256) {
         hs_set_error("hs_partition_ids: bad arguments");
         return HS_E_ARG;
+    }
+    if (key->kind == HS_I32 && !sel && n_parts <= 127 && (((uintptr_t)key->data) & 15) == 0 && (((uintptr_t)part) & 3) == 0) {
+        hipLaunchKernelGGL(k_partition_ids_i32, dim3(grid_for((nrows + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const int32_t*)key->data, nrows, n_parts, part);
+        HS_CHECK_LAUNCH("hs_partition_ids");
+        return HS_OK;
     }
     hipLaunchKernelGGL(k_partition_ids, dim3(grid_for(nrows, 256)), dim3(256), 0, (hipStream_t)stream, *key, sel, nrows,
                        n_parts, part);

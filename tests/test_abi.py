@@ -200,7 +200,10 @@ def test_the_fused_probe_translates_and_compiles_for_gfx950_without_a_gpu():
     assert rc == 0, (lib.hs_last_error(), lib.hs_jit_last_log()[:3000])
     text = src.value.decode()
     assert "hs_agg_shared_body<JitProg>" in text and text.count("hs_join8_lookup(A.join") == 4
-    assert text.count("hs_py_partition(") == 4 and "hs_unit_key(" in text and "k1 == k0 ? b0" in text
+    assert text.count("hs_py_partition_inv(") == 4 and "hs_unit_key(" in text and "same ? vb[0] : x.jb[1]" in text
+    # the loads ask, run() sorts out: nothing in load() depends on a byte it has just requested
+    load_body = text[text.index("void load(const AggMainArgs"):text.index("void load_keys(")]
+    assert "hs_py_partition" not in load_body and "vb[" not in load_body
     # outside the shared tier with that unit column the translator refuses (the caller then materialises the probe)
     rc = lib.hs_jit_compile_check_shared(cols, n + 1, low.key_slot, -1, C.byref(prog), C.byref(spec), b"gfx950",
                                          C.byref(nbytes), src, len(src))
