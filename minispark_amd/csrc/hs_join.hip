@@ -494,11 +494,16 @@ struct Join8Args {
 };
 
 // window of row i's key, or -1 (padding row of a segment / key outside the table: flagged)
-__device__ __forceinline__ int hsj8_window(const Join8Args& A, int64_t i, int32_t key, uint32_t& off, uint32_t& err) {
-    if (A.seg_counts) {
-        const uint32_t seg = (uint32_t)((uint64_t)i / (uint64_t)A.seg_len);
-        if (i - (int64_t)seg * A.seg_len >= A.seg_counts[seg]) return -1;
-    }
+// valid rows of the quad starting at row q (a multiple of 4; segments are multiples of 4 rows long, so a quad lies in one
+// segment): one 32-bit division per QUAD (n_build < 2^32), not a 64-bit one per row
+__device__ __forceinline__ int hsj8_quad_valid(const Join8Args& A, int64_t q) {
+    if (!A.seg_counts) return 4;
+    const uint32_t seg = (uint32_t)q / (uint32_t)A.seg_len;
+    const int64_t left = A.seg_counts[seg] - (q - (int64_t)seg * A.seg_len);
+    return left >= 4 ? 4 : (left < 0 ? 0 : (int)left);
+}
+__device__ __forceinline__ int hsj8_window(const Join8Args& A, bool valid, int32_t key, uint32_t& off, uint32_t& err) {
+    if (!valid) return -1;
     const int64_t o = (int64_t)key - (int64_t)A.key_min;
     if ((uint64_t)o >= (uint64_t)A.slots) {
         err |= HS_FLAG_BAD_PROGRAM;
@@ -517,11 +522,12 @@ __global__ void __launch_bounds__(512) k_join8_hist(const Join8Args A) {
     for (int64_t q = r0 + (int64_t)threadIdx.x * 4; q < r1; q += (int64_t)blockDim.x * 4) {
         const int4 kv = *reinterpret_cast<const int4*>(A.keys + q);  // buffers carry slack past the last row
         const int32_t k[4] = {kv.x, kv.y, kv.z, kv.w};
+        const int nvalid = hsj8_quad_valid(A, q);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (q + j >= r1) break;
             uint32_t off;
-            const int w = hsj8_window(A, q + j, k[j], off, err);
+            const int w = hsj8_window(A, j < nvalid, k[j], off, err);
             if (w >= 0) atomicAdd(&s_hist[w], 1u);
         }
     }
@@ -612,13 +618,14 @@ __global__ void __launch_bounds__(512) k_join8_scatter(const Join8Args A) {
     for (int64_t q = r0 + (int64_t)threadIdx.x * 4; q < r1; q += (int64_t)blockDim.x * 4) {
         const int4 kv = *reinterpret_cast<const int4*>(A.keys + q);
         const int32_t k[4] = {kv.x, kv.y, kv.z, kv.w};
+        const int nvalid = hsj8_quad_valid(A, q);
         uint32_t pv = 0;
         if (A.payload) pv = *reinterpret_cast<const uint32_t*>(A.payload + q);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (q + j >= r1) break;
             uint32_t off;
-            const int w = hsj8_window(A, q + j, k[j], off, err);
+            const int w = hsj8_window(A, j < nvalid, k[j], off, err);
             if (w < 0) continue;
             const uint32_t code = (pv >> (8 * j)) & 0xffu;
             if (code == 0xffu) err |= HS_FLAG_BAD_PROGRAM;  // 0xff is the table's "no such key"
@@ -674,13 +681,14 @@ __global__ void __launch_bounds__(512) k_join8_scatter_staged(const Join8Args A)
     for (int64_t q = r0 + (int64_t)tid * 4; q < r1; q += (int64_t)nthr * 4) {
         const int4 kv = *reinterpret_cast<const int4*>(A.keys + q);
         const int32_t k[4] = {kv.x, kv.y, kv.z, kv.w};
+        const int nvalid = hsj8_quad_valid(A, q);
         uint32_t pv = 0;
         if (A.payload) pv = *reinterpret_cast<const uint32_t*>(A.payload + q);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (q + j >= r1) break;
             uint32_t off;
-            const int w = hsj8_window(A, q + j, k[j], off, err);
+            const int w = hsj8_window(A, j < nvalid, k[j], off, err);
             if (w < 0) continue;
             const uint32_t code = (pv >> (8 * j)) & 0xffu;
             if (code == 0xffu) err |= HS_FLAG_BAD_PROGRAM;
