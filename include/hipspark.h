@@ -142,7 +142,8 @@ typedef struct hs_agg_spec {
 const char* hs_last_error(void);
 int hs_version(void);
 /* sizeof() of ABI structure `which` as compiled: 0 hs_col, 1 hs_program, 2 hs_agg_spec, 3 hs_agg_geom, 4 hs_chunk,
- * 5 hs_slab_desc, 6 hs_finish_out, 7 hs_finish_spec, 8 hs_stage_plan, 9 hs_result_col, 10 hs_join8 (0 for anything else) - lets a
+ * 5 hs_slab_desc, 6 hs_finish_out, 7 hs_finish_spec, 8 hs_stage_plan, 9 hs_result_col, 10 hs_join8, 11 hs_join_stage_plan (0 for
+ * anything else) - lets a
  * binding verify its mirror. */
 size_t hs_sizeof(int32_t which);
 
@@ -729,6 +730,41 @@ int hs_stage_grow(hs_stage* stage);
 int hs_stage_stats(const hs_stage* stage, int64_t* stats);
 int hs_result_columns(const hs_stage* stage, hs_result_col* out, int32_t cap, int32_t* n);
 int hs_result_write_blockfile(const hs_stage* stage, const char* path);
+
+/* ---- the JOIN stage behind the same boundary (round 3) --------------------------------------------------------------
+ * The reference's JoinJob per shuffle partition (jobs.py:45-79, plan.py:99-109: tasks.py:201-240 build + probe feeding
+ * the partial aggregate tasks.py:284-289) and the final stage after it, for the primary-key / foreign-key case of
+ * DESIGN.md 4.6, end to end without Python: both tables through the BlockFile reader, dictionary coding of the ONE
+ * build-side column the aggregate reads, key range, byte table (hs_join8_build), probe inside the aggregate scan
+ * (hs_agg_shared_join8), raw unit tables -> exchange slab -> finish launch -> result image -> result BlockFile; capacity
+ * retry and steady-state replay like hs_stage_run.  HS_E_LIMIT for anything else (non-INTEGER or duplicate build keys, a
+ * sparse key range, a second build-side column, a GROUP BY key wider than 4 bytes): those belong to the per-operator ABI. */
+typedef struct hs_join_stage hs_join_stage;
+#define HS_JOIN_STAGE_PLAN_VERSION 1
+typedef struct hs_join_stage_plan {
+    int32_t version;               /* HS_JOIN_STAGE_PLAN_VERSION */
+    int32_t build_key_col;         /* build table: INTEGER column holding every key once */
+    int32_t build_payload_col;     /* build table: the STRING column the aggregate reads (<= 255 distinct values), or -1 */
+    int32_t probe_key_col;         /* probe table: INTEGER column */
+    int32_t n_parts;               /* shuffle partitions = JoinJobs (the reference's SHUFFLE_PARTITIONS, 10) */
+    int32_t n_cols;                /* column slots of `prog` (the unit column is added behind them) */
+    int32_t col_ids[HS_MAX_COLS];  /* slot -> probe table column, or -1 = the build-side column (its dictionary code) */
+    int32_t key_slot;              /* slot of the GROUP BY column */
+    int32_t group_cap, merge_cap;  /* starting capacities per JoinJob / of the final merge (0 = 4 / 16); grown on overflow */
+    hs_program prog;               /* [filter ... FILTER]* KEY [argument ... AGG acc]* over the slots */
+    hs_agg_spec spec;
+    hs_finish_spec fin;            /* as in hs_stage_plan */
+    hs_program fin_prog;
+    int32_t out_types[HS_FINISH_MAX_OUT];
+    char out_names[HS_FINISH_MAX_OUT][64];
+} hs_join_stage_plan;
+int hs_join_stage_prepare(hs_engine* engine, hs_table* build, hs_table* probe, const hs_join_stage_plan* plan, size_t plan_bytes,
+                          hs_join_stage** out);
+int hs_join_stage_run(hs_join_stage* stage, void* stream, uint32_t* flags_out, int64_t* n_rows_out);
+/* stats[8]: runs, replays, grows, group_cap, merge_cap, dictionary entries, table slots, slots per unit table */
+int hs_join_stage_stats(const hs_join_stage* stage, int64_t* stats);
+int hs_join_result_write_blockfile(const hs_join_stage* stage, const char* path);
+void hs_join_stage_destroy(hs_join_stage* stage);
 
 /* =================================================================================================
  * Launch capture: the native replay of a recorded query (reference: the Zig worker re-runs its compiled plan per job,

@@ -23,6 +23,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -1005,6 +1006,454 @@ extern "C" int hs_result_write_blockfile(const hs_stage* s, const char* path) {
     const bool ok = fclose(f) == 0;
     if (!ok) {
         hs_set_error("hs_result_write_blockfile: write to %s failed", path);
+        return HS_E_ARG;
+    }
+    return HS_OK;
+}
+
+// =====================================================================================================================
+// Round 3: the JOIN stage behind the same boundary - the reference's JoinJob (jobs.py:45-79, plan.py:99-109: one per
+// shuffle partition; tasks.py:201-240 build + probe, tasks.py:284-289 partial aggregate) and the final stage after it,
+// end to end without Python: BlockFile reader for BOTH tables, dictionary coding of the one build-side column the
+// aggregate reads, key range, byte table (hs_join8_build), probe inside the aggregate scan (hs_agg_shared_join8), raw unit
+// tables -> exchange slab (hs_agg_units_to_slab), finish launch, result image, result BlockFile.  Covers the primary-key /
+// foreign-key case of DESIGN.md 4.6 (INTEGER keys, dense key range, unique build keys, GROUP BY the build-side column or a
+// probe-side column of at most 4 bytes); anything else returns HS_E_LIMIT and belongs to the per-operator ABI.
+// =====================================================================================================================
+extern "C" int hs_dict_build(void* stream, const hs_col* col, int64_t nrows, int32_t cap, uint64_t* slot_words, int64_t* slot_reps,
+                             int32_t* count, uint32_t* flags);
+extern "C" int hs_dict_assign(void* stream, const hs_col* col, int64_t nrows, int32_t cap, uint64_t* slot_words, int64_t* slot_reps,
+                              const uint8_t* slot_code, uint8_t* out_codes, uint32_t* flags);
+extern "C" int hs_minmax_i32(void* stream, const int32_t* values, int64_t n, int32_t* minmax);
+
+struct hs_join_stage {
+    hs_engine* engine = nullptr;
+    hs_table *build = nullptr, *probe = nullptr;
+    hs_join_stage_plan plan{};
+    std::vector<std::string> dict;  // the payload column's distinct strings, sorted: code = index
+    DevBuf codes;                   // one code byte per build row
+    int32_t key_min = 0;
+    int64_t slots = 0;
+    DevBuf table, build_ws;
+    hs_col cols[HS_MAX_COLS + 1]{};
+    hs_agg_geom geom{};
+    DevBuf chunks, out_rep, xbuf, ws, slab, scratch;
+    int32_t group_cap = 4, merge_cap = 16, unit_cap = 0, n_units = 0, key_bytes = 1, key_kind = HS_STR;
+    bool key_is_payload = false, ready = false;
+    hs_slab_desc desc{};
+    hs_finish_spec fin{};
+    int64_t image_bytes = 0;
+    void *image_host = nullptr, *image_dev = nullptr, *capture = nullptr;
+    int64_t runs = 0, replays = 0, grows = 0;
+    uint32_t last_flags = 0;
+    int64_t last_rows = 0;
+    ~hs_join_stage() {
+        if (capture) hs_capture_free(capture);
+        if (image_host) (void)hipHostFree(image_host);
+    }
+};
+
+namespace {
+
+// bytes of row `row` of a STRING column (device) -> host; false on a copy error
+bool fetch_string(const hs_col& c, int64_t row, std::string& out) {
+    uint8_t len = 0;
+    int64_t off = 0;
+    if (c.fixed_len >= 0) {
+        len = (uint8_t)c.fixed_len;
+        off = row * (int64_t)c.fixed_len;
+    } else {
+        if (hipMemcpy(&len, c.lens + row, 1, hipMemcpyDeviceToHost) != hipSuccess) return false;
+        if (hipMemcpy(&off, c.offs + row, 8, hipMemcpyDeviceToHost) != hipSuccess) return false;
+    }
+    out.assign((size_t)len, '\0');
+    return len == 0 || hipMemcpy(&out[0], (const char*)c.data + off, len, hipMemcpyDeviceToHost) == hipSuccess;
+}
+
+// Device.dict_encode natively: distinct strings of the column (device set, representative rows read back), sorted, codes
+// named BY STRING, one code byte per row.  HS_E_LIMIT when the column has more than 255 distinct values.
+int join_encode_payload(hs_join_stage* s, const hs_col& col, int64_t n) {
+    const int32_t cap = 4096;
+    DevBuf words, reps, state, slot_code;
+    if (!words.alloc((size_t)cap * 8) || !reps.alloc((size_t)cap * 8) || !state.alloc(8, true) || !slot_code.alloc(cap, true) ||
+        !s->codes.alloc((size_t)(n > 0 ? n : 1))) {
+        hs_set_error("hs_join_stage: out of device memory");
+        return HS_E_LAUNCH;
+    }
+    int rc = hs_dict_build(nullptr, &col, n, cap, (uint64_t*)words.p, (int64_t*)reps.p, (int32_t*)state.p, (uint32_t*)state.p + 1);
+    if (rc) return rc;
+    int32_t st[2] = {0, 0};
+    std::vector<int64_t> host_reps((size_t)cap);
+    if (hipMemcpy(st, state.p, 8, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(host_reps.data(), reps.p, (size_t)cap * 8, hipMemcpyDeviceToHost) != hipSuccess)
+        return HS_E_LAUNCH;
+    if (st[1]) {
+        hs_set_error("hs_join_stage: the build-side column has too many distinct values for a code byte");
+        return HS_E_LIMIT;
+    }
+    std::vector<std::pair<int, std::string>> found;  // (slot, string)
+    for (int sl = 0; sl < cap; ++sl) {
+        if (host_reps[(size_t)sl] < 0) continue;
+        std::string text;
+        if (!fetch_string(col, host_reps[(size_t)sl], text)) return HS_E_LAUNCH;
+        found.emplace_back(sl, std::move(text));
+    }
+    s->dict.clear();
+    for (const auto& f : found) s->dict.push_back(f.second);
+    std::sort(s->dict.begin(), s->dict.end());
+    s->dict.erase(std::unique(s->dict.begin(), s->dict.end()), s->dict.end());
+    if (s->dict.size() > 255) {
+        hs_set_error("hs_join_stage: the build-side column has %zu distinct values (> 255)", s->dict.size());
+        return HS_E_LIMIT;
+    }
+    std::vector<uint8_t> codes_of_slot((size_t)cap, 0);
+    for (const auto& f : found)
+        codes_of_slot[(size_t)f.first] = (uint8_t)(std::lower_bound(s->dict.begin(), s->dict.end(), f.second) - s->dict.begin());
+    if (hipMemcpy(slot_code.p, codes_of_slot.data(), (size_t)cap, hipMemcpyHostToDevice) != hipSuccess) return HS_E_LAUNCH;
+    if (n > 0) {
+        rc = hs_dict_assign(nullptr, &col, n, cap, (uint64_t*)words.p, (int64_t*)reps.p, (const uint8_t*)slot_code.p, (uint8_t*)s->codes.p,
+                            (uint32_t*)state.p + 1);
+        if (rc) return rc;
+    }
+    if (hipDeviceSynchronize() != hipSuccess) return HS_E_LAUNCH;  // the temporaries above go out of scope
+    return HS_OK;
+}
+
+int join_prepare_aggregate(hs_join_stage* s) {
+    const hs_join_stage_plan& P = s->plan;
+    if (s->capture) {
+        hs_capture_free(s->capture);
+        s->capture = nullptr;
+    }
+    s->ready = false;
+    s->n_units = P.n_parts;
+    int cap = 16;
+    while (cap < (s->group_cap > 4 ? s->group_cap : 4) * s->n_units) cap *= 2;
+    if (cap > 4096) cap = 4096;
+    const int64_t unit_rows[2] = {0, s->probe->nrows};
+    int rc = hs_agg_shared_geom(unit_rows, 1, P.spec.n_acc, cap, &s->geom);
+    if (rc) return rc;
+    std::vector<hs_chunk> chunks((size_t)(s->geom.n_chunks > 0 ? s->geom.n_chunks : 1));
+    int64_t chunk0[2] = {0, 0};
+    rc = hs_agg_partial_chunks(unit_rows, 1, &s->geom, chunks.data(), chunk0);
+    if (rc) return rc;
+    int per_unit = cap / s->n_units, small = 16;
+    if (per_unit < 4) per_unit = 4;
+    while (small < 4 * per_unit) small *= 2;
+    if (s->geom.pad > small) s->geom.pad = small;  // slots of ONE unit's table
+    s->unit_cap = s->geom.pad;
+    const int64_t slots = (int64_t)s->n_units * s->unit_cap;
+    const int n_acc = P.spec.n_acc;
+    bool ok = s->chunks.alloc(chunks.size() * sizeof(hs_chunk)) &&
+              hipMemcpy(s->chunks.p, chunks.data(), chunks.size() * sizeof(hs_chunk), hipMemcpyHostToDevice) == hipSuccess &&
+              s->out_rep.alloc((size_t)slots * 8) && s->xbuf.alloc((size_t)(16 + slots * 8 * (1 + n_acc)), true) &&
+              s->ws.alloc((size_t)(s->geom.n_chunks > 0 ? s->geom.n_chunks : 1) * (size_t)slots * (size_t)(n_acc > 0 ? n_acc : 1) * 8, true);
+    // slab: header | order key i64 x M | key column | accumulator columns (4 bytes per row); unit u owns rows [u * cap, (u + 1) * cap)
+    hs_slab_desc& d = s->desc;
+    memset(&d, 0, sizeof(d));
+    d.slab_rows = slots;
+    int64_t pos = 16;
+    d.order_off = pos;
+    pos += 8 * d.slab_rows;
+    pos = (pos + 15) & ~(int64_t)15;
+    d.key_off = pos;
+    pos += (int64_t)s->key_bytes * d.slab_rows;
+    d.n_acc = n_acc;
+    for (int a = 0; a < n_acc; ++a) {
+        pos = (pos + 15) & ~(int64_t)15;
+        d.acc_off[a] = pos;
+        d.acc_kind[a] = P.spec.is_int[a] ? HS_I32 : HS_F32;
+        pos += 4 * d.slab_rows;
+    }
+    d.stride = (pos + 15) & ~(int64_t)15;
+    d.key_kind = s->key_kind;
+    d.key_len = s->key_kind == HS_STR ? s->key_bytes : 0;
+    ok = ok && s->slab.alloc((size_t)d.stride, true);
+    s->fin = P.fin;
+    pos = 16;
+    for (int o = 0; o < s->fin.n_out; ++o) {
+        hs_finish_out& out = s->fin.outs[o];
+        const int width = out.src == 0 ? s->key_bytes : (out.kind == HS_I64 ? 8 : 4);
+        out.offset = pos;
+        pos = (pos + (int64_t)s->merge_cap * width + 15) & ~(int64_t)15;
+    }
+    s->image_bytes = pos;
+    if (s->image_host) (void)hipHostFree(s->image_host);
+    s->image_host = s->image_dev = nullptr;
+    ok = ok && hipHostMalloc(&s->image_host, (size_t)s->image_bytes + kPad, hipHostMallocMapped) == hipSuccess &&
+         hipHostGetDevicePointer(&s->image_dev, s->image_host, 0) == hipSuccess && s->image_dev;
+    if (ok) memset(s->image_host, 0, (size_t)s->image_bytes + kPad);
+    ok = ok && s->scratch.alloc(hs_agg_finish_scratch_bytes(s->merge_cap, s->fin.n_fold), true);
+    if (!ok) {
+        hs_set_error("hs_join_stage: out of device / pinned memory");
+        return HS_E_LAUNCH;
+    }
+    s->ready = true;
+    return HS_OK;
+}
+
+int join_launch(hs_join_stage* s, void* stream) {
+    const hs_join_stage_plan& P = s->plan;
+    uint32_t* flags = (uint32_t*)s->engine->flags.p;
+    const hs_col& bk = s->build->cols[P.build_key_col].col;
+    int rc = hs_join8_build(stream, (const int32_t*)bk.data, P.build_payload_col >= 0 ? (const uint8_t*)s->codes.p : nullptr,
+                            s->build->nrows, 0, nullptr, s->key_min, s->slots, (uint8_t*)s->table.p, s->build_ws.p, flags);
+    if (rc) return rc;
+    const hs_join8 J{(const uint8_t*)s->table.p, s->slots, s->key_min, P.n_parts};
+    const int64_t slots = (int64_t)s->n_units * s->unit_cap;
+    uint64_t* keys = (uint64_t*)((char*)s->xbuf.p + 16);
+    uint64_t* acc = keys + slots;
+    rc = hs_agg_shared_join8(stream, s->cols, P.n_cols + 1, P.key_slot, P.n_cols, &J, s->n_units, &P.prog, &P.spec,
+                             (const hs_chunk*)s->chunks.p, &s->geom, (int64_t*)s->out_rep.p, keys, acc, s->ws.p, flags, nullptr, nullptr);
+    if (rc) return rc;
+    rc = hs_agg_units_to_slab(stream, keys, acc, s->n_units, s->unit_cap, &P.spec, (uint8_t*)s->slab.p, &s->desc, flags);
+    if (rc) return rc;
+    return hs_agg_finish(stream, (const uint8_t*)s->slab.p, 1, &s->desc, &s->fin, P.fin_prog.n_ins ? &P.fin_prog : nullptr,
+                         s->n_units, s->merge_cap, (uint8_t*)s->image_dev, s->scratch.p, flags, (uint32_t*)s->slab.p);
+}
+
+}  // namespace
+
+extern "C" int hs_join_stage_prepare(hs_engine* e, hs_table* build, hs_table* probe, const hs_join_stage_plan* plan,
+                                     size_t plan_bytes, hs_join_stage** out) {
+    if (!e || !build || !probe || !plan || !out || plan_bytes != sizeof(hs_join_stage_plan) ||
+        plan->version != HS_JOIN_STAGE_PLAN_VERSION || plan->n_cols < 1 || plan->n_cols >= 8 /* HS_FUSED_COLS: preloaded slots, one is the unit column */ ||
+        plan->key_slot < 0 || plan->key_slot >= plan->n_cols || plan->n_parts < 1 || plan->n_parts > 127 ||
+        plan->build_key_col < 0 || plan->build_key_col >= (int)build->cols.size() || plan->probe_key_col < 0 ||
+        plan->probe_key_col >= (int)probe->cols.size() || plan->build_payload_col >= (int)build->cols.size()) {
+        hs_set_error("hs_join_stage_prepare: bad plan blob (size %zu, expected %zu)", plan_bytes, sizeof(hs_join_stage_plan));
+        return HS_E_ARG;
+    }
+    if (hipSetDevice(e->device) != hipSuccess) return HS_E_LAUNCH;
+    if (kind_of_type(build->cols[plan->build_key_col].type) != HS_I32 || kind_of_type(probe->cols[plan->probe_key_col].type) != HS_I32) {
+        hs_set_error("hs_join_stage_prepare: join keys must be INTEGER columns");
+        return HS_E_LIMIT;
+    }
+    // read what the query references: build key (+ payload), probe key + the program's probe-side columns
+    std::vector<int32_t> bcols{plan->build_key_col}, pcols{plan->probe_key_col};
+    if (plan->build_payload_col >= 0) bcols.push_back(plan->build_payload_col);
+    for (int i = 0; i < plan->n_cols; ++i) {
+        if (plan->col_ids[i] >= (int)probe->cols.size()) {
+            hs_set_error("hs_join_stage_prepare: slot %d names probe column %d", i, plan->col_ids[i]);
+            return HS_E_ARG;
+        }
+        if (plan->col_ids[i] >= 0) pcols.push_back(plan->col_ids[i]);
+    }
+    int rc = hs_table_load(e, build, bcols.data(), (int32_t)bcols.size());
+    if (!rc) rc = hs_table_load(e, probe, pcols.data(), (int32_t)pcols.size());
+    if (rc) return rc;
+    if (build->nrows <= 0 || build->nrows >= 0xffffffffll || probe->nrows >= 0xffffffffll) {
+        hs_set_error("hs_join_stage_prepare: empty build side or more than 2^32 rows");
+        return HS_E_LIMIT;
+    }
+    hs_join_stage* s = new hs_join_stage();
+    s->engine = e;
+    s->build = build;
+    s->probe = probe;
+    s->plan = *plan;
+    s->group_cap = plan->group_cap > 0 ? plan->group_cap : 4;
+    s->merge_cap = plan->merge_cap > 0 ? plan->merge_cap : 16;
+    auto fail = [&](int code) {
+        delete s;
+        return code;
+    };
+    if (plan->build_payload_col >= 0) {
+        const hs_col& pc = build->cols[plan->build_payload_col].col;
+        if (pc.kind != HS_STR) {
+            hs_set_error("hs_join_stage_prepare: the build-side column must be a STRING column");
+            return fail(HS_E_LIMIT);
+        }
+        rc = join_encode_payload(s, pc, build->nrows);
+        if (rc) return fail(rc);
+    }
+    // key range of the build side -> direct addressing
+    DevBuf mm;
+    int32_t minmax[2] = {0, 0};
+    const hs_col& bk = build->cols[plan->build_key_col].col;
+    if (!mm.alloc(8) || hs_minmax_i32(nullptr, (const int32_t*)bk.data, build->nrows, (int32_t*)mm.p) != HS_OK ||
+        hipMemcpy(minmax, mm.p, 8, hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(HS_E_LAUNCH);
+    s->key_min = minmax[0];
+    s->slots = (int64_t)minmax[1] - (int64_t)minmax[0] + 1;
+    if (s->slots > (1ll << 30) || s->slots > 32 * build->nrows) {
+        hs_set_error("hs_join_stage_prepare: the build side's key range (%lld slots for %lld keys) is too sparse for the byte table",
+                     (long long)s->slots, (long long)build->nrows);
+        return fail(HS_E_LIMIT);
+    }
+    if (!s->table.alloc(hs_join8_table_bytes(s->slots)) || !s->build_ws.alloc(hs_join8_ws_bytes(build->nrows, s->slots))) {
+        hs_set_error("hs_join_stage_prepare: out of device memory");
+        return fail(HS_E_LAUNCH);
+    }
+    // column slots of the program: probe-side columns as loaded, the payload as the virtual code column, the unit column last
+    const hs_col& pk = probe->cols[plan->probe_key_col].col;
+    for (int i = 0; i < plan->n_cols; ++i) {
+        if (plan->col_ids[i] >= 0) s->cols[i] = probe->cols[plan->col_ids[i]].col;
+        else s->cols[i] = hs_col{HS_JOIN8_CODE, 1, pk.data, nullptr, nullptr};
+    }
+    s->cols[plan->n_cols] = hs_col{HS_JOIN8_UNIT, -1, pk.data, nullptr, nullptr};
+    const hs_col& kc = s->cols[plan->key_slot];
+    s->key_is_payload = kc.kind == HS_JOIN8_CODE;
+    if (s->key_is_payload) {
+        s->key_kind = HS_STR;
+        s->key_bytes = 1;
+    } else if (kc.kind == HS_I32) {
+        s->key_kind = HS_I32;
+        s->key_bytes = 4;
+    } else if (kc.kind == HS_STR && (kc.fixed_len == 1 || kc.fixed_len == 2 || kc.fixed_len == 4)) {
+        s->key_kind = HS_STR;
+        s->key_bytes = kc.fixed_len;
+    } else {
+        hs_set_error("hs_join_stage_prepare: the GROUP BY key must be the build-side column, an INTEGER or a short fixed string");
+        return fail(HS_E_LIMIT);
+    }
+    rc = join_prepare_aggregate(s);
+    if (rc) return fail(rc);
+    *out = s;
+    return HS_OK;
+}
+
+extern "C" void hs_join_stage_destroy(hs_join_stage* s) { delete s; }
+
+extern "C" int hs_join_stage_run(hs_join_stage* s, void* stream, uint32_t* flags_out, int64_t* n_rows_out) {
+    if (!s) {
+        hs_set_error("hs_join_stage_run: null stage");
+        return HS_E_ARG;
+    }
+    for (int attempt = 0; attempt < 12; ++attempt) {
+        int rc = HS_OK;
+        if (!s->ready) rc = join_prepare_aggregate(s);
+        if (rc) return rc;
+        if (s->capture) {
+            rc = hs_capture_replay(s->capture, stream);
+            ++s->replays;
+        } else {
+            const bool record = s->runs >= 1;
+            if (record) rc = hs_capture_begin();
+            if (!rc) rc = join_launch(s, stream);
+            if (record) {
+                int32_t n_ops = 0;
+                void* handle = nullptr;
+                const int rc2 = hs_capture_end(&handle, &n_ops);
+                if (!rc && !rc2 && n_ops > 0) s->capture = handle;
+                else if (handle) hs_capture_free(handle);
+            }
+        }
+        if (rc) return rc;
+        volatile uint32_t* done = (volatile uint32_t*)s->image_host + 1;
+        for (int64_t spins = 0; *done == 0; ++spins) {
+            if (spins > 2000000) {
+                if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess || *done == 0) {
+                    hs_set_error("hs_join_stage_run: the finish launch did not hand its result over");
+                    return HS_E_LAUNCH;
+                }
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        s->last_flags = *(volatile uint32_t*)s->image_host;
+        const int64_t n = *(volatile int64_t*)((char*)s->image_host + 8);
+        s->last_rows = n < s->merge_cap ? n : s->merge_cap;
+        *done = 0;
+        ++s->runs;
+        if (s->last_flags & HS_FLAG_JOIN_DUP) {
+            hs_set_error("hs_join_stage_run: the build side holds a key twice: not a primary-key / foreign-key join (use hs_join_build / count / fill)");
+            return HS_E_LIMIT;
+        }
+        if (s->last_flags & (HS_FLAG_DICT_FULL | HS_FLAG_MERGE_FULL)) {
+            const bool unit_full = s->last_flags & HS_FLAG_DICT_FULL, merge_full = s->last_flags & HS_FLAG_MERGE_FULL;
+            if ((unit_full && s->group_cap * s->n_units >= 4096) || (merge_full && s->merge_cap >= 4096)) {
+                hs_set_error("hs_join_stage_run: GROUP BY cardinality exceeds the on-chip tiers of this path");
+                return HS_E_LIMIT;
+            }
+            if (unit_full) s->group_cap *= 4;
+            if (merge_full) s->merge_cap *= 4;
+            if (s->merge_cap < 4 * s->group_cap) s->merge_cap = 4 * s->group_cap;
+            if (s->merge_cap > 4096) s->merge_cap = 4096;
+            s->ready = false;
+            s->runs = 0;
+            ++s->grows;
+            continue;
+        }
+        if (flags_out) *flags_out = s->last_flags;
+        if (n_rows_out) *n_rows_out = s->last_rows;
+        return HS_OK;
+    }
+    hs_set_error("hs_join_stage_run: capacities did not settle");
+    return HS_E_LIMIT;
+}
+
+extern "C" int hs_join_stage_stats(const hs_join_stage* s, int64_t* stats) {
+    if (!s || !stats) return HS_E_ARG;
+    stats[0] = s->runs;
+    stats[1] = s->replays;
+    stats[2] = s->grows;
+    stats[3] = s->group_cap;
+    stats[4] = s->merge_cap;
+    stats[5] = (int64_t)s->dict.size();
+    stats[6] = s->slots;
+    stats[7] = s->unit_cap;
+    return HS_OK;
+}
+
+// The result as a one-block BlockFile (tasks.py:400-410, io.py:47-109).  A key that is the build-side column arrives as
+// code bytes: decoded through the stage's dictionary here.
+extern "C" int hs_join_result_write_blockfile(const hs_join_stage* s, const char* path) {
+    if (!s || !s->ready || !path) {
+        hs_set_error("hs_join_result_write_blockfile: bad arguments");
+        return HS_E_ARG;
+    }
+    if (s->last_rows == 0) return HS_OK;  // empty result: the reference writes no file (tasks.py:405)
+    FILE* f = fopen(path, "wb");
+    if (!f) {
+        hs_set_error("hs_join_result_write_blockfile: cannot create %s", path);
+        return HS_E_ARG;
+    }
+    const int n_out = s->fin.n_out;
+    const uint8_t nc = (uint8_t)n_out;
+    fwrite(&nc, 1, 1, f);
+    for (int o = 0; o < n_out; ++o) {
+        const uint8_t type = (uint8_t)s->plan.out_types[o];
+        const uint8_t len = (uint8_t)strnlen(s->plan.out_names[o], sizeof(s->plan.out_names[o]));
+        fwrite(&type, 1, 1, f);
+        fwrite(&len, 1, 1, f);
+        fwrite(s->plan.out_names[o], 1, len, f);
+    }
+    const uint64_t block_start = (uint64_t)ftell(f);
+    const uint32_t rows = (uint32_t)s->last_rows;
+    fwrite(&rows, 4, 1, f);
+    bool ok = true;
+    for (int o = 0; o < n_out; ++o) {
+        const hs_finish_out& d = s->fin.outs[o];
+        const uint8_t* col = (const uint8_t*)s->image_host + d.offset;
+        if (d.src == 0 && s->key_is_payload) {  // code bytes -> the strings they stand for
+            uint64_t bytes = rows;
+            for (uint32_t r = 0; r < rows; ++r) {
+                if (col[r] >= s->dict.size()) ok = false;
+                else bytes += s->dict[col[r]].size();
+            }
+            fwrite(&bytes, 8, 1, f);
+            for (uint32_t r = 0; ok && r < rows; ++r) {
+                const uint8_t len = (uint8_t)s->dict[col[r]].size();
+                fwrite(&len, 1, 1, f);
+            }
+            for (uint32_t r = 0; ok && r < rows; ++r) fwrite(s->dict[col[r]].data(), 1, s->dict[col[r]].size(), f);
+            continue;
+        }
+        const bool is_key_string = d.src == 0 && s->key_kind == HS_STR;
+        const int width = d.src == 0 ? s->key_bytes : (d.kind == HS_I64 ? 8 : 4);
+        const uint64_t bytes = (uint64_t)rows * (uint64_t)width + (is_key_string ? rows : 0);
+        fwrite(&bytes, 8, 1, f);
+        if (is_key_string) {
+            const uint8_t w = (uint8_t)width;
+            for (uint32_t r = 0; r < rows; ++r) fwrite(&w, 1, 1, f);
+        }
+        fwrite(col, 1, (size_t)rows * (size_t)width, f);
+    }
+    fwrite(&block_start, 8, 1, f);
+    const uint32_t nblocks = 1;
+    fwrite(&nblocks, 4, 1, f);
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) {
+        hs_set_error("hs_join_result_write_blockfile: write to %s failed (or a key code outside the dictionary)", path);
         return HS_E_ARG;
     }
     return HS_OK;

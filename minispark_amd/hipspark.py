@@ -168,6 +168,30 @@ class hs_stage_plan(C.Structure):
     ]
 
 
+HS_JOIN_STAGE_PLAN_VERSION = 1
+
+
+class hs_join_stage_plan(C.Structure):
+    _fields_ = [
+        ("version", C.c_int32),
+        ("build_key_col", C.c_int32),
+        ("build_payload_col", C.c_int32),
+        ("probe_key_col", C.c_int32),
+        ("n_parts", C.c_int32),
+        ("n_cols", C.c_int32),
+        ("col_ids", C.c_int32 * HS_MAX_COLS),
+        ("key_slot", C.c_int32),
+        ("group_cap", C.c_int32),
+        ("merge_cap", C.c_int32),
+        ("prog", hs_program),
+        ("spec", hs_agg_spec),
+        ("fin", hs_finish_spec),
+        ("fin_prog", hs_program),
+        ("out_types", C.c_int32 * HS_FINISH_MAX_OUT),
+        ("out_names", (C.c_char * 64) * HS_FINISH_MAX_OUT),
+    ]
+
+
 class hs_trace_slice(C.Structure):
     _fields_ = [("name", C.c_char * 96), ("start_us", C.c_double), ("dur_us", C.c_double)]
 
@@ -287,6 +311,11 @@ SIGNATURES: dict[str, tuple] = {
     "hs_table_load": (C.c_int, [_P, _P, C.POINTER(_I32), _I32]),
     "hs_table_column": (C.c_int, [_P, _I32, _COLP, C.POINTER(_I64)]),
     "hs_table_attach": (C.c_int, [_P, _I32, _COLP, C.POINTER(_I32), C.POINTER(_I64), _I32, C.POINTER(_P)]),
+    "hs_join_stage_prepare": (C.c_int, [_P, _P, _P, C.POINTER(hs_join_stage_plan), C.c_size_t, C.POINTER(_P)]),
+    "hs_join_stage_run": (C.c_int, [_P, _P, C.POINTER(C.c_uint32), C.POINTER(_I64)]),
+    "hs_join_stage_stats": (C.c_int, [_P, C.POINTER(_I64)]),
+    "hs_join_result_write_blockfile": (C.c_int, [_P, C.c_char_p]),
+    "hs_join_stage_destroy": (None, [_P]),
     "hs_stage_prepare": (C.c_int, [_P, _P, C.POINTER(hs_stage_plan), C.c_size_t, _I32, C.POINTER(_P)]),
     "hs_stage_destroy": (None, [_P]),
     "hs_stage_run": (C.c_int, [_P, _P, C.POINTER(C.c_uint32), C.POINTER(_I64)]),

@@ -91,6 +91,145 @@ def lower_stage_plan(full_task: Any, plan: Any = None) -> tuple[hs.hs_stage_plan
     return blob, Path(scan.producer.file_path), out_schema
 
 
+def lower_join_stage_plan(full_task: Any, plan: Any = None, n_parts: int | None = None) -> tuple[hs.hs_join_stage_plan, Path, Path, Schema]:
+    """orders JOIN lineitem ... GROUP BY (BASELINE config 4's shape) -> (plan blob of the native JOIN stage, build table path,
+    probe table path, result schema).  The reference plans such a query as four stages: shuffle of
+    either input by the join key, [join -> partial aggregate -> shuffle], final; the native stage runs the last two
+    over the tables themselves, with the JoinJob of a row given by hash(key) % n_parts (plan.py:99-109, tasks.py:362)."""
+    from . import constants  # noqa: PLC0415
+
+    if plan is None:
+        from .plan import PhysicalPlan  # noqa: PLC0415
+
+        plan = PhysicalPlan.generate_physical_plan(full_task)
+    stages = list(plan.stages)
+    join = next((st for st in stages if _cls(st.producer) == "BroadcastHashJoinTask"), None)
+    final = next((st for st in stages if _cls(st.producer) == "LoadShuffleFilesTask" and _cls(st.writer) == "WriteToLocalFileTask"), None)
+    if join is None or final is None or len(stages) != 4 or len(join.dependencies) != 2:
+        raise StageUnsupported("not a [scan, scan, join -> partial aggregate, final] plan")
+    sides = []
+    for dep in join.dependencies:  # the two inputs: plain scans, at most a projection that only selects columns
+        if _cls(dep.producer) != "LoadTableBlockTask":
+            raise StageUnsupported("a join input is not a table scan")
+        for task in dep.consumers:
+            if _cls(task) != "ProjectTask" or any(_cls(_bare(c)) not in ("Col", "SchemaCol") for c in task.columns):
+                raise StageUnsupported(f"{_cls(task)} between a table and the join")
+        sides.append(dep.producer)
+    build, probe = sides
+    task = join.producer
+    filters, partial = [], None
+    for t in join.consumers:
+        if _cls(t) == "FilterTask" and partial is None:
+            filters.append(t.condition)
+        elif _cls(t) == "AggregateTask" and t.before_shuffle and partial is None:
+            partial = t
+        else:
+            raise StageUnsupported(f"{_cls(t)} in the join stage")
+    consumers = list(final.consumers)
+    if partial is None or not consumers or _cls(consumers[0]) != "AggregateTask" or consumers[0].before_shuffle:
+        raise StageUnsupported("no partial / final aggregate pair")
+    if len(consumers) > 2 or (len(consumers) == 2 and _cls(consumers[1]) != "ProjectTask"):
+        raise StageUnsupported("more than a projection after the final aggregate")
+    merge = consumers[0]
+    project = list(consumers[1].columns) if len(consumers) == 2 else None
+    out_schema = list(final.writer.inferred_schema)
+
+    def table_names(producer: Any) -> list[str]:
+        prefix = f"{producer.alias}." if getattr(producer, "alias", "") else ""
+        return [prefix + n for n, _ in BlockFile(Path(producer.file_path)).file_schema]
+
+    bnames, pnames = table_names(build), table_names(probe)
+    bschema, pschema = list(BlockFile(Path(build.file_path)).file_schema), list(BlockFile(Path(probe.file_path)).file_schema)
+    lname, rname = task.left_key.name, task.right_key.name
+    if lname not in bnames or rname not in pnames:
+        raise StageUnsupported("join keys are not plain columns of the two tables")
+    # the aggregate's view: every probe-side column under its name + the build-side columns it names
+    used = set()
+    for expr in [*filters, partial.group_by_column, *[a.original_col for a in partial.agg_columns]]:
+        used.update(c.name for c in expr.all_nested_columns if _cls(c) in ("Col", "SchemaCol"))
+    wanted_build = sorted(n for n in used if n in bnames and n not in pnames)
+    if len(wanted_build) > 1:
+        raise StageUnsupported("the aggregate reads more than one build-side column")
+    payload = wanted_build[0] if wanted_build else None
+    if payload is not None and any(c.name == payload for f in filters for c in f.all_nested_columns if _cls(c) in ("Col", "SchemaCol")):
+        raise StageUnsupported("a predicate on the build-side column")  # it exists as a table byte only
+    schema = [(n, t) for n, (_, t) in zip(pnames, pschema)]
+    if payload is not None:
+        if bschema[bnames.index(payload)][1] != ColumnType.STRING:
+            raise StageUnsupported("the build-side column must be a STRING column")
+        schema.append((payload, ColumnType.STRING))
+    kinds = [_FILE_KIND[t] for _, t in schema]
+    # the payload is lowered as a dictionary-coded string (one code byte): the dictionary itself is built natively, its
+    # contents do not matter to the program as long as no predicate looks inside the strings
+    dicts = [None] * len(pnames) + ([(b"",)] if payload is not None else [])
+    low = lower_aggregate(schema, kinds, filters, partial.group_by_column, partial.agg_columns, dicts)
+    if low.program.code_columns:
+        raise StageUnsupported("a predicate on dictionary codes")
+    if low.numeric_slots >= hs.HS_FUSED_COLS:
+        raise StageUnsupported(f"more than {hs.HS_FUSED_COLS - 1} column slots")
+    acc_kinds = [hs.I32 if is_int else hs.F32 for is_int in low.acc_is_int]
+    key_idx = low.program.columns[low.key_slot]
+    fin, fin_prog, outs = lower_finish(low.agg_to_acc, acc_kinds, kinds[key_idx], merge.agg_columns, merge.inferred_schema,
+                                       project, out_schema)
+    blob = hs.hs_join_stage_plan()
+    blob.version = hs.HS_JOIN_STAGE_PLAN_VERSION
+    blob.build_key_col = bnames.index(lname)
+    blob.build_payload_col = bnames.index(payload) if payload is not None else -1
+    blob.probe_key_col = pnames.index(rname)
+    blob.n_parts = n_parts if n_parts is not None else constants.SHUFFLE_PARTITIONS
+    blob.n_cols = len(low.program.columns)
+    for slot, idx in enumerate(low.program.columns):
+        blob.col_ids[slot] = idx if idx < len(pnames) else -1
+    blob.key_slot = low.key_slot
+    blob.group_cap, blob.merge_cap = 4, 16
+    blob.prog = low.program.to_struct()
+    blob.spec = low.spec()
+    blob.fin = fin
+    if fin_prog is not None:
+        blob.fin_prog = fin_prog
+    for o, (name, ctype) in enumerate(out_schema):
+        blob.out_types[o] = _TYPE_CODE[ctype]
+        blob.out_names[o].value = name.split(".", 1)[-1].encode()[:63] if "." in name else name.encode()[:63]
+    return blob, Path(build.file_path), Path(probe.file_path), out_schema
+
+
+def _bare(col: Any) -> Any:
+    from .lowering import unalias  # noqa: PLC0415
+
+    return unalias(col)
+
+
+class NativeJoinStage:
+    """A prepared join + GROUP BY query behind the C ABI: ``run()`` -> rows (through the result BlockFile the library writes)."""
+
+    def __init__(self, engine: "NativeEngine", full_task: Any, plan: Any = None) -> None:
+        self.engine, self.lib = engine, engine.lib
+        self.blob, self.build_path, self.probe_path, self.schema = lower_join_stage_plan(full_task, plan)
+        self.handle = C.c_void_p()
+        hs.check(self.lib.hs_join_stage_prepare(engine.handle, engine.table(self.build_path), engine.table(self.probe_path),
+                                                C.byref(self.blob), C.sizeof(self.blob), C.byref(self.handle)), "hs_join_stage_prepare")
+
+    def run(self, out_path: Path | str, stream: int | None = None) -> list[Row]:
+        flags, nrows = C.c_uint32(0), C.c_int64(0)
+        hs.check(self.lib.hs_join_stage_run(self.handle, stream, C.byref(flags), C.byref(nrows)), "hs_join_stage_run")
+        raise_for_flags(flags.value)
+        if nrows.value == 0:
+            return []
+        Path(out_path).parent.mkdir(parents=True, exist_ok=True)
+        hs.check(self.lib.hs_join_result_write_blockfile(self.handle, str(out_path).encode()), "hs_join_result_write_blockfile")
+        return read_result_file(out_path)
+
+    def stats(self) -> dict:
+        s = (C.c_int64 * 8)()
+        hs.check(self.lib.hs_join_stage_stats(self.handle, s), "hs_join_stage_stats")
+        return dict(zip(("runs", "replays", "grows", "group_cap", "merge_cap", "dictionary", "table_slots", "unit_cap"), (int(v) for v in s)))
+
+    def close(self) -> None:
+        if self.handle:
+            self.lib.hs_join_stage_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
 class NativeEngine:
     """hs_engine + the tables it has open."""
 

@@ -37,7 +37,7 @@ def test_struct_layouts_match_the_header():
     # and the sizes the library was compiled with
     lib = hs.load_library()
     mirrors = [hs.hs_col, hs.hs_program, hs.hs_agg_spec, hs.hs_agg_geom, hs.hs_chunk, hs.hs_slab_desc, hs.hs_finish_out,
-               hs.hs_finish_spec, hs.hs_stage_plan, hs.hs_result_col, hs.hs_join8]
+               hs.hs_finish_spec, hs.hs_stage_plan, hs.hs_result_col, hs.hs_join8, hs.hs_join_stage_plan]
     for which, mirror in enumerate(mirrors):
         assert lib.hs_sizeof(which) == C.sizeof(mirror), mirror.__name__
     assert lib.hs_sizeof(len(mirrors)) == 0
@@ -231,6 +231,37 @@ def test_stage_plan_blob_lowers_without_a_gpu_and_matches_the_library_mirror():
     assert blob.fin_prog.n_ins > 0  # the three AVG = sum / count projections
     assert [blob.out_names[o].value.decode() for o in range(9)] == [n for n, _ in schema]
     assert blob.out_types[0] == 1 and blob.out_types[8] == 0  # STRING key ... INTEGER count
+
+
+def test_join_stage_plan_blob_lowers_without_a_gpu():
+    """minispark_amd/stage.py lower_join_stage_plan: BASELINE config 4's query -> hs_join_stage_plan (what a cgo / JNI host
+    would build for the native JOIN stage); shapes the stage does not hold are refused on the host."""
+    import pytest
+
+    from minispark_amd.dataframe import DataFrame
+    from minispark_amd.sql import Col, Functions, Lit
+    from minispark_amd.stage import StageUnsupported, lower_join_stage_plan
+    from minispark_amd.workloads import api_namespace, join_group
+
+    lib = hs.load_library()
+    assert lib.hs_sizeof(11) == C.sizeof(hs.hs_join_stage_plan)
+    g = load_golden("join_group")
+    api = api_namespace(lambda: DataFrame(engine=object()), Col, Functions, Lit)
+    blob, build, probe, schema = lower_join_stage_plan(join_group(api, g["paths"]["orders"], g["paths"]["lineitem"]).task)
+    assert (str(build), str(probe)) == (g["paths"]["orders"], g["paths"]["lineitem"])
+    assert blob.version == hs.HS_JOIN_STAGE_PLAN_VERSION and blob.n_parts == 10
+    assert (blob.build_key_col, blob.build_payload_col, blob.probe_key_col) == (0, 1, 0)
+    assert blob.n_cols == 3 and list(blob.col_ids)[:3] == [-1, 1, 2] and blob.key_slot == 0  # the key is the build-side column
+    assert blob.spec.n_acc == 4 and blob.fin.n_fold == 4 and blob.fin.n_out == len(schema) == 5
+    assert [blob.out_names[o].value.decode() for o in range(5)] == ["o_orderpriority", "n", "qty", "revenue", "max_price"]
+    C_, F = api.Col, api.F
+    o = api.DataFrame().table(g["paths"]["orders"]).select(C_("o_orderkey"), C_("o_orderpriority"))
+    li = api.DataFrame().table(g["paths"]["lineitem"]).select(C_("l_orderkey"), C_("l_quantity"))
+    with pytest.raises(StageUnsupported, match="predicate on the build-side column"):
+        lower_join_stage_plan(o.join(li, on=C_("o_orderkey") == C_("l_orderkey"), how="inner").filter(C_("o_orderpriority").like("1%"))
+                              .group_by(C_("o_orderpriority")).agg(F.count()).task)
+    with pytest.raises(StageUnsupported):
+        lower_join_stage_plan(api.DataFrame().table(g["paths"]["lineitem"]).group_by(C_("l_orderkey")).agg(F.count()).task)
 
 
 def test_radix_tier_plan_is_host_only_and_sizes_its_workspace():

@@ -173,3 +173,62 @@ def test_random_scan_group_by_queries_through_the_stage_abi(tmp_path, seed):
             assert "exceeds the on-chip tiers" in str(e) and len(want) > 16, (key, len(want), e)
         finally:
             stage.close()
+
+
+# ---- round 3: the JOIN stage behind the same boundary -----------------------------------------------------------------
+def test_join_group_runs_through_the_native_join_stage(tmp_path):
+    """The reference's join + GROUP BY golden (`join_group`: orders JOIN lineitem GROUP BY o_orderpriority, tables
+    written by the reference's writer) through hs_join_stage_* alone - no Device, no torch: native reader for both tables,
+    native dictionary coding of o_orderpriority, byte table, probe inside the aggregate scan, finish launch, result
+    BlockFile with the codes decoded."""
+    from minispark_amd.stage import NativeEngine, NativeJoinStage
+
+    golden = load_golden("join_group")
+    task = case_by_name("join_group").build(_api(), golden["paths"]).task
+    with NativeEngine(0) as engine:
+        stage = NativeJoinStage(engine, task)
+        for i in range(4):  # first run, recorded run, replays
+            rows = stage.run(tmp_path / f"result{i}.bin")
+            flips = assert_rows_match(rows, golden["rows"], max_ulps=1)
+            assert flips <= 2  # the shared-dictionary tier adds in hardware order
+        stats = stage.stats()
+        assert stats["replays"] >= 1 and stats["dictionary"] == 5 and stats["table_slots"] > 0
+        stage.close()
+
+
+def test_native_join_stage_on_generated_tables_filters_keys_and_refusals(tmp_path):
+    """INTEGER probe-side GROUP BY key, a WHERE on the probe side, lineitems without an order, more groups per JoinJob than
+    the starting capacity (the library grows by itself) - against the Python oracle; and what the stage must refuse
+    (HS_E_LIMIT -> the per-operator ABI): duplicate build keys, a second build-side column."""
+    from minispark_amd.hipspark import HipSparkLimit
+    from minispark_amd.stage import NativeEngine, NativeJoinStage, StageUnsupported
+    from oracle.py_engine import run_query
+    from tests.test_gpu_join_dict import _join_queries, _join_tables
+
+    orders, lineitem = _join_tables(tmp_path, 3000, 20_000, seed=31)
+    api = _api()
+    queries = _join_queries(api, orders, lineitem)
+    with NativeEngine(0) as engine:
+        for name in ("config4", "filtered_on_the_probe_side", "count_only"):
+            want = run_query(queries[name].task)
+            stage = NativeJoinStage(engine, queries[name].task)
+            for i in range(3):
+                assert assert_rows_match(stage.run(tmp_path / f"{name}{i}.bin"), want, max_ulps=1) <= 2
+            stage.close()
+        with pytest.raises(StageUnsupported):
+            NativeJoinStage(engine, queries["filtered_with_build_side_argument"].task)  # two build-side columns
+    small_orders, small_li = _join_tables(tmp_path / "k", 300, 5000, seed=32)
+    by_key = _join_queries(api, small_orders, small_li)["probe_side_int_key"]
+    want = run_query(by_key.task)
+    with NativeEngine(0) as engine:
+        stage = NativeJoinStage(engine, by_key.task)
+        for i in range(3):
+            assert_rows_match(stage.run(tmp_path / f"bykey{i}.bin"), want, max_ulps=1)
+        assert stage.stats()["grows"] >= 1
+        stage.close()
+    dup_orders, dup_li = _join_tables(tmp_path / "d", 2000, 9000, seed=22, dup=True)
+    with NativeEngine(0) as engine:
+        stage = NativeJoinStage(engine, _join_queries(api, dup_orders, dup_li)["config4"].task)
+        with pytest.raises(HipSparkLimit, match="key twice"):
+            stage.run(tmp_path / "dup.bin")
+        stage.close()
