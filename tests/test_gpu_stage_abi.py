@@ -217,6 +217,8 @@ def test_native_join_stage_on_generated_tables_filters_keys_and_refusals(tmp_pat
             stage.close()
         with pytest.raises(StageUnsupported):
             NativeJoinStage(engine, queries["filtered_with_build_side_argument"].task)  # two build-side columns
+    (tmp_path / "k").mkdir()
+    (tmp_path / "d").mkdir()
     small_orders, small_li = _join_tables(tmp_path / "k", 300, 5000, seed=32)
     by_key = _join_queries(api, small_orders, small_li)["probe_side_int_key"]
     want = run_query(by_key.task)
