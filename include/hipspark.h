@@ -142,8 +142,8 @@ typedef struct hs_agg_spec {
 const char* hs_last_error(void);
 int hs_version(void);
 /* sizeof() of ABI structure `which` as compiled: 0 hs_col, 1 hs_program, 2 hs_agg_spec, 3 hs_agg_geom, 4 hs_chunk,
- * 5 hs_slab_desc, 6 hs_finish_out, 7 hs_finish_spec, 8 hs_stage_plan, 9 hs_result_col, 10 hs_join8, 11 hs_join_stage_plan (0 for
- * anything else) - lets a
+ * 5 hs_slab_desc, 6 hs_finish_out, 7 hs_finish_spec, 8 hs_stage_plan, 9 hs_result_col, 10 hs_join8, 11 hs_join_stage_plan, 12 hs_select_stage_plan
+ * (0 for anything else) - lets a
  * binding verify its mirror. */
 size_t hs_sizeof(int32_t which);
 
@@ -765,6 +765,34 @@ int hs_join_stage_run(hs_join_stage* stage, void* stream, uint32_t* flags_out, i
 int hs_join_stage_stats(const hs_join_stage* stage, int64_t* stats);
 int hs_join_result_write_blockfile(const hs_join_stage* stage, const char* path);
 void hs_join_stage_destroy(hs_join_stage* stage);
+
+/* ---- the SELECT / WHERE stage behind the same boundary (round 3) -------------------------------------------------------
+ * A ScanJob whose rows go to the result file (jobs.py:45-60; FilterTask tasks.py:167-177, ProjectTask tasks.py:32-35,
+ * WriteToLocalFileTask tasks.py:391-410): table -> [WHERE] -> selected columns.  An output is either a table column passed
+ * through as stored, or output k of the `project` program (a numeric expression, evaluated in f64 / i64 over the surviving
+ * rows and rounded to the file's FLOAT / INTEGER with the reference's overflow errors).  The result is held on the host
+ * after a run; hs_select_result_write_blockfile writes it as blocks of rows_per_block rows (the reference: 2 097 152). */
+typedef struct hs_select_stage hs_select_stage;
+#define HS_SELECT_STAGE_PLAN_VERSION 1
+typedef struct hs_select_stage_plan {
+    int32_t version;                       /* HS_SELECT_STAGE_PLAN_VERSION */
+    int32_t n_cols;                        /* column slots of `filter` */
+    int32_t col_ids[HS_MAX_COLS];          /* slot -> table column */
+    hs_program filter;                     /* one HS_OP_OUT 0 = the row survives (HS_U8 mask); n_ins 0 = no WHERE */
+    int32_t n_pcols;                       /* column slots of `project` */
+    int32_t pcol_ids[HS_MAX_COLS];
+    hs_program project;                    /* HS_OP_OUT k = computed column k; n_ins 0 = none */
+    int32_t project_kinds[HS_MAX_OUTS];    /* HS_F64 / HS_I64 per computed column */
+    int32_t n_out;
+    int32_t out_src[HS_FINISH_MAX_OUT];    /* >= 0: table column passed through; -1 - k: computed column k */
+    int32_t out_types[HS_FINISH_MAX_OUT];  /* BlockFile type code of every result column */
+    char out_names[HS_FINISH_MAX_OUT][64];
+} hs_select_stage_plan;
+int hs_select_stage_prepare(hs_engine* engine, hs_table* table, const hs_select_stage_plan* plan, size_t plan_bytes,
+                            hs_select_stage** out);
+int hs_select_stage_run(hs_select_stage* stage, void* stream, uint32_t* flags_out, int64_t* n_rows_out);
+int hs_select_result_write_blockfile(const hs_select_stage* stage, const char* path, int64_t rows_per_block);
+void hs_select_stage_destroy(hs_select_stage* stage);
 
 /* =================================================================================================
  * Launch capture: the native replay of a recorded query (reference: the Zig worker re-runs its compiled plan per job,

@@ -1458,3 +1458,240 @@ extern "C" int hs_join_result_write_blockfile(const hs_join_stage* s, const char
     }
     return HS_OK;
 }
+
+// =====================================================================================================================
+// Round 3: the SELECT / WHERE stage behind the same boundary - a ScanJob whose rows go to the result file
+// (jobs.py:45-60; FilterTask tasks.py:167-177, ProjectTask tasks.py:32-35, WriteToLocalFileTask tasks.py:391-410): native
+// reader -> predicate (hs_eval) -> stable compaction (hs_compact) -> gathers of the passed-through columns / evaluation of
+// the computed ones over the surviving rows (hs_eval with a row list) -> rounding to the stored kinds (hs_quantise) ->
+// one device->host copy per column -> BlockFile blocks of ROWS_PER_BLOCK rows, appended in table order.
+// =====================================================================================================================
+struct hs_select_stage {
+    hs_engine* engine = nullptr;
+    hs_table* table = nullptr;
+    hs_select_stage_plan plan{};
+    hs_col cols[HS_MAX_COLS]{}, pcols[HS_MAX_COLS]{};
+    // last result, host side: per output column the stored values (strings: lens + payload)
+    struct Out {
+        std::vector<uint8_t> data, lens;
+        int width = 0;
+    };
+    std::vector<Out> outs;
+    int64_t last_rows = 0;
+    uint32_t last_flags = 0;
+};
+
+extern "C" int hs_select_stage_prepare(hs_engine* e, hs_table* t, const hs_select_stage_plan* plan, size_t plan_bytes,
+                                       hs_select_stage** out) {
+    if (!e || !t || !plan || !out || plan_bytes != sizeof(hs_select_stage_plan) || plan->version != HS_SELECT_STAGE_PLAN_VERSION ||
+        plan->n_cols < 0 || plan->n_cols > HS_MAX_COLS || plan->n_pcols < 0 || plan->n_pcols > HS_MAX_COLS || plan->n_out < 1 ||
+        plan->n_out > HS_FINISH_MAX_OUT) {
+        hs_set_error("hs_select_stage_prepare: bad plan blob (size %zu, expected %zu)", plan_bytes, sizeof(hs_select_stage_plan));
+        return HS_E_ARG;
+    }
+    if (hipSetDevice(e->device) != hipSuccess) return HS_E_LAUNCH;
+    std::vector<int32_t> need(plan->col_ids, plan->col_ids + plan->n_cols);
+    need.insert(need.end(), plan->pcol_ids, plan->pcol_ids + plan->n_pcols);
+    for (int o = 0; o < plan->n_out; ++o) {
+        const int src = plan->out_src[o];
+        if (src >= (int)t->cols.size() || (src < 0 && (-1 - src) >= HS_MAX_OUTS)) {
+            hs_set_error("hs_select_stage_prepare: output %d is malformed", o);
+            return HS_E_ARG;
+        }
+        if (src >= 0) need.push_back(src);
+    }
+    for (int32_t c : need) {
+        if (c < 0 || c >= (int)t->cols.size()) {
+            hs_set_error("hs_select_stage_prepare: no such column %d", c);
+            return HS_E_ARG;
+        }
+    }
+    const int rc = hs_table_load(e, t, need.data(), (int32_t)need.size());
+    if (rc) return rc;
+    hs_select_stage* s = new hs_select_stage();
+    s->engine = e;
+    s->table = t;
+    s->plan = *plan;
+    for (int i = 0; i < plan->n_cols; ++i) s->cols[i] = t->cols[plan->col_ids[i]].col;
+    for (int i = 0; i < plan->n_pcols; ++i) s->pcols[i] = t->cols[plan->pcol_ids[i]].col;
+    *out = s;
+    return HS_OK;
+}
+
+extern "C" void hs_select_stage_destroy(hs_select_stage* s) { delete s; }
+
+extern "C" int hs_select_stage_run(hs_select_stage* s, void* stream_, uint32_t* flags_out, int64_t* n_rows_out) {
+    if (!s) {
+        hs_set_error("hs_select_stage_run: null stage");
+        return HS_E_ARG;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    const hs_select_stage_plan& P = s->plan;
+    hs_table* t = s->table;
+    const int64_t n = t->nrows;
+    uint32_t* flags = (uint32_t*)s->engine->flags.p;
+    if (hipMemsetAsync(flags, 0, 4, stream) != hipSuccess) return HS_E_LAUNCH;
+    int rc = HS_OK;
+    // WHERE: mask -> ascending list of the surviving rows
+    DevBuf mask, sel, count, scan_ws;
+    int64_t kept = n;
+    const bool filtered = P.filter.n_ins > 0;
+    if (filtered && n > 0) {
+        if (!mask.alloc((size_t)n) || !sel.alloc((size_t)n * 8) || !count.alloc(8) || !scan_ws.alloc(hs_scan_ws_bytes(n))) {
+            hs_set_error("hs_select_stage_run: out of device memory");
+            return HS_E_LAUNCH;
+        }
+        void* outs[1] = {mask.p};
+        const int32_t kinds[1] = {HS_U8};
+        rc = hs_eval(stream, s->cols, P.n_cols, &P.filter, nullptr, n, nullptr, outs, kinds, 1, flags);
+        if (!rc) rc = hs_compact(stream, (const uint8_t*)mask.p, n, (int64_t*)sel.p, (int64_t*)count.p, scan_ws.p);
+        if (rc) return rc;
+        if (hipMemcpyAsync(&kept, count.p, 8, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+            return HS_E_LAUNCH;
+    }
+    const int64_t* rows = filtered && n > 0 ? (const int64_t*)sel.p : nullptr;
+    // computed columns over the surviving rows (in-flight f64 / i64), then rounded to what the file stores
+    DevBuf computed[HS_MAX_OUTS], stored[HS_MAX_OUTS];
+    int n_prog_out = 0;
+    for (int o = 0; o < P.n_out; ++o)
+        if (P.out_src[o] < 0 && -1 - P.out_src[o] + 1 > n_prog_out) n_prog_out = -1 - P.out_src[o] + 1;
+    if (n_prog_out > 0 && kept > 0) {
+        void* outs[HS_MAX_OUTS] = {};
+        int32_t kinds[HS_MAX_OUTS] = {};
+        for (int k = 0; k < n_prog_out; ++k) {
+            if (!computed[k].alloc((size_t)kept * 8)) return HS_E_LAUNCH;
+            outs[k] = computed[k].p;
+            kinds[k] = P.project_kinds[k];
+        }
+        rc = hs_eval(stream, s->pcols, P.n_pcols, &P.project, rows, kept, nullptr, outs, kinds, n_prog_out, flags);
+        for (int k = 0; !rc && k < n_prog_out; ++k) {
+            if (!stored[k].alloc((size_t)kept * 4)) return HS_E_LAUNCH;
+            rc = hs_quantise(stream, computed[k].p, kinds[k], kept, nullptr, stored[k].p, flags);
+        }
+        if (rc) return rc;
+    }
+    // every output column -> host
+    s->outs.assign((size_t)P.n_out, hs_select_stage::Out());
+    for (int o = 0; o < P.n_out && kept > 0; ++o) {
+        hs_select_stage::Out& out = s->outs[(size_t)o];
+        const int src = P.out_src[o];
+        if (src < 0) {
+            out.width = 4;
+            out.data.resize((size_t)kept * 4);
+            if (hipMemcpyAsync(out.data.data(), stored[-1 - src].p, out.data.size(), hipMemcpyDeviceToHost, stream) != hipSuccess) return HS_E_LAUNCH;
+            continue;
+        }
+        const hs_col& c = t->cols[src].col;
+        if (c.kind != HS_STR) {
+            const int w = elem_bytes(c.kind);
+            out.width = w;
+            out.data.resize((size_t)kept * (size_t)w);
+            if (!rows) {
+                if (hipMemcpyAsync(out.data.data(), c.data, out.data.size(), hipMemcpyDeviceToHost, stream) != hipSuccess) return HS_E_LAUNCH;
+            } else {
+                DevBuf g;
+                if (!g.alloc(out.data.size())) return HS_E_LAUNCH;
+                rc = hs_gather_fixed(stream, c.data, w, n, rows, kept, nullptr, g.p, flags);
+                if (rc) return rc;
+                if (hipMemcpyAsync(out.data.data(), g.p, out.data.size(), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+                    hipStreamSynchronize(stream) != hipSuccess)
+                    return HS_E_LAUNCH;
+            }
+            continue;
+        }
+        // STRING: lengths, offsets, bytes of the surviving rows
+        DevBuf lens, offs, mm, ws, data;
+        if (!lens.alloc((size_t)kept) || !offs.alloc((size_t)(kept + 1) * 8) || !mm.alloc(8) || !ws.alloc(hs_scan_ws_bytes(kept))) return HS_E_LAUNCH;
+        std::vector<int64_t> iota;
+        DevBuf all_rows;
+        const int64_t* idx = rows;
+        if (!idx) {  // no WHERE: the gathers still want a row list
+            iota.resize((size_t)kept);
+            for (int64_t i = 0; i < kept; ++i) iota[(size_t)i] = i;
+            if (!all_rows.alloc((size_t)kept * 8) || hipMemcpy(all_rows.p, iota.data(), (size_t)kept * 8, hipMemcpyHostToDevice) != hipSuccess)
+                return HS_E_LAUNCH;
+            idx = (const int64_t*)all_rows.p;
+        }
+        rc = hs_gather_str_lens(stream, &c, n, idx, kept, (uint8_t*)lens.p, flags);
+        if (!rc) rc = hs_str_offsets(stream, (const uint8_t*)lens.p, kept, (int64_t*)offs.p, (int32_t*)mm.p, ws.p);
+        if (rc) return rc;
+        int64_t total = 0;
+        if (hipMemcpyAsync(&total, (const int64_t*)offs.p + kept, 8, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+            hipStreamSynchronize(stream) != hipSuccess)
+            return HS_E_LAUNCH;
+        if (!data.alloc((size_t)(total > 0 ? total : 1))) return HS_E_LAUNCH;
+        rc = hs_gather_str_bytes(stream, &c, n, idx, kept, (const int64_t*)offs.p, (uint8_t*)data.p);
+        if (rc) return rc;
+        out.width = -1;
+        out.lens.resize((size_t)kept);
+        out.data.resize((size_t)total);
+        if (hipMemcpyAsync(out.lens.data(), lens.p, (size_t)kept, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+            (total > 0 && hipMemcpyAsync(out.data.data(), data.p, (size_t)total, hipMemcpyDeviceToHost, stream) != hipSuccess) ||
+            hipStreamSynchronize(stream) != hipSuccess)
+            return HS_E_LAUNCH;
+    }
+    uint32_t f = 0;
+    if (hipMemcpyAsync(&f, flags, 4, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return HS_E_LAUNCH;
+    s->last_flags = f;
+    s->last_rows = kept;
+    if (flags_out) *flags_out = f;
+    if (n_rows_out) *n_rows_out = kept;
+    return HS_OK;
+}
+
+// The rows of the last run as a BlockFile of rows_per_block-row blocks (reference tasks.py:391-410 + io.py:217-252: a
+// result larger than a block continues in further blocks; an empty result writes no file).
+extern "C" int hs_select_result_write_blockfile(const hs_select_stage* s, const char* path, int64_t rows_per_block) {
+    if (!s || !path || rows_per_block < 1) {
+        hs_set_error("hs_select_result_write_blockfile: bad arguments");
+        return HS_E_ARG;
+    }
+    if (s->last_rows == 0) return HS_OK;
+    FILE* f = fopen(path, "wb");
+    if (!f) {
+        hs_set_error("hs_select_result_write_blockfile: cannot create %s", path);
+        return HS_E_ARG;
+    }
+    const hs_select_stage_plan& P = s->plan;
+    const uint8_t nc = (uint8_t)P.n_out;
+    fwrite(&nc, 1, 1, f);
+    for (int o = 0; o < P.n_out; ++o) {
+        const uint8_t type = (uint8_t)P.out_types[o];
+        const uint8_t len = (uint8_t)strnlen(P.out_names[o], sizeof(P.out_names[o]));
+        fwrite(&type, 1, 1, f);
+        fwrite(&len, 1, 1, f);
+        fwrite(P.out_names[o], 1, len, f);
+    }
+    std::vector<uint64_t> starts;
+    std::vector<int64_t> str_pos((size_t)P.n_out, 0);  // byte position inside a string column's payload
+    for (int64_t lo = 0; lo < s->last_rows; lo += rows_per_block) {
+        const int64_t hi = lo + rows_per_block < s->last_rows ? lo + rows_per_block : s->last_rows;
+        const uint32_t rows = (uint32_t)(hi - lo);
+        starts.push_back((uint64_t)ftell(f));
+        fwrite(&rows, 4, 1, f);
+        for (int o = 0; o < P.n_out; ++o) {
+            const hs_select_stage::Out& out = s->outs[(size_t)o];
+            if (out.width > 0) {
+                const uint64_t bytes = (uint64_t)rows * (uint64_t)out.width;
+                fwrite(&bytes, 8, 1, f);
+                fwrite(out.data.data() + (size_t)lo * (size_t)out.width, 1, (size_t)bytes, f);
+            } else {
+                uint64_t payload = 0;
+                for (int64_t r = lo; r < hi; ++r) payload += out.lens[(size_t)r];
+                const uint64_t bytes = rows + payload;
+                fwrite(&bytes, 8, 1, f);
+                fwrite(out.lens.data() + lo, 1, rows, f);
+                fwrite(out.data.data() + str_pos[(size_t)o], 1, (size_t)payload, f);
+                str_pos[(size_t)o] += (int64_t)payload;
+            }
+        }
+    }
+    fwrite(starts.data(), 8, starts.size(), f);
+    const uint32_t nblocks = (uint32_t)starts.size();
+    fwrite(&nblocks, 4, 1, f);
+    if (fclose(f) != 0) {
+        hs_set_error("hs_select_result_write_blockfile: write to %s failed", path);
+        return HS_E_ARG;
+    }
+    return HS_OK;
+}

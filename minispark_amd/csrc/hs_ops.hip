@@ -36,6 +36,7 @@ extern "C" size_t hs_sizeof(int32_t which) {
         case 9: return sizeof(hs_result_col);
         case 10: return sizeof(hs_join8);
         case 11: return sizeof(hs_join_stage_plan);
+        case 12: return sizeof(hs_select_stage_plan);
         default: return 0;
     }
 }

@@ -921,6 +921,7 @@ class HipExecutionEngine(ExecutionEngine):
                 continue
             width = agree_string_width(self.dist, col.fixed_len, col.n, self.dev.device, self.group)
             table.columns[cid] = self.dev.with_string_width(col, width)
+            table.columns[cid]._hs_width_agreed = True  # (see _agree_key_width)
             agreed.add(cid)
 
     @staticmethod
@@ -1081,9 +1082,17 @@ class HipExecutionEngine(ExecutionEngine):
         col = batch.cols[idx]
         if col.kind != hs.STR:
             return batch
+        if col.dict is not None or getattr(col, "_hs_width_agreed", False):
+            # one code byte per row under a dictionary all ranks share, or a table column whose width was agreed when the
+            # table was opened: the width IS global - no collective per run.  (Round 3: this collective is not part of a
+            # recorded run; a rank replaying its recording while another took the full path - recordings become available
+            # at rank-local moments - left the other rank alone in it: fuzz seed 610 on 2 ranks hung.)
+            return batch
         if batch.lazy:
             batch = self.dev.resolve(batch)
             col = batch.cols[idx]
+        if self.dev.rec is not None:
+            self.dev.rec.poisoned = True  # a run with a collective of its own is never replayed, on any rank
         width = agree_string_width(self.dist, col.fixed_len, col.n, self.dev.device, self.group)
         if width == col.fixed_len:
             return batch

@@ -192,6 +192,26 @@ class hs_join_stage_plan(C.Structure):
     ]
 
 
+HS_SELECT_STAGE_PLAN_VERSION = 1
+
+
+class hs_select_stage_plan(C.Structure):
+    _fields_ = [
+        ("version", C.c_int32),
+        ("n_cols", C.c_int32),
+        ("col_ids", C.c_int32 * HS_MAX_COLS),
+        ("filter", hs_program),
+        ("n_pcols", C.c_int32),
+        ("pcol_ids", C.c_int32 * HS_MAX_COLS),
+        ("project", hs_program),
+        ("project_kinds", C.c_int32 * HS_MAX_OUTS),
+        ("n_out", C.c_int32),
+        ("out_src", C.c_int32 * HS_FINISH_MAX_OUT),
+        ("out_types", C.c_int32 * HS_FINISH_MAX_OUT),
+        ("out_names", (C.c_char * 64) * HS_FINISH_MAX_OUT),
+    ]
+
+
 class hs_trace_slice(C.Structure):
     _fields_ = [("name", C.c_char * 96), ("start_us", C.c_double), ("dur_us", C.c_double)]
 
@@ -311,6 +331,10 @@ SIGNATURES: dict[str, tuple] = {
     "hs_table_load": (C.c_int, [_P, _P, C.POINTER(_I32), _I32]),
     "hs_table_column": (C.c_int, [_P, _I32, _COLP, C.POINTER(_I64)]),
     "hs_table_attach": (C.c_int, [_P, _I32, _COLP, C.POINTER(_I32), C.POINTER(_I64), _I32, C.POINTER(_P)]),
+    "hs_select_stage_prepare": (C.c_int, [_P, _P, C.POINTER(hs_select_stage_plan), C.c_size_t, C.POINTER(_P)]),
+    "hs_select_stage_run": (C.c_int, [_P, _P, C.POINTER(C.c_uint32), C.POINTER(_I64)]),
+    "hs_select_result_write_blockfile": (C.c_int, [_P, C.c_char_p, _I64]),
+    "hs_select_stage_destroy": (None, [_P]),
     "hs_join_stage_prepare": (C.c_int, [_P, _P, _P, C.POINTER(hs_join_stage_plan), C.c_size_t, C.POINTER(_P)]),
     "hs_join_stage_run": (C.c_int, [_P, _P, C.POINTER(C.c_uint32), C.POINTER(_I64)]),
     "hs_join_stage_stats": (C.c_int, [_P, C.POINTER(_I64)]),

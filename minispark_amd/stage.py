@@ -193,6 +193,120 @@ def lower_join_stage_plan(full_task: Any, plan: Any = None, n_parts: int | None 
     return blob, Path(build.file_path), Path(probe.file_path), out_schema
 
 
+def lower_select_stage_plan(full_task: Any, plan: Any = None) -> tuple[hs.hs_select_stage_plan, Path, Schema]:
+    """table -> [filter]* -> [select] (one stage, rows to the result file) -> (plan blob of the native SELECT / WHERE stage,
+    table path, result schema)."""
+    from .lowering import ProgramBuilder, unalias  # noqa: PLC0415
+
+    if plan is None:
+        from .plan import PhysicalPlan  # noqa: PLC0415
+
+        plan = PhysicalPlan.generate_physical_plan(full_task)
+    stages = list(plan.stages)
+    if len(stages) != 1 or _cls(stages[0].producer) != "LoadTableBlockTask" or _cls(stages[0].writer) != "WriteToLocalFileTask":
+        raise StageUnsupported("not a one-stage scan to the result file")
+    stage = stages[0]
+    filters, project = [], None
+    for task in stage.consumers:
+        if _cls(task) == "FilterTask" and project is None:
+            filters.append(task.condition)
+        elif _cls(task) == "ProjectTask" and project is None:
+            project = task
+        else:
+            raise StageUnsupported(f"{_cls(task)} after the projection")
+    out_schema = list(stage.writer.inferred_schema)
+    table_schema = list(stage.producer.inferred_schema)
+    names = [n for n, _ in table_schema]
+    kinds = [_FILE_KIND[t] for _, t in table_schema]
+    blob = hs.hs_select_stage_plan()
+    blob.version = hs.HS_SELECT_STAGE_PLAN_VERSION
+    if filters:
+        cond = filters[0]
+        for extra in filters[1:]:
+            cond = cond & extra
+        fb = ProgramBuilder(table_schema, kinds)
+        if fb.emit_out(0, cond) != "B":
+            fb = ProgramBuilder(table_schema, kinds)
+            fb.emit_out(0, cond != 0)
+        fprog = fb.finish()
+        blob.n_cols = len(fprog.columns)
+        for slot, idx in enumerate(fprog.columns):
+            blob.col_ids[slot] = idx
+        blob.filter = fprog.to_struct()
+    columns = list(project.columns) if project is not None else None
+    if columns is None:  # every column as it is
+        if len(out_schema) != len(table_schema):
+            raise StageUnsupported("writer schema differs from the table's")
+        srcs = list(range(len(table_schema)))
+    else:
+        pb = ProgramBuilder(table_schema, kinds)
+        srcs, n_prog = [], 0
+        for o, col in enumerate(columns):
+            bare = unalias(col)
+            if _cls(bare) in ("Col", "SchemaCol"):
+                if bare.name not in names:
+                    raise ValueError(f'Column "{bare.name}" not found in schema {table_schema}')
+                srcs.append(names.index(bare.name))
+                continue
+            if pb.string_tag(bare):
+                raise StageUnsupported("string expression in the projection")
+            if n_prog >= hs.HS_MAX_OUTS:
+                raise StageUnsupported("too many computed columns")
+            tag = pb.emit_out(n_prog, col)
+            if tag == "B":
+                raise AssertionError("a comparison cannot be selected as a column (the reference has no BOOL type)")
+            want = out_schema[o][1]
+            if (tag, want) not in (("F", ColumnType.FLOAT), ("I", ColumnType.INTEGER)):
+                raise StageUnsupported(f"computed column of tag {tag} stored as {want}")
+            blob.project_kinds[n_prog] = hs.F64 if tag == "F" else hs.I64
+            srcs.append(-1 - n_prog)
+            n_prog += 1
+        if n_prog:
+            pprog = pb.finish()
+            blob.n_pcols = len(pprog.columns)
+            for slot, idx in enumerate(pprog.columns):
+                blob.pcol_ids[slot] = idx
+            blob.project = pprog.to_struct()
+    if len(srcs) != len(out_schema) or len(srcs) > hs.HS_FINISH_MAX_OUT:
+        raise StageUnsupported("result schema does not match the selected columns")
+    blob.n_out = len(srcs)
+    prefix = f"{stage.producer.alias}." if getattr(stage.producer, "alias", "") else ""
+    for o, ((name, ctype), src) in enumerate(zip(out_schema, srcs)):
+        blob.out_src[o] = src
+        blob.out_types[o] = _TYPE_CODE[ctype]
+        blob.out_names[o].value = name[len(prefix):].encode()[:63] if prefix and name.startswith(prefix) else name.encode()[:63]
+    return blob, Path(stage.producer.file_path), out_schema
+
+
+class NativeSelectStage:
+    """A prepared select / where query behind the C ABI: ``run(path)`` -> rows (through the result BlockFile the library writes)."""
+
+    def __init__(self, engine: "NativeEngine", full_task: Any, plan: Any = None) -> None:
+        self.engine, self.lib = engine, engine.lib
+        self.blob, self.table_path, self.schema = lower_select_stage_plan(full_task, plan)
+        self.handle = C.c_void_p()
+        hs.check(self.lib.hs_select_stage_prepare(engine.handle, engine.table(self.table_path), C.byref(self.blob),
+                                                  C.sizeof(self.blob), C.byref(self.handle)), "hs_select_stage_prepare")
+
+    def run(self, out_path: Path | str, rows_per_block: int | None = None, stream: int | None = None) -> list[Row]:
+        from . import constants  # noqa: PLC0415
+
+        flags, nrows = C.c_uint32(0), C.c_int64(0)
+        hs.check(self.lib.hs_select_stage_run(self.handle, stream, C.byref(flags), C.byref(nrows)), "hs_select_stage_run")
+        raise_for_flags(flags.value)
+        if nrows.value == 0:
+            return []
+        Path(out_path).parent.mkdir(parents=True, exist_ok=True)
+        hs.check(self.lib.hs_select_result_write_blockfile(self.handle, str(out_path).encode(),
+                                                           rows_per_block or constants.ROWS_PER_BLOCK), "hs_select_result_write_blockfile")
+        return read_result_file(out_path)
+
+    def close(self) -> None:
+        if self.handle:
+            self.lib.hs_select_stage_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
 def _bare(col: Any) -> Any:
     from .lowering import unalias  # noqa: PLC0415
 

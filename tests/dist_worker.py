@@ -17,6 +17,10 @@ sys.path.insert(0, str(ROOT))
 
 def main() -> None:
     case_name, out_path, backend = sys.argv[1], sys.argv[2], sys.argv[3]
+    if os.environ.get("HIPSPARK_WORKER_DUMP_AFTER"):  # a hung collective: every thread's stack after N seconds, then exit
+        import faulthandler
+
+        faulthandler.dump_traceback_later(int(os.environ["HIPSPARK_WORKER_DUMP_AFTER"]), exit=True)
     import torch
     import torch.distributed as dist
 

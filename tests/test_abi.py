@@ -37,7 +37,8 @@ def test_struct_layouts_match_the_header():
     # and the sizes the library was compiled with
     lib = hs.load_library()
     mirrors = [hs.hs_col, hs.hs_program, hs.hs_agg_spec, hs.hs_agg_geom, hs.hs_chunk, hs.hs_slab_desc, hs.hs_finish_out,
-               hs.hs_finish_spec, hs.hs_stage_plan, hs.hs_result_col, hs.hs_join8, hs.hs_join_stage_plan]
+               hs.hs_finish_spec, hs.hs_stage_plan, hs.hs_result_col, hs.hs_join8, hs.hs_join_stage_plan,
+               hs.hs_select_stage_plan]
     for which, mirror in enumerate(mirrors):
         assert lib.hs_sizeof(which) == C.sizeof(mirror), mirror.__name__
     assert lib.hs_sizeof(len(mirrors)) == 0
