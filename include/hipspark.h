@@ -657,13 +657,15 @@ int hs_jit_compile_check_eval(const hs_col* cols, int32_t n_cols, const hs_progr
  * parallel pread into pinned staging, async host-to-device copies; reference block_file.zig:225-306), chunk geometry,
  * the exchange slab and result-image layouts, workspaces, the capacity retry on a dictionary overflow, the
  * steady-state replay of a run's launches, and the zero-copy result hand-over.  Queries that do not fit the on-chip
- * tiers of this path (variable-length GROUP BY keys, > 4096 groups, > 8 numeric columns) return HS_E_LIMIT.
+ * tiers of this path (variable-length GROUP BY keys, more partial rows than the on-chip final merge holds, > 8 numeric
+ * columns) return HS_E_LIMIT.  Up to 16 groups per block: per-lane tables + the one-launch finish, replayed; more: the
+ * shared-dictionary scan + hs_agg_pack / hs_agg_merge / hs_eval / hs_quantise issued by hs_stage_run itself (one GPU).
  * ===============================================================================================*/
 typedef struct hs_engine hs_engine;
 typedef struct hs_table hs_table;
 typedef struct hs_stage hs_stage;
 
-#define HS_STAGE_PLAN_VERSION 1
+#define HS_STAGE_PLAN_VERSION 2
 /* The plan of [scan -> WHERE -> partial aggregate per file block] + [final merge -> projection -> result write]
  * (reference plan.py:182-204), as minispark_amd/stage.py lowers it from the reference's task objects. */
 typedef struct hs_stage_plan {
@@ -678,6 +680,14 @@ typedef struct hs_stage_plan {
     hs_program fin_prog;           /* projection after the merge (AVG = sum / count ...); n_ins 0 = none */
     int32_t out_types[HS_FINISH_MAX_OUT];    /* BlockFile type code of every result column (0 INTEGER 1 STRING 2 FLOAT 3 TIMESTAMP) */
     char out_names[HS_FINISH_MAX_OUT][64];   /* ... and its name (hs_result_write_blockfile) */
+    /* version 2: a COMPUTED GROUP BY key (SELECT (l_orderkey % 331 - 100) AS bucket ... GROUP BY bucket: a ProjectTask
+     * in front of the aggregate, reference tasks.py:32-35).  col_ids[key_slot] = -1; every run evaluates key_prog (one
+     * HS_OP_OUT 0, INTEGER-valued; the lowering only hands over expressions whose value provably fits the stored
+     * INTEGER and cannot raise, so rows the WHERE drops may be evaluated too) over the table columns kcol_ids into a
+     * 4-byte key column that lives next to the table's.  Projected columns used elsewhere are inlined into `prog`. */
+    int32_t key_computed, n_kcols;
+    int32_t kcol_ids[HS_MAX_COLS];
+    hs_program key_prog;
 } hs_stage_plan;
 
 typedef struct hs_result_col {

@@ -663,6 +663,14 @@ struct hs_stage {
     int32_t key_bytes = 0;
     int64_t n_units = 0, slab_bytes = 0, image_bytes = 0;
     DevBuf chunks, chunk0, unit_ids, slab, ws, scratch;
+    // round 3: tens to thousands of groups per block - the shared-dictionary tier + the general operator sequence after it
+    // (pack -> key gather -> merge -> key gather / projection -> rounding), all behind hs_stage_run
+    int32_t tier = 0;  // 0: per-lane tables + the one-launch finish; 1: shared dictionary + general tail
+    DevBuf key_col, key_wide;  // a computed GROUP BY key (plan version 2): the 4-byte column the scan reads + its i64 evaluation
+    hs_col kcols[HS_MAX_COLS];
+    DevBuf sh_rep, sh_acc, sh_ngroups, sh_pack_start, sh_dense_rep, sh_order, sh_key, sh_accs, sh_mrep, sh_macc, sh_mgroups, sh_mkey,
+        sh_prog_out, sh_image;
+    int64_t sh_slots = 0;
     void* image_host = nullptr;  // pinned, mapped
     void* image_dev = nullptr;
     void* capture = nullptr;     // steady state: the launches of one run
@@ -678,6 +686,35 @@ struct hs_stage {
 
 namespace {
 
+// program slots -> the table's columns; a computed key (plan version 2) gets its own 4-byte column next to them
+int bind_columns(hs_stage* s) {
+    hs_table* t = s->table;
+    const hs_stage_plan& P = s->plan;
+    for (int i = 0; i < P.n_cols; ++i)
+        if (i != P.key_slot || !P.key_computed) s->cols[i] = t->cols[P.col_ids[i]].col;
+    if (!P.key_computed) return HS_OK;
+    for (int i = 0; i < P.n_kcols; ++i) s->kcols[i] = t->cols[P.kcol_ids[i]].col;
+    const size_t rows = (size_t)(t->nrows > 0 ? t->nrows : 1);
+    if (!s->key_col.p && !(s->key_col.alloc(rows * 4 + kPad, true) && s->key_wide.alloc(rows * 8 + kPad))) {
+        hs_set_error("hs_stage: out of device memory for the computed key column");
+        return HS_E_LAUNCH;
+    }
+    s->cols[P.key_slot] = hs_col{HS_I32, -1, s->key_col.p, nullptr, nullptr};
+    return HS_OK;
+}
+
+// ProjectTask in front of the aggregate (reference tasks.py:32-35), for the key column alone: one evaluation per run
+int compute_key(hs_stage* s, void* stream) {
+    const hs_stage_plan& P = s->plan;
+    if (!P.key_computed || s->table->nrows == 0) return HS_OK;
+    void* outs[1] = {s->key_wide.p};
+    const int32_t kinds[1] = {HS_I64};
+    uint32_t* flags = (uint32_t*)s->engine->flags.p;
+    int rc = hs_eval(stream, s->kcols, P.n_kcols, &P.key_prog, nullptr, s->table->nrows, nullptr, outs, kinds, 1, flags);
+    if (!rc) rc = hs_quantise(stream, s->key_wide.p, HS_I64, s->table->nrows, nullptr, s->key_col.p, flags);
+    return rc;
+}
+
 int stage_prepare(hs_stage* s) {
     hs_table* t = s->table;
     const hs_stage_plan& P = s->plan;
@@ -686,7 +723,7 @@ int stage_prepare(hs_stage* s) {
         s->capture = nullptr;
     }
     s->ready = false;
-    for (int i = 0; i < P.n_cols; ++i) s->cols[i] = t->cols[P.col_ids[i]].col;
+    if (const int rc0 = bind_columns(s)) return rc0;
     const hs_col& kc = s->cols[P.key_slot];
     // the exchange slab holds keys in their stored kinds, packed into the 64-bit key word by the finish launch
     if (kc.kind == HS_STR) {
@@ -774,6 +811,7 @@ uint32_t* engine_flags(hs_stage* s) { return (uint32_t*)s->engine->flags.p; }
 int launch_partial(hs_stage* s, void* stream) {
     const hs_stage_plan& P = s->plan;
     if (s->n_units == 0) return HS_OK;
+    if (const int rc = compute_key(s, stream)) return rc;
     return hs_agg_partial_slab(stream, s->cols, P.n_cols, P.key_slot, &P.prog, &P.spec, (const hs_chunk*)s->chunks.p,
                                (const int64_t*)s->chunk0.p, s->n_units, &s->geom, (const int64_t*)s->unit_ids.p,
                                (uint8_t*)s->slab.p, &s->desc, s->ws.p, engine_flags(s), nullptr, nullptr);
@@ -806,6 +844,179 @@ int wait_result(hs_stage* s, void* stream) {
 
 }  // namespace
 
+namespace {
+
+// ---- the shared-dictionary tier behind hs_stage_run ------------------------------------------------------------------------
+int shared_prepare(hs_stage* s) {
+    hs_table* t = s->table;
+    const hs_stage_plan& P = s->plan;
+    s->ready = false;
+    if (s->world != 1) {
+        hs_set_error("hs_stage: more than 16 groups per block on several ranks belongs to the per-operator ABI");
+        return HS_E_LIMIT;
+    }
+    if (const int rc0 = bind_columns(s)) return rc0;
+    const hs_col& kc = s->cols[P.key_slot];
+    if (kc.kind == HS_STR) {
+        if (kc.fixed_len != 1 && kc.fixed_len != 2 && kc.fixed_len != 4) {
+            hs_set_error("hs_stage: a string GROUP BY key needs a fixed length of 1, 2 or 4 bytes on this path");
+            return HS_E_LIMIT;
+        }
+        s->key_bytes = kc.fixed_len;
+    } else if (kc.kind == HS_I32 || kc.kind == HS_F32 || kc.kind == HS_I64) {
+        s->key_bytes = elem_bytes(kc.kind);
+    } else {
+        hs_set_error("hs_stage: GROUP BY key is not a stored column kind");
+        return HS_E_LIMIT;
+    }
+    s->n_units = (int64_t)t->block_rows.size();
+    std::vector<int64_t> unit_rows(s->n_units + 1, 0);
+    for (int64_t u = 0; u < s->n_units; ++u) unit_rows[u + 1] = unit_rows[u] + t->block_rows[u];
+    int rc = hs_agg_shared_geom(unit_rows.data(), s->n_units, P.spec.n_acc, s->group_cap, &s->geom);
+    if (rc) return rc;
+    std::vector<hs_chunk> chunks((size_t)(s->geom.n_chunks > 0 ? s->geom.n_chunks : 1));
+    std::vector<int64_t> chunk0((size_t)s->n_units + 1, 0);
+    rc = hs_agg_partial_chunks(unit_rows.data(), s->n_units, &s->geom, chunks.data(), chunk0.data());
+    if (rc) return rc;
+    const int unit_cap = s->geom.pad, n_acc = P.spec.n_acc, nf = s->plan.fin.n_fold;
+    s->sh_slots = s->n_units * (int64_t)unit_cap;
+    const int64_t slots = s->sh_slots > 0 ? s->sh_slots : 1;
+    bool ok = s->chunks.alloc(chunks.size() * sizeof(hs_chunk)) &&
+              hipMemcpy(s->chunks.p, chunks.data(), chunks.size() * sizeof(hs_chunk), hipMemcpyHostToDevice) == hipSuccess &&
+              s->ws.alloc(s->geom.ws_bytes, true) && s->sh_rep.alloc((size_t)slots * 8) &&
+              s->sh_acc.alloc((size_t)slots * (size_t)(n_acc > 0 ? n_acc : 1) * 8) && s->sh_ngroups.alloc((size_t)(s->n_units + 1) * 4) &&
+              s->sh_pack_start.alloc((size_t)(s->n_units + 1) * 8) && s->sh_dense_rep.alloc((size_t)slots * 8) &&
+              s->sh_order.alloc((size_t)slots * 8) && s->sh_key.alloc((size_t)slots * 8) &&
+              s->sh_accs.alloc((size_t)slots * 4 * (size_t)(n_acc > 0 ? n_acc : 1)) && s->sh_mrep.alloc((size_t)s->merge_cap * 8) &&
+              s->sh_macc.alloc((size_t)s->merge_cap * 8 * (size_t)(nf > 0 ? nf : 1)) && s->sh_mgroups.alloc(8) &&
+              s->sh_mkey.alloc((size_t)s->merge_cap * 8) && s->sh_prog_out.alloc((size_t)s->merge_cap * 8 * HS_MAX_OUTS);
+    // result image: the layout of the on-chip path (hs_result_columns / hs_result_write_blockfile read it)
+    s->fin = P.fin;
+    int64_t pos = 16;
+    for (int o = 0; o < s->fin.n_out; ++o) {
+        hs_finish_out& out = s->fin.outs[o];
+        const int width = out.src == 0 ? s->key_bytes : (out.kind == HS_I64 ? 8 : 4);
+        out.offset = pos;
+        pos = (pos + (int64_t)s->merge_cap * width + 15) & ~(int64_t)15;
+    }
+    s->image_bytes = pos;
+    if (s->image_host) (void)hipHostFree(s->image_host);
+    s->image_host = s->image_dev = nullptr;
+    ok = ok && hipHostMalloc(&s->image_host, (size_t)s->image_bytes + kPad, hipHostMallocDefault) == hipSuccess &&
+         s->sh_image.alloc((size_t)s->image_bytes, true);
+    if (!ok) {
+        hs_set_error("hs_stage: out of device / pinned memory");
+        return HS_E_LAUNCH;
+    }
+    memset(s->image_host, 0, (size_t)s->image_bytes + kPad);
+    memset(&s->desc, 0, sizeof(s->desc));
+    s->desc.key_kind = kc.kind;
+    s->desc.key_len = kc.kind == HS_STR ? kc.fixed_len : 0;
+    s->ready = true;
+    return HS_OK;
+}
+
+// scan with one LDS dictionary per workgroup -> dense partial rows -> merge in unit order -> result columns in the image
+int shared_run(hs_stage* s, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const hs_stage_plan& P = s->plan;
+    uint32_t* flags = (uint32_t*)s->engine->flags.p;
+    const int n_acc = P.spec.n_acc, nf = s->fin.n_fold, unit_cap = s->geom.pad, cap = s->merge_cap;
+    const int64_t slots = s->sh_slots;
+    s->last_rows = 0;
+    if (hipMemsetAsync(flags, 0, 4, stream) != hipSuccess) return HS_E_LAUNCH;
+    if (s->n_units == 0 || slots == 0) {
+        s->last_flags = 0;
+        return HS_OK;
+    }
+    int rc = compute_key(s, stream);
+    if (rc) return rc;
+    rc = hs_agg_shared(stream, s->cols, P.n_cols, P.key_slot, &P.prog, &P.spec, (const hs_chunk*)s->chunks.p, s->n_units, &s->geom,
+                           (int64_t*)s->sh_rep.p, (uint64_t*)s->sh_acc.p, (int32_t*)s->sh_ngroups.p, s->ws.p, flags, nullptr, nullptr);
+    if (rc) return rc;
+    // dense partial rows = the reference's shuffle-file content: accumulators in their stored kinds, unit of every row
+    void* acc_ptrs[HS_MAX_ACC] = {};
+    int32_t acc_kinds[HS_MAX_ACC] = {};
+    for (int a = 0; a < n_acc; ++a) {
+        acc_ptrs[a] = (char*)s->sh_accs.p + (size_t)a * (size_t)slots * 4;
+        acc_kinds[a] = P.spec.is_int[a] ? HS_I32 : HS_F32;
+    }
+    rc = hs_agg_pack(stream, (const int64_t*)s->sh_rep.p, (const uint64_t*)s->sh_acc.p, (const int32_t*)s->sh_ngroups.p, s->n_units, unit_cap,
+                     &P.spec, (int64_t*)s->sh_pack_start.p, (int64_t*)s->sh_dense_rep.p, acc_ptrs, acc_kinds, nullptr, (int64_t*)s->sh_order.p);
+    if (rc) return rc;
+    const int64_t* n_dense = (const int64_t*)s->sh_pack_start.p + s->n_units;
+    const hs_col& kc = s->cols[P.key_slot];
+    rc = hs_gather_fixed(stream, kc.data, s->key_bytes, s->table->nrows, (const int64_t*)s->sh_dense_rep.p, slots, n_dense, s->sh_key.p, flags);
+    if (rc) return rc;
+    // final merge (tasks.py:290-292): fold j = fold_op[j] over the dense accumulator column fold_src[j], partials in unit order
+    hs_col key_dense{kc.kind, kc.kind == HS_STR ? kc.fixed_len : -1, s->sh_key.p, nullptr, nullptr};
+    hs_col fold_cols[HS_MAX_ACC];
+    hs_agg_spec mspec{};
+    mspec.n_acc = nf;
+    for (int j = 0; j < nf; ++j) {
+        const int src = s->fin.fold_src[j];
+        fold_cols[j] = hs_col{acc_kinds[src], -1, acc_ptrs[src], nullptr, nullptr};
+        mspec.op[j] = (uint8_t)s->fin.fold_op[j];
+        mspec.is_int[j] = P.spec.is_int[src];
+    }
+    rc = hs_agg_merge(stream, &key_dense, fold_cols, &mspec, (const int64_t*)s->sh_order.p, s->n_units, slots, n_dense, cap,
+                      (int64_t*)s->sh_mrep.p, (uint64_t*)s->sh_macc.p, (int64_t*)s->sh_mgroups.p, flags);
+    if (rc) return rc;  // HS_E_LIMIT: more partial rows than the on-chip merge holds
+    const int64_t* ng = (const int64_t*)s->sh_mgroups.p;
+    rc = hs_gather_fixed(stream, s->sh_key.p, s->key_bytes, slots, (const int64_t*)s->sh_mrep.p, cap, ng, s->sh_mkey.p, flags);
+    if (rc) return rc;
+    // projection after the merge (AVG = sum / count ...): the merged cells are its columns (slot -> key / fold j)
+    int n_prog_out = 0;
+    for (int o = 0; o < s->fin.n_out; ++o)
+        if (s->fin.outs[o].src == 2 && s->fin.outs[o].index + 1 > n_prog_out) n_prog_out = s->fin.outs[o].index + 1;
+    int32_t prog_kinds[HS_MAX_OUTS] = {};
+    if (n_prog_out > 0) {
+        hs_col pcols[HS_MAX_COLS];
+        for (int i = 0; i < HS_MAX_COLS; ++i) {
+            const int j = s->fin.prog_src[i];
+            if (j >= 0 && j < nf) pcols[i] = hs_col{mspec.is_int[j] ? HS_I64 : HS_F64, -1, (char*)s->sh_macc.p + (size_t)j * (size_t)cap * 8, nullptr, nullptr};
+            else pcols[i] = hs_col{kc.kind == HS_STR ? HS_U8 : kc.kind, -1, s->sh_mkey.p, nullptr, nullptr};
+        }
+        void* outs[HS_MAX_OUTS] = {};
+        for (int o = 0; o < s->fin.n_out; ++o) {
+            const hs_finish_out& d = s->fin.outs[o];
+            if (d.src == 2) prog_kinds[d.index] = d.kind == HS_F32 ? HS_F64 : HS_I64;
+        }
+        for (int k = 0; k < n_prog_out; ++k) outs[k] = (char*)s->sh_prog_out.p + (size_t)k * (size_t)cap * 8;
+        rc = hs_eval(stream, pcols, HS_MAX_COLS, &P.fin_prog, nullptr, cap, ng, outs, prog_kinds, n_prog_out, flags);
+        if (rc) return rc;
+    }
+    // result columns in their stored kinds, at the image's offsets
+    for (int o = 0; o < s->fin.n_out; ++o) {
+        const hs_finish_out& d = s->fin.outs[o];
+        char* dst = (char*)s->sh_image.p + d.offset;
+        if (d.src == 0) {
+            if (hipMemcpyAsync(dst, s->sh_mkey.p, (size_t)cap * (size_t)s->key_bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) return HS_E_LAUNCH;
+            continue;
+        }
+        const void* cells = d.src == 1 ? (const char*)s->sh_macc.p + (size_t)d.index * (size_t)cap * 8
+                                       : (const char*)s->sh_prog_out.p + (size_t)d.index * (size_t)cap * 8;
+        const bool is_int = d.src == 1 ? mspec.is_int[d.index] != 0 : prog_kinds[d.index] == HS_I64;
+        if (d.kind == HS_I64) {
+            if (hipMemcpyAsync(dst, cells, (size_t)cap * 8, hipMemcpyDeviceToDevice, stream) != hipSuccess) return HS_E_LAUNCH;
+        } else {
+            rc = hs_quantise(stream, cells, is_int ? HS_I64 : HS_F64, cap, ng, dst, flags);
+            if (rc) return rc;
+        }
+    }
+    int64_t n_groups = 0;
+    uint32_t f = 0;
+    if (hipMemcpyAsync((char*)s->image_host, s->sh_image.p, (size_t)s->image_bytes, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        hipMemcpyAsync(&n_groups, ng, 8, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        hipMemcpyAsync(&f, flags, 4, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)
+        return HS_E_LAUNCH;
+    s->last_flags = f;
+    s->last_rows = n_groups < cap ? n_groups : cap;
+    return HS_OK;
+}
+
+}  // namespace
+
 extern "C" int hs_stage_prepare(hs_engine* e, hs_table* t, const hs_stage_plan* plan, size_t plan_bytes, int32_t world,
                                 hs_stage** out) {
     if (!e || !t || !plan || !out || plan_bytes != sizeof(hs_stage_plan) || plan->version != HS_STAGE_PLAN_VERSION ||
@@ -814,7 +1025,22 @@ extern "C" int hs_stage_prepare(hs_engine* e, hs_table* t, const hs_stage_plan* 
         return HS_E_ARG;
     }
     if (hipSetDevice(e->device) != hipSuccess) return HS_E_LAUNCH;
-    int rc = hs_table_load(e, t, plan->col_ids, plan->n_cols);
+    if (plan->key_computed && (plan->n_kcols < 1 || plan->n_kcols > HS_MAX_COLS || plan->key_prog.n_ins < 1)) {
+        hs_set_error("hs_stage_prepare: a computed key needs its program and columns");
+        return HS_E_ARG;
+    }
+    // only the columns the programs name are read from the file
+    int32_t want[2 * HS_MAX_COLS];
+    int32_t n_want = 0;
+    auto add = [&](int32_t c) {
+        for (int k = 0; k < n_want; ++k)
+            if (want[k] == c) return;
+        want[n_want++] = c;
+    };
+    for (int i = 0; i < plan->n_cols; ++i)
+        if (i != plan->key_slot || !plan->key_computed) add(plan->col_ids[i]);
+    for (int i = 0; plan->key_computed && i < plan->n_kcols; ++i) add(plan->kcol_ids[i]);
+    int rc = n_want ? hs_table_load(e, t, want, n_want) : HS_OK;
     if (rc) return rc;
     hs_stage* s = new hs_stage();
     s->engine = e;
@@ -845,9 +1071,43 @@ extern "C" int hs_stage_run(hs_stage* s, void* stream, uint32_t* flags_out, int6
         hs_set_error("hs_stage_run: a multi-rank stage runs as hs_stage_launch_partial / collective / hs_stage_launch_finish");
         return HS_E_ARG;
     }
-    for (int attempt = 0; attempt < 10; ++attempt) {
+    for (int attempt = 0; attempt < 14; ++attempt) {
         int rc = HS_OK;
+        if (s->tier == 1) {
+            // tens to thousands of groups per block: shared-dictionary scan + the general operator sequence
+            if (!s->ready) rc = shared_prepare(s);
+            if (!rc) rc = shared_run(s, stream);
+            if (rc) return rc;
+            ++s->runs;
+            if (s->last_flags & HS_FLAG_MERGE_ROWS) {
+                hs_set_error("hs_stage_run: more partial rows than the on-chip final merge holds (the HBM tier belongs to the per-operator ABI)");
+                return HS_E_LIMIT;
+            }
+            if (s->last_flags & (HS_FLAG_DICT_FULL | HS_FLAG_MERGE_FULL)) {
+                const bool unit_full = s->last_flags & HS_FLAG_DICT_FULL, merge_full = s->last_flags & HS_FLAG_MERGE_FULL;
+                if ((unit_full && s->group_cap >= 4096) || (merge_full && s->merge_cap >= 4096)) {
+                    hs_set_error("hs_stage_run: GROUP BY cardinality exceeds the on-chip tiers of this path");
+                    return HS_E_LIMIT;
+                }
+                if (unit_full) s->group_cap *= 4;
+                if (merge_full) s->merge_cap *= 4;
+                if (s->merge_cap < s->group_cap) s->merge_cap = s->group_cap;
+                if (s->merge_cap > 4096) s->merge_cap = 4096;
+                s->ready = false;
+                ++s->grows;
+                continue;
+            }
+            if (flags_out) *flags_out = s->last_flags;
+            if (n_rows_out) *n_rows_out = s->last_rows;
+            return HS_OK;
+        }
         if (!s->ready) rc = stage_prepare(s);
+        if (rc == HS_E_LIMIT && s->world == 1) {  // the per-lane tables do not hold this query: the shared dictionary may
+            s->tier = 1;
+            if (s->group_cap < 16) s->group_cap = 16;
+            if (s->merge_cap < 64) s->merge_cap = 64;
+            continue;
+        }
         if (rc) return rc;
         if (s->capture) {
             rc = hs_capture_replay(s->capture, stream);
@@ -873,9 +1133,23 @@ extern "C" int hs_stage_run(hs_stage* s, void* stream, uint32_t* flags_out, int6
             // more groups than a dictionary was sized for: x2 per workgroup (per-lane tables), x4 for the merge - each
             // grows on its own flag; the merge also keeps up with the per-unit capacity (it holds at least as many keys)
             const bool unit_full = s->last_flags & HS_FLAG_DICT_FULL, merge_full = s->last_flags & HS_FLAG_MERGE_FULL;
-            if ((unit_full && s->group_cap >= 16) || (merge_full && s->merge_cap >= 4096)) {
+            if (merge_full && s->merge_cap >= 4096) {
                 hs_set_error("hs_stage_run: GROUP BY cardinality exceeds the on-chip tiers of this path");
                 return HS_E_LIMIT;
+            }
+            if (unit_full && s->group_cap >= 16) {
+                // past the per-lane tables: the shared-dictionary tier takes over (round 3; round 2 answered HS_E_LIMIT here)
+                if (s->capture) {
+                    hs_capture_free(s->capture);
+                    s->capture = nullptr;
+                }
+                s->tier = 1;
+                s->group_cap = 64;
+                if (s->merge_cap < 256) s->merge_cap = 256;
+                s->ready = false;
+                s->runs = 0;
+                ++s->grows;
+                continue;
             }
             if (unit_full) s->group_cap *= 2;
             if (merge_full) s->merge_cap *= 4;

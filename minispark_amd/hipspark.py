@@ -165,6 +165,10 @@ class hs_stage_plan(C.Structure):
         ("fin_prog", hs_program),
         ("out_types", C.c_int32 * HS_FINISH_MAX_OUT),
         ("out_names", (C.c_char * 64) * HS_FINISH_MAX_OUT),
+        ("key_computed", C.c_int32),
+        ("n_kcols", C.c_int32),
+        ("kcol_ids", C.c_int32 * HS_MAX_COLS),
+        ("key_prog", hs_program),
     ]
 
 
@@ -224,7 +228,7 @@ class hs_radix_plan(C.Structure):
     _fields_ = [("f", C.c_int64 * 48)]
 
 
-HS_STAGE_PLAN_VERSION = 1
+HS_STAGE_PLAN_VERSION = 2
 
 _P = C.c_void_p
 _I64 = C.c_int64

@@ -5,7 +5,8 @@ No torch, no :class:`minispark_amd.device.Device`: this is the whole host a cgo 
  - everything else (BlockFile reading, buffers, geometry, retries, replay, hand-over) happens
 behind the ABI.  The query shape it covers is the hot path's: ``table -> [filter]* -> group_by(col).agg(...)``, i.e. the
 reference's two stages [Load -> Filter* -> Aggregate(before) -> shuffle] + [shuffle -> Aggregate(after) -> (Project) ->
-result] (plan.py:182-204).
+result] (plan.py:182-204); round 3: a SELECT in front of the GROUP BY (its columns inlined, a computed INTEGER key
+materialised by the library), and any number of groups per block the on-chip tiers hold.
 """
 
 from __future__ import annotations
@@ -19,7 +20,8 @@ import numpy as np
 from . import hipspark as hs
 from .constants import ColumnType, Row, Schema
 from .io import BlockFile, StrCol, rows_from_raw
-from .lowering import lower_aggregate, lower_finish
+from .lowering import ProgramBuilder, lower_aggregate, lower_finish, unalias
+from .sql import Col
 
 _FILE_KIND = {ColumnType.INTEGER: hs.I32, ColumnType.FLOAT: hs.F32, ColumnType.TIMESTAMP: hs.I64, ColumnType.STRING: hs.STR}
 _TYPE_CODE = {ColumnType.INTEGER: 0, ColumnType.STRING: 1, ColumnType.FLOAT: 2, ColumnType.TIMESTAMP: 3}
@@ -32,6 +34,61 @@ class StageUnsupported(NotImplementedError):
 
 def _cls(obj: Any) -> str:
     return type(obj).__name__
+
+
+def _substitute(node: Any, defs: dict[str, Any] | None) -> Any:
+    """``node`` over the columns a ProjectTask produced -> the same expression over the table's columns (every projected
+    name replaced by its definition): the projection is a pure function of the row (reference tasks.py:32-35,
+    sql.py:262-266) and its values are not stored in between, so inlining it gives the same values."""
+    if defs is None:
+        return node
+    name = _cls(node)
+    if name == "AliasColumn":
+        return _substitute(node.original_col, defs)
+    if name in ("Col", "SchemaCol"):
+        if node.name not in defs:
+            raise ValueError(f'Column "{node.name}" not found in schema {list(defs)}')
+        return defs[node.name]
+    if name == "Lit":
+        return node
+    if name == "LikeColumn":
+        return type(node)(_substitute(node.original_col, defs), node.pattern)
+    if name == "BinaryOperatorColumn":
+        return type(node)(_substitute(node.left_side, defs), _substitute(node.right_side, defs), node.operator)
+    raise StageUnsupported(f"{name} over a projected column")
+
+
+def _int_bits(node: Any, schema: Schema) -> int | None:
+    """b with |value| <= 2**b for an INTEGER-valued expression that cannot raise on ANY row (no division by a column,
+    no overflow of the 64-bit cells), else None.  A computed GROUP BY key is evaluated over all rows of the table -
+    also the ones the WHERE drops - which is only the reference's behaviour when nothing can go wrong on those rows."""
+    name = _cls(node)
+    if name == "AliasColumn":
+        return _int_bits(node.original_col, schema)
+    if name in ("Col", "SchemaCol"):
+        types = dict(schema)
+        return 31 if types.get(node.name) == ColumnType.INTEGER else None
+    if name == "Lit":
+        return node.value.bit_length() if type(node.value) is int else None
+    if name != "BinaryOperatorColumn":
+        return None
+    op = node.operator.__name__
+    left = _int_bits(node.left_side, schema)
+    if left is None:
+        return None
+    if op in ("mod", "floordiv"):
+        right = unalias(node.right_side)
+        if _cls(right) != "Lit" or type(right.value) is not int or right.value == 0:
+            return None
+        return abs(right.value).bit_length() if op == "mod" else left + 1
+    right_bits = _int_bits(node.right_side, schema)
+    if right_bits is None:
+        return None
+    bits = {"add": max(left, right_bits) + 1, "sub": max(left, right_bits) + 1, "mul": left + right_bits}.get(op)
+    return bits if bits is not None and bits <= 62 else None
+
+
+COMPUTED_KEY = "__hs_computed_key"
 
 
 def lower_stage_plan(full_task: Any, plan: Any = None) -> tuple[hs.hs_stage_plan, Path, Schema]:
@@ -47,9 +104,15 @@ def lower_stage_plan(full_task: Any, plan: Any = None) -> tuple[hs.hs_stage_plan
     if _cls(scan.producer) != "LoadTableBlockTask" or _cls(final.producer) != "LoadShuffleFilesTask":
         raise StageUnsupported("not a scan stage feeding a final stage")
     filters, partial = [], None
+    defs: dict[str, Any] | None = None  # after a ProjectTask: projected name -> its expression over the table's columns
     for task in scan.consumers:
         if _cls(task) == "FilterTask" and partial is None:
-            filters.append(task.condition)
+            filters.append(_substitute(task.condition, defs))
+        elif _cls(task) == "ProjectTask" and partial is None:
+            names = [n for n, _ in task.inferred_schema]
+            if len(names) != len(task.columns) or any(getattr(unalias(c), "name", "") == "*" for c in task.columns):
+                raise StageUnsupported("SELECT * in the scan stage")
+            defs = {n: _substitute(unalias(c), defs) for n, c in zip(names, task.columns)}
         elif _cls(task) == "AggregateTask" and task.before_shuffle and partial is None:
             partial = task
         else:
@@ -66,7 +129,28 @@ def lower_stage_plan(full_task: Any, plan: Any = None) -> tuple[hs.hs_stage_plan
     table_schema = list(scan.producer.inferred_schema)
     prefix = f"{scan.producer.alias}." if getattr(scan.producer, "alias", "") else ""
     kinds = [_FILE_KIND[t] for _, t in table_schema]
-    low = lower_aggregate(table_schema, kinds, filters, partial.group_by_column, partial.agg_columns)
+    group_by, agg_columns = partial.group_by_column, list(partial.agg_columns)
+    key_program = None
+    if defs is not None:  # the projection, inlined (values are not stored between a ProjectTask and its consumer)
+        import copy  # noqa: PLC0415
+
+        group_by = _substitute(group_by, defs)
+        for i, agg in enumerate(agg_columns):
+            agg_columns[i] = copy.copy(agg)
+            agg_columns[i].original_col = _substitute(agg.original_col, defs)
+        if _cls(unalias(group_by)) not in ("Col", "SchemaCol"):
+            # GROUP BY a computed column: materialised per run by the library as a stored INTEGER column next to the table's
+            bits = _int_bits(group_by, table_schema)
+            if bits is None or bits > 30:
+                raise StageUnsupported("a computed GROUP BY key must be an INTEGER expression that provably fits the stored type")
+            kb = ProgramBuilder(table_schema, kinds)
+            if kb.emit_out(0, group_by) != "I":
+                raise StageUnsupported("a computed GROUP BY key must be INTEGER-valued")
+            key_program = kb.finish()
+            table_schema = table_schema + [(COMPUTED_KEY, ColumnType.INTEGER)]
+            kinds = kinds + [hs.I32]
+            group_by = Col(COMPUTED_KEY)
+    low = lower_aggregate(table_schema, kinds, filters, group_by, agg_columns)
     if low.numeric_slots > hs.HS_FUSED_COLS:
         raise StageUnsupported(f"more than {hs.HS_FUSED_COLS} numeric columns")
     acc_kinds = [hs.I32 if is_int else hs.F32 for is_int in low.acc_is_int]
@@ -77,7 +161,14 @@ def lower_stage_plan(full_task: Any, plan: Any = None) -> tuple[hs.hs_stage_plan
     blob.version = hs.HS_STAGE_PLAN_VERSION
     blob.n_cols = len(low.program.columns)
     for slot, idx in enumerate(low.program.columns):
-        blob.col_ids[slot] = idx
+        blob.col_ids[slot] = -1 if key_program is not None and idx == len(table_schema) - 1 else idx
+    if key_program is not None:
+        if any(idx == len(table_schema) - 1 for s_, idx in enumerate(low.program.columns) if s_ != low.key_slot):
+            raise AssertionError("the computed key column is read by name only as the key")
+        blob.key_computed, blob.n_kcols = 1, len(key_program.columns)
+        for slot, idx in enumerate(key_program.columns):
+            blob.kcol_ids[slot] = idx
+        blob.key_prog = key_program.to_struct()
     blob.key_slot = low.key_slot
     blob.group_cap, blob.merge_cap = 4, 16
     blob.prog = low.program.to_struct()

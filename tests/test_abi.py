@@ -288,3 +288,35 @@ def test_radix_tier_plan_is_host_only_and_sizes_its_workspace():
     assert 32 * 60_000_000 <= mid <= 48 * 60_000_000
     assert ws(1000, 1, 1000, key_kind=hs.STR)[0] != 0 and ws(0, 1, 1)[0] != 0 and ws(10, 0, 10)[0] != 0
     assert b"hs_group_radix_plan" in lib.hs_last_error()
+
+
+def test_scan_stage_lowering_inlines_a_projection_and_hands_over_a_computed_key():
+    """Round 3: SELECT (l_orderkey % 331 - 100) AS bucket, ... GROUP BY bucket lowers to plan version 2 - the key as its own
+    program over the table's columns, the other projected columns inlined; expressions that could raise on rows the WHERE
+    drops, or that may not fit the stored INTEGER, are refused (the engine's general path takes them)."""
+    import pytest
+
+    from minispark_amd.dataframe import DataFrame
+    from minispark_amd.io import BlockFile
+    from minispark_amd.sql import Col, Functions as F, Lit
+    from minispark_amd.stage import StageUnsupported, lower_stage_plan
+    from tests.conftest import load_golden
+
+    path = load_golden("many_groups")["paths"]["lineitem"]
+    def frame(key):
+        return (DataFrame(object()).table(path).filter(Col("l_shipdate") > "1992-03-01")
+                .select(key.alias("bucket"), Col("l_extendedprice").alias("price"), (Col("l_tax") * 2).alias("t2"))
+                .filter(Col("t2") < 0.15).group_by(Col("bucket")).agg(F.sum(Col("price") * (Lit(1) + Col("t2"))).alias("g"), F.count()))
+
+    blob, table, schema = lower_stage_plan(frame(Col("l_orderkey") % 331 - 100).task)
+    assert blob.version == 2 and blob.key_computed == 1 and blob.n_kcols == 1 and blob.col_ids[blob.key_slot] == -1
+    names = [n for n, _ in BlockFile(path).file_schema]
+    assert names[blob.kcol_ids[0]] == "l_orderkey"
+    used = {names[blob.col_ids[i]] for i in range(blob.n_cols) if i != blob.key_slot}
+    assert used == {"l_shipdate", "l_extendedprice", "l_tax"}  # projected names resolved to the table's columns
+    assert [n for n, _ in schema][0] == "bucket" and Path(table) == Path(path)
+    for bad in (Col("l_orderkey") // Col("l_orderkey"),  # may divide by zero on a row the WHERE drops
+                Col("l_orderkey") * 4,                    # may not fit the stored INTEGER
+                Col("l_orderkey") * Col("l_orderkey")):
+        with pytest.raises(StageUnsupported):
+            lower_stage_plan(frame(bad).task)
