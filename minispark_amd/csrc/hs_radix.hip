@@ -94,7 +94,7 @@ struct RxPass {
     int64_t n_seg;
     int32_t shift, bits;       // bin = (mix(key word) >> shift) & (2^bits - 1); raw: ((key + 1) >> shift) & ... (hs_sort_by_order)
     int32_t n_cols, first;     // columns that travel (0 = key); first pass reads the key through `key` / `sel`
-    int32_t raw, pad;
+    int32_t raw, key4;         // key4: the key is a 4-byte integer (bins from a 32-bit mix: a quarter of hs_mix64's multiplies)
     hs_col key;
     const int64_t* sel;
     int64_t row0;
@@ -110,6 +110,19 @@ __device__ __forceinline__ uint64_t rx_key(const RxPass& A, int64_t i) {
 }
 __device__ __forceinline__ uint32_t rx_bin(uint64_t word, int shift, int bits, int raw) {
     return (uint32_t)((raw ? word + 1 : hs_mix64(word)) >> shift) & ((1u << bits) - 1u);
+}
+// 4-byte keys: which partition a key lands in only has to be a function of the key that spreads well - one 32-bit multiply
+// and a fold of the high half into the low (the passes take bits 0 .. 15) instead of hs_mix64's 64-bit multiplies, in the
+// histogram and the scatter of either pass alike
+__device__ __forceinline__ uint32_t rx_mix32(uint32_t k) {
+    uint32_t h = k * 0x9E3779B1u;
+    h ^= h >> 15;
+    h *= 0x85EBCA77u;
+    return h ^ (h >> 16);
+}
+__device__ __forceinline__ uint32_t rx_bin4(uint32_t key, int shift, int bits) { return (rx_mix32(key) >> shift) & ((1u << bits) - 1u); }
+__device__ __forceinline__ uint32_t rx_bin_of(const RxPass& A, uint64_t word) {
+    return A.key4 ? rx_bin4((uint32_t)word, A.shift, A.bits) : rx_bin(word, A.shift, A.bits, A.raw);
 }
 __device__ __forceinline__ void rx_move(const void* src, void* dst, int esize, int64_t from, int64_t to) {
     if (esize == 4) ((uint32_t*)dst)[to] = ((const uint32_t*)src)[from];
@@ -136,7 +149,7 @@ __global__ void __launch_bounds__(RX_THREADS) k_rx_hist(const RxPass A_kernarg) 
     }
 #pragma unroll
     for (int j = 0; j < RX_PER; ++j)
-        if (b + tid + (int64_t)j * RX_THREADS < e) atomicAdd(&hist[w][rx_bin(word[j], A.shift, A.bits, A.raw)], 1u);
+        if (b + tid + (int64_t)j * RX_THREADS < e) atomicAdd(&hist[w][rx_bin_of(A, word[j])], 1u);
     __syncthreads();
     const int64_t nt = A.tile_base[seg + 1] - A.tile_base[seg];
     if (tid < F) {
@@ -183,7 +196,7 @@ __global__ void __launch_bounds__(RX_THREADS) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
     for (int j = 0; j < RX_PER; ++j) {
         const bool valid = first + j * HS_WAVE < e;
-        bin[j] = valid ? rx_bin(word[j], A.shift, A.bits, A.raw) : 0u;
+        bin[j] = valid ? rx_bin_of(A, word[j]) : 0u;
         uint64_t peers = __ballot(valid);
         for (int bit = 0; bit < A.bits; ++bit) {
             const bool on = (bin[j] >> bit) & 1u;
@@ -307,6 +320,160 @@ __global__ void __launch_bounds__(RX_THREADS) __attribute__((amdgpu_waves_per_eu
             if (es == 4) ((uint32_t*)dst)[to[j]] = (uint32_t)v[j];
             else if (es == 8) ((uint64_t*)dst)[to[j]] = v[j];
             else ((uint8_t*)dst)[to[j]] = (uint8_t)v[j];
+        }
+    }
+}
+
+// ---- the pass for 4-byte tuples (round 3) --------------------------------------------------------------------------
+// INTEGER key + up to three 4-byte value columns (f32 / i32: what SUM, AVG, COUNT over stored columns carry): the same
+// tile, ranking and staging as k_rx_hist / k_rx_scatter<true> with everything that was decided per element at run time
+// (element size, first pass or later, selection, key kind) decided at compile time, tile-local 32-bit indexing and the
+// 32-bit bin mix.  FIRST: the key is read from the table's INTEGER column at row0 + position (no selection).
+template <bool FIRST>
+__device__ __forceinline__ const int32_t* rx4_keys(const RxPass& A) {
+    return FIRST ? (const int32_t*)A.key.data + A.row0 : (const int32_t*)A.src[0];
+}
+
+template <bool FIRST>
+__global__ void __launch_bounds__(RX_THREADS) k_rx_hist4(const RxPass A_kernarg) {
+    HS_KERNARG(RxPass, A);
+    __shared__ uint32_t hist[RX_WAVES][1 << RX_MAX_BITS];
+    int64_t seg, t;
+    if (!rx_find_tile(A.tile_base, A.n_seg, blockIdx.x, seg, t)) return;
+    const int tid = threadIdx.x, w = tid / HS_WAVE, F = 1 << A.bits;
+    for (int i = tid; i < RX_WAVES * F; i += RX_THREADS) hist[i / F][i % F] = 0;
+    const int64_t b = A.seg_start[seg] + t * RX_TILE;
+    const int64_t left = A.seg_start[seg + 1] - b;
+    const int rows = left < RX_TILE ? (int)left : RX_TILE;
+    const int32_t* keys = rx4_keys<FIRST>(A) + b;
+    uint32_t key[RX_PER];
+#pragma unroll
+    for (int j = 0; j < RX_PER; ++j) {
+        const int i = tid + j * RX_THREADS;
+        key[j] = i < rows ? (uint32_t)keys[i] : 0u;
+    }
+    __syncthreads();
+    const int shift = A.shift, bits = A.bits;
+#pragma unroll
+    for (int j = 0; j < RX_PER; ++j)
+        if (tid + j * RX_THREADS < rows) atomicAdd(&hist[w][rx_bin4(key[j], shift, bits)], 1u);
+    __syncthreads();
+    const int64_t nt = A.tile_base[seg + 1] - A.tile_base[seg];
+    if (tid < F) {
+        uint32_t total = 0;
+#pragma unroll
+        for (int k = 0; k < RX_WAVES; ++k) total += hist[k][tid];
+        A.counters[(A.tile_base[seg] << A.bits) + (int64_t)tid * nt + t] = total;
+    }
+}
+
+template <int NV, bool FIRST>
+__global__ void __launch_bounds__(RX_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) k_rx_scatter4(const RxPass A_kernarg) {
+    HS_KERNARG(RxPass, A);
+    __shared__ uint32_t whist[RX_WAVES][1 << RX_MAX_BITS];
+    __shared__ int64_t gbase[1 << RX_MAX_BITS];
+    __shared__ uint32_t s_wave_tot[4];
+    __shared__ uint8_t sbin[RX_TILE];
+    __shared__ uint32_t stage[RX_TILE];
+    int64_t seg, t;
+    if (!rx_find_tile(A.tile_base, A.n_seg, blockIdx.x, seg, t)) return;
+    const int tid = threadIdx.x, lane = tid & (HS_WAVE - 1), w = tid / HS_WAVE, F = 1 << A.bits;
+    const int64_t b = A.seg_start[seg] + t * RX_TILE;
+    const int64_t left = A.seg_start[seg + 1] - b;
+    const int rows = left < RX_TILE ? (int)left : RX_TILE;
+    const int32_t* keys = rx4_keys<FIRST>(A) + b;
+    constexpr int NVR = NV > 0 ? NV : 1;
+    uint32_t key[RX_PER], val[NVR][RX_PER];
+    const int first = w * RX_SUB + lane;  // tile-local row of step 0
+#pragma unroll
+    for (int j = 0; j < RX_PER; ++j) key[j] = first + j * HS_WAVE < rows ? (uint32_t)keys[first + j * HS_WAVE] : 0u;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        const uint32_t* src = (const uint32_t*)A.src[1 + c] + b;
+#pragma unroll
+        for (int j = 0; j < RX_PER; ++j) val[c][j] = first + j * HS_WAVE < rows ? src[first + j * HS_WAVE] : 0u;
+    }
+    for (int i = tid; i < RX_WAVES * F; i += RX_THREADS) whist[i / F][i % F] = 0;
+    __syncthreads();
+    const int shift = A.shift, bits = A.bits;
+    const uint64_t below = (1ull << lane) - 1ull;
+    uint32_t bl[RX_PER];  // bin | rank inside (wave, bin) << 8
+#pragma unroll
+    for (int j = 0; j < RX_PER; ++j) {
+        const bool valid = first + j * HS_WAVE < rows;
+        const uint32_t bin = valid ? rx_bin4(key[j], shift, bits) : 0u;
+        uint64_t peers = __ballot(valid);
+        for (int bit = 0; bit < bits; ++bit) {
+            const bool on = (bin >> bit) & 1u;
+            const uint64_t bal = __ballot(valid && on);
+            peers &= on ? bal : ~bal;
+        }
+        const uint32_t prior = valid ? whist[w][bin] : 0u;
+        const uint32_t rank = (uint32_t)__popcll(peers & below);
+        bl[j] = bin | ((prior + rank) << 8);
+        if (valid && rank == 0) whist[w][bin] = prior + (uint32_t)__popcll(peers);
+    }
+    __syncthreads();
+    const int64_t nt = A.tile_base[seg + 1] - A.tile_base[seg];
+    uint32_t bin_total = 0;
+    if (tid < F) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < RX_WAVES; ++k) {
+            const uint32_t c = whist[k][tid];
+            whist[k][tid] = run;
+            run += c;
+        }
+        bin_total = run;
+        gbase[tid] = A.counters[(A.tile_base[seg] << A.bits) + (int64_t)tid * nt + t];
+    }
+    uint32_t x = bin_total;
+    for (int d = 1; d < HS_WAVE; d <<= 1) {
+        const uint32_t up = __shfl_up(x, d, HS_WAVE);
+        if (lane >= d) x += up;
+    }
+    if (w < 4 && lane == HS_WAVE - 1) s_wave_tot[w] = x;
+    __syncthreads();
+    if (tid < F) {
+        uint32_t before = 0;
+        for (int k = 0; k < w; ++k) before += s_wave_tot[k];
+        const uint32_t bin_start = before + x - bin_total;
+        gbase[tid] -= bin_start;  // global position minus tile-local position
+#pragma unroll
+        for (int k = 0; k < RX_WAVES; ++k) whist[k][tid] += bin_start;
+    }
+    __syncthreads();
+    uint32_t at[RX_PER];  // tile-local position of my rows in bin order
+#pragma unroll
+    for (int j = 0; j < RX_PER; ++j) {
+        const bool valid = first + j * HS_WAVE < rows;
+        at[j] = valid ? whist[w][bl[j] & 0xffu] + (bl[j] >> 8) : 0xffffffffu;
+        if (valid) {
+            sbin[at[j]] = (uint8_t)bl[j];
+            stage[at[j]] = key[j];
+        }
+    }
+    __syncthreads();
+    {
+        int32_t* dst = (int32_t*)A.dst[0];
+#pragma unroll
+        for (int k = 0; k < RX_PER; ++k) {
+            const int i = tid + k * RX_THREADS;
+            if (i < rows) dst[gbase[sbin[i]] + i] = (int32_t)stage[i];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < RX_PER; ++j)
+            if (at[j] != 0xffffffffu) stage[at[j]] = val[c][j];
+        __syncthreads();
+        uint32_t* dst = (uint32_t*)A.dst[1 + c];
+#pragma unroll
+        for (int k = 0; k < RX_PER; ++k) {
+            const int i = tid + k * RX_THREADS;
+            if (i < rows) dst[gbase[sbin[i]] + i] = stage[i];
         }
     }
 }
@@ -574,6 +741,163 @@ __global__ void __launch_bounds__(256) k_rx_fold(const RxAgg A_kernarg) {
     }
 }
 
+// ---- the fold, specialised for SUMs (round 3) ---------------------------------------------------------------------
+// What SUM / AVG / COUNT lower to: every aggregate is a SUM whose argument is an f32 column (class 0: f64 cell), an i32
+// column (class 1: i64 cell) or an integer constant (class 2: COUNT).  Same tables, same launches (small table first,
+// overflow list, big table) and the same order of additions as k_rx_fold - a group's f64 cell takes its rows' values in
+// row order - at about a quarter of the instructions: the classes are compile-time (no per-value switches on kind and
+// operator), the dictionary probe is the compare-and-swap itself, values travel as the 32 bits they are, and the rows of
+// a step that share a group are folded in RANK ROUNDS - round r: the lanes whose rank among their group's lanes is r add
+// their value to the group's cell in LDS (distinct cells within a round; LDS executes a wave's instructions in order, so
+// round r + 1 reads what round r wrote) - instead of a leader lane collecting its peers' values with shuffles.  Integer
+// cells are order-free: one LDS atomic per lane (COUNT: one per group and step, with the group's lane count).
+template <int NA, int CLS>
+__global__ void __launch_bounds__(256) k_rx_fold_sum(const RxAgg A_kernarg) {
+    HS_KERNARG(RxAgg, A);
+    extern __shared__ __align__(16) uint64_t rx_lds[];
+    const int lane = threadIdx.x & (HS_WAVE - 1), w = threadIdx.x / HS_WAVE, wpb = blockDim.x / HS_WAVE;
+    const int cap = A.cap;
+    const size_t per_wave = (size_t)cap * (1 + NA) + (size_t)cap / 4;  // as k_rx_fold: the host sizes LDS once
+    uint64_t* keys = rx_lds + (size_t)w * per_wave;
+    uint64_t* acc = keys + cap;
+    uint16_t* order = (uint16_t*)(acc + (size_t)NA * cap);
+    const uint32_t mask = (uint32_t)cap - 1u;
+    const int limit = A.last ? cap : cap - cap / 4;
+    const uint64_t below = (1ull << lane) - 1ull;
+    constexpr auto cls = [](int a) { return (CLS >> (2 * a)) & 3; };
+    constexpr int NC = (NA > 0 && cls(0) < 2 ? 1 : 0) + (NA > 1 && cls(1) < 2 ? 1 : 0) + (NA > 2 && cls(2) < 2 ? 1 : 0);
+    constexpr int NCR = NC > 0 ? NC : 1;
+    constexpr auto col_of = [](int a) {  // carried columns are numbered in aggregate order (hs_group_radix_run)
+        int c = 0;
+        for (int k = 0; k < a; ++k) c += ((CLS >> (2 * k)) & 3) < 2 ? 1 : 0;
+        return c;
+    };
+    constexpr bool any_float = (NA > 0 && cls(0) == 0) || (NA > 1 && cls(1) == 0) || (NA > 2 && cls(2) == 0);
+    int slot_bits = 0;
+    while ((1 << slot_bits) < cap) ++slot_bits;
+    uint32_t err = 0;
+    for (int s = lane; s < cap; s += HS_WAVE) keys[s] = HS_EMPTY_KEY;
+    for (int s = lane; s < NA * cap; s += HS_WAVE) acc[s] = 0;  // the identity of SUM, f64 and i64 alike
+    const int64_t n_todo = A.list ? *A.list_count : A.n_parts;
+    for (int64_t q = (int64_t)blockIdx.x * wpb + w; q < n_todo; q += (int64_t)gridDim.x * wpb) {
+        const int64_t p = A.list ? A.list[q] : q;
+        const int64_t b = A.seg_start[p], e = A.seg_start[p + 1];
+        if (b >= e) {
+            if (lane == 0) A.pcount[p] = 0;
+            continue;
+        }
+        uint64_t nk[RX_CHUNK];
+        uint32_t nx[RX_CHUNK][NCR];
+        auto load_chunk = [&](int64_t base) {
+#pragma unroll
+            for (int j = 0; j < RX_CHUNK; ++j) {
+                const int64_t i = base + j * HS_WAVE + lane;
+                const bool valid = i < e;
+                nk[j] = !valid ? 0 : (A.esize[0] == 4 ? (uint64_t)(int64_t)((const int32_t*)A.src[0])[i] : ((const uint64_t*)A.src[0])[i]);
+#pragma unroll
+                for (int c = 0; c < NC; ++c) nx[j][c] = valid ? ((const uint32_t*)A.src[1 + c])[i] : 0u;
+            }
+        };
+        load_chunk(b);
+        int ngroups = 0;
+        bool full = false;
+        for (int64_t base = b; base < e && !full; base += RX_CHUNK * HS_WAVE) {
+            uint64_t ck[RX_CHUNK];
+            uint32_t cx[RX_CHUNK][NCR];
+#pragma unroll
+            for (int j = 0; j < RX_CHUNK; ++j) {
+                ck[j] = nk[j];
+#pragma unroll
+                for (int c = 0; c < NCR; ++c) cx[j][c] = NC > 0 ? nx[j][c] : 0u;
+            }
+            if (base + RX_CHUNK * HS_WAVE < e) load_chunk(base + RX_CHUNK * HS_WAVE);
+#pragma unroll
+            for (int j = 0; j < RX_CHUNK; ++j) {
+                if (base + j * HS_WAVE >= e || full) break;
+                const bool valid = base + j * HS_WAVE + lane < e;
+                int slot = valid ? -1 : 0;
+                bool inserted = false;
+                if (valid) {
+                    const uint64_t k = ck[j];
+                    uint32_t h = (uint32_t)(hs_mix64(k) >> 36) & mask;
+                    for (uint32_t probe = 0; probe <= mask; ++probe) {
+                        const uint64_t cur = atomicCAS((unsigned long long*)&keys[h], (unsigned long long)HS_EMPTY_KEY, (unsigned long long)k);
+                        if (cur == HS_EMPTY_KEY || cur == k) {
+                            inserted = cur == HS_EMPTY_KEY;
+                            slot = (int)h;
+                            break;
+                        }
+                        h = (h + 1) & mask;
+                    }
+                }
+                const uint64_t fresh = __ballot(inserted);
+                if (inserted) order[ngroups + __popcll(fresh & below)] = (uint16_t)slot;
+                ngroups += __popcll(fresh);
+                if (ngroups > limit || __ballot(valid && slot < 0) != 0ull) {
+                    full = true;
+                    break;
+                }
+                uint64_t peers = __ballot(valid);
+                for (int bit = 0; bit < slot_bits; ++bit) {
+                    const bool on = (slot >> bit) & 1;
+                    peers &= ~(__ballot(valid && on) ^ (on ? ~0ull : 0ull));
+                }
+                const int rank = valid ? __popcll(peers & below) : -1;
+#pragma unroll
+                for (int a = 0; a < NA; ++a) {  // integer cells: any order
+                    if (cls(a) == 1) {
+                        if (valid) atomicAdd((unsigned long long*)&acc[a * cap + slot], (unsigned long long)(int64_t)(int32_t)cx[j][col_of(a)]);
+                    } else if (cls(a) == 2) {
+                        if (rank == 0) atomicAdd((unsigned long long*)&acc[a * cap + slot], A.const_cell[a] * (uint64_t)__popcll(peers));
+                    }
+                }
+                if constexpr (any_float) {
+                    for (int r = 0; __ballot(rank == r) != 0ull; ++r) {
+                        if (rank == r) {
+#pragma unroll
+                            for (int a = 0; a < NA; ++a) {
+                                if (cls(a) != 0) continue;
+                                uint64_t* cell = &acc[a * cap + slot];
+                                *cell = hs_d2u(hs_u2d(*cell) + (double)__uint_as_float(cx[j][col_of(a)]));
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+            }
+        }
+        if (full) {
+            if (A.last) err |= HS_FLAG_DICT_FULL;
+            else if (lane == 0) A.overflow[atomicAdd((unsigned long long*)A.overflow_count, 1ull)] = p;
+            if (lane == 0) A.pcount[p] = 0;
+        }
+        for (int g0 = 0; g0 < ngroups; g0 += HS_WAVE) {
+            const int g = g0 + lane;
+            if (g >= ngroups) continue;
+            const int s = order[g];
+            const int64_t at = b + g;
+            if (!full) A.prov_key[at] = keys[s];
+            keys[s] = HS_EMPTY_KEY;
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                const bool is_int = cls(a) != 0;
+                uint64_t v = acc[a * cap + s];
+                acc[a * cap + s] = 0;
+                if (full) continue;
+                if (A.quantise) {
+                    v = hs_quantise_cell(is_int, v, err);
+                    if (is_int) ((int32_t*)A.prov_acc[a])[at] = (int32_t)(int64_t)v;
+                    else ((float*)A.prov_acc[a])[at] = (float)hs_u2d(v);
+                } else {
+                    ((uint64_t*)A.prov_acc[a])[at] = v;
+                }
+            }
+        }
+        if (!full && lane == 0) A.pcount[p] = ngroups;
+    }
+    if (err) atomicOr(A.flags, err);
+}
+
 // ---- dense output -----------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_rx_unit_groups(const int64_t* pscan, int64_t parts_per_unit, int32_t n_units,
                                                         int64_t* out) {
@@ -633,18 +957,40 @@ static int rx_pass(hipStream_t stream, RxPass& P, int64_t max_tiles, int64_t* co
     const int64_t ncnt = max_tiles << P.bits;
     hs_memset_async(counters, 0, (size_t)ncnt * 8, stream);
     P.counters = counters;
-    hipLaunchKernelGGL(k_rx_hist, dim3((unsigned)max_tiles), dim3(RX_THREADS), 0, stream, P);
+    // 4-byte tuples (INTEGER key, f32 / i32 values): the specialised kernels
+    static const bool generic = getenv("HIPSPARK_RADIX_GENERIC") != nullptr;
+    static const bool direct = getenv("HIPSPARK_RADIX_DIRECT") != nullptr;
+    bool four = !generic && !direct && !P.raw && P.n_cols <= 4 &&
+                (P.first ? (P.key.kind == HS_I32 && P.sel == nullptr) : P.esize[0] == 4);
+    for (int c = 1; c < P.n_cols; ++c) four = four && P.esize[c] == 4;
+    P.key4 = four ? 1 : 0;
+    if (four) {
+        if (P.first) hipLaunchKernelGGL(k_rx_hist4<true>, dim3((unsigned)max_tiles), dim3(RX_THREADS), 0, stream, P);
+        else hipLaunchKernelGGL(k_rx_hist4<false>, dim3((unsigned)max_tiles), dim3(RX_THREADS), 0, stream, P);
+    } else {
+        hipLaunchKernelGGL(k_rx_hist, dim3((unsigned)max_tiles), dim3(RX_THREADS), 0, stream, P);
+    }
     RX_CHECK_LAUNCH("radix pass (histogram)");
     const int rc = hs_exclusive_scan_i64(stream, counters, ncnt, scanned, scan_ws);
     if (rc != HS_OK) return rc;
     P.counters = scanned;
-    static const bool direct = getenv("HIPSPARK_RADIX_DIRECT") != nullptr;
     int widest = 1;
     for (int c = 0; c < P.n_cols; ++c) widest = P.esize[c] > widest ? P.esize[c] : widest;
     static unsigned long long attr_set = 0;
     if (hs_first_on_device(attr_set))  // 8-byte columns stage 72 KB + 18 KB static: above the 64 KB a launch gets unasked
         (void)hipFuncSetAttribute((const void*)k_rx_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, RX_TILE * 9);
-    if (direct) hipLaunchKernelGGL(k_rx_scatter<false>, dim3((unsigned)max_tiles), dim3(RX_THREADS), 0, stream, P);
+    if (four) {
+#define RX_S4(NV)                                                                                                         \
+    if (P.first) hipLaunchKernelGGL((k_rx_scatter4<NV, true>), dim3((unsigned)max_tiles), dim3(RX_THREADS), 0, stream, P); \
+    else hipLaunchKernelGGL((k_rx_scatter4<NV, false>), dim3((unsigned)max_tiles), dim3(RX_THREADS), 0, stream, P)
+        switch (P.n_cols - 1) {
+            case 0: RX_S4(0); break;
+            case 1: RX_S4(1); break;
+            case 2: RX_S4(2); break;
+            default: RX_S4(3); break;
+        }
+#undef RX_S4
+    } else if (direct) hipLaunchKernelGGL(k_rx_scatter<false>, dim3((unsigned)max_tiles), dim3(RX_THREADS), 0, stream, P);
     else hipLaunchKernelGGL(k_rx_scatter<true>, dim3((unsigned)max_tiles), dim3(RX_THREADS), (size_t)RX_TILE * (1 + widest), stream, P);
     RX_CHECK_LAUNCH("radix pass (scatter)");
     if (next_seg) {
@@ -847,6 +1193,19 @@ extern "C" int hs_group_radix_run(void* stream_, const hs_radix_plan* plan, cons
     G.debug = stamps ? 1 : 0;
     int64_t* overflow = (int64_t*)(ws + f[PL_OFF_OVERFLOW]);  // [0] = count, [1 ..] = partitions
     hs_memset_async(overflow, 0, 8, stream);
+    // every aggregate a SUM over an f32 / i32 column or an integer constant: the specialised fold (k_rx_fold_sum)
+    int sum_cls = NA >= 1 && NA <= 3 ? 0 : -1;
+    static const bool lean_off = getenv("HIPSPARK_RADIX_LEAN") != nullptr && getenv("HIPSPARK_RADIX_LEAN")[0] == '0';
+    for (int a = 0; a < NA && sum_cls >= 0; ++a) {
+        const bool is_int = spec->is_int[a] != 0;
+        int c = -1;
+        if (spec->op[a] != HS_AGG_SUM) c = -1;
+        else if (G.carried[a] && G.val_kind[a] == HS_F32 && !is_int) c = 0;
+        else if (G.carried[a] && G.val_kind[a] == HS_I32 && is_int) c = 1;
+        else if (!G.carried[a] && is_int) c = 2;
+        sum_cls = c < 0 ? -1 : (sum_cls | (c << (2 * a)));
+    }
+    if (lean_off || stamps) sum_cls = -1;
     auto fold = [&](int cap, bool listed) {
         G.cap = cap;
         G.last = cap == (int)f[PL_CAP] ? 1 : 0;
@@ -863,6 +1222,30 @@ extern "C" int hs_group_radix_run(void* stream_, const hs_radix_plan* plan, cons
 #define RX_FOLD(NC)                                                                                    \
     if (cap <= 512) hipLaunchKernelGGL((k_rx_fold<NC, 9>), g, t, per_wave * wpb, stream, G);           \
     else hipLaunchKernelGGL((k_rx_fold<NC, 12>), g, t, per_wave * wpb, stream, G)
+#define RX_SUM1(C0) \
+    case (C0): hipLaunchKernelGGL((k_rx_fold_sum<1, (C0)>), g, t, per_wave * wpb, stream, G); return;
+#define RX_SUM2(C0, C1) \
+    case ((C0) | ((C1) << 2)): hipLaunchKernelGGL((k_rx_fold_sum<2, ((C0) | ((C1) << 2))>), g, t, per_wave * wpb, stream, G); return;
+#define RX_SUM3(C0, C1, C2) \
+    case ((C0) | ((C1) << 2) | ((C2) << 4)): \
+        hipLaunchKernelGGL((k_rx_fold_sum<3, ((C0) | ((C1) << 2) | ((C2) << 4))>), g, t, per_wave * wpb, stream, G); return;
+#define RX_SUM3_LAST(C0, C1) RX_SUM3(C0, C1, 0) RX_SUM3(C0, C1, 1) RX_SUM3(C0, C1, 2)
+#define RX_SUM3_MID(C0) RX_SUM3_LAST(C0, 0) RX_SUM3_LAST(C0, 1) RX_SUM3_LAST(C0, 2)
+        if (sum_cls >= 0 && NA == 1) {
+            switch (sum_cls) { RX_SUM1(0) RX_SUM1(1) RX_SUM1(2) default: break; }
+        } else if (sum_cls >= 0 && NA == 2) {
+            switch (sum_cls) {
+                RX_SUM2(0, 0) RX_SUM2(1, 0) RX_SUM2(2, 0) RX_SUM2(0, 1) RX_SUM2(1, 1) RX_SUM2(2, 1) RX_SUM2(0, 2) RX_SUM2(1, 2) RX_SUM2(2, 2)
+                default: break;
+            }
+        } else if (sum_cls >= 0 && NA == 3) {
+            switch (sum_cls) { RX_SUM3_MID(0) RX_SUM3_MID(1) RX_SUM3_MID(2) default: break; }
+        }
+#undef RX_SUM1
+#undef RX_SUM2
+#undef RX_SUM3
+#undef RX_SUM3_LAST
+#undef RX_SUM3_MID
         switch ((int)f[PL_NCARRIED]) {
             case 0: RX_FOLD(0); break;
             case 1: RX_FOLD(1); break;
