@@ -19,6 +19,7 @@
 // Everything is sized on the host from the row count and the largest unit; no host round trip inside
 // hs_group_radix_run.  A partition that meets more distinct keys than its dictionary holds raises HS_FLAG_DICT_FULL
 // (the caller takes the round-1 path).  Keys: INTEGER / TIMESTAMP (the key word is the value).
+#include <type_traits>
 #include "hs_device.h"
 
 #include <cstdlib>
@@ -334,35 +335,38 @@ __device__ __forceinline__ const int32_t* rx4_keys(const RxPass& A) {
     return FIRST ? (const int32_t*)A.key.data + A.row0 : (const int32_t*)A.src[0];
 }
 
+constexpr int RX_H4_THREADS = 256;                   // the histogram of a tile needs no ranking: four waves, 32 keys per lane
+constexpr int RX_H4_PER = RX_TILE / RX_H4_THREADS;
 template <bool FIRST>
-__global__ void __launch_bounds__(RX_THREADS) k_rx_hist4(const RxPass A_kernarg) {
+__global__ void __launch_bounds__(RX_H4_THREADS) k_rx_hist4(const RxPass A_kernarg) {
     HS_KERNARG(RxPass, A);
-    __shared__ uint32_t hist[RX_WAVES][1 << RX_MAX_BITS];
+    constexpr int WAVES = RX_H4_THREADS / HS_WAVE;
+    __shared__ uint32_t hist[WAVES][1 << RX_MAX_BITS];
     int64_t seg, t;
     if (!rx_find_tile(A.tile_base, A.n_seg, blockIdx.x, seg, t)) return;
     const int tid = threadIdx.x, w = tid / HS_WAVE, F = 1 << A.bits;
-    for (int i = tid; i < RX_WAVES * F; i += RX_THREADS) hist[i / F][i % F] = 0;
+    for (int i = tid; i < WAVES * F; i += RX_H4_THREADS) hist[i / F][i % F] = 0;
     const int64_t b = A.seg_start[seg] + t * RX_TILE;
     const int64_t left = A.seg_start[seg + 1] - b;
     const int rows = left < RX_TILE ? (int)left : RX_TILE;
     const int32_t* keys = rx4_keys<FIRST>(A) + b;
-    uint32_t key[RX_PER];
+    uint32_t key[RX_H4_PER];
 #pragma unroll
-    for (int j = 0; j < RX_PER; ++j) {
-        const int i = tid + j * RX_THREADS;
+    for (int j = 0; j < RX_H4_PER; ++j) {
+        const int i = tid + j * RX_H4_THREADS;
         key[j] = i < rows ? (uint32_t)keys[i] : 0u;
     }
     __syncthreads();
     const int shift = A.shift, bits = A.bits;
 #pragma unroll
-    for (int j = 0; j < RX_PER; ++j)
-        if (tid + j * RX_THREADS < rows) atomicAdd(&hist[w][rx_bin4(key[j], shift, bits)], 1u);
+    for (int j = 0; j < RX_H4_PER; ++j)
+        if (tid + j * RX_H4_THREADS < rows) atomicAdd(&hist[w][rx_bin4(key[j], shift, bits)], 1u);
     __syncthreads();
     const int64_t nt = A.tile_base[seg + 1] - A.tile_base[seg];
     if (tid < F) {
         uint32_t total = 0;
 #pragma unroll
-        for (int k = 0; k < RX_WAVES; ++k) total += hist[k][tid];
+        for (int k = 0; k < WAVES; ++k) total += hist[k][tid];
         A.counters[(A.tile_base[seg] << A.bits) + (int64_t)tid * nt + t] = total;
     }
 }
@@ -435,8 +439,7 @@ __global__ void __launch_bounds__(RX_THREADS) __attribute__((amdgpu_waves_per_eu
     if (w < 4 && lane == HS_WAVE - 1) s_wave_tot[w] = x;
     __syncthreads();
     if (tid < F) {
-        uint32_t before = 0;
-        for (int k = 0; k < w; ++k) before += s_wave_tot[k];
+        const uint32_t before = (w > 0 ? s_wave_tot[0] : 0u) + (w > 1 ? s_wave_tot[1] : 0u) + (w > 2 ? s_wave_tot[2] : 0u);
         const uint32_t bin_start = before + x - bin_total;
         gbase[tid] -= bin_start;  // global position minus tile-local position
 #pragma unroll
@@ -567,6 +570,7 @@ __global__ void __launch_bounds__(256) k_rx_fold(const RxAgg A_kernarg) {
     constexpr int NCR = NC > 0 ? NC : 1;
     uint32_t err = 0;
     long long t_init = 0, t_slot = 0, t_rank = 0, t_fold = 0, t_emit = 0, t_wait = 0;
+    if ((int64_t)blockIdx.x * wpb + w >= (A.list ? *A.list_count : A.n_parts)) return;  // nothing for this wave: no table to clear
     for (int s = lane; s < cap; s += HS_WAVE) keys[s] = HS_EMPTY_KEY;
     for (int a = 0; a < NA; ++a) {
         const uint64_t id = hs_acc_identity(A.spec.op[a], A.spec.is_int[a] != 0);
@@ -751,7 +755,7 @@ __global__ void __launch_bounds__(256) k_rx_fold(const RxAgg A_kernarg) {
 // their value to the group's cell in LDS (distinct cells within a round; LDS executes a wave's instructions in order, so
 // round r + 1 reads what round r wrote) - instead of a leader lane collecting its peers' values with shuffles.  Integer
 // cells are order-free: one LDS atomic per lane (COUNT: one per group and step, with the group's lane count).
-template <int NA, int CLS>
+template <int NA, int CLS, bool KEY4>
 __global__ void __launch_bounds__(256) k_rx_fold_sum(const RxAgg A_kernarg) {
     HS_KERNARG(RxAgg, A);
     extern __shared__ __align__(16) uint64_t rx_lds[];
@@ -776,9 +780,10 @@ __global__ void __launch_bounds__(256) k_rx_fold_sum(const RxAgg A_kernarg) {
     int slot_bits = 0;
     while ((1 << slot_bits) < cap) ++slot_bits;
     uint32_t err = 0;
+    const int64_t n_todo = A.list ? *A.list_count : A.n_parts;
+    if ((int64_t)blockIdx.x * wpb + w >= n_todo) return;  // nothing listed for this wave: no table to clear either
     for (int s = lane; s < cap; s += HS_WAVE) keys[s] = HS_EMPTY_KEY;
     for (int s = lane; s < NA * cap; s += HS_WAVE) acc[s] = 0;  // the identity of SUM, f64 and i64 alike
-    const int64_t n_todo = A.list ? *A.list_count : A.n_parts;
     for (int64_t q = (int64_t)blockIdx.x * wpb + w; q < n_todo; q += (int64_t)gridDim.x * wpb) {
         const int64_t p = A.list ? A.list[q] : q;
         const int64_t b = A.seg_start[p], e = A.seg_start[p + 1];
@@ -786,14 +791,15 @@ __global__ void __launch_bounds__(256) k_rx_fold_sum(const RxAgg A_kernarg) {
             if (lane == 0) A.pcount[p] = 0;
             continue;
         }
-        uint64_t nk[RX_CHUNK];
+        using KeyReg = std::conditional_t<KEY4, uint32_t, uint64_t>;  // as loaded: widening a key right after its load would wait for it
+        KeyReg nk[RX_CHUNK];
         uint32_t nx[RX_CHUNK][NCR];
         auto load_chunk = [&](int64_t base) {
 #pragma unroll
             for (int j = 0; j < RX_CHUNK; ++j) {
                 const int64_t i = base + j * HS_WAVE + lane;
                 const bool valid = i < e;
-                nk[j] = !valid ? 0 : (A.esize[0] == 4 ? (uint64_t)(int64_t)((const int32_t*)A.src[0])[i] : ((const uint64_t*)A.src[0])[i]);
+                nk[j] = valid ? ((const KeyReg*)A.src[0])[i] : 0;
 #pragma unroll
                 for (int c = 0; c < NC; ++c) nx[j][c] = valid ? ((const uint32_t*)A.src[1 + c])[i] : 0u;
             }
@@ -802,7 +808,7 @@ __global__ void __launch_bounds__(256) k_rx_fold_sum(const RxAgg A_kernarg) {
         int ngroups = 0;
         bool full = false;
         for (int64_t base = b; base < e && !full; base += RX_CHUNK * HS_WAVE) {
-            uint64_t ck[RX_CHUNK];
+            KeyReg ck[RX_CHUNK];
             uint32_t cx[RX_CHUNK][NCR];
 #pragma unroll
             for (int j = 0; j < RX_CHUNK; ++j) {
@@ -818,8 +824,15 @@ __global__ void __launch_bounds__(256) k_rx_fold_sum(const RxAgg A_kernarg) {
                 int slot = valid ? -1 : 0;
                 bool inserted = false;
                 if (valid) {
-                    const uint64_t k = ck[j];
-                    uint32_t h = (uint32_t)(hs_mix64(k) >> 36) & mask;
+                    const uint64_t k = KEY4 ? (uint64_t)(int64_t)(int32_t)ck[j] : (uint64_t)ck[j];
+                    uint32_t h;
+                    if constexpr (KEY4) {  // two 32-bit multiplies; bits independent of the ones the partitions were cut on
+                        uint32_t m = (uint32_t)k * 0xCC9E2D51u;
+                        m ^= m >> 17;
+                        h = ((m * 0x1B873593u) >> 12) & mask;
+                    } else {
+                        h = (uint32_t)(hs_mix64(k) >> 36) & mask;
+                    }
                     for (uint32_t probe = 0; probe <= mask; ++probe) {
                         const uint64_t cur = atomicCAS((unsigned long long*)&keys[h], (unsigned long long)HS_EMPTY_KEY, (unsigned long long)k);
                         if (cur == HS_EMPTY_KEY || cur == k) {
@@ -965,8 +978,8 @@ static int rx_pass(hipStream_t stream, RxPass& P, int64_t max_tiles, int64_t* co
     for (int c = 1; c < P.n_cols; ++c) four = four && P.esize[c] == 4;
     P.key4 = four ? 1 : 0;
     if (four) {
-        if (P.first) hipLaunchKernelGGL(k_rx_hist4<true>, dim3((unsigned)max_tiles), dim3(RX_THREADS), 0, stream, P);
-        else hipLaunchKernelGGL(k_rx_hist4<false>, dim3((unsigned)max_tiles), dim3(RX_THREADS), 0, stream, P);
+        if (P.first) hipLaunchKernelGGL(k_rx_hist4<true>, dim3((unsigned)max_tiles), dim3(RX_H4_THREADS), 0, stream, P);
+        else hipLaunchKernelGGL(k_rx_hist4<false>, dim3((unsigned)max_tiles), dim3(RX_H4_THREADS), 0, stream, P);
     } else {
         hipLaunchKernelGGL(k_rx_hist, dim3((unsigned)max_tiles), dim3(RX_THREADS), 0, stream, P);
     }
@@ -1223,14 +1236,23 @@ extern "C" int hs_group_radix_run(void* stream_, const hs_radix_plan* plan, cons
     if (cap <= 512) hipLaunchKernelGGL((k_rx_fold<NC, 9>), g, t, per_wave * wpb, stream, G);           \
     else hipLaunchKernelGGL((k_rx_fold<NC, 12>), g, t, per_wave * wpb, stream, G)
 #define RX_SUM1(C0) \
-    case (C0): hipLaunchKernelGGL((k_rx_fold_sum<1, (C0)>), g, t, per_wave * wpb, stream, G); return;
+    case (C0):                                                                                              \
+        if (key4) hipLaunchKernelGGL((k_rx_fold_sum<1, (C0), true>), g, t, per_wave * wpb, stream, G);      \
+        else hipLaunchKernelGGL((k_rx_fold_sum<1, (C0), false>), g, t, per_wave * wpb, stream, G);          \
+        return;
 #define RX_SUM2(C0, C1) \
-    case ((C0) | ((C1) << 2)): hipLaunchKernelGGL((k_rx_fold_sum<2, ((C0) | ((C1) << 2))>), g, t, per_wave * wpb, stream, G); return;
+    case ((C0) | ((C1) << 2)):                                                                                             \
+        if (key4) hipLaunchKernelGGL((k_rx_fold_sum<2, ((C0) | ((C1) << 2)), true>), g, t, per_wave * wpb, stream, G);      \
+        else hipLaunchKernelGGL((k_rx_fold_sum<2, ((C0) | ((C1) << 2)), false>), g, t, per_wave * wpb, stream, G);          \
+        return;
 #define RX_SUM3(C0, C1, C2) \
     case ((C0) | ((C1) << 2) | ((C2) << 4)): \
-        hipLaunchKernelGGL((k_rx_fold_sum<3, ((C0) | ((C1) << 2) | ((C2) << 4))>), g, t, per_wave * wpb, stream, G); return;
+        if (key4) hipLaunchKernelGGL((k_rx_fold_sum<3, ((C0) | ((C1) << 2) | ((C2) << 4)), true>), g, t, per_wave * wpb, stream, G);   \
+        else hipLaunchKernelGGL((k_rx_fold_sum<3, ((C0) | ((C1) << 2) | ((C2) << 4)), false>), g, t, per_wave * wpb, stream, G);       \
+        return;
 #define RX_SUM3_LAST(C0, C1) RX_SUM3(C0, C1, 0) RX_SUM3(C0, C1, 1) RX_SUM3(C0, C1, 2)
 #define RX_SUM3_MID(C0) RX_SUM3_LAST(C0, 0) RX_SUM3_LAST(C0, 1) RX_SUM3_LAST(C0, 2)
+        const bool key4 = G.esize[0] == 4;
         if (sum_cls >= 0 && NA == 1) {
             switch (sum_cls) { RX_SUM1(0) RX_SUM1(1) RX_SUM1(2) default: break; }
         } else if (sum_cls >= 0 && NA == 2) {

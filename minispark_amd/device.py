@@ -1468,21 +1468,25 @@ class Device:
         hs.check(self.lib.hs_group_radix_plan(key.kind, n, n_units, max(int(max_unit_rows), 1), kinds, C.byref(spec),
                                               1 if quantise else 0, C.byref(plan)), "hs_group_radix_plan")
         ws = self.workspace(self.lib.hs_group_radix_ws_bytes(C.byref(plan)))
-        unit_groups = self.empty(n_units + 1, torch.int64)
-        radix_flags = self.empty(1, torch.int32)  # own word: an overflow here is answered by the other path, not raised
-        radix_flags.zero_()
+        # the group counts per unit and, behind them, the tier's own status word (an overflow here is answered by the other
+        # path, not raised): one buffer, so the host reads both with ONE copy
+        status = self.empty(n_units + 2, torch.int64)
+        unit_groups = status[: n_units + 1]
+        radix_flags = status[n_units + 1:].view(torch.int32)[:1]
+        status[n_units + 1:].zero_()
         k = key.as_hs()
         hs.check(self.lib.hs_group_radix_run(self.stream, C.byref(plan), C.byref(k), sel.data_ptr() if sel is not None else None,
                                              0, bounds.data_ptr(), cols, consts, C.byref(spec), ws.data_ptr(),
                                              unit_groups.data_ptr(), radix_flags.data_ptr()), "hs_group_radix_run")
         if self.rec is not None:
             self.rec.poisoned = True  # the group count sizes the outputs
-        flags = int(radix_flags.item())
+        host = status.tolist()  # the one host round trip of the tier
+        flags = int(host[-1]) & 0xFFFFFFFF
         if flags & hs.FLAG_DICT_FULL:
             return None
         if flags:
             self.flags[0:1] |= radix_flags  # data-dependent errors surface where the other operators' do
-        unit_rows = [int(v) for v in unit_groups.tolist()]
+        unit_rows = [int(v) for v in host[: n_units + 1]]
         ng = unit_rows[-1]
         out_key = self.empty(max(ng, 1), _TORCH_DTYPE[key.kind])
         okind = [(hs.I32 if integer else hs.F32) if quantise else (hs.I64 if integer else hs.F64) for _, _, integer in values]
