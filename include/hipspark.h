@@ -378,7 +378,9 @@ int hs_group_build_units(void* stream, const hs_col* key, const int64_t* sel, in
 int hs_lower_bound_i64(void* stream, const int64_t* sorted, int64_t n, const int64_t* n_dev, const int64_t* queries,
                        int64_t n_queries, int64_t* out);
 /* ---- the HBM tier as a radix partition + on-chip ordered fold (csrc/hs_radix.hip; reference tasks.py:284-310) ----
- * GROUP BY of any cardinality over every unit of a batch, INTEGER / TIMESTAMP keys: the (key, value...) tuples are moved
+ * GROUP BY of any cardinality over every unit of a batch; keys whose 64-bit key word is the key itself - INTEGER /
+ * TIMESTAMP, FLOAT (also computed f64; 0.0 and -0.0 are one group, as in a Python dict), STRING columns of one fixed length
+ * <= 7 bytes (key_kind = HS_STR + 256 x length; HS_E_LIMIT for other strings): the (key, value...) tuples are moved
  * by one or two stable partition passes on hash bits of the key until a partition (a few hundred rows of one unit, still
  * in row order) fits a wave's LDS dictionary; one wave folds a partition's rows in order - the reference's sequential
  * fp64 / int sums, bit for bit - and the groups are made dense.  Three calls:

@@ -935,8 +935,13 @@ __global__ void __launch_bounds__(256) k_rx_emit(const RxEmit A_kernarg) {
         const int64_t from = A.seg_start[p], to = A.pscan[p], cnt = A.pscan[p + 1] - to;
         for (int64_t q = lane; q < cnt; q += HS_WAVE) {
             const uint64_t k = A.prov_key[from + q];
-            if (A.key_kind == HS_I32) ((int32_t*)A.out_key)[to + q] = (int32_t)(int64_t)k;
-            else ((uint64_t*)A.out_key)[to + q] = k;
+            const int base = A.key_kind & 0xff;
+            if (base == HS_I32) ((int32_t*)A.out_key)[to + q] = (int32_t)(int64_t)k;
+            else if (base == HS_F32) ((float*)A.out_key)[to + q] = (float)hs_u2d(k);  // the word: the f32 widened, exactly
+            else if (base == HS_STR) {
+                const int len = A.key_kind >> 8;  // hs_pack_str: byte i of the string = byte i of the word
+                for (int i = 0; i < len; ++i) ((uint8_t*)A.out_key)[(to + q) * len + i] = (uint8_t)(k >> (8 * i));
+            } else ((uint64_t*)A.out_key)[to + q] = k;
             for (int a = 0; a < A.n_acc; ++a) rx_move(A.prov_acc[a], A.out_acc[a], A.osize, from + q, to + q);
         }
     }
@@ -1018,9 +1023,18 @@ static int rx_pass(hipStream_t stream, RxPass& P, int64_t max_tiles, int64_t* co
 extern "C" int hs_group_radix_plan(int32_t key_kind, int64_t n, int32_t n_units, int64_t max_unit_rows, const int32_t* val_kinds,
                                    const hs_agg_spec* spec, int32_t quantise, hs_radix_plan* plan) {
     if (!plan || !spec || n < 1 || n_units < 1 || max_unit_rows < 1 || spec->n_acc < 0 || spec->n_acc > HS_MAX_ACC ||
-        (spec->n_acc > 0 && !val_kinds) || (key_kind != HS_I32 && key_kind != HS_I64)) {
-        hs_set_error("hs_group_radix_plan: bad arguments (keys: HS_I32 / HS_I64)");
+        (spec->n_acc > 0 && !val_kinds)) {
+        hs_set_error("hs_group_radix_plan: bad arguments");
         return HS_E_ARG;
+    }
+    {   // keys whose 64-bit key word IS the key: integers, floats (0.0 == -0.0, as one Python dict key), strings of a fixed
+        // length <= 7 bytes (key_kind = HS_STR + 256 x length)
+        const int base = key_kind & 0xff, len = key_kind >> 8;
+        const bool ok = base == HS_STR ? (len >= 1 && len <= 7) : (len == 0 && (base == HS_I32 || base == HS_I64 || base == HS_F32 || base == HS_F64));
+        if (!ok) {
+            hs_set_error("hs_group_radix_plan: key kind %d (HS_I32 / I64 / F32 / F64, or HS_STR + 256 x fixed length <= 7)", (int)key_kind);
+            return HS_E_LIMIT;
+        }
     }
     int64_t* f = plan->f;
     for (int i = 0; i < 48; ++i) f[i] = 0;
@@ -1115,7 +1129,8 @@ extern "C" int hs_group_radix_run(void* stream_, const hs_radix_plan* plan, cons
                                   const int64_t* unit_bounds, const hs_col* val_cols, const uint64_t* const_cells,
                                   const hs_agg_spec* spec, void* ws_, int64_t* out_unit_groups, uint32_t* flags) {
     if (!plan || !key || !unit_bounds || !spec || !ws_ || !out_unit_groups || !flags || spec->n_acc != (int)plan->f[PL_NA] ||
-        key->kind != (int32_t)plan->f[PL_KEYKIND] || (spec->n_acc > 0 && (!val_cols || !const_cells))) {
+        key->kind != (int32_t)(plan->f[PL_KEYKIND] & 0xff) || (key->kind == HS_STR && key->fixed_len != (int32_t)(plan->f[PL_KEYKIND] >> 8)) ||
+        (spec->n_acc > 0 && (!val_cols || !const_cells))) {
         hs_set_error("hs_group_radix_run: bad arguments");
         return HS_E_ARG;
     }

@@ -1465,7 +1465,7 @@ class Device:
             consts[a] = cell
             cols[a] = col.as_hs() if col is not None else hs.hs_col(hs.U8, -1, None, None, None)
         plan = hs.hs_radix_plan()
-        hs.check(self.lib.hs_group_radix_plan(key.kind, n, n_units, max(int(max_unit_rows), 1), kinds, C.byref(spec),
+        hs.check(self.lib.hs_group_radix_plan(self.radix_key_code(key), n, n_units, max(int(max_unit_rows), 1), kinds, C.byref(spec),
                                               1 if quantise else 0, C.byref(plan)), "hs_group_radix_plan")
         ws = self.workspace(self.lib.hs_group_radix_ws_bytes(C.byref(plan)))
         # the group counts per unit and, behind them, the tier's own status word (an overflow here is answered by the other
@@ -1488,13 +1488,33 @@ class Device:
             self.flags[0:1] |= radix_flags  # data-dependent errors surface where the other operators' do
         unit_rows = [int(v) for v in host[: n_units + 1]]
         ng = unit_rows[-1]
-        out_key = self.empty(max(ng, 1), _TORCH_DTYPE[key.kind])
+        if key.kind == hs.STR:
+            out_key = self.empty(max(ng, 1) * key.fixed_len, torch.uint8)
+        else:
+            out_key = self.empty(max(ng, 1), _TORCH_DTYPE[key.kind])
         okind = [(hs.I32 if integer else hs.F32) if quantise else (hs.I64 if integer else hs.F64) for _, _, integer in values]
         outs = [self.empty(max(ng, 1), _TORCH_DTYPE[kd]) for kd in okind]
         ptrs = (C.c_void_p * max(na, 1))(*[o.data_ptr() for o in outs])
         hs.check(self.lib.hs_group_radix_emit(self.stream, C.byref(plan), ws.data_ptr(), out_key.data_ptr(), ptrs),
                  "hs_group_radix_emit")
-        return DCol(key.kind, out_key, ng), [DCol(kd, o, ng) for kd, o in zip(okind, outs)], unit_rows
+        if key.kind == hs.STR:
+            lens = torch.full((max(ng, 1),), key.fixed_len, dtype=torch.uint8, device=self.device)
+            key_out = DCol(hs.STR, out_key, ng, lens=lens, offs=None, fixed_len=key.fixed_len)
+        else:
+            key_out = DCol(key.kind, out_key, ng)
+        return key_out, [DCol(kd, o, ng) for kd, o in zip(okind, outs)], unit_rows
+
+    @staticmethod
+    def radix_key_code(key: DCol) -> int | None:
+        """key_kind of hs_group_radix_plan for a GROUP BY column the radix tier takes (its 64-bit key word is the key itself),
+        else None: integers, floats, strings of one fixed length <= 7 bytes that are not dictionary codes."""
+        if key.dict is not None or key.virtual:
+            return None
+        if key.kind in (hs.I32, hs.I64, hs.F32, hs.F64):
+            return key.kind
+        if key.kind == hs.STR and key.fixed_len is not None and 1 <= key.fixed_len <= 7:
+            return hs.STR + 256 * key.fixed_len
+        return None
 
     def aggregate_partial_global(self, batch: DBatch, filters: Sequence[Any], group_by: Any,
                                  agg_columns: Sequence[Any], out_schema: Schema) -> DBatch:
@@ -1531,7 +1551,7 @@ class Device:
             out_cols = [empty_key] + [DCol(FILE_KIND[t], self.empty(0, _TORCH_DTYPE[FILE_KIND[t]]), 0)
                                       for _, t in out_schema[1:]]
             return DBatch(list(out_schema), out_cols, 0, [0] * (n_units + 1))
-        if self.radix_enabled and key.kind in (hs.I32, hs.I64) and key.dict is None:
+        if self.radix_enabled and self.radix_key_code(key) is not None:
             biggest = max(batch.unit_rows[u + 1] - batch.unit_rows[u] for u in range(n_units))
             done = self.group_radix(key, sel, n, bounds, n_units, biggest, self._radix_values(batch, args, sel, n), ops,
                                     quantise=True)

@@ -111,6 +111,101 @@ def test_radix_tier_matches_the_ordered_fold(dev, n, units, groups, seed, quanti
     _same(got, _expected(keys, values, ops, is_int, bounds, quantise))
 
 
+@pytest.mark.parametrize("classes", ["f", "i", "c", "fc", "if", "cf", "ffc", "icf", "cii", "fif"])
+@pytest.mark.parametrize(("n", "units", "groups"), [(60_000, 4, 9_000), (3_000_000, 2, 400_000)])
+def test_radix_sum_fold_in_every_class_combination(dev, classes, n, units, groups):
+    """Round 3: SUMs over f32 / i32 columns and integer constants (what SUM, AVG and COUNT lower to) run a fold specialised
+    at compile time per class combination (k_rx_fold_sum), INTEGER keys the 4-byte partition kernels - same order of
+    additions, so still bit for bit the reference's fold; one and two partition passes, ragged units."""
+    from minispark_amd import hipspark as hs
+
+    rng = np.random.default_rng(len(classes) * 7 + n % 13)
+    keys = rng.integers(-groups // 2, groups - groups // 2, n).astype(np.int32)
+    cuts = np.sort(rng.integers(0, n + 1, units - 1)).tolist()
+    bounds = [0] + cuts + [n]
+    values, is_int = [], []
+    for c in classes:
+        if c == "f":
+            values.append((rng.normal(0, 1, n) * np.exp2(rng.integers(-10, 10, n))).astype(np.float32))
+        elif c == "i":
+            values.append(rng.integers(-100_000, 100_000, n).astype(np.int32))
+        else:
+            values.append(1 if len(values) % 2 == 0 else 3)
+        is_int.append(c != "f")
+    ops = [hs.AGG_SUM] * len(values)
+    for quantise in (True, False):
+        got = _run(dev, keys, hs.I32, None, bounds, values, ops, quantise)
+        _same(got, _expected(keys, values, ops, is_int, bounds, quantise))
+
+
+def test_radix_tier_takes_float_and_short_string_keys(dev):
+    """Round 3: keys whose 64-bit key word is the key itself - stored FLOAT, computed f64 (0.0 and -0.0 one group, as in
+    a Python dict), STRING columns of one fixed length <= 7 bytes - take the radix tier too; longer strings are refused by
+    the plan (the engine keeps the hash-table tier for those)."""
+    import ctypes as C
+
+    import torch
+
+    from minispark_amd import hipspark as hs
+    from minispark_amd.device import DCol
+
+    rng = np.random.default_rng(77)
+    n, bounds = 500_000, [0, 170_000, 170_000, 500_000]
+    v = rng.normal(0, 10, n).astype(np.float32)
+    values, ops, is_int = [v, 1], [hs.AGG_SUM, hs.AGG_SUM], [False, True]
+    pool = np.concatenate([rng.normal(0, 100, 40_000), [0.0, -0.0, 1e300, -1e-300]])
+    for kind, dtype in ((hs.F64, np.float64), (hs.F32, np.float32)):
+        keys = pool[rng.integers(0, len(pool), n)].astype(dtype)
+        tb = torch.from_numpy(np.asarray(bounds, dtype=np.int64)).cuda()
+        done = dev.group_radix(DCol(kind, torch.from_numpy(keys).cuda(), n), None, n, tb, len(bounds) - 1, 330_000,
+                               [(DCol(hs.F32, torch.from_numpy(v).cuda(), n), 0, False), (None, 1, True)], ops, True)
+        assert done is not None
+        key_col, accs, unit_rows = done
+        k = key_col.data[: key_col.n].cpu().numpy()
+        a = [c.data[: c.n].cpu().numpy() for c in accs]
+        assert k.dtype == dtype
+        for u, (lo, hi) in enumerate(zip(unit_rows, unit_rows[1:])):
+            got = {float(k[i]): (a[0][i].item(), a[1][i].item()) for i in range(lo, hi)}
+            assert len(got) == hi - lo
+            want: dict = {}
+            for key, x in zip(keys[bounds[u]:bounds[u + 1]].tolist(), v[bounds[u]:bounds[u + 1]].astype(np.float64).tolist()):
+                s, c = want.get(key, (0.0, 0))  # a Python dict: 0.0 and -0.0 meet in one entry, sums in row order
+                want[key] = (s + x, c + 1)
+            assert got.keys() == want.keys()
+            for key, (s, c) in want.items():
+                assert got[key] == (np.float32(s).item(), c), (kind, u, key)
+    # strings of one fixed length
+    for length in (1, 3, 7):
+        alphabet = np.frombuffer(b"ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghij0123456789", dtype=np.uint8)
+        words = alphabet[rng.integers(0, len(alphabet), (min(30_000, len(alphabet) ** length), length))]
+        rows = words[rng.integers(0, len(words), n)]
+        data = torch.from_numpy(np.ascontiguousarray(rows).reshape(-1)).cuda()
+        lens = torch.full((n,), length, dtype=torch.uint8, device="cuda")
+        key = DCol(hs.STR, data, n, lens=lens, offs=None, fixed_len=length)
+        tb = torch.from_numpy(np.asarray(bounds, dtype=np.int64)).cuda()
+        done = dev.group_radix(key, None, n, tb, len(bounds) - 1, 330_000,
+                               [(DCol(hs.F32, torch.from_numpy(v).cuda(), n), 0, False), (None, 1, True)], ops, True)
+        assert done is not None
+        key_col, accs, unit_rows = done
+        assert key_col.kind == hs.STR and key_col.fixed_len == length
+        kb = key_col.data[: key_col.n * length].cpu().numpy().reshape(-1, length)
+        a = [c.data[: c.n].cpu().numpy() for c in accs]
+        as_int = lambda m: [bytes(r) for r in m]  # noqa: E731
+        for u, (lo, hi) in enumerate(zip(unit_rows, unit_rows[1:])):
+            got = {key: (a[0][lo + i].item(), a[1][lo + i].item()) for i, key in enumerate(as_int(kb[lo:hi]))}
+            assert len(got) == hi - lo
+            want = {}
+            for key, x in zip(as_int(rows[bounds[u]:bounds[u + 1]]), v[bounds[u]:bounds[u + 1]].astype(np.float64).tolist()):
+                s, c = want.get(key, (0.0, 0))
+                want[key] = (s + x, c + 1)
+            assert got.keys() == want.keys()
+            for key, (s, c) in want.items():
+                assert got[key] == (np.float32(s).item(), c), (length, u, key)
+    plan, spec = hs.hs_radix_plan(), hs.hs_agg_spec()
+    rc = dev.lib.hs_group_radix_plan(hs.STR + 256 * 12, 1000, 1, 1000, (C.c_int32 * 1)(hs.F32), C.byref(spec), 1, C.byref(plan))
+    assert rc == 2  # HS_E_LIMIT: not a key this tier moves as one word
+
+
 def test_radix_tier_over_a_selection_and_timestamp_keys(dev):
     """WHERE survivors arrive as an ascending row list; the key is read through it, values are position-indexed."""
     from minispark_amd import hipspark as hs
