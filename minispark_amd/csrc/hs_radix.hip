@@ -95,6 +95,7 @@ struct RxPass {
     int64_t n_seg;
     int32_t shift, bits;       // bin = (mix(key word) >> shift) & (2^bits - 1); raw: ((key + 1) >> shift) & ... (hs_sort_by_order)
     int32_t n_cols, first;     // columns that travel (0 = key); first pass reads the key through `key` / `sel`
+    int32_t wide, pad_w;       // wide: a STRING key of one fixed length 8 .. 16: two key words, columns 0 and 1 (round 3)
     int32_t raw, key4;         // key4: the key is a 4-byte integer (bins from a 32-bit mix: a quarter of hs_mix64's multiplies)
     hs_col key;
     const int64_t* sel;
@@ -105,7 +106,28 @@ struct RxPass {
     int64_t* counters;         // [(tiles) << bits] laid out (segment, bin, tile): counts, then their exclusive scan
 };
 
+// a wide key's two words at position i: from the string column (first pass) or from columns 0 and 1 of the tuples
+__device__ __forceinline__ void rx_wide_words(const RxPass& A, int64_t i, uint64_t& w0, uint64_t& w1) {
+    if (A.first) {
+        const int64_t row = A.sel ? A.sel[i] : A.row0 + i;
+        hs_str_words16((const uint8_t*)A.key.data + row * A.key.fixed_len, (uint32_t)A.key.fixed_len, w0, w1);
+    } else {
+        w0 = ((const uint64_t*)A.src[0])[i];
+        w1 = A.esize[1] == 4 ? (uint64_t)((const uint32_t*)A.src[1])[i] : ((const uint64_t*)A.src[1])[i];
+    }
+}
+__device__ __forceinline__ uint64_t rx_wide_w1(const RxPass& A, int64_t i) {
+    uint64_t w0, w1;
+    rx_wide_words(A, i, w0, w1);
+    return w1;
+}
+// the value of column 0 at position i
 __device__ __forceinline__ uint64_t rx_key(const RxPass& A, int64_t i) {
+    if (A.wide) {
+        uint64_t w0, w1;
+        rx_wide_words(A, i, w0, w1);
+        return w0;
+    }
     if (A.first) return hs_key_at(A.key, A.sel ? A.sel[i] : A.row0 + i);
     return A.esize[0] == 4 ? (uint64_t)(int64_t)((const int32_t*)A.src[0])[i] : ((const uint64_t*)A.src[0])[i];
 }
@@ -122,6 +144,13 @@ __device__ __forceinline__ uint32_t rx_mix32(uint32_t k) {
     return h ^ (h >> 16);
 }
 __device__ __forceinline__ uint32_t rx_bin4(uint32_t key, int shift, int bits) { return (rx_mix32(key) >> shift) & ((1u << bits) - 1u); }
+// the word a position's bin is cut from: the key word, or both words of a wide key folded into one
+__device__ __forceinline__ uint64_t rx_binword(const RxPass& A, int64_t i) {
+    if (!A.wide) return rx_key(A, i);
+    uint64_t w0, w1;
+    rx_wide_words(A, i, w0, w1);
+    return w0 ^ hs_mix64(w1);
+}
 __device__ __forceinline__ uint32_t rx_bin_of(const RxPass& A, uint64_t word) {
     return A.key4 ? rx_bin4((uint32_t)word, A.shift, A.bits) : rx_bin(word, A.shift, A.bits, A.raw);
 }
@@ -146,7 +175,7 @@ __global__ void __launch_bounds__(RX_THREADS) k_rx_hist(const RxPass A_kernarg) 
 #pragma unroll
     for (int j = 0; j < RX_PER; ++j) {
         const int64_t i = b + tid + (int64_t)j * RX_THREADS;
-        word[j] = i < e ? rx_key(A, i) : 0;
+        word[j] = i < e ? rx_binword(A, i) : 0;
     }
 #pragma unroll
     for (int j = 0; j < RX_PER; ++j)
@@ -197,7 +226,7 @@ __global__ void __launch_bounds__(RX_THREADS) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
     for (int j = 0; j < RX_PER; ++j) {
         const bool valid = first + j * HS_WAVE < e;
-        bin[j] = valid ? rx_bin_of(A, word[j]) : 0u;
+        bin[j] = valid ? rx_bin_of(A, A.wide ? word[j] ^ hs_mix64(rx_wide_w1(A, first + j * HS_WAVE)) : word[j]) : 0u;
         uint64_t peers = __ballot(valid);
         for (int bit = 0; bit < A.bits; ++bit) {
             const bool on = (bin[j] >> bit) & 1u;
@@ -283,7 +312,9 @@ __global__ void __launch_bounds__(RX_THREADS) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
             for (int j = 0; j < RX_PER; ++j) {
                 const int64_t i = first + j * HS_WAVE;
-                v[j] = lpos(j) == 0xffffu ? 0 : (es == 4 ? (uint64_t)((const uint32_t*)src)[i] : es == 8 ? ((const uint64_t*)src)[i] : (uint64_t)((const uint8_t*)src)[i]);
+                if (lpos(j) == 0xffffu) v[j] = 0;
+                else if (A.wide && A.first && c == 1) v[j] = rx_wide_w1(A, i);
+                else v[j] = es == 4 ? (uint64_t)((const uint32_t*)src)[i] : es == 8 ? ((const uint64_t*)src)[i] : (uint64_t)((const uint8_t*)src)[i];
             }
 #pragma unroll
             for (int j = 0; j < RX_PER; ++j) {
@@ -313,7 +344,9 @@ __global__ void __launch_bounds__(RX_THREADS) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
         for (int j = 0; j < RX_PER; ++j) {
             const int64_t i = first + j * HS_WAVE;
-            v[j] = to[j] < 0 ? 0 : (es == 4 ? (uint64_t)((const uint32_t*)src)[i] : es == 8 ? ((const uint64_t*)src)[i] : (uint64_t)((const uint8_t*)src)[i]);
+            if (to[j] < 0) v[j] = 0;
+            else if (A.wide && A.first && c == 1) v[j] = rx_wide_w1(A, i);
+            else v[j] = es == 4 ? (uint64_t)((const uint32_t*)src)[i] : es == 8 ? ((const uint64_t*)src)[i] : (uint64_t)((const uint8_t*)src)[i];
         }
 #pragma unroll
         for (int j = 0; j < RX_PER; ++j) {
@@ -509,6 +542,7 @@ struct RxAgg {
     int32_t cap, quantise;
     int32_t debug, last;           // last: no later launch takes what this one cannot hold
     uint64_t* prov_key;            // [n] a partition's groups, from the partition's own start
+    uint64_t* prov_key1;           // [n] wide keys: the second word
     void* prov_acc[HS_MAX_ACC];    // [n] each: f32 / i32 when quantising, f64 / i64 bits otherwise
     int64_t* pcount;               // [n_parts] groups of the partition
     uint32_t* flags;
@@ -755,15 +789,20 @@ __global__ void __launch_bounds__(256) k_rx_fold(const RxAgg A_kernarg) {
 // their value to the group's cell in LDS (distinct cells within a round; LDS executes a wave's instructions in order, so
 // round r + 1 reads what round r wrote) - instead of a leader lane collecting its peers' values with shuffles.  Integer
 // cells are order-free: one LDS atomic per lane (COUNT: one per group and step, with the group's lane count).
-template <int NA, int CLS, bool KEY4>
+// KM: 0 = 4-byte key column, 1 = 8-byte key words, 2 / 3 = wide keys (two words: columns 0 and 1 - the second one carried
+// as 8 / as 4 bytes, strings of <= 12 bytes; values from column 2)
+template <int NA, int CLS, int KM>
 __global__ void __launch_bounds__(256) k_rx_fold_sum(const RxAgg A_kernarg) {
+    constexpr bool KEY4 = KM == 0, WIDE = KM >= 2;
+    using Key1Reg = std::conditional_t<KM == 3, uint32_t, uint64_t>;
     HS_KERNARG(RxAgg, A);
     extern __shared__ __align__(16) uint64_t rx_lds[];
     const int lane = threadIdx.x & (HS_WAVE - 1), w = threadIdx.x / HS_WAVE, wpb = blockDim.x / HS_WAVE;
     const int cap = A.cap;
-    const size_t per_wave = (size_t)cap * (1 + NA) + (size_t)cap / 4;  // as k_rx_fold: the host sizes LDS once
+    const size_t per_wave = (size_t)cap * (1 + (WIDE ? 1 : 0) + NA) + (size_t)cap / 4;  // the host sizes LDS by the same rule
     uint64_t* keys = rx_lds + (size_t)w * per_wave;
-    uint64_t* acc = keys + cap;
+    uint64_t* keys1 = keys + cap;  // WIDE: the second key word of every slot
+    uint64_t* acc = keys + (WIDE ? 2 : 1) * cap;
     uint16_t* order = (uint16_t*)(acc + (size_t)NA * cap);
     const uint32_t mask = (uint32_t)cap - 1u;
     const int limit = A.last ? cap : cap - cap / 4;
@@ -793,6 +832,7 @@ __global__ void __launch_bounds__(256) k_rx_fold_sum(const RxAgg A_kernarg) {
         }
         using KeyReg = std::conditional_t<KEY4, uint32_t, uint64_t>;  // as loaded: widening a key right after its load would wait for it
         KeyReg nk[RX_CHUNK];
+        Key1Reg nk1[RX_CHUNK];
         uint32_t nx[RX_CHUNK][NCR];
         auto load_chunk = [&](int64_t base) {
 #pragma unroll
@@ -800,8 +840,9 @@ __global__ void __launch_bounds__(256) k_rx_fold_sum(const RxAgg A_kernarg) {
                 const int64_t i = base + j * HS_WAVE + lane;
                 const bool valid = i < e;
                 nk[j] = valid ? ((const KeyReg*)A.src[0])[i] : 0;
+                nk1[j] = WIDE && valid ? ((const Key1Reg*)A.src[1])[i] : 0;
 #pragma unroll
-                for (int c = 0; c < NC; ++c) nx[j][c] = valid ? ((const uint32_t*)A.src[1 + c])[i] : 0u;
+                for (int c = 0; c < NC; ++c) nx[j][c] = valid ? ((const uint32_t*)A.src[(WIDE ? 2 : 1) + c])[i] : 0u;
             }
         };
         load_chunk(b);
@@ -809,10 +850,12 @@ __global__ void __launch_bounds__(256) k_rx_fold_sum(const RxAgg A_kernarg) {
         bool full = false;
         for (int64_t base = b; base < e && !full; base += RX_CHUNK * HS_WAVE) {
             KeyReg ck[RX_CHUNK];
+            Key1Reg ck1[RX_CHUNK];
             uint32_t cx[RX_CHUNK][NCR];
 #pragma unroll
             for (int j = 0; j < RX_CHUNK; ++j) {
                 ck[j] = nk[j];
+                ck1[j] = nk1[j];
 #pragma unroll
                 for (int c = 0; c < NCR; ++c) cx[j][c] = NC > 0 ? nx[j][c] : 0u;
             }
@@ -830,12 +873,24 @@ __global__ void __launch_bounds__(256) k_rx_fold_sum(const RxAgg A_kernarg) {
                         uint32_t m = (uint32_t)k * 0xCC9E2D51u;
                         m ^= m >> 17;
                         h = ((m * 0x1B873593u) >> 12) & mask;
+                    } else if constexpr (WIDE) {
+                        h = (uint32_t)(hs_mix64(k ^ hs_mix64(ck1[j])) >> 36) & mask;
                     } else {
                         h = (uint32_t)(hs_mix64(k) >> 36) & mask;
                     }
                     for (uint32_t probe = 0; probe <= mask; ++probe) {
                         const uint64_t cur = atomicCAS((unsigned long long*)&keys[h], (unsigned long long)HS_EMPTY_KEY, (unsigned long long)k);
-                        if (cur == HS_EMPTY_KEY || cur == k) {
+                        if constexpr (WIDE) {
+                            // the lane that claimed the slot completes it before any lane of the wave - this probe round or a
+                            // later one - compares the second word (LDS executes the wave's instructions in order)
+                            if (cur == HS_EMPTY_KEY) keys1[h] = ck1[j];
+                            __builtin_amdgcn_wave_barrier();
+                            if (cur == HS_EMPTY_KEY || (cur == k && keys1[h] == ck1[j])) {
+                                inserted = cur == HS_EMPTY_KEY;
+                                slot = (int)h;
+                                break;
+                            }
+                        } else if (cur == HS_EMPTY_KEY || cur == k) {
                             inserted = cur == HS_EMPTY_KEY;
                             slot = (int)h;
                             break;
@@ -890,6 +945,7 @@ __global__ void __launch_bounds__(256) k_rx_fold_sum(const RxAgg A_kernarg) {
             const int s = order[g];
             const int64_t at = b + g;
             if (!full) A.prov_key[at] = keys[s];
+            if (WIDE && !full) A.prov_key1[at] = keys1[s];
             keys[s] = HS_EMPTY_KEY;
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
@@ -923,6 +979,7 @@ struct RxEmit {
     const int64_t* pscan;
     int64_t n_parts;
     const uint64_t* prov_key;
+    const uint64_t* prov_key1;
     const void* prov_acc[HS_MAX_ACC];
     int32_t n_acc, osize, key_kind, pad;
     void* out_key;
@@ -939,8 +996,10 @@ __global__ void __launch_bounds__(256) k_rx_emit(const RxEmit A_kernarg) {
             if (base == HS_I32) ((int32_t*)A.out_key)[to + q] = (int32_t)(int64_t)k;
             else if (base == HS_F32) ((float*)A.out_key)[to + q] = (float)hs_u2d(k);  // the word: the f32 widened, exactly
             else if (base == HS_STR) {
-                const int len = A.key_kind >> 8;  // hs_pack_str: byte i of the string = byte i of the word
-                for (int i = 0; i < len; ++i) ((uint8_t*)A.out_key)[(to + q) * len + i] = (uint8_t)(k >> (8 * i));
+                const int len = A.key_kind >> 8;  // hs_pack_str / hs_str_words16: byte i of the string = byte i of the word(s)
+                const uint64_t k1 = len > 8 ? A.prov_key1[from + q] : 0ull;
+                for (int i = 0; i < len; ++i)
+                    ((uint8_t*)A.out_key)[(to + q) * len + i] = (uint8_t)(i < 8 ? k >> (8 * i) : k1 >> (8 * (i - 8)));
             } else ((uint64_t*)A.out_key)[to + q] = k;
             for (int a = 0; a < A.n_acc; ++a) rx_move(A.prov_acc[a], A.out_acc[a], A.osize, from + q, to + q);
         }
@@ -959,6 +1018,9 @@ static int rx_esize(int32_t kind) {
     }
 }
 static size_t rx_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// key_kind of a plan: a STRING key of one fixed length 8 .. 16 bytes = two key words per tuple
+static bool rx_plan_wide(int64_t key_kind) { return (key_kind & 0xff) == HS_STR && (key_kind >> 8) > 7; }
 
 // field use of the public plan (include/hipspark.h keeps it opaque: int64 f[48])
 enum {
@@ -1030,9 +1092,23 @@ extern "C" int hs_group_radix_plan(int32_t key_kind, int64_t n, int32_t n_units,
     {   // keys whose 64-bit key word IS the key: integers, floats (0.0 == -0.0, as one Python dict key), strings of a fixed
         // length <= 7 bytes (key_kind = HS_STR + 256 x length)
         const int base = key_kind & 0xff, len = key_kind >> 8;
-        const bool ok = base == HS_STR ? (len >= 1 && len <= 7) : (len == 0 && (base == HS_I32 || base == HS_I64 || base == HS_F32 || base == HS_F64));
+        const bool ok = base == HS_STR ? (len >= 1 && len <= 16) : (len == 0 && (base == HS_I32 || base == HS_I64 || base == HS_F32 || base == HS_F64));
         if (!ok) {
-            hs_set_error("hs_group_radix_plan: key kind %d (HS_I32 / I64 / F32 / F64, or HS_STR + 256 x fixed length <= 7)", (int)key_kind);
+            hs_set_error("hs_group_radix_plan: key kind %d (HS_I32 / I64 / F32 / F64, or HS_STR + 256 x fixed length <= 16)", (int)key_kind);
+            return HS_E_LIMIT;
+        }
+    }
+    // strings of 8 .. 16 bytes travel as TWO key words (columns 0 and 1) and are compared on both: exact, no hashing.  Only
+    // the SUM-specialised fold knows them: SUM / AVG / COUNT over f32 / i32 columns and integer constants, <= 3 aggregates
+    const bool wide = rx_plan_wide(key_kind);
+    if (wide) {
+        bool sums = spec->n_acc >= 1 && spec->n_acc <= 3;
+        for (int a = 0; a < spec->n_acc && sums; ++a) {
+            const bool is_int = spec->is_int[a] != 0;
+            sums = spec->op[a] == HS_AGG_SUM && ((val_kinds[a] == HS_F32 && !is_int) || (val_kinds[a] == HS_I32 && is_int) || (val_kinds[a] < 0 && is_int));
+        }
+        if (!sums) {
+            hs_set_error("hs_group_radix_plan: a STRING key of 8 .. 16 bytes needs SUM / COUNT aggregates over f32 / i32 columns (<= 3)");
             return HS_E_LIMIT;
         }
     }
@@ -1040,7 +1116,7 @@ extern "C" int hs_group_radix_plan(int32_t key_kind, int64_t n, int32_t n_units,
     for (int i = 0; i < 48; ++i) f[i] = 0;
     const int NA = spec->n_acc;
     int cap = 2048;
-    while (cap > 64 && ((size_t)cap * (1 + NA) + (size_t)cap / 4) * 8 > 65536) cap >>= 1;
+    while (cap > 64 && ((size_t)cap * (1 + (wide ? 1 : 0) + NA) + (size_t)cap / 4) * 8 > 65536) cap >>= 1;
     // rows per partition: half the slots of the LARGE table.  Partitions that turn out to hold few distinct keys - the
     // usual case - are folded by the 512-slot launch anyway.  HIPSPARK_RADIX_FINE=1 cuts down to half the slots of the
     // small table where two passes can (units of file-block size): measured at 600 M rows / 287 units, it makes
@@ -1073,7 +1149,9 @@ extern "C" int hs_group_radix_plan(int32_t key_kind, int64_t n, int32_t n_units,
     f[PL_COUNTERS] = c1 > c2 ? c1 : c2;
     f[PL_OSIZE] = quantise ? 4 : 8;
     f[PL_ESIZE0] = key_kind == HS_I32 ? 4 : 8;
-    int64_t tuple = f[PL_ESIZE0];
+    const int kcols = wide ? 2 : 1;  // key columns of a tuple; the value columns follow
+    if (wide) f[PL_ESIZE0 + 1] = (key_kind >> 8) <= 12 ? 4 : 8;  // the second word of <= 12 bytes holds <= 4 of them
+    int64_t tuple = f[PL_ESIZE0] + (wide ? f[PL_ESIZE0 + 1] : 0);
     int carried = 0;
     for (int a = 0; a < NA; ++a) {
         if (val_kinds[a] < 0) continue;  // a constant: does not travel
@@ -1082,7 +1160,7 @@ extern "C" int hs_group_radix_plan(int32_t key_kind, int64_t n, int32_t n_units,
             hs_set_error("hs_group_radix_plan: value column %d has kind %d", a, (int)val_kinds[a]);
             return HS_E_ARG;
         }
-        f[PL_ESIZE0 + 1 + carried] = es;
+        f[PL_ESIZE0 + kcols + carried] = es;
         tuple += es;
         ++carried;
     }
@@ -1095,7 +1173,7 @@ extern "C" int hs_group_radix_plan(int32_t key_kind, int64_t n, int32_t n_units,
     };
     // a buffer set = the columns back to back, each n elements
     size_t set_bytes = 0;
-    for (int c = 0; c <= carried; ++c) set_bytes += rx_align((size_t)n * f[PL_ESIZE0 + c]);
+    for (int c = 0; c < kcols + carried; ++c) set_bytes += rx_align((size_t)n * f[PL_ESIZE0 + c]);
     take(PL_OFF_BUF_A, set_bytes);
     take(PL_OFF_BUF_B, bits2 ? set_bytes : 0);
     take(PL_OFF_SEG1, (size_t)(f[PL_NSEG1] + 1) * 8);
@@ -1106,7 +1184,7 @@ extern "C" int hs_group_radix_plan(int32_t key_kind, int64_t n, int32_t n_units,
     take(PL_OFF_SCAN, (size_t)(f[PL_COUNTERS] + 1) * 8);
     const int64_t scan_n = f[PL_COUNTERS] > f[PL_PARTS] ? f[PL_COUNTERS] : f[PL_PARTS];
     take(PL_OFF_SCANWS, hs_scan_ws_bytes(scan_n));
-    take(PL_OFF_PKEY, (size_t)n * 8);
+    take(PL_OFF_PKEY, (size_t)n * 8 * kcols);
     take(PL_OFF_PACC, (size_t)NA * rx_align((size_t)n * f[PL_OSIZE]));
     take(PL_OFF_PCOUNT, (size_t)f[PL_PARTS] * 8);
     take(PL_OFF_PSCAN, (size_t)(f[PL_PARTS] + 1) * 8);
@@ -1119,7 +1197,7 @@ extern "C" size_t hs_group_radix_ws_bytes(const hs_radix_plan* plan) { return pl
 
 static void rx_set_cols(const int64_t* f, uint8_t* ws, int field, void** cols) {
     size_t off = (size_t)f[field];
-    for (int c = 0; c <= (int)f[PL_NCARRIED]; ++c) {
+    for (int c = 0; c < (rx_plan_wide(f[PL_KEYKIND]) ? 2 : 1) + (int)f[PL_NCARRIED]; ++c) {
         cols[c] = ws + off;
         off += rx_align((size_t)f[PL_N] * f[PL_ESIZE0 + c]);
     }
@@ -1155,7 +1233,10 @@ extern "C" int hs_group_radix_run(void* stream_, const hs_radix_plan* plan, cons
     std::memset(&G, 0, sizeof(G));
     RxPass P;
     std::memset(&P, 0, sizeof(P));
-    P.n_cols = 1 + (int)f[PL_NCARRIED];
+    const bool wide = rx_plan_wide(f[PL_KEYKIND]);
+    const int kcols = wide ? 2 : 1;
+    P.n_cols = kcols + (int)f[PL_NCARRIED];
+    P.wide = wide ? 1 : 0;
     P.key = *key;
     P.sel = sel;
     P.row0 = row0;
@@ -1168,12 +1249,12 @@ extern "C" int hs_group_radix_run(void* stream_, const hs_radix_plan* plan, cons
             continue;
         }
         ++carried;
-        if (carried > (int)f[PL_NCARRIED] || rx_esize(val_cols[a].kind) != (int)f[PL_ESIZE0 + carried]) {
+        if (carried > (int)f[PL_NCARRIED] || rx_esize(val_cols[a].kind) != (int)f[PL_ESIZE0 + kcols - 1 + carried]) {
             hs_set_error("hs_group_radix_run: value column %d does not match the plan", a);
             return HS_E_ARG;
         }
-        P.src[carried] = val_cols[a].data;
-        G.carried[a] = carried;
+        P.src[kcols - 1 + carried] = val_cols[a].data;
+        G.carried[a] = kcols - 1 + carried;
         G.val_kind[a] = val_cols[a].kind;
     }
     if (carried != (int)f[PL_NCARRIED]) {
@@ -1214,6 +1295,7 @@ extern "C" int hs_group_radix_run(void* stream_, const hs_radix_plan* plan, cons
     G.cap = (int)f[PL_CAP];
     G.quantise = (int)f[PL_QUANTISE];
     G.prov_key = (uint64_t*)(ws + f[PL_OFF_PKEY]);
+    G.prov_key1 = G.prov_key + n;
     for (int a = 0; a < NA; ++a) G.prov_acc[a] = ws + f[PL_OFF_PACC] + (size_t)a * rx_align((size_t)n * f[PL_OSIZE]);
     G.pcount = (int64_t*)(ws + f[PL_OFF_PCOUNT]);
     G.flags = flags;
@@ -1233,7 +1315,11 @@ extern "C" int hs_group_radix_run(void* stream_, const hs_radix_plan* plan, cons
         else if (!G.carried[a] && is_int) c = 2;
         sum_cls = c < 0 ? -1 : (sum_cls | (c << (2 * a)));
     }
-    if (lean_off || stamps) sum_cls = -1;
+    if ((lean_off || stamps) && !wide) sum_cls = -1;
+    if (wide && sum_cls < 0) {
+        hs_set_error("hs_group_radix_run: a wide STRING key needs the SUM-specialised fold");
+        return HS_E_LIMIT;
+    }
     auto fold = [&](int cap, bool listed) {
         G.cap = cap;
         G.last = cap == (int)f[PL_CAP] ? 1 : 0;
@@ -1241,7 +1327,7 @@ extern "C" int hs_group_radix_run(void* stream_, const hs_radix_plan* plan, cons
         G.list_count = listed ? overflow : nullptr;
         G.overflow = overflow + 1;
         G.overflow_count = overflow;
-        const size_t per_wave = ((size_t)cap * (1 + NA) + (size_t)cap / 4) * 8;
+        const size_t per_wave = ((size_t)cap * (kcols + NA) + (size_t)cap / 4) * 8;
         int wpb = (int)(65536 / per_wave);
         wpb = wpb < 1 ? 1 : (wpb > 4 ? 4 : wpb);
         int64_t grid = (parts + wpb - 1) / wpb;
@@ -1252,22 +1338,28 @@ extern "C" int hs_group_radix_run(void* stream_, const hs_radix_plan* plan, cons
     else hipLaunchKernelGGL((k_rx_fold<NC, 12>), g, t, per_wave * wpb, stream, G)
 #define RX_SUM1(C0) \
     case (C0):                                                                                              \
-        if (key4) hipLaunchKernelGGL((k_rx_fold_sum<1, (C0), true>), g, t, per_wave * wpb, stream, G);      \
-        else hipLaunchKernelGGL((k_rx_fold_sum<1, (C0), false>), g, t, per_wave * wpb, stream, G);          \
+        if (km == 0) hipLaunchKernelGGL((k_rx_fold_sum<1, (C0), 0>), g, t, per_wave * wpb, stream, G);      \
+        else if (km == 1) hipLaunchKernelGGL((k_rx_fold_sum<1, (C0), 1>), g, t, per_wave * wpb, stream, G); \
+        else if (km == 2) hipLaunchKernelGGL((k_rx_fold_sum<1, (C0), 2>), g, t, per_wave * wpb, stream, G); \
+        else hipLaunchKernelGGL((k_rx_fold_sum<1, (C0), 3>), g, t, per_wave * wpb, stream, G);              \
         return;
 #define RX_SUM2(C0, C1) \
     case ((C0) | ((C1) << 2)):                                                                                             \
-        if (key4) hipLaunchKernelGGL((k_rx_fold_sum<2, ((C0) | ((C1) << 2)), true>), g, t, per_wave * wpb, stream, G);      \
-        else hipLaunchKernelGGL((k_rx_fold_sum<2, ((C0) | ((C1) << 2)), false>), g, t, per_wave * wpb, stream, G);          \
+        if (km == 0) hipLaunchKernelGGL((k_rx_fold_sum<2, ((C0) | ((C1) << 2)), 0>), g, t, per_wave * wpb, stream, G);      \
+        else if (km == 1) hipLaunchKernelGGL((k_rx_fold_sum<2, ((C0) | ((C1) << 2)), 1>), g, t, per_wave * wpb, stream, G); \
+        else if (km == 2) hipLaunchKernelGGL((k_rx_fold_sum<2, ((C0) | ((C1) << 2)), 2>), g, t, per_wave * wpb, stream, G); \
+        else hipLaunchKernelGGL((k_rx_fold_sum<2, ((C0) | ((C1) << 2)), 3>), g, t, per_wave * wpb, stream, G);              \
         return;
 #define RX_SUM3(C0, C1, C2) \
     case ((C0) | ((C1) << 2) | ((C2) << 4)): \
-        if (key4) hipLaunchKernelGGL((k_rx_fold_sum<3, ((C0) | ((C1) << 2) | ((C2) << 4)), true>), g, t, per_wave * wpb, stream, G);   \
-        else hipLaunchKernelGGL((k_rx_fold_sum<3, ((C0) | ((C1) << 2) | ((C2) << 4)), false>), g, t, per_wave * wpb, stream, G);       \
+        if (km == 0) hipLaunchKernelGGL((k_rx_fold_sum<3, ((C0) | ((C1) << 2) | ((C2) << 4)), 0>), g, t, per_wave * wpb, stream, G);      \
+        else if (km == 1) hipLaunchKernelGGL((k_rx_fold_sum<3, ((C0) | ((C1) << 2) | ((C2) << 4)), 1>), g, t, per_wave * wpb, stream, G); \
+        else if (km == 2) hipLaunchKernelGGL((k_rx_fold_sum<3, ((C0) | ((C1) << 2) | ((C2) << 4)), 2>), g, t, per_wave * wpb, stream, G); \
+        else hipLaunchKernelGGL((k_rx_fold_sum<3, ((C0) | ((C1) << 2) | ((C2) << 4)), 3>), g, t, per_wave * wpb, stream, G);              \
         return;
 #define RX_SUM3_LAST(C0, C1) RX_SUM3(C0, C1, 0) RX_SUM3(C0, C1, 1) RX_SUM3(C0, C1, 2)
 #define RX_SUM3_MID(C0) RX_SUM3_LAST(C0, 0) RX_SUM3_LAST(C0, 1) RX_SUM3_LAST(C0, 2)
-        const bool key4 = G.esize[0] == 4;
+        const int km = wide ? (G.esize[1] == 4 ? 3 : 2) : (G.esize[0] == 4 ? 0 : 1);
         if (sum_cls >= 0 && NA == 1) {
             switch (sum_cls) { RX_SUM1(0) RX_SUM1(1) RX_SUM1(2) default: break; }
         } else if (sum_cls >= 0 && NA == 2) {
@@ -1325,6 +1417,7 @@ extern "C" int hs_group_radix_emit(void* stream_, const hs_radix_plan* plan, voi
     E.pscan = (const int64_t*)(ws + f[PL_OFF_PSCAN]);
     E.n_parts = f[PL_PARTS];
     E.prov_key = (const uint64_t*)(ws + f[PL_OFF_PKEY]);
+    E.prov_key1 = E.prov_key + f[PL_N];
     E.n_acc = (int)f[PL_NA];
     E.osize = (int)f[PL_OSIZE];
     E.key_kind = (int)f[PL_KEYKIND];

@@ -1465,8 +1465,11 @@ class Device:
             consts[a] = cell
             cols[a] = col.as_hs() if col is not None else hs.hs_col(hs.U8, -1, None, None, None)
         plan = hs.hs_radix_plan()
-        hs.check(self.lib.hs_group_radix_plan(self.radix_key_code(key), n, n_units, max(int(max_unit_rows), 1), kinds, C.byref(spec),
-                                              1 if quantise else 0, C.byref(plan)), "hs_group_radix_plan")
+        rc = self.lib.hs_group_radix_plan(self.radix_key_code(key), n, n_units, max(int(max_unit_rows), 1), kinds, C.byref(spec),
+                                          1 if quantise else 0, C.byref(plan))
+        if rc == 2:  # HS_E_LIMIT: not a shape this tier moves (a wide STRING key with MIN / MAX ...): the other HBM tier takes it
+            return None
+        hs.check(rc, "hs_group_radix_plan")
         ws = self.workspace(self.lib.hs_group_radix_ws_bytes(C.byref(plan)))
         # the group counts per unit and, behind them, the tier's own status word (an overflow here is answered by the other
         # path, not raised): one buffer, so the host reads both with ONE copy
@@ -1507,13 +1510,13 @@ class Device:
     @staticmethod
     def radix_key_code(key: DCol) -> int | None:
         """key_kind of hs_group_radix_plan for a GROUP BY column the radix tier takes (its 64-bit key word is the key itself),
-        else None: integers, floats, strings of one fixed length <= 7 bytes that are not dictionary codes."""
+        else None: integers, floats, strings of one fixed length <= 16 bytes that are not dictionary codes."""
         if key.dict is not None or key.virtual:
             return None
         if key.kind in (hs.I32, hs.I64, hs.F32, hs.F64):
             return key.kind
-        if key.kind == hs.STR and key.fixed_len is not None and 1 <= key.fixed_len <= 7:
-            return hs.STR + 256 * key.fixed_len
+        if key.kind == hs.STR and key.fixed_len is not None and 1 <= key.fixed_len <= 16:
+            return hs.STR + 256 * key.fixed_len  # <= 7 bytes: one packed key word; 8 .. 16: two words, compared on both
         return None
 
     def aggregate_partial_global(self, batch: DBatch, filters: Sequence[Any], group_by: Any,

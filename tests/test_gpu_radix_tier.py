@@ -140,8 +140,9 @@ def test_radix_sum_fold_in_every_class_combination(dev, classes, n, units, group
 
 def test_radix_tier_takes_float_and_short_string_keys(dev):
     """Round 3: keys whose 64-bit key word is the key itself - stored FLOAT, computed f64 (0.0 and -0.0 one group, as in
-    a Python dict), STRING columns of one fixed length <= 7 bytes - take the radix tier too; longer strings are refused by
-    the plan (the engine keeps the hash-table tier for those)."""
+    a Python dict), STRING columns of one fixed length <= 7 bytes; and strings of 8 .. 16 bytes as TWO key words compared exactly (no hashing) -
+    take the radix tier too; longer or variable-length strings are refused by the plan (the engine keeps the hash-table
+    tier for those)."""
     import ctypes as C
 
     import torch
@@ -175,9 +176,11 @@ def test_radix_tier_takes_float_and_short_string_keys(dev):
             for key, (s, c) in want.items():
                 assert got[key] == (np.float32(s).item(), c), (kind, u, key)
     # strings of one fixed length
-    for length in (1, 3, 7):
+    for length in (1, 3, 7, 8, 12, 16):  # <= 7: one packed key word; 8 .. 16: two key words per tuple, compared on both
         alphabet = np.frombuffer(b"ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghij0123456789", dtype=np.uint8)
         words = alphabet[rng.integers(0, len(alphabet), (min(30_000, len(alphabet) ** length), length))]
+        if length > 8:
+            words[: len(words) // 2, :8] = words[0, :8]  # many keys that agree in their first word
         rows = words[rng.integers(0, len(words), n)]
         data = torch.from_numpy(np.ascontiguousarray(rows).reshape(-1)).cuda()
         lens = torch.full((n,), length, dtype=torch.uint8, device="cuda")
@@ -202,8 +205,12 @@ def test_radix_tier_takes_float_and_short_string_keys(dev):
             for key, (s, c) in want.items():
                 assert got[key] == (np.float32(s).item(), c), (length, u, key)
     plan, spec = hs.hs_radix_plan(), hs.hs_agg_spec()
-    rc = dev.lib.hs_group_radix_plan(hs.STR + 256 * 12, 1000, 1, 1000, (C.c_int32 * 1)(hs.F32), C.byref(spec), 1, C.byref(plan))
-    assert rc == 2  # HS_E_LIMIT: not a key this tier moves as one word
+    spec.n_acc, spec.op[0], spec.is_int[0] = 1, hs.AGG_SUM, 0
+    kinds = (C.c_int32 * 1)(hs.F32)
+    assert dev.lib.hs_group_radix_plan(hs.STR + 256 * 17, 1000, 1, 1000, kinds, C.byref(spec), 1, C.byref(plan)) == 2  # HS_E_LIMIT
+    assert dev.lib.hs_group_radix_plan(hs.STR + 256 * 12, 1000, 1, 1000, kinds, C.byref(spec), 1, C.byref(plan)) == 0
+    spec.op[0] = hs.AGG_MIN  # two-word keys only know the SUM-specialised fold
+    assert dev.lib.hs_group_radix_plan(hs.STR + 256 * 12, 1000, 1, 1000, kinds, C.byref(spec), 1, C.byref(plan)) == 2
 
 
 def test_radix_tier_over_a_selection_and_timestamp_keys(dev):

@@ -16,6 +16,15 @@ engine = HipExecutionEngine(0)
 dev = engine.dev
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 keys = DCol(hs.I32, torch.randint(0, G, (N,), dtype=torch.int32, device="cuda", generator=g), N)
+int_keys = keys
+STR = int(os.environ.get("RADIX_BENCH_STR", "0"))  # GROUP BY a STRING column of this fixed length: the key's decimal digits
+if STR:
+    digits = torch.empty((N, STR), dtype=torch.uint8, device="cuda")
+    k64 = keys.data[:N].to(torch.int64)
+    for i in range(STR):
+        digits[:, STR - 1 - i] = ((k64 // 10 ** i) % 10 + 48).to(torch.uint8)
+    del k64
+    keys = DCol(hs.STR, digits.reshape(-1), N, lens=torch.full((N,), STR, dtype=torch.uint8, device="cuda"), offs=None, fixed_len=STR)
 vals = DCol(hs.F32, torch.rand(N, dtype=torch.float32, device="cuda", generator=g), N)
 bounds = torch.tensor([N * u // U for u in range(U + 1)], dtype=torch.int64, device="cuda")
 biggest = max(N * (u + 1) // U - N * u // U for u in range(U))
@@ -27,7 +36,7 @@ for r in range(reps):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     a.record(); out = dev.group_radix(keys, None, N, bounds, U, biggest, VALUES, OPS, True); b.record()
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(f"rows {N} groups {G} units {U}: run {r}: {a.elapsed_time(b):7.3f} ms (host {dt * 1e3:7.3f} ms) = "
+    print(f"rows {N} groups {G} units {U}{f' string key of {STR} bytes' if STR else ''}: run {r}: {a.elapsed_time(b):7.3f} ms (host {dt * 1e3:7.3f} ms) = "
           f"{N / a.elapsed_time(b) / 1e6:6.2f} G rows/s, {out[0].n} groups", flush=True)
     if os.environ.get("HIPSPARK_RADIX_STAMPS"):
         import ctypes
@@ -39,8 +48,13 @@ for r in range(reps):
 # the timed result, checked over ALL rows (checker = plain torch, fp64: order-free, so a tolerance of a few f32 ulps)
 if U == 1:
     key_col, accs, _ = out
-    got_k, got_s = key_col.data[: key_col.n].to(torch.int64), accs[0].data[: key_col.n].to(torch.float64)
-    uniq, inv = torch.unique(keys.data[:N].to(torch.int64), return_inverse=True)
+    if STR:
+        d = key_col.data[: key_col.n * STR].reshape(-1, STR).to(torch.int64) - 48
+        got_k = sum(d[:, STR - 1 - i] * 10 ** i for i in range(STR))
+    else:
+        got_k = key_col.data[: key_col.n].to(torch.int64)
+    got_s = accs[0].data[: key_col.n].to(torch.float64)
+    uniq, inv = torch.unique(int_keys.data[:N].to(torch.int64), return_inverse=True)
     want = torch.zeros(uniq.numel(), dtype=torch.float64, device="cuda").index_add_(0, inv, vals.data[:N].to(torch.float64))
     o = torch.argsort(got_k)
     assert torch.equal(got_k[o], uniq), "group keys differ"
