@@ -372,7 +372,7 @@ class Q1Workload:
             "launch": self.engine.dev.last_scan,
         }
         if self.world == 1 and self.total_units == 600_037_902:
-            out.update(pmc_traffic("r02_pmc_hbm_traffic_q1_sf100.json"))
+            out.update(pmc_traffic("r03_pmc_hbm_traffic_q1_sf100.json"))
             if out["traffic"]:
                 out["hbm_frac"] = out["traffic"] / (kernel_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
         return out
