@@ -337,6 +337,9 @@ class Q1Workload:
         return self.engine.dev.exchange_ms()
 
     def exchange_text(self, backend: str) -> str:
+        if os.environ.get("HIPSPARK_P2P_SLABS") == "1":
+            return (f"partial-row slabs stored into every peer's hipIpc-mapped buffer + device-side flags, no collective "
+                    f"(prototype; process group: {backend})")
         return f"one all_gather of partial-row slabs per query ({backend})"
 
     def algorithmic_bytes_per_launch(self) -> float:

@@ -54,6 +54,7 @@ extern "C" {
 #define HS_FLAG_JOIN_DUP 0x80u     /* hs_join_build_unique met a key twice: the caller takes the general (CSR) join */
 #define HS_FLAG_MERGE_ROWS 0x200u /* hs_agg_merge_small was given an upper bound of rows that does not fit LDS and
                                     ran with what fits; the device-side count turned out larger: use the HBM-tier merge */
+#define HS_FLAG_PEER_TIMEOUT 0x400u /* hs_slab_wait: a peer's slab did not arrive within the time limit (peer-to-peer exchange) */
 #define HS_FLAG_MERGE_FULL 0x100u /* the FINAL merge met more distinct keys than merge_cap (hs_agg_merge_small /
                                     hs_agg_finish): grow that capacity, the per-unit one (HS_FLAG_DICT_FULL) is fine */
 
@@ -615,6 +616,20 @@ typedef struct hs_segment {
     int64_t bytes;
 } hs_segment;
 int hs_copy_segments(void* stream, const hs_segment* segments_dev, int32_t n_segments, int64_t max_bytes);
+
+/* Peer-to-peer exchange of the short tail's slabs (prototype; csrc/hs_exchange.hip): instead of an all-gather every rank
+ * stores its slab straight into a buffer of every peer (mapped through hipIpc handles by the host) and raises a flag there;
+ * the receiver waits for `world` flags on the device and lays the slots out as the gathered slabs hs_agg_finish reads.
+ * A rank's buffer: hs_slab_p2p_bytes(world, slot_bytes) bytes, zeroed once; slot_bytes a multiple of 16 >= the slab.
+ * peers_dev: device array of `world` pointers - every rank's buffer as mapped in this process (own buffer at [rank]);
+ * epochs_dev: two device uint64, zeroed once ([0] pushes, [1] waits of this rank).  The wait gives up after timeout_ms
+ * with HS_FLAG_PEER_TIMEOUT in *flags.  Replaces the reference's shuffle-file hand-over (tasks.py:347-375, 144-150) for
+ * the partial rows of a GROUP BY. */
+size_t hs_slab_p2p_bytes(int32_t world, int64_t slot_bytes);
+int hs_slab_push(void* stream, const void* slab, int64_t slab_bytes, void* const* peers_dev, int32_t world, int32_t rank,
+                 int64_t slot_bytes, uint64_t* epochs_dev);
+int hs_slab_wait(void* stream, void* own_buf, int32_t world, int64_t slot_bytes, int64_t slab_bytes, uint64_t* epochs_dev,
+                 void* gathered, int64_t out_stride, uint32_t* flags, int64_t timeout_ms);
 
 /* =================================================================================================
  * Run-time specialisation (reference: codegen.py:230-247 compiles every query with `zig build`).

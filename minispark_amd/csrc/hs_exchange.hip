@@ -58,3 +58,125 @@ extern "C" int hs_copy_segments(void* stream, const hs_segment* segments_dev, in
     }
     return HS_OK;
 }
+
+
+// ---- peer-to-peer exchange of the partial-row slabs (prototype, round 3; HIPSPARK_P2P_SLABS=1) -----------------------
+// The short tail's one exchange step is an all-gather of a few KB per rank.  As a collective it
+// costs a library call, stream hand-overs and a ring over xGMI for what is, per rank, one small store to every peer.
+// Here every rank owns ONE buffer that its peers map (hipIpc handles, exchanged once by the host side:
+// minispark_amd/distributed.py PeerSlabs):
+//     [parity 0 | parity 1] x [world slots of slot_bytes]  |  flags: [2][world] uint64
+// hs_slab_push   (one workgroup) stores the rank's slab into slot `rank` of EVERY peer's buffer - over xGMI these are
+//                plain stores -, makes them visible system-wide and then sets flags[parity][rank] = epoch in every peer;
+// hs_slab_wait   (one workgroup) spins until all `world` flags of the current parity carry this run's epoch, then copies
+//                the slots into the gathered layout hs_agg_finish reads.
+// No host involvement, no collective.  Epochs are device-side counters (both launches are replayable with unchanged
+// arguments); a rank can be at most one run ahead of a peer that has not finished reading (its next push needs the
+// peer's push of that run, which the peer issues after its own finish launch), hence two parities.  The wait is bounded:
+// after timeout_ms it raises HS_FLAG_PEER_TIMEOUT and returns, so a lost peer becomes an error, not a hung GPU.
+struct SlabPushArgs {
+    const uint8_t* slab;
+    int64_t slab_bytes, slot_bytes;
+    uint8_t* const* peers;  // [world] every rank's buffer as mapped here (own buffer at [rank])
+    uint64_t* epoch;        // [0]: pushes so far
+    int32_t world, rank;
+};
+
+__device__ __forceinline__ uint64_t* slab_flags(uint8_t* buf, int world, int64_t slot_bytes) {
+    return (uint64_t*)(buf + 2 * (int64_t)world * slot_bytes);
+}
+
+__global__ void __launch_bounds__(1024) k_slab_push(const SlabPushArgs A) {
+    const uint64_t e = A.epoch[0] + 1;
+    const int parity = (int)(e & 1);
+    const int64_t words = (A.slab_bytes + 15) / 16;  // slabs and slots are multiples of 16 bytes
+    for (int p = 0; p < A.world; ++p) {
+        uint4* dst = (uint4*)(A.peers[p] + ((int64_t)parity * A.world + A.rank) * A.slot_bytes);
+        const uint4* src = (const uint4*)A.slab;
+        for (int64_t i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if ((int)threadIdx.x < A.world) {
+        uint64_t* flags = slab_flags(A.peers[threadIdx.x], A.world, A.slot_bytes);
+        __hip_atomic_store(&flags[parity * A.world + A.rank], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (threadIdx.x == 0) A.epoch[0] = e;
+}
+
+struct SlabWaitArgs {
+    uint8_t* own;           // this rank's buffer
+    int64_t slab_bytes, slot_bytes, out_stride;
+    uint8_t* gathered;      // [world] x out_stride
+    uint64_t* epoch;        // [1]: waits so far
+    uint32_t* flags;
+    int64_t timeout_ticks;  // wall_clock64 ticks (100 MHz)
+    int32_t world, pad;
+};
+
+__global__ void __launch_bounds__(1024) k_slab_wait(const SlabWaitArgs A) {
+    __shared__ int s_late;
+    const uint64_t e = A.epoch[1] + 1;
+    const int parity = (int)(e & 1);
+    if (threadIdx.x == 0) s_late = 0;
+    __syncthreads();
+    if ((int)threadIdx.x < A.world) {
+        uint64_t* flag = slab_flags(A.own, A.world, A.slot_bytes) + parity * A.world + threadIdx.x;
+        const long long t0 = (long long)wall_clock64();
+        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < e) {
+            if ((long long)wall_clock64() - t0 > A.timeout_ticks) {  // every wave reaches the exit: a lost peer is an error, not a hang
+                s_late = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+    if (s_late) {
+        if (threadIdx.x == 0) atomicOr(A.flags, HS_FLAG_PEER_TIMEOUT);
+    } else {
+        const int64_t words = (A.slab_bytes + 15) / 16;
+        for (int r = 0; r < A.world; ++r) {
+            const uint4* src = (const uint4*)(A.own + ((int64_t)parity * A.world + r) * A.slot_bytes);
+            uint4* dst = (uint4*)(A.gathered + (int64_t)r * A.out_stride);
+            for (int64_t i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+        }
+    }
+    if (threadIdx.x == 0) A.epoch[1] = e;
+}
+
+extern "C" size_t hs_slab_p2p_bytes(int32_t world, int64_t slot_bytes) {
+    return world < 1 || slot_bytes < 16 ? 0 : (size_t)(2 * (int64_t)world * slot_bytes + 2 * (int64_t)world * 8);
+}
+
+extern "C" int hs_slab_push(void* stream, const void* slab, int64_t slab_bytes, void* const* peers_dev, int32_t world, int32_t rank,
+                            int64_t slot_bytes, uint64_t* epochs_dev) {
+    if (!slab || !peers_dev || !epochs_dev || world < 1 || world > 1024 || rank < 0 || rank >= world || slab_bytes < 16 ||
+        slab_bytes > slot_bytes || (slot_bytes & 15) || ((uintptr_t)slab & 15)) {
+        hs_set_error("hs_slab_push: bad arguments (slab %lld B, slot %lld B, world %d)", (long long)slab_bytes, (long long)slot_bytes, (int)world);
+        return HS_E_ARG;
+    }
+    SlabPushArgs A{(const uint8_t*)slab, slab_bytes, slot_bytes, (uint8_t* const*)peers_dev, epochs_dev, world, rank};
+    hipLaunchKernelGGL(k_slab_push, dim3(1), dim3(1024), 0, (hipStream_t)stream, A);
+    if (hipGetLastError() != hipSuccess) {
+        hs_set_error("hs_slab_push: kernel launch failed");
+        return HS_E_LAUNCH;
+    }
+    return HS_OK;
+}
+
+extern "C" int hs_slab_wait(void* stream, void* own_buf, int32_t world, int64_t slot_bytes, int64_t slab_bytes, uint64_t* epochs_dev,
+                            void* gathered, int64_t out_stride, uint32_t* flags, int64_t timeout_ms) {
+    if (!own_buf || !epochs_dev || !gathered || !flags || world < 1 || world > 1024 || slab_bytes < 16 || slab_bytes > slot_bytes ||
+        (slot_bytes & 15) || out_stride < slab_bytes || (out_stride & 15) || ((uintptr_t)gathered & 15) || timeout_ms < 1) {
+        hs_set_error("hs_slab_wait: bad arguments");
+        return HS_E_ARG;
+    }
+    SlabWaitArgs A{(uint8_t*)own_buf, slab_bytes, slot_bytes, out_stride, (uint8_t*)gathered, epochs_dev, flags, timeout_ms * 100000, world, 0};
+    hipLaunchKernelGGL(k_slab_wait, dim3(1), dim3(1024), 0, (hipStream_t)stream, A);
+    if (hipGetLastError() != hipSuccess) {
+        hs_set_error("hs_slab_wait: kernel launch failed");
+        return HS_E_LAUNCH;
+    }
+    return HS_OK;
+}

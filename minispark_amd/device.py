@@ -404,6 +404,8 @@ class Device:
             raise ValueError("string longer than 255 bytes cannot be stored in a BlockFile")
         if flags & hs.FLAG_BAD_PROGRAM:
             raise DeviceError("internal error: device interpreter rejected the program")
+        if flags & hs.FLAG_PEER_TIMEOUT:
+            raise DeviceError("peer-to-peer exchange: the partial rows of a rank did not arrive within the time limit")
 
     # ---- columns ---------------------------------------------------------------------------------
     def fixed_col(self, kind: int, arr: np.ndarray) -> DCol:

@@ -217,3 +217,84 @@ def or_flags(dist: Any, flags: int, device: torch.device, group: Any = None) -> 
     bits = torch.tensor([(flags >> b) & 1 for b in range(FLAG_BITS)], dtype=torch.int32, device=dev)
     dist.all_reduce(bits, op=dist.ReduceOp.MAX, group=group)
     return sum(int(v) << b for b, v in enumerate(bits.tolist()))
+
+
+class PeerSlabs:
+    """Peer-to-peer exchange of the short tail's slabs (prototype, HIPSPARK_P2P_SLABS=1; csrc/hs_exchange.hip hs_slab_push /
+    hs_slab_wait): every rank owns one device buffer that all peers map through hipIpc handles (exchanged ONCE here, over the
+    process group's object collective); per query a rank stores its slab into every peer's buffer and raises a flag there,
+    and waits on the device for the flags of all ranks - no collective, no host step in the data path.  Replaces
+    ``all_gather_slabs_into`` for slabs of at most ``SLOT`` bytes; on one node only (hipIpc); tested at world 1 over RCCL
+    and with 2 - 3 processes sharing the test box's GPU - the 8-GPU xGMI case has not run anywhere."""
+
+    SLOT = 256 * 1024
+    TIMEOUT_MS = 20_000
+
+    class _Handle(__import__("ctypes").Structure):
+        _fields_ = [("reserved", __import__("ctypes").c_char * 64)]
+
+    def __init__(self, dist: Any, group: Any, rank: int, world: int, device: Any, lib: Any) -> None:
+        import ctypes as C  # noqa: PLC0415
+
+        self.lib, self.rank, self.world, self.device = lib, rank, world, device
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipIpcOpenMemHandle.argtypes = [C.POINTER(C.c_void_p), PeerSlabs._Handle, C.c_uint]
+        self.nbytes = int(lib.hs_slab_p2p_bytes(world, self.SLOT))
+        with torch.cuda.device(device):
+            own = C.c_void_p()
+            self._check(self.hip.hipMalloc(C.byref(own), C.c_size_t(self.nbytes)), "hipMalloc")
+            self._check(self.hip.hipMemset(own, 0, C.c_size_t(self.nbytes)), "hipMemset")
+            self._check(self.hip.hipDeviceSynchronize(), "hipDeviceSynchronize")
+            self.own = own.value
+            self.opened: list[int] = []
+            peers = [self.own] * world
+            if world > 1:
+                handle = PeerSlabs._Handle()
+                self._check(self.hip.hipIpcGetMemHandle(C.byref(handle), own), "hipIpcGetMemHandle")
+                handles: list = [None] * world
+                dist.all_gather_object(handles, C.string_at(C.byref(handle), 64), group=group)  # all 64 bytes (they contain NULs)
+                for p in range(world):
+                    if p == rank:
+                        continue
+                    h = PeerSlabs._Handle()
+                    if len(handles[p]) != 64:
+                        raise RuntimeError("peer-to-peer slabs: a rank sent a malformed IPC handle")
+                    C.memmove(C.byref(h), handles[p], 64)
+                    ptr = C.c_void_p()
+                    self._check(self.hip.hipIpcOpenMemHandle(C.byref(ptr), h, 1), f"hipIpcOpenMemHandle (rank {p})")  # lazy peer access
+                    peers[p] = ptr.value
+                    self.opened.append(ptr.value)
+            self.peers_dev = torch.tensor(peers, dtype=torch.int64, device=device)
+            self.epochs = torch.zeros(2, dtype=torch.int64, device=device)
+        if world > 1:
+            dist.barrier(group=group)  # every buffer is zeroed and mapped before the first push
+
+    @staticmethod
+    def _check(rc: int, what: str) -> None:
+        if rc != 0:
+            raise RuntimeError(f"peer-to-peer slabs: {what} failed with hip error {rc}")
+
+    def fits(self, slab_bytes: int) -> bool:
+        return 16 <= slab_bytes <= self.SLOT
+
+    def push(self, stream: Any, slab: torch.Tensor) -> None:
+        from . import hipspark as hs  # noqa: PLC0415
+
+        hs.check(self.lib.hs_slab_push(stream, slab.data_ptr(), slab.numel(), self.peers_dev.data_ptr(), self.world, self.rank,
+                                       self.SLOT, self.epochs.data_ptr()), "hs_slab_push")
+
+    def wait_into(self, stream: Any, slab_bytes: int, gathered: torch.Tensor, flags_ptr: int) -> None:
+        from . import hipspark as hs  # noqa: PLC0415
+
+        hs.check(self.lib.hs_slab_wait(stream, self.own, self.world, self.SLOT, slab_bytes, self.epochs.data_ptr(),
+                                       gathered.data_ptr(), slab_bytes, flags_ptr, self.TIMEOUT_MS), "hs_slab_wait")
+
+    def close(self) -> None:
+        import ctypes as C  # noqa: PLC0415
+
+        for ptr in self.opened:
+            self.hip.hipIpcCloseMemHandle(C.c_void_p(ptr))
+        self.opened = []
+        if self.own:
+            self.hip.hipFree(C.c_void_p(self.own))
+            self.own = 0

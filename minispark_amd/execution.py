@@ -172,6 +172,8 @@ class HipExecutionEngine(ExecutionEngine):
         self.fused_joins = 0
         self._no_short_tail: set[Any] = set()  # partial AggregateTask ids that must take the general path
         self.short_tails = 0  # queries finished by the short tail (first runs and recordings; replays count in `replays`)
+        self._p2p: Any = None  # peer-to-peer slab exchange (prototype, HIPSPARK_P2P_SLABS=1), set up at its first use
+        self.p2p_exchanges = 0
         self._plan_runs: dict[Any, int] = {}
         self._owned_dirs: set[Path] = set()
         self._result_root: Path | None = None
@@ -265,6 +267,14 @@ class HipExecutionEngine(ExecutionEngine):
     def __exit__(self, exc_type, exc_value, traceback) -> None:  # noqa: ANN001
         if self.tracer is not None:
             self.tracer.save(self.trace_file)
+        if self._p2p is not None:
+            import torch  # noqa: PLC0415
+
+            torch.cuda.synchronize(self.dev.device)  # no launch of ours still reads the mapped buffers
+            if self.dist is not None and exc_type is None:
+                self.dist.barrier(group=self.group)  # ... and no peer still writes into ours
+            self._p2p.close()
+            self._p2p = None
         for d in self._owned_dirs:
             shutil.rmtree(d, ignore_errors=True)
         self._owned_dirs.clear()
@@ -1506,7 +1516,17 @@ class HipExecutionEngine(ExecutionEngine):
             timed = self.dev.exchange_events
             if timed is not None:
                 self.dev.op(timed[0].record)
-            self.dev.op(all_gather_slabs_into, self.dist, slab, gathered, self.group)
+            peers = self._peer_slabs(tail["layout"].nbytes)
+            if peers is not None:
+                # prototype (HIPSPARK_P2P_SLABS=1): stores into every peer's mapped buffer + device-side flags, no collective
+                # (two library launches: recorded and replayed like every other launch of the query, arguments unchanged)
+                peers.push(self.dev.stream, slab)
+                peers.wait_into(self.dev.stream, tail["layout"].nbytes, gathered, self.dev.flags.data_ptr())
+                if self.dev.rec is not None:
+                    self.dev.rec.keep.append((slab, gathered))
+                self.p2p_exchanges += 1
+            else:
+                self.dev.op(all_gather_slabs_into, self.dist, slab, gathered, self.group)
             if timed is not None:
                 self.dev.op(timed[1].record)
             world, n_order = self.world, batch.total_units
@@ -1530,6 +1550,17 @@ class HipExecutionEngine(ExecutionEngine):
             self._generic_exchange_used = False
         self._act_on_flags(flags)
         return self._emit_result(raw, nrows, schema, stage_id)
+
+    def _peer_slabs(self, slab_bytes: int) -> Any:
+        """The peer-to-peer slab exchange when it is switched on and the slab fits a slot (the same answer on every rank: the
+        layout is), set up at the first such query - a collective moment, like the query itself."""
+        if os.environ.get("HIPSPARK_P2P_SLABS", "0") != "1" or self.dist is None:
+            return None
+        if self._p2p is None:
+            from .distributed import PeerSlabs  # noqa: PLC0415
+
+            self._p2p = PeerSlabs(self.dist, self.group, self.rank, self.world, self.dev.device, self.dev.lib)
+        return self._p2p if self._p2p.fits(slab_bytes) and slab_bytes % 16 == 0 else None
 
     def _emit_result(self, raw: list, nrows: int, schema: Schema, stage_id: str) -> JobResult:
         self._job_seq += 1

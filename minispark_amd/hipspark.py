@@ -37,7 +37,8 @@ FLAG_BAD_PROGRAM = 0x10
 FLAG_STR_TOO_LONG = 0x20
 FLAG_TYPE_ASSERT = 0x40
 FLAG_JOIN_DUP = 0x80
-FLAG_KNOWN = 0x3FF  # every HS_FLAG_* bit include/hipspark.h defines
+FLAG_PEER_TIMEOUT = 0x400
+FLAG_KNOWN = 0x7FF  # every HS_FLAG_* bit include/hipspark.h defines
 
 AGG_SUM, AGG_MIN, AGG_MAX = 0, 1, 2
 
@@ -313,6 +314,9 @@ SIGNATURES: dict[str, tuple] = {
     "hs_quantise_many": (C.c_int, [_P, _I32, C.POINTER(_P), C.POINTER(_I32), _I64, _P, C.POINTER(_P), _P]),
     "hs_slab_unpack": (C.c_int, [_P, _P, _I32, _I64, _I64, _I64, _I32, C.POINTER(_I64), C.POINTER(_I32),
                                  C.POINTER(_P), _P, _P]),
+    "hs_slab_p2p_bytes": (C.c_size_t, [_I32, _I64]),
+    "hs_slab_push": (C.c_int, [_P, _P, _I64, _P, _I32, _I32, _I64, _P]),
+    "hs_slab_wait": (C.c_int, [_P, _P, _I32, _I64, _I64, _P, _P, _I64, _P, _I64]),
     "hs_copy_segments": (C.c_int, [_P, _P, _I32, _I64]),
     "hs_jit_set_enabled": (None, [C.c_int]),
     "hs_jit_get_enabled": (C.c_int, []),

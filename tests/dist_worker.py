@@ -100,6 +100,8 @@ def main() -> None:
         rows = None
         for _ in range(4):  # later runs exercise the plan / launch caches and the recorded replay
             rows = frame.collect()
+        if os.environ.get("HIPSPARK_WORKER_EXPECT_P2P"):
+            assert engine.p2p_exchanges >= 1 and engine.replays >= 1, (engine.p2p_exchanges, engine.replays)
         if case_name.startswith("q1"):
             assert engine.replays >= 1, "the recorded replay path must have been exercised"
         if rank == 0:

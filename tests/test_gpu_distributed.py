@@ -88,11 +88,11 @@ def test_random_queries_on_n_ranks_match_the_oracle(tmp_path, seed, world):
     assert_rows_match(_run_ranks(f"fuzz:{seed}", world, out, port, want), want, max_ulps=1)
 
 
-def _run_ranks(case: str, world: int, out, port: int, want: list, backend: str = "gloo") -> list:
+def _run_ranks(case: str, world: int, out, port: int, want: list, backend: str = "gloo", extra_env: dict | None = None) -> list:
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
+                   MASTER_PORT=str(port), **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, str(ROOT / "tests" / "dist_worker.py"), case, str(out), backend],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = [p.communicate(timeout=300)[0].decode() for p in procs]
@@ -249,6 +249,20 @@ def test_rccl_world1_matches_reference(tmp_path, case_name):
     rows = _run_ranks(case_name, 1, tmp_path / "rows.json", _free_port(), golden, backend="nccl")
     flips = assert_rows_match(rows, golden, max_ulps=1)
     assert flips <= (2 if case_name == "many_groups" else 0)
+
+
+@pytest.mark.parametrize("case_name,world,backend", [("q1_multiblock", 1, "nccl"), ("q1_multiblock", 2, "gloo"),
+                                                     ("q1_ragged_blocks", 3, "gloo"), ("edge_int_key", 2, "gloo"),
+                                                     ("q1_selective", 3, "gloo")])
+def test_peer_to_peer_slab_exchange_matches_reference(tmp_path, case_name, world, backend):
+    """Round 3 prototype (HIPSPARK_P2P_SLABS=1): the short tail's slabs travel as stores into buffers the peers map through
+    hipIpc handles, with device-side flags instead of a collective (csrc/hs_exchange.hip hs_slab_push / hs_slab_wait).  World 1
+    under RCCL's process group, and 2 - 3 PROCESSES sharing the test box's GPU (real hipIpc mappings between processes; the
+    xGMI hop itself needs a multi-GPU node).  Four runs per rank: first, recorded, replays - the epochs must stay in step."""
+    golden = load_golden(case_name)["rows"]
+    rows = _run_ranks(case_name, world, tmp_path / "rows.json", _free_port(), golden, backend=backend,
+                      extra_env={"HIPSPARK_P2P_SLABS": "1", "HIPSPARK_WORKER_EXPECT_P2P": "1"})
+    assert assert_rows_match(rows, golden, max_ulps=1) == 0
 
 
 def test_bench_runs_over_rccl_world1(tmp_path):
