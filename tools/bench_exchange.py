@@ -2,7 +2,7 @@
 -> pack -> size matrix -> all_to_all_single -> unpack) on N ranks:
 
     HIPSPARK_DIST_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 3 --master-addr 127.0.0.1 \
-        --master-port P tools/bench_exchange.py [rows per rank] [--legacy tools/_legacy_execution.py]
+        --master-port P tools/bench_exchange.py [rows per rank] [--legacy /tmp/round2_execution.py]   (git show 9993950:minispark_amd/execution.py > /tmp/round2_execution.py: the before/after of profiles/r03_exchange_pack_3ranks_gloo.txt)
 
 An e2e_join_select-shaped batch per rank: INTEGER key, FLOAT value, a variable-length STRING.  --legacy FILE binds the
 _exchange_rows of another version of minispark_amd/execution.py (round 2's Python-side packing) for a before / after on
