@@ -381,7 +381,7 @@ int hs_lower_bound_i64(void* stream, const int64_t* sorted, int64_t n, const int
 /* ---- the HBM tier as a radix partition + on-chip ordered fold (csrc/hs_radix.hip; reference tasks.py:284-310) ----
  * GROUP BY of any cardinality over every unit of a batch; keys whose 64-bit key word is the key itself - INTEGER /
  * TIMESTAMP, FLOAT (also computed f64; 0.0 and -0.0 are one group, as in a Python dict), STRING columns of one fixed length
- * <= 7 bytes - or, as TWO key words that are compared exactly, of one fixed length 8 .. 16 bytes with SUM / COUNT aggregates
+ * <= 7 bytes - or, as 2 .. 4 four-byte key word columns that are compared exactly, of one fixed length 8 .. 16 bytes with SUM / COUNT aggregates
  * over f32 / i32 columns (key_kind = HS_STR + 256 x length; HS_E_LIMIT for other strings): the (key, value...) tuples are moved
  * by one or two stable partition passes on hash bits of the key until a partition (a few hundred rows of one unit, still
  * in row order) fits a wave's LDS dictionary; one wave folds a partition's rows in order - the reference's sequential

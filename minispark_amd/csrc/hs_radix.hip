@@ -95,7 +95,7 @@ struct RxPass {
     int64_t n_seg;
     int32_t shift, bits;       // bin = (mix(key word) >> shift) & (2^bits - 1); raw: ((key + 1) >> shift) & ... (hs_sort_by_order)
     int32_t n_cols, first;     // columns that travel (0 = key); first pass reads the key through `key` / `sel`
-    int32_t wide, pad_w;       // wide: a STRING key of one fixed length 8 .. 16: two key words, columns 0 and 1 (round 3)
+    int32_t wide, pad_w;       // wide: a STRING key of one fixed length 8 .. 16 travels as this many 4-byte word columns (2 .. 4), round 3
     int32_t raw, key4;         // key4: the key is a 4-byte integer (bins from a 32-bit mix: a quarter of hs_mix64's multiplies)
     hs_col key;
     const int64_t* sel;
@@ -106,28 +106,8 @@ struct RxPass {
     int64_t* counters;         // [(tiles) << bits] laid out (segment, bin, tile): counts, then their exclusive scan
 };
 
-// a wide key's two words at position i: from the string column (first pass) or from columns 0 and 1 of the tuples
-__device__ __forceinline__ void rx_wide_words(const RxPass& A, int64_t i, uint64_t& w0, uint64_t& w1) {
-    if (A.first) {
-        const int64_t row = A.sel ? A.sel[i] : A.row0 + i;
-        hs_str_words16((const uint8_t*)A.key.data + row * A.key.fixed_len, (uint32_t)A.key.fixed_len, w0, w1);
-    } else {
-        w0 = ((const uint64_t*)A.src[0])[i];
-        w1 = A.esize[1] == 4 ? (uint64_t)((const uint32_t*)A.src[1])[i] : ((const uint64_t*)A.src[1])[i];
-    }
-}
-__device__ __forceinline__ uint64_t rx_wide_w1(const RxPass& A, int64_t i) {
-    uint64_t w0, w1;
-    rx_wide_words(A, i, w0, w1);
-    return w1;
-}
 // the value of column 0 at position i
 __device__ __forceinline__ uint64_t rx_key(const RxPass& A, int64_t i) {
-    if (A.wide) {
-        uint64_t w0, w1;
-        rx_wide_words(A, i, w0, w1);
-        return w0;
-    }
     if (A.first) return hs_key_at(A.key, A.sel ? A.sel[i] : A.row0 + i);
     return A.esize[0] == 4 ? (uint64_t)(int64_t)((const int32_t*)A.src[0])[i] : ((const uint64_t*)A.src[0])[i];
 }
@@ -144,13 +124,6 @@ __device__ __forceinline__ uint32_t rx_mix32(uint32_t k) {
     return h ^ (h >> 16);
 }
 __device__ __forceinline__ uint32_t rx_bin4(uint32_t key, int shift, int bits) { return (rx_mix32(key) >> shift) & ((1u << bits) - 1u); }
-// the word a position's bin is cut from: the key word, or both words of a wide key folded into one
-__device__ __forceinline__ uint64_t rx_binword(const RxPass& A, int64_t i) {
-    if (!A.wide) return rx_key(A, i);
-    uint64_t w0, w1;
-    rx_wide_words(A, i, w0, w1);
-    return w0 ^ hs_mix64(w1);
-}
 __device__ __forceinline__ uint32_t rx_bin_of(const RxPass& A, uint64_t word) {
     return A.key4 ? rx_bin4((uint32_t)word, A.shift, A.bits) : rx_bin(word, A.shift, A.bits, A.raw);
 }
@@ -175,7 +148,7 @@ __global__ void __launch_bounds__(RX_THREADS) k_rx_hist(const RxPass A_kernarg) 
 #pragma unroll
     for (int j = 0; j < RX_PER; ++j) {
         const int64_t i = b + tid + (int64_t)j * RX_THREADS;
-        word[j] = i < e ? rx_binword(A, i) : 0;
+        word[j] = i < e ? rx_key(A, i) : 0;
     }
 #pragma unroll
     for (int j = 0; j < RX_PER; ++j)
@@ -226,7 +199,7 @@ __global__ void __launch_bounds__(RX_THREADS) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
     for (int j = 0; j < RX_PER; ++j) {
         const bool valid = first + j * HS_WAVE < e;
-        bin[j] = valid ? rx_bin_of(A, A.wide ? word[j] ^ hs_mix64(rx_wide_w1(A, first + j * HS_WAVE)) : word[j]) : 0u;
+        bin[j] = valid ? rx_bin_of(A, word[j]) : 0u;
         uint64_t peers = __ballot(valid);
         for (int bit = 0; bit < A.bits; ++bit) {
             const bool on = (bin[j] >> bit) & 1u;
@@ -312,9 +285,7 @@ __global__ void __launch_bounds__(RX_THREADS) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
             for (int j = 0; j < RX_PER; ++j) {
                 const int64_t i = first + j * HS_WAVE;
-                if (lpos(j) == 0xffffu) v[j] = 0;
-                else if (A.wide && A.first && c == 1) v[j] = rx_wide_w1(A, i);
-                else v[j] = es == 4 ? (uint64_t)((const uint32_t*)src)[i] : es == 8 ? ((const uint64_t*)src)[i] : (uint64_t)((const uint8_t*)src)[i];
+                v[j] = lpos(j) == 0xffffu ? 0 : (es == 4 ? (uint64_t)((const uint32_t*)src)[i] : es == 8 ? ((const uint64_t*)src)[i] : (uint64_t)((const uint8_t*)src)[i]);
             }
 #pragma unroll
             for (int j = 0; j < RX_PER; ++j) {
@@ -344,9 +315,7 @@ __global__ void __launch_bounds__(RX_THREADS) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
         for (int j = 0; j < RX_PER; ++j) {
             const int64_t i = first + j * HS_WAVE;
-            if (to[j] < 0) v[j] = 0;
-            else if (A.wide && A.first && c == 1) v[j] = rx_wide_w1(A, i);
-            else v[j] = es == 4 ? (uint64_t)((const uint32_t*)src)[i] : es == 8 ? ((const uint64_t*)src)[i] : (uint64_t)((const uint8_t*)src)[i];
+            v[j] = to[j] < 0 ? 0 : (es == 4 ? (uint64_t)((const uint32_t*)src)[i] : es == 8 ? ((const uint64_t*)src)[i] : (uint64_t)((const uint8_t*)src)[i]);
         }
 #pragma unroll
         for (int j = 0; j < RX_PER; ++j) {
@@ -506,6 +475,182 @@ __global__ void __launch_bounds__(RX_THREADS) __attribute__((amdgpu_waves_per_eu
             if (at[j] != 0xffffffffu) stage[at[j]] = val[c][j];
         __syncthreads();
         uint32_t* dst = (uint32_t*)A.dst[1 + c];
+#pragma unroll
+        for (int k = 0; k < RX_PER; ++k) {
+            const int i = tid + k * RX_THREADS;
+            if (i < rows) dst[gbase[sbin[i]] + i] = stage[i];
+        }
+    }
+}
+
+// ---- the pass for wide STRING keys (round 3) -------------------------------------------------------------------------
+// A STRING key of one fixed length 8 .. 16 bytes travels as KW = ceil(length / 4) four-byte word columns (columns 0 .. KW - 1;
+// zero-padded; the value columns follow), so its tuples are 4-byte columns like an INTEGER key's and take the same tile
+// shape, ranking and 32 KB staging at two workgroups per CU; the bin is cut from a mix of all KW words.  FIRST: the words
+// come from the string column itself (any alignment: hs_str_words16), through the row list when there is one.
+template <bool FIRST, int KW>
+__device__ __forceinline__ void rx_words(const RxPass& A, int64_t pos, uint32_t* w) {
+    if constexpr (FIRST) {
+        const int64_t row = A.sel ? A.sel[pos] : A.row0 + pos;
+        uint64_t w0, w1;
+        hs_str_words16((const uint8_t*)A.key.data + row * A.key.fixed_len, (uint32_t)A.key.fixed_len, w0, w1);
+        w[0] = (uint32_t)w0;
+        w[1] = (uint32_t)(w0 >> 32);
+        if constexpr (KW > 2) w[2] = (uint32_t)w1;
+        if constexpr (KW > 3) w[3] = (uint32_t)(w1 >> 32);
+    } else {
+#pragma unroll
+        for (int k = 0; k < KW; ++k) w[k] = ((const uint32_t*)A.src[k])[pos];
+    }
+}
+template <int KW>
+__device__ __forceinline__ uint32_t rx_binw(const uint32_t* w, int shift, int bits) {
+    uint32_t h = rx_mix32(w[0]);
+#pragma unroll
+    for (int k = 1; k < KW; ++k) h = rx_mix32(h ^ w[k]);
+    return (h >> shift) & ((1u << bits) - 1u);
+}
+
+template <bool FIRST, int KW>
+__global__ void __launch_bounds__(RX_H4_THREADS) k_rx_histw(const RxPass A_kernarg) {
+    HS_KERNARG(RxPass, A);
+    constexpr int WAVES = RX_H4_THREADS / HS_WAVE;
+    __shared__ uint32_t hist[WAVES][1 << RX_MAX_BITS];
+    int64_t seg, t;
+    if (!rx_find_tile(A.tile_base, A.n_seg, blockIdx.x, seg, t)) return;
+    const int tid = threadIdx.x, w = tid / HS_WAVE, F = 1 << A.bits;
+    for (int i = tid; i < WAVES * F; i += RX_H4_THREADS) hist[i / F][i % F] = 0;
+    const int64_t b = A.seg_start[seg] + t * RX_TILE;
+    const int64_t left = A.seg_start[seg + 1] - b;
+    const int rows = left < RX_TILE ? (int)left : RX_TILE;
+    const int shift = A.shift, bits = A.bits;
+    __syncthreads();
+    for (int j0 = 0; j0 < RX_H4_PER; j0 += 8) {
+        uint32_t words[8][KW];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = tid + (j0 + j) * RX_H4_THREADS;
+            if (i < rows) rx_words<FIRST, KW>(A, b + i, words[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (tid + (j0 + j) * RX_H4_THREADS < rows) atomicAdd(&hist[w][rx_binw<KW>(words[j], shift, bits)], 1u);
+    }
+    __syncthreads();
+    const int64_t nt = A.tile_base[seg + 1] - A.tile_base[seg];
+    if (tid < F) {
+        uint32_t total = 0;
+#pragma unroll
+        for (int k = 0; k < WAVES; ++k) total += hist[k][tid];
+        A.counters[(A.tile_base[seg] << A.bits) + (int64_t)tid * nt + t] = total;
+    }
+}
+
+template <bool FIRST, int KW>
+__global__ void __launch_bounds__(RX_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) k_rx_scatterw(const RxPass A_kernarg) {
+    HS_KERNARG(RxPass, A);
+    __shared__ uint32_t whist[RX_WAVES][1 << RX_MAX_BITS];
+    __shared__ int64_t gbase[1 << RX_MAX_BITS];
+    __shared__ uint32_t s_wave_tot[4];
+    __shared__ uint8_t sbin[RX_TILE];
+    __shared__ uint32_t stage[RX_TILE];
+    int64_t seg, t;
+    if (!rx_find_tile(A.tile_base, A.n_seg, blockIdx.x, seg, t)) return;
+    const int tid = threadIdx.x, lane = tid & (HS_WAVE - 1), w = tid / HS_WAVE, F = 1 << A.bits;
+    const int64_t b = A.seg_start[seg] + t * RX_TILE;
+    const int64_t left = A.seg_start[seg + 1] - b;
+    const int rows = left < RX_TILE ? (int)left : RX_TILE;
+    const int first = w * RX_SUB + lane;
+    for (int i = tid; i < RX_WAVES * F; i += RX_THREADS) whist[i / F][i % F] = 0;
+    const int shift = A.shift, bits = A.bits;
+    uint32_t bin8[RX_PER];
+    {
+        uint32_t words[RX_PER][KW];
+#pragma unroll
+        for (int j = 0; j < RX_PER; ++j)
+            if (first + j * HS_WAVE < rows) rx_words<FIRST, KW>(A, b + first + j * HS_WAVE, words[j]);
+#pragma unroll
+        for (int j = 0; j < RX_PER; ++j) bin8[j] = first + j * HS_WAVE < rows ? rx_binw<KW>(words[j], shift, bits) : 0u;
+    }
+    __syncthreads();
+    const uint64_t below = (1ull << lane) - 1ull;
+    uint32_t bl[RX_PER];  // bin | rank inside (wave, bin) << 8
+#pragma unroll
+    for (int j = 0; j < RX_PER; ++j) {
+        const bool valid = first + j * HS_WAVE < rows;
+        const uint32_t bin = bin8[j];
+        uint64_t peers = __ballot(valid);
+        for (int bit = 0; bit < bits; ++bit) {
+            const bool on = (bin >> bit) & 1u;
+            const uint64_t bal = __ballot(valid && on);
+            peers &= on ? bal : ~bal;
+        }
+        const uint32_t prior = valid ? whist[w][bin] : 0u;
+        const uint32_t rank = (uint32_t)__popcll(peers & below);
+        bl[j] = bin | ((prior + rank) << 8);
+        if (valid && rank == 0) whist[w][bin] = prior + (uint32_t)__popcll(peers);
+    }
+    __syncthreads();
+    const int64_t nt = A.tile_base[seg + 1] - A.tile_base[seg];
+    uint32_t bin_total = 0;
+    if (tid < F) {
+        uint32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < RX_WAVES; ++k) {
+            const uint32_t c = whist[k][tid];
+            whist[k][tid] = run;
+            run += c;
+        }
+        bin_total = run;
+        gbase[tid] = A.counters[(A.tile_base[seg] << A.bits) + (int64_t)tid * nt + t];
+    }
+    uint32_t x = bin_total;
+    for (int d = 1; d < HS_WAVE; d <<= 1) {
+        const uint32_t up = __shfl_up(x, d, HS_WAVE);
+        if (lane >= d) x += up;
+    }
+    if (w < 4 && lane == HS_WAVE - 1) s_wave_tot[w] = x;
+    __syncthreads();
+    if (tid < F) {
+        const uint32_t before = (w > 0 ? s_wave_tot[0] : 0u) + (w > 1 ? s_wave_tot[1] : 0u) + (w > 2 ? s_wave_tot[2] : 0u);
+        const uint32_t bin_start = before + x - bin_total;
+        gbase[tid] -= bin_start;
+#pragma unroll
+        for (int k = 0; k < RX_WAVES; ++k) whist[k][tid] += bin_start;
+    }
+    __syncthreads();
+    uint32_t at[RX_PER];
+#pragma unroll
+    for (int j = 0; j < RX_PER; ++j) {
+        const bool valid = first + j * HS_WAVE < rows;
+        at[j] = valid ? whist[w][bl[j] & 0xffu] + (bl[j] >> 8) : 0xffffffffu;
+        if (valid) sbin[at[j]] = (uint8_t)bl[j];
+    }
+    // one column at a time through the 32 KB stage: key words first (FIRST: cut from the string again - the bytes are in L2),
+    // then the value columns
+    for (int c = 0; c < A.n_cols; ++c) {
+        uint32_t v[RX_PER];
+        if (FIRST && c < KW) {
+#pragma unroll
+            for (int j = 0; j < RX_PER; ++j) {
+                uint32_t words[KW] = {};
+                if (at[j] != 0xffffffffu) rx_words<FIRST, KW>(A, b + first + j * HS_WAVE, words);
+                uint32_t pick = words[0];
+#pragma unroll
+                for (int k = 1; k < KW; ++k) pick = c == k ? words[k] : pick;
+                v[j] = pick;
+            }
+        } else {
+            const uint32_t* src = (const uint32_t*)A.src[c] + b;
+#pragma unroll
+            for (int j = 0; j < RX_PER; ++j) v[j] = at[j] != 0xffffffffu ? src[first + j * HS_WAVE] : 0u;
+        }
+        __syncthreads();  // the previous column has left the stage (first column: sbin is complete)
+#pragma unroll
+        for (int j = 0; j < RX_PER; ++j)
+            if (at[j] != 0xffffffffu) stage[at[j]] = v[j];
+        __syncthreads();
+        uint32_t* dst = (uint32_t*)A.dst[c];
 #pragma unroll
         for (int k = 0; k < RX_PER; ++k) {
             const int i = tid + k * RX_THREADS;
@@ -789,12 +934,12 @@ __global__ void __launch_bounds__(256) k_rx_fold(const RxAgg A_kernarg) {
 // their value to the group's cell in LDS (distinct cells within a round; LDS executes a wave's instructions in order, so
 // round r + 1 reads what round r wrote) - instead of a leader lane collecting its peers' values with shuffles.  Integer
 // cells are order-free: one LDS atomic per lane (COUNT: one per group and step, with the group's lane count).
-// KM: 0 = 4-byte key column, 1 = 8-byte key words, 2 / 3 = wide keys (two words: columns 0 and 1 - the second one carried
-// as 8 / as 4 bytes, strings of <= 12 bytes; values from column 2)
+// KM: 0 = 4-byte key column, 1 = 8-byte key words, 2 .. 4 = a wide STRING key in that many 4-byte word columns (compared as
+// two 64-bit words; the value columns follow the key's)
 template <int NA, int CLS, int KM>
 __global__ void __launch_bounds__(256) k_rx_fold_sum(const RxAgg A_kernarg) {
-    constexpr bool KEY4 = KM == 0, WIDE = KM >= 2;
-    using Key1Reg = std::conditional_t<KM == 3, uint32_t, uint64_t>;
+    constexpr bool WIDE = KM >= 2, KEY4 = KM == 0 || WIDE;
+    constexpr int KW = WIDE ? KM : 1;
     HS_KERNARG(RxAgg, A);
     extern __shared__ __align__(16) uint64_t rx_lds[];
     const int lane = threadIdx.x & (HS_WAVE - 1), w = threadIdx.x / HS_WAVE, wpb = blockDim.x / HS_WAVE;
@@ -832,7 +977,7 @@ __global__ void __launch_bounds__(256) k_rx_fold_sum(const RxAgg A_kernarg) {
         }
         using KeyReg = std::conditional_t<KEY4, uint32_t, uint64_t>;  // as loaded: widening a key right after its load would wait for it
         KeyReg nk[RX_CHUNK];
-        Key1Reg nk1[RX_CHUNK];
+        uint32_t nw[RX_CHUNK][KW];  // WIDE: key words 1 .. KW - 1 ([0] unused)
         uint32_t nx[RX_CHUNK][NCR];
         auto load_chunk = [&](int64_t base) {
 #pragma unroll
@@ -840,9 +985,10 @@ __global__ void __launch_bounds__(256) k_rx_fold_sum(const RxAgg A_kernarg) {
                 const int64_t i = base + j * HS_WAVE + lane;
                 const bool valid = i < e;
                 nk[j] = valid ? ((const KeyReg*)A.src[0])[i] : 0;
-                nk1[j] = WIDE && valid ? ((const Key1Reg*)A.src[1])[i] : 0;
 #pragma unroll
-                for (int c = 0; c < NC; ++c) nx[j][c] = valid ? ((const uint32_t*)A.src[(WIDE ? 2 : 1) + c])[i] : 0u;
+                for (int q = 1; q < KW; ++q) nw[j][q] = valid ? ((const uint32_t*)A.src[q])[i] : 0u;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) nx[j][c] = valid ? ((const uint32_t*)A.src[KW + c])[i] : 0u;
             }
         };
         load_chunk(b);
@@ -850,12 +996,13 @@ __global__ void __launch_bounds__(256) k_rx_fold_sum(const RxAgg A_kernarg) {
         bool full = false;
         for (int64_t base = b; base < e && !full; base += RX_CHUNK * HS_WAVE) {
             KeyReg ck[RX_CHUNK];
-            Key1Reg ck1[RX_CHUNK];
+            uint32_t cw[RX_CHUNK][KW];
             uint32_t cx[RX_CHUNK][NCR];
 #pragma unroll
             for (int j = 0; j < RX_CHUNK; ++j) {
                 ck[j] = nk[j];
-                ck1[j] = nk1[j];
+#pragma unroll
+                for (int q = 1; q < KW; ++q) cw[j][q] = nw[j][q];
 #pragma unroll
                 for (int c = 0; c < NCR; ++c) cx[j][c] = NC > 0 ? nx[j][c] : 0u;
             }
@@ -867,14 +1014,21 @@ __global__ void __launch_bounds__(256) k_rx_fold_sum(const RxAgg A_kernarg) {
                 int slot = valid ? -1 : 0;
                 bool inserted = false;
                 if (valid) {
-                    const uint64_t k = KEY4 ? (uint64_t)(int64_t)(int32_t)ck[j] : (uint64_t)ck[j];
+                    uint64_t k, k1 = 0;
+                    if constexpr (WIDE) {
+                        k = (uint64_t)ck[j] | ((uint64_t)cw[j][1] << 32);
+                        if constexpr (KW > 2) k1 = (uint64_t)cw[j][2];
+                        if constexpr (KW > 3) k1 |= (uint64_t)cw[j][3] << 32;
+                    } else {
+                        k = KEY4 ? (uint64_t)(int64_t)(int32_t)ck[j] : (uint64_t)ck[j];
+                    }
                     uint32_t h;
-                    if constexpr (KEY4) {  // two 32-bit multiplies; bits independent of the ones the partitions were cut on
+                    if constexpr (KEY4 && !WIDE) {  // two 32-bit multiplies; bits independent of the ones the partitions were cut on
                         uint32_t m = (uint32_t)k * 0xCC9E2D51u;
                         m ^= m >> 17;
                         h = ((m * 0x1B873593u) >> 12) & mask;
                     } else if constexpr (WIDE) {
-                        h = (uint32_t)(hs_mix64(k ^ hs_mix64(ck1[j])) >> 36) & mask;
+                        h = (uint32_t)(hs_mix64(k ^ hs_mix64(k1)) >> 36) & mask;
                     } else {
                         h = (uint32_t)(hs_mix64(k) >> 36) & mask;
                     }
@@ -883,9 +1037,9 @@ __global__ void __launch_bounds__(256) k_rx_fold_sum(const RxAgg A_kernarg) {
                         if constexpr (WIDE) {
                             // the lane that claimed the slot completes it before any lane of the wave - this probe round or a
                             // later one - compares the second word (LDS executes the wave's instructions in order)
-                            if (cur == HS_EMPTY_KEY) keys1[h] = ck1[j];
+                            if (cur == HS_EMPTY_KEY) keys1[h] = k1;
                             __builtin_amdgcn_wave_barrier();
-                            if (cur == HS_EMPTY_KEY || (cur == k && keys1[h] == ck1[j])) {
+                            if (cur == HS_EMPTY_KEY || (cur == k && keys1[h] == k1)) {
                                 inserted = cur == HS_EMPTY_KEY;
                                 slot = (int)h;
                                 break;
@@ -1020,7 +1174,9 @@ static int rx_esize(int32_t kind) {
 static size_t rx_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // key_kind of a plan: a STRING key of one fixed length 8 .. 16 bytes = two key words per tuple
-static bool rx_plan_wide(int64_t key_kind) { return (key_kind & 0xff) == HS_STR && (key_kind >> 8) > 7; }
+static int rx_plan_wide(int64_t key_kind) {  // -> number of 4-byte key word columns (2 .. 4), 0: not a wide key
+    return (key_kind & 0xff) == HS_STR && (key_kind >> 8) > 7 ? (int)(((key_kind >> 8) + 3) / 4) : 0;
+}
 
 // field use of the public plan (include/hipspark.h keeps it opaque: int64 f[48])
 enum {
@@ -1044,7 +1200,18 @@ static int rx_pass(hipStream_t stream, RxPass& P, int64_t max_tiles, int64_t* co
                 (P.first ? (P.key.kind == HS_I32 && P.sel == nullptr) : P.esize[0] == 4);
     for (int c = 1; c < P.n_cols; ++c) four = four && P.esize[c] == 4;
     P.key4 = four ? 1 : 0;
-    if (four) {
+#define RX_WIDE(KERNEL, THREADS)                                                                                          \
+    switch (P.wide * 2 + (P.first ? 1 : 0)) {                                                                             \
+        case 4: hipLaunchKernelGGL((KERNEL<false, 2>), dim3((unsigned)max_tiles), dim3(THREADS), 0, stream, P); break;    \
+        case 5: hipLaunchKernelGGL((KERNEL<true, 2>), dim3((unsigned)max_tiles), dim3(THREADS), 0, stream, P); break;     \
+        case 6: hipLaunchKernelGGL((KERNEL<false, 3>), dim3((unsigned)max_tiles), dim3(THREADS), 0, stream, P); break;    \
+        case 7: hipLaunchKernelGGL((KERNEL<true, 3>), dim3((unsigned)max_tiles), dim3(THREADS), 0, stream, P); break;     \
+        case 8: hipLaunchKernelGGL((KERNEL<false, 4>), dim3((unsigned)max_tiles), dim3(THREADS), 0, stream, P); break;    \
+        default: hipLaunchKernelGGL((KERNEL<true, 4>), dim3((unsigned)max_tiles), dim3(THREADS), 0, stream, P); break;    \
+    }
+    if (P.wide) {
+        RX_WIDE(k_rx_histw, RX_H4_THREADS)
+    } else if (four) {
         if (P.first) hipLaunchKernelGGL(k_rx_hist4<true>, dim3((unsigned)max_tiles), dim3(RX_H4_THREADS), 0, stream, P);
         else hipLaunchKernelGGL(k_rx_hist4<false>, dim3((unsigned)max_tiles), dim3(RX_H4_THREADS), 0, stream, P);
     } else {
@@ -1059,7 +1226,9 @@ static int rx_pass(hipStream_t stream, RxPass& P, int64_t max_tiles, int64_t* co
     static unsigned long long attr_set = 0;
     if (hs_first_on_device(attr_set))  // 8-byte columns stage 72 KB + 18 KB static: above the 64 KB a launch gets unasked
         (void)hipFuncSetAttribute((const void*)k_rx_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, RX_TILE * 9);
-    if (four) {
+    if (P.wide) {
+        RX_WIDE(k_rx_scatterw, RX_THREADS)
+    } else if (four) {
 #define RX_S4(NV)                                                                                                         \
     if (P.first) hipLaunchKernelGGL((k_rx_scatter4<NV, true>), dim3((unsigned)max_tiles), dim3(RX_THREADS), 0, stream, P); \
     else hipLaunchKernelGGL((k_rx_scatter4<NV, false>), dim3((unsigned)max_tiles), dim3(RX_THREADS), 0, stream, P)
@@ -1070,6 +1239,7 @@ static int rx_pass(hipStream_t stream, RxPass& P, int64_t max_tiles, int64_t* co
             default: RX_S4(3); break;
         }
 #undef RX_S4
+#undef RX_WIDE
     } else if (direct) hipLaunchKernelGGL(k_rx_scatter<false>, dim3((unsigned)max_tiles), dim3(RX_THREADS), 0, stream, P);
     else hipLaunchKernelGGL(k_rx_scatter<true>, dim3((unsigned)max_tiles), dim3(RX_THREADS), (size_t)RX_TILE * (1 + widest), stream, P);
     RX_CHECK_LAUNCH("radix pass (scatter)");
@@ -1098,9 +1268,10 @@ extern "C" int hs_group_radix_plan(int32_t key_kind, int64_t n, int32_t n_units,
             return HS_E_LIMIT;
         }
     }
-    // strings of 8 .. 16 bytes travel as TWO key words (columns 0 and 1) and are compared on both: exact, no hashing.  Only
-    // the SUM-specialised fold knows them: SUM / AVG / COUNT over f32 / i32 columns and integer constants, <= 3 aggregates
-    const bool wide = rx_plan_wide(key_kind);
+    // strings of 8 .. 16 bytes travel as 2 .. 4 four-byte key word columns and are compared on all of them: exact, no
+    // hashing.  Only the SUM-specialised fold knows them: SUM / AVG / COUNT over f32 / i32 columns and integer constants,
+    // <= 3 aggregates
+    const int wide = rx_plan_wide(key_kind);
     if (wide) {
         bool sums = spec->n_acc >= 1 && spec->n_acc <= 3;
         for (int a = 0; a < spec->n_acc && sums; ++a) {
@@ -1148,10 +1319,10 @@ extern "C" int hs_group_radix_plan(int32_t key_kind, int64_t n, int32_t n_units,
     const int64_t c1 = f[PL_TILES1] << bits1, c2 = f[PL_TILES2] << bits2;
     f[PL_COUNTERS] = c1 > c2 ? c1 : c2;
     f[PL_OSIZE] = quantise ? 4 : 8;
-    f[PL_ESIZE0] = key_kind == HS_I32 ? 4 : 8;
-    const int kcols = wide ? 2 : 1;  // key columns of a tuple; the value columns follow
-    if (wide) f[PL_ESIZE0 + 1] = (key_kind >> 8) <= 12 ? 4 : 8;  // the second word of <= 12 bytes holds <= 4 of them
-    int64_t tuple = f[PL_ESIZE0] + (wide ? f[PL_ESIZE0 + 1] : 0);
+    f[PL_ESIZE0] = key_kind == HS_I32 || wide ? 4 : 8;
+    const int kcols = wide ? wide : 1;  // key columns of a tuple; the value columns follow
+    for (int q = 1; q < kcols; ++q) f[PL_ESIZE0 + q] = 4;
+    int64_t tuple = f[PL_ESIZE0] * kcols;
     int carried = 0;
     for (int a = 0; a < NA; ++a) {
         if (val_kinds[a] < 0) continue;  // a constant: does not travel
@@ -1184,7 +1355,7 @@ extern "C" int hs_group_radix_plan(int32_t key_kind, int64_t n, int32_t n_units,
     take(PL_OFF_SCAN, (size_t)(f[PL_COUNTERS] + 1) * 8);
     const int64_t scan_n = f[PL_COUNTERS] > f[PL_PARTS] ? f[PL_COUNTERS] : f[PL_PARTS];
     take(PL_OFF_SCANWS, hs_scan_ws_bytes(scan_n));
-    take(PL_OFF_PKEY, (size_t)n * 8 * kcols);
+    take(PL_OFF_PKEY, (size_t)n * 8 * (wide ? 2 : 1));
     take(PL_OFF_PACC, (size_t)NA * rx_align((size_t)n * f[PL_OSIZE]));
     take(PL_OFF_PCOUNT, (size_t)f[PL_PARTS] * 8);
     take(PL_OFF_PSCAN, (size_t)(f[PL_PARTS] + 1) * 8);
@@ -1197,7 +1368,7 @@ extern "C" size_t hs_group_radix_ws_bytes(const hs_radix_plan* plan) { return pl
 
 static void rx_set_cols(const int64_t* f, uint8_t* ws, int field, void** cols) {
     size_t off = (size_t)f[field];
-    for (int c = 0; c < (rx_plan_wide(f[PL_KEYKIND]) ? 2 : 1) + (int)f[PL_NCARRIED]; ++c) {
+    for (int c = 0; c < (rx_plan_wide(f[PL_KEYKIND]) ? rx_plan_wide(f[PL_KEYKIND]) : 1) + (int)f[PL_NCARRIED]; ++c) {
         cols[c] = ws + off;
         off += rx_align((size_t)f[PL_N] * f[PL_ESIZE0 + c]);
     }
@@ -1233,10 +1404,10 @@ extern "C" int hs_group_radix_run(void* stream_, const hs_radix_plan* plan, cons
     std::memset(&G, 0, sizeof(G));
     RxPass P;
     std::memset(&P, 0, sizeof(P));
-    const bool wide = rx_plan_wide(f[PL_KEYKIND]);
-    const int kcols = wide ? 2 : 1;
+    const int wide = rx_plan_wide(f[PL_KEYKIND]);
+    const int kcols = wide ? wide : 1;
     P.n_cols = kcols + (int)f[PL_NCARRIED];
-    P.wide = wide ? 1 : 0;
+    P.wide = wide;
     P.key = *key;
     P.sel = sel;
     P.row0 = row0;
@@ -1327,7 +1498,7 @@ extern "C" int hs_group_radix_run(void* stream_, const hs_radix_plan* plan, cons
         G.list_count = listed ? overflow : nullptr;
         G.overflow = overflow + 1;
         G.overflow_count = overflow;
-        const size_t per_wave = ((size_t)cap * (kcols + NA) + (size_t)cap / 4) * 8;
+        const size_t per_wave = ((size_t)cap * ((wide ? 2 : 1) + NA) + (size_t)cap / 4) * 8;
         int wpb = (int)(65536 / per_wave);
         wpb = wpb < 1 ? 1 : (wpb > 4 ? 4 : wpb);
         int64_t grid = (parts + wpb - 1) / wpb;
@@ -1338,28 +1509,37 @@ extern "C" int hs_group_radix_run(void* stream_, const hs_radix_plan* plan, cons
     else hipLaunchKernelGGL((k_rx_fold<NC, 12>), g, t, per_wave * wpb, stream, G)
 #define RX_SUM1(C0) \
     case (C0):                                                                                              \
-        if (km == 0) hipLaunchKernelGGL((k_rx_fold_sum<1, (C0), 0>), g, t, per_wave * wpb, stream, G);      \
-        else if (km == 1) hipLaunchKernelGGL((k_rx_fold_sum<1, (C0), 1>), g, t, per_wave * wpb, stream, G); \
-        else if (km == 2) hipLaunchKernelGGL((k_rx_fold_sum<1, (C0), 2>), g, t, per_wave * wpb, stream, G); \
-        else hipLaunchKernelGGL((k_rx_fold_sum<1, (C0), 3>), g, t, per_wave * wpb, stream, G);              \
+        switch (km) { \
+            case 0: hipLaunchKernelGGL((k_rx_fold_sum<1, (C0), 0>), g, t, per_wave * wpb, stream, G); break; \
+            case 1: hipLaunchKernelGGL((k_rx_fold_sum<1, (C0), 1>), g, t, per_wave * wpb, stream, G); break; \
+            case 2: hipLaunchKernelGGL((k_rx_fold_sum<1, (C0), 2>), g, t, per_wave * wpb, stream, G); break; \
+            case 3: hipLaunchKernelGGL((k_rx_fold_sum<1, (C0), 3>), g, t, per_wave * wpb, stream, G); break; \
+            case 4: hipLaunchKernelGGL((k_rx_fold_sum<1, (C0), 4>), g, t, per_wave * wpb, stream, G); break; \
+        } \
         return;
 #define RX_SUM2(C0, C1) \
     case ((C0) | ((C1) << 2)):                                                                                             \
-        if (km == 0) hipLaunchKernelGGL((k_rx_fold_sum<2, ((C0) | ((C1) << 2)), 0>), g, t, per_wave * wpb, stream, G);      \
-        else if (km == 1) hipLaunchKernelGGL((k_rx_fold_sum<2, ((C0) | ((C1) << 2)), 1>), g, t, per_wave * wpb, stream, G); \
-        else if (km == 2) hipLaunchKernelGGL((k_rx_fold_sum<2, ((C0) | ((C1) << 2)), 2>), g, t, per_wave * wpb, stream, G); \
-        else hipLaunchKernelGGL((k_rx_fold_sum<2, ((C0) | ((C1) << 2)), 3>), g, t, per_wave * wpb, stream, G);              \
+        switch (km) { \
+            case 0: hipLaunchKernelGGL((k_rx_fold_sum<2, ((C0) | ((C1) << 2)), 0>), g, t, per_wave * wpb, stream, G); break; \
+            case 1: hipLaunchKernelGGL((k_rx_fold_sum<2, ((C0) | ((C1) << 2)), 1>), g, t, per_wave * wpb, stream, G); break; \
+            case 2: hipLaunchKernelGGL((k_rx_fold_sum<2, ((C0) | ((C1) << 2)), 2>), g, t, per_wave * wpb, stream, G); break; \
+            case 3: hipLaunchKernelGGL((k_rx_fold_sum<2, ((C0) | ((C1) << 2)), 3>), g, t, per_wave * wpb, stream, G); break; \
+            case 4: hipLaunchKernelGGL((k_rx_fold_sum<2, ((C0) | ((C1) << 2)), 4>), g, t, per_wave * wpb, stream, G); break; \
+        } \
         return;
 #define RX_SUM3(C0, C1, C2) \
     case ((C0) | ((C1) << 2) | ((C2) << 4)): \
-        if (km == 0) hipLaunchKernelGGL((k_rx_fold_sum<3, ((C0) | ((C1) << 2) | ((C2) << 4)), 0>), g, t, per_wave * wpb, stream, G);      \
-        else if (km == 1) hipLaunchKernelGGL((k_rx_fold_sum<3, ((C0) | ((C1) << 2) | ((C2) << 4)), 1>), g, t, per_wave * wpb, stream, G); \
-        else if (km == 2) hipLaunchKernelGGL((k_rx_fold_sum<3, ((C0) | ((C1) << 2) | ((C2) << 4)), 2>), g, t, per_wave * wpb, stream, G); \
-        else hipLaunchKernelGGL((k_rx_fold_sum<3, ((C0) | ((C1) << 2) | ((C2) << 4)), 3>), g, t, per_wave * wpb, stream, G);              \
+        switch (km) { \
+            case 0: hipLaunchKernelGGL((k_rx_fold_sum<3, ((C0) | ((C1) << 2) | ((C2) << 4)), 0>), g, t, per_wave * wpb, stream, G); break; \
+            case 1: hipLaunchKernelGGL((k_rx_fold_sum<3, ((C0) | ((C1) << 2) | ((C2) << 4)), 1>), g, t, per_wave * wpb, stream, G); break; \
+            case 2: hipLaunchKernelGGL((k_rx_fold_sum<3, ((C0) | ((C1) << 2) | ((C2) << 4)), 2>), g, t, per_wave * wpb, stream, G); break; \
+            case 3: hipLaunchKernelGGL((k_rx_fold_sum<3, ((C0) | ((C1) << 2) | ((C2) << 4)), 3>), g, t, per_wave * wpb, stream, G); break; \
+            case 4: hipLaunchKernelGGL((k_rx_fold_sum<3, ((C0) | ((C1) << 2) | ((C2) << 4)), 4>), g, t, per_wave * wpb, stream, G); break; \
+        } \
         return;
 #define RX_SUM3_LAST(C0, C1) RX_SUM3(C0, C1, 0) RX_SUM3(C0, C1, 1) RX_SUM3(C0, C1, 2)
 #define RX_SUM3_MID(C0) RX_SUM3_LAST(C0, 0) RX_SUM3_LAST(C0, 1) RX_SUM3_LAST(C0, 2)
-        const int km = wide ? (G.esize[1] == 4 ? 3 : 2) : (G.esize[0] == 4 ? 0 : 1);
+        const int km = wide ? kcols : (G.esize[0] == 4 ? 0 : 1);
         if (sum_cls >= 0 && NA == 1) {
             switch (sum_cls) { RX_SUM1(0) RX_SUM1(1) RX_SUM1(2) default: break; }
         } else if (sum_cls >= 0 && NA == 2) {
