@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(RX_THREADS) __attribute__((amdgpu_waves_per_eu
 // INTEGER key + up to three 4-byte value columns (f32 / i32: what SUM, AVG, COUNT over stored columns carry): the same
 // tile, ranking and staging as k_rx_hist / k_rx_scatter<true> with everything that was decided per element at run time
 // (element size, first pass or later, selection, key kind) decided at compile time, tile-local 32-bit indexing and the
-// 32-bit bin mix.  FIRST: the key is read from the table's INTEGER column at row0 + position (no selection).
+// 32-bit bin mix.  FIRST: the key is read from the table's INTEGER column at row0 + position, or through the row list.
 template <bool FIRST>
 __device__ __forceinline__ const int32_t* rx4_keys(const RxPass& A) {
     return FIRST ? (const int32_t*)A.key.data + A.row0 : (const int32_t*)A.src[0];
@@ -352,11 +352,12 @@ __global__ void __launch_bounds__(RX_H4_THREADS) k_rx_hist4(const RxPass A_kerna
     const int64_t left = A.seg_start[seg + 1] - b;
     const int rows = left < RX_TILE ? (int)left : RX_TILE;
     const int32_t* keys = rx4_keys<FIRST>(A) + b;
+    const int64_t* sel = FIRST && A.sel ? A.sel + b : nullptr;  // behind a WHERE the first pass reads the key through the row list
     uint32_t key[RX_H4_PER];
 #pragma unroll
     for (int j = 0; j < RX_H4_PER; ++j) {
         const int i = tid + j * RX_H4_THREADS;
-        key[j] = i < rows ? (uint32_t)keys[i] : 0u;
+        key[j] = i >= rows ? 0u : (uint32_t)(sel ? ((const int32_t*)A.key.data)[sel[i]] : keys[i]);
     }
     __syncthreads();
     const int shift = A.shift, bits = A.bits;
@@ -391,8 +392,12 @@ __global__ void __launch_bounds__(RX_THREADS) __attribute__((amdgpu_waves_per_eu
     constexpr int NVR = NV > 0 ? NV : 1;
     uint32_t key[RX_PER], val[NVR][RX_PER];
     const int first = w * RX_SUB + lane;  // tile-local row of step 0
+    const int64_t* sel = FIRST && A.sel ? A.sel + b : nullptr;
 #pragma unroll
-    for (int j = 0; j < RX_PER; ++j) key[j] = first + j * HS_WAVE < rows ? (uint32_t)keys[first + j * HS_WAVE] : 0u;
+    for (int j = 0; j < RX_PER; ++j) {
+        const int i = first + j * HS_WAVE;
+        key[j] = i >= rows ? 0u : (uint32_t)(sel ? ((const int32_t*)A.key.data)[sel[i]] : keys[i]);
+    }
 #pragma unroll
     for (int c = 0; c < NV; ++c) {
         const uint32_t* src = (const uint32_t*)A.src[1 + c] + b;
@@ -1197,7 +1202,7 @@ static int rx_pass(hipStream_t stream, RxPass& P, int64_t max_tiles, int64_t* co
     static const bool generic = getenv("HIPSPARK_RADIX_GENERIC") != nullptr;
     static const bool direct = getenv("HIPSPARK_RADIX_DIRECT") != nullptr;
     bool four = !generic && !direct && !P.raw && P.n_cols <= 4 &&
-                (P.first ? (P.key.kind == HS_I32 && P.sel == nullptr) : P.esize[0] == 4);
+                (P.first ? P.key.kind == HS_I32 : P.esize[0] == 4);
     for (int c = 1; c < P.n_cols; ++c) four = four && P.esize[c] == 4;
     P.key4 = four ? 1 : 0;
 #define RX_WIDE(KERNEL, THREADS)                                                                                          \

@@ -1401,8 +1401,8 @@ class Device:
 
     def _radix_values(self, batch: DBatch, args: Sequence[Any], sel: torch.Tensor | None, n: int):
         """Aggregate arguments for the radix tier -> per argument (value column | None, constant cell, is_int).
-        A literal (COUNT's 1) does not travel with the rows; a stored numeric column of an unfiltered batch travels as it
-        is (4 B); anything else is evaluated first (8 B cells, one launch for all of them)."""
+        A literal (COUNT's 1) does not travel with the rows; a stored numeric column travels as it is (4 B; gathered through
+        the row list behind a WHERE); anything else is evaluated first (8 B cells, one launch for all of them)."""
         import struct  # noqa: PLC0415
 
         from .lowering import unalias  # noqa: PLC0415
@@ -1416,10 +1416,12 @@ class Device:
                 out[i] = (None, int(e.value) & (2**64 - 1), True)
             elif cls == "Lit" and isinstance(e.value, float):
                 out[i] = (None, struct.unpack("<Q", struct.pack("<d", e.value))[0], False)
-            elif cls == "Col" and sel is None and any(name == e.name for name, _ in batch.schema):
+            elif cls == "Col" and any(name == e.name for name, _ in batch.schema):
                 col = batch.cols[batch.column_index(e.name)]
                 if col.kind in (hs.I32, hs.F32, hs.I64) and col.dict is None:
-                    out[i] = (col, 0, col.kind != hs.F32)
+                    # a stored column travels in its stored width (4 B for INTEGER / FLOAT: the tier's fast kernels); behind a
+                    # WHERE it is gathered through the row list first - values are indexed by POSITION
+                    out[i] = (col if sel is None else self.gather_col(col, sel, n), 0, col.kind != hs.F32)
                 else:
                     todo.append(i)
             else:

@@ -368,3 +368,52 @@ def test_random_high_cardinality_queries_match_the_oracle(tmp_path, seed):
         for _ in range(2):
             assert_rows_match(frame.collect(), want, max_ulps=0)
         assert engine._global_partial and engine.dev.last_global_tier == "radix"
+
+
+@pytest.mark.parametrize("key,length", [("x", 0), ("q", 0), ("s", 5), ("s", 10), ("s", 16)])
+@pytest.mark.parametrize("sums_only", [True, False])
+def test_engine_takes_float_and_fixed_length_string_keys_to_the_hbm_tier(tmp_path, key, length, sums_only):
+    """Round 3: GROUP BY a stored FLOAT column, a computed FLOAT expression or a STRING column whose rows all have one
+    length (<= 16 bytes), thousands of values per block, through the whole engine: the radix tier where it holds the shape
+    (wide strings: SUM / AVG / COUNT only - otherwise the hash-table tier), equal to the Python oracle bit for bit."""
+    from minispark_amd import constants
+    from minispark_amd.constants import ColumnType as T
+    from minispark_amd.dataframe import DataFrame
+    from minispark_amd.execution import HipExecutionEngine
+    from minispark_amd.io import BlockFile, StrCol
+    from minispark_amd.sql import Col, Functions as F
+    from oracle.py_engine import run_query
+    from tests.conftest import assert_rows_match
+
+    constants.SHUFFLE_FOLDER = tmp_path / "shuffle"
+    rng = np.random.default_rng(31 + length)
+    n, distinct = 50_000, 9_000
+    pool = np.round(rng.normal(0, 100, distinct), 2).astype(np.float32)
+    alphabet = "abcdefghijklmnopqrstuvwxyzABCDEF0123456789"
+    words = ["".join(alphabet[c] for c in rng.integers(0, len(alphabet), max(length, 1))) for _ in range(distinct)]
+    pick = rng.integers(0, distinct, n)
+    cols = {"x": pool[pick], "s": [words[p] for p in pick], "f": rng.normal(0, 1e3, n).astype(np.float32),
+            "i": rng.integers(-10**4, 10**4, n).astype(np.int32)}
+    schema = [("x", T.FLOAT), ("s", T.STRING), ("f", T.FLOAT), ("i", T.INTEGER)]
+    cuts = [0, 17_000, 17_001, 40_000, n]
+    BlockFile(tmp_path / "t.bin").write_raw_blocks(schema, [[cols["x"][lo:hi], StrCol.from_strings(cols["s"][lo:hi]), cols["f"][lo:hi],
+                                                            cols["i"][lo:hi]] for lo, hi in zip(cuts, cuts[1:])])
+
+    def query(engine):
+        df = DataFrame(engine).table(str(tmp_path / "t.bin")).filter(Col("i") % 7 != 0)
+        if key == "q":  # a computed FLOAT key: an f64 that exists nowhere in the file
+            df = df.select((Col("x") * 0.5 + 1.25).alias("q"), Col("f"), Col("i"))
+        aggs = [F.sum(Col("f")).alias("sf"), F.avg(Col("i")).alias("ai"), F.count()]
+        if not sums_only:
+            aggs += [F.min(Col("f")).alias("lo"), F.max(Col("i")).alias("hi")]
+        return df.group_by(Col(key)).agg(*aggs)
+
+    want = run_query(query(object()).task)
+    assert len(want) > 4096
+    with HipExecutionEngine(0) as engine:
+        frame = query(engine)
+        for _ in range(2):
+            assert_rows_match(frame.collect(), want, max_ulps=0)
+        assert engine._global_partial
+        if key != "s" or length <= 7 or sums_only:
+            assert engine.dev.last_global_tier == "radix", engine.dev.last_global_tier
