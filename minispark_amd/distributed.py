@@ -242,7 +242,11 @@ class PeerSlabs:
         self.nbytes = int(lib.hs_slab_p2p_bytes(world, self.SLOT))
         with torch.cuda.device(device):
             own = C.c_void_p()
-            self._check(self.hip.hipMalloc(C.byref(own), C.c_size_t(self.nbytes)), "hipMalloc")
+            # fine-grained device memory: a peer's stores and flag writes arrive over the fabric, not through this GPU's L2 -
+            # the waiting kernel's system-scope loads must see them while it runs (what RCCL does for its own flags)
+            self.fine_grained = self.hip.hipExtMallocWithFlags(C.byref(own), C.c_size_t(self.nbytes), C.c_uint(0x1)) == 0
+            if not self.fine_grained:
+                self._check(self.hip.hipMalloc(C.byref(own), C.c_size_t(self.nbytes)), "hipMalloc")
             self._check(self.hip.hipMemset(own, 0, C.c_size_t(self.nbytes)), "hipMemset")
             self._check(self.hip.hipDeviceSynchronize(), "hipDeviceSynchronize")
             self.own = own.value
