@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import struct
 from dataclasses import dataclass, field
 from typing import Any, Sequence
 
@@ -22,7 +23,7 @@ import torch
 
 from . import hipspark as hs
 from .constants import ColumnType, Schema
-from .io import StrCol
+from .io import LazyRaw, StrCol, timestamp_to_datetime
 from .lowering import NeedsDecoded, ProgramBuilder, StringParts, lower_aggregate
 
 PAD = 64  # bytes of slack behind every buffer
@@ -33,6 +34,19 @@ def _strcol_bytes(col: StrCol) -> list[bytes]:
         out.append(data[pos: pos + ln])
         pos += ln
     return out
+
+
+SMALL_RESULT_ROWS = 16  # results up to this many rows are decoded with struct straight from the result image
+_IMAGE_HEADER = struct.Struct("<IIq")  # flags, "done" word, row count
+_SMALL_STRUCTS: dict[tuple[int, int], Any] = {}
+
+
+def _small_struct(kind: int, n: int) -> Any:
+    st = _SMALL_STRUCTS.get((kind, n))
+    if st is None:
+        code = {hs.I32: "i", hs.F32: "f", hs.I64: "q", hs.F64: "d"}[kind]
+        st = _SMALL_STRUCTS[(kind, n)] = struct.Struct(f"<{n}{code}")
+    return st
 
 
 def _decode_codes(codes: np.ndarray, entries: tuple) -> StrCol:
@@ -1247,7 +1261,9 @@ class Device:
         key_dict = tail.get("key_dict")
         stream = torch.cuda.current_stream(self.device)
 
-        def finish() -> tuple[list[Any], int, int]:
+        key_text = tuple(e.decode("utf-8") for e in key_dict) if key_dict is not None else ()
+
+        def finish() -> tuple[Any, int, int]:
             if mapped is not None:
                 # zero-copy hand-over: the launch stored the image into mapped host memory and set "done" last
                 done = mapped[4:8].view(np.uint32)
@@ -1264,22 +1280,43 @@ class Device:
             else:
                 host = result.cpu().numpy()  # the single synchronising copy
             private = host is not mapped
-            flags = int(host[0:4].view(np.uint32)[0])
-            n = min(int(host[8:16].view(np.int64)[0]), cap)
-            raw: list[Any] = []
-            for off, kind, width in columns:
-                if kind == hs.STR:
-                    if key_dict is not None:
-                        raw.append(_decode_codes(host[off: off + n], key_dict))
+            flags, _, n = _IMAGE_HEADER.unpack_from(host, 0)
+            n = min(n, cap)
+
+            def raw_columns() -> list[Any]:
+                raw: list[Any] = []
+                for off, kind, width in columns:
+                    if kind == hs.STR:
+                        if key_dict is not None:
+                            raw.append(_decode_codes(host[off: off + n], key_dict))
+                        else:
+                            data = host[off: off + n * width]
+                            raw.append(StrCol(np.full(n, width, dtype=np.uint8), data if private else data.copy()))
                     else:
-                        data = host[off: off + n * width]
-                        raw.append(StrCol(np.full(n, width, dtype=np.uint8), data if private else data.copy()))
-                else:
-                    data = host[off: off + n * width].view(_NP_DTYPE[kind])
-                    raw.append(data if private else data.copy())
+                        data = host[off: off + n * width].view(_NP_DTYPE[kind])
+                        raw.append(data if private else data.copy())
+                return raw
+
+            if private and 0 < n <= SMALL_RESULT_ROWS:
+                # the usual handful of groups: Python values straight from the (private copy of the) image; numpy columns only
+                # if the file or the column-wise form is asked for
+                py: list[Any] = []
+                for off, kind, width in columns:
+                    if kind == hs.STR:
+                        if key_dict is not None:
+                            py.append([key_text[c] for c in host[off: off + n].tolist()])
+                        else:
+                            text = host[off: off + n * width].tobytes()
+                            py.append([text[i * width: (i + 1) * width].decode("utf-8") for i in range(n)])
+                    else:
+                        vals = _small_struct(kind, n).unpack_from(host, off)
+                        py.append([timestamp_to_datetime(v) for v in vals] if kind == hs.I64 else list(vals))
+                out: Any = LazyRaw(py, raw_columns)
+            else:
+                out = raw_columns()
             if mapped is not None:
                 done[0] = 0  # ready for the next launch into this image
-            return raw, n, flags
+            return out, n, flags
 
         if self.rec is not None:
             self.rec.finish = finish

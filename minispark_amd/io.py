@@ -570,6 +570,23 @@ def python_columns(schema: Schema, cols: Sequence[RawColumn]) -> list[list]:
     return values
 
 
+class LazyRaw:
+    """A SMALL result as it left the device: the Python values of its columns, decoded straight from the image bytes
+    (`py_columns`: what rows are made of), and the raw numpy columns only when somebody asks for the file or the
+    column-wise form (`build()`).  A query with a handful of result rows spends more host time wrapping them in numpy
+    views than the finish launch takes to produce them."""
+
+    __slots__ = ("py_columns", "_build", "_raw")
+
+    def __init__(self, py_columns: list, build: Any) -> None:
+        self.py_columns, self._build, self._raw = py_columns, build, None
+
+    def build(self) -> list:
+        if self._raw is None:
+            self._raw = self._build()
+        return self._raw
+
+
 _ROW_BUILDERS: dict[int, Any] = {}
 
 

@@ -25,11 +25,19 @@ class ResultFile:
     device->host copy, so ``collect_results`` serves them directly.  It still stands for the BlockFile the
     reference's engines write (tasks.py:391-410): reading ``file_path`` writes that file on first use."""
 
-    __slots__ = ("_path", "partition", "schema", "raw", "nrows", "_written")
+    __slots__ = ("_path", "partition", "schema", "_raw", "nrows", "_written")
 
     def __init__(self, path: Path, schema: list, raw: list, nrows: int, partition: int = 0) -> None:
-        self._path, self.partition, self.schema, self.raw, self.nrows = path, partition, schema, raw, nrows
+        self._path, self.partition, self.schema, self._raw, self.nrows = path, partition, schema, raw, nrows
         self._written = False
+
+    @property
+    def raw(self) -> list:
+        from .io import LazyRaw  # noqa: PLC0415
+
+        if isinstance(self._raw, LazyRaw):
+            self._raw = self._raw.build()
+        return self._raw
 
     @property
     def file_path(self) -> Path:
@@ -46,8 +54,11 @@ class ResultFile:
         return self._path
 
     def rows(self):  # noqa: ANN201
-        from .io import rows_list_from_raw  # noqa: PLC0415
+        from .io import LazyRaw, _row_builder, rows_list_from_raw  # noqa: PLC0415
 
+        if isinstance(self._raw, LazyRaw):  # a small result: its values were decoded with the hand-over
+            names = [n for n, _ in self.schema]
+            return _row_builder(len(names))(names, self._raw.py_columns) if names else []
         return rows_list_from_raw(self.schema, self.raw)
 
     def columns(self) -> dict:

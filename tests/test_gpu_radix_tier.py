@@ -367,7 +367,10 @@ def test_random_high_cardinality_queries_match_the_oracle(tmp_path, seed):
         frame = _hc_query(random.Random(seed), api_namespace(lambda: DataFrame(engine), Col, Functions, Lit), str(path))
         for _ in range(2):
             assert_rows_match(frame.collect(), want, max_ulps=0)
-        assert engine._global_partial and engine.dev.last_global_tier == "radix"
+        if seed < 8:  # the committed sample is sized for the HBM tier; a wider hunt may meet queries the LDS tiers hold
+            assert engine._global_partial
+        if engine._global_partial:
+            assert engine.dev.last_global_tier == "radix"
 
 
 @pytest.mark.parametrize("key,length", [("x", 0), ("q", 0), ("s", 5), ("s", 10), ("s", 16)])

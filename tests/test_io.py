@@ -172,3 +172,27 @@ def test_rows_from_raw_columns_as_a_list_and_column_wise():
     assert len(big) == 10_000 and big[9_999] == {"i": 9_999, "f": 9_999.0}
     cols = ResultFile(None, schema, raw, 3).columns()
     assert cols["s"] == ["a", "", "long string"] and cols["i"].tolist() == [1, -2, 3] and cols["t"].dtype == np.int64
+
+
+def test_small_results_decoded_with_the_hand_over_equal_their_raw_columns(tmp_path):
+    """Round 3: results of a handful of rows are handed over as Python values decoded straight from the result image
+    (io.LazyRaw); the numpy columns - and with them the result BlockFile and the column-wise form - are built only on
+    demand and must describe the same rows."""
+    from datetime import datetime
+
+    from minispark_amd.constants import ColumnType as T
+    from minispark_amd.io import BlockFile, LazyRaw, StrCol
+    from minispark_amd.jobs import ResultFile
+
+    schema = [("flag", T.STRING), ("s", T.FLOAT), ("n", T.INTEGER), ("t", T.TIMESTAMP)]
+    raw = [StrCol.from_strings(["A", "N", "R"]), np.array([1.5, -2.25, 3.0], np.float32), np.array([7, -8, 9], np.int32),
+           np.array([0, 86_400_000_000, 946_684_800_000_000], np.int64)]
+    py = [["A", "N", "R"], [1.5, -2.25, 3.0], [7, -8, 9],
+          [datetime(1970, 1, 1), datetime(1970, 1, 2), datetime(2000, 1, 1)]]
+    built = []
+    lazy = ResultFile(tmp_path / "a" / "result.bin", schema, LazyRaw(py, lambda: built.append(1) or raw), 3)
+    plain = ResultFile(tmp_path / "b" / "result.bin", schema, raw, 3)
+    assert lazy.rows() == plain.rows() and not built          # rows: no numpy column was built
+    assert lazy.rows() is not lazy.rows()                       # fresh dicts per call
+    assert set(lazy.columns()) == {"flag", "s", "n", "t"} and built == [1]
+    assert list(BlockFile(lazy.file_path).read_data_rows()) == plain.rows() and built == [1]
