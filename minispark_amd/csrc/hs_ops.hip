@@ -920,13 +920,46 @@ extern "C" int hs_partition_ids(void* stream, const hs_col* key, const int64_t* 
 #define HS_MAX_PARTS_SORT 32
 __global__ void __launch_bounds__(SCAN_WG) k_part_hist(const uint8_t* part, int64_t n, int32_t n_parts, int64_t ntiles,
                                                        int64_t* hist /* [n_parts][ntiles] */) {
+    // round 3: a lane takes its 8 ids as ONE 8-byte load and counts every partition with a byte-compare in the word
+    // (round 2: eight byte loads and eight LDS atomics on n_parts hot addresses per lane); waves add up with shuffles
     __shared__ int s_hist[HS_MAX_PARTS_SORT];
     if (threadIdx.x < HS_MAX_PARTS_SORT) s_hist[threadIdx.x] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    static_assert(SCAN_ITEMS == 8, "one 64-bit word of ids per lane");
+    uint64_t w = ~0ull;  // 0xff = no row
+    if (base + SCAN_ITEMS <= n && (((uintptr_t)part) & 7) == 0) {
+        w = *(const uint64_t*)(part + base);
+    } else {
+        for (int k = 0; k < SCAN_ITEMS; ++k)
+            if (base + k < n) w = (w & ~(0xffull << (8 * k))) | ((uint64_t)part[base + k] << (8 * k));
+    }
+    const int lane = threadIdx.x & (HS_WAVE - 1);
+    // a lane's counts (<= 8 each) go into 10-bit fields, six partitions per 64-bit word: ONE shuffle reduction per word sums
+    // them over the wave (<= 512 per field)
+    constexpr int PER = 6, WORDS = (HS_MAX_PARTS_SORT + PER - 1) / PER;
+    uint64_t acc[WORDS] = {};
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k)
-        if (base + k < n) atomicAdd(&s_hist[part[base + k]], 1);
+    for (int r = 0; r < WORDS; ++r) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int p = r * PER + q;
+            if (p < n_parts) {
+                const uint64_t x = w ^ (0x0101010101010101ull * (uint64_t)p);  // bytes equal to p become zero
+                const uint64_t zero = ~(((x & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | x) & 0x8080808080808080ull;
+                acc[r] += (uint64_t)__popcll(zero) << (10 * q);
+            }
+        }
+        if (r * PER < n_parts) {
+            for (int d = HS_WAVE / 2; d >= 1; d >>= 1) acc[r] += __shfl_down(acc[r], d, HS_WAVE);
+            if (lane == 0) {
+                for (int q = 0; q < PER && r * PER + q < n_parts; ++q) {
+                    const int c = (int)((acc[r] >> (10 * q)) & 1023u);
+                    if (c) atomicAdd(&s_hist[r * PER + q], c);
+                }
+            }
+        }
+    }
     __syncthreads();
     if ((int)threadIdx.x < n_parts) hist[(int64_t)threadIdx.x * ntiles + blockIdx.x] = s_hist[threadIdx.x];
 }
@@ -935,36 +968,76 @@ __global__ void __launch_bounds__(SCAN_WG) k_part_starts(const int64_t* hist_sca
     if ((int)threadIdx.x < n_parts) part_start[threadIdx.x] = hist_scanned[(int64_t)threadIdx.x * ntiles];
     if (threadIdx.x == 0) part_start[n_parts] = total;
 }
+// Round 3: rows are taken STRIPED (step k of a wave = 64 consecutive rows), so a row's rank among the rows of its
+// partition is "rows of the partition in earlier (step, wave) segments" + its rank among the lanes of its own step - one
+// ballot per id bit, as in the radix tier's scatter - and the tile leaves through LDS in partition order, i.e. as one
+// contiguous run of 8-byte stores per partition.  (Round 2: every lane owned 8 consecutive rows and kept its own counter per
+// partition in LDS; the per-partition scan over 256 lanes ran on n_parts threads and the stores were scattered.)
 __global__ void __launch_bounds__(SCAN_WG) k_part_scatter(const uint8_t* part, int64_t n, int32_t n_parts,
                                                           int64_t ntiles, const int64_t* hist_scanned, int64_t* perm) {
-    __shared__ int s_cnt[HS_MAX_PARTS_SORT][SCAN_WG + 1];
-    const int tid = threadIdx.x;
-    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)tid * SCAN_ITEMS;
-    for (int p = 0; p < n_parts; ++p) s_cnt[p][tid] = 0;
+    constexpr int WAVES = SCAN_WG / HS_WAVE, SEGS = SCAN_ITEMS * WAVES;
+    __shared__ int s_seg[SEGS + 1][HS_MAX_PARTS_SORT];   // rows of partition p in segment (step, wave); then exclusive over segments
+    __shared__ int s_start[HS_MAX_PARTS_SORT + 1];        // tile-local start of every partition
+    __shared__ int64_t s_gbase[HS_MAX_PARTS_SORT];        // global position of the partition's first row of this tile
+    __shared__ uint16_t s_row[SCAN_TILE];                 // tile-local row ids in partition order
+    const int tid = threadIdx.x, lane = tid & (HS_WAVE - 1), w = tid / HS_WAVE;
+    const int64_t tile0 = (int64_t)blockIdx.x * SCAN_TILE;
+    for (int i = tid; i < (SEGS + 1) * HS_MAX_PARTS_SORT; i += SCAN_WG) (&s_seg[0][0])[i] = 0;
     uint8_t mine[SCAN_ITEMS];
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
-        mine[k] = base + k < n ? part[base + k] : 255;
-        if (mine[k] != 255) s_cnt[mine[k]][tid] += 1;
+        const int64_t r = tile0 + k * SCAN_WG + tid;
+        mine[k] = r < n ? part[r] : 255;
     }
     __syncthreads();
-    if (tid < n_parts) {  // exclusive scan over lanes for partition `tid`
+    const uint64_t below = (1ull << lane) - 1ull;
+    int rank[SCAN_ITEMS];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const bool valid = mine[k] != 255;
+        const int p = valid ? mine[k] : 0;
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 5; ++bit) {  // ids < 32
+            const bool on = (p >> bit) & 1;
+            const uint64_t bal = __ballot(valid && on);
+            peers &= on ? bal : ~bal;
+        }
+        rank[k] = __popcll(peers & below);
+        if (valid && rank[k] == 0) s_seg[k * WAVES + w][p] = __popcll(peers);
+    }
+    __syncthreads();
+    if (tid < n_parts) {  // exclusive scan over the segments, in (step, wave) order = row order
         int run = 0;
-        for (int t = 0; t < SCAN_WG; ++t) {
-            const int c = s_cnt[tid][t];
-            s_cnt[tid][t] = run;
+        for (int sg = 0; sg <= SEGS; ++sg) {
+            const int c = s_seg[sg][tid];
+            s_seg[sg][tid] = run;
             run += c;
         }
+        s_gbase[tid] = hist_scanned[(int64_t)tid * ntiles + blockIdx.x];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int p = 0; p < n_parts; ++p) {
+            s_start[p] = run;
+            run += s_seg[SEGS][p];
+        }
+        s_start[n_parts] = run;
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
-        if (mine[k] != 255) {
-            const int p = mine[k];
-            const int64_t pos = hist_scanned[(int64_t)p * ntiles + blockIdx.x] + s_cnt[p][tid];
-            s_cnt[p][tid] += 1;
-            perm[pos] = base + k;
-        }
+        if (mine[k] == 255) continue;
+        const int p = mine[k];
+        s_row[s_start[p] + s_seg[k * WAVES + w][p] + rank[k]] = (uint16_t)(k * SCAN_WG + tid);
+    }
+    __syncthreads();
+    const int rows = s_start[n_parts];
+    for (int i = tid; i < rows; i += SCAN_WG) {
+        int p = 0;
+        while (s_start[p + 1] <= i) ++p;  // <= 32 partitions: a short walk
+        perm[s_gbase[p] + (i - s_start[p])] = tile0 + s_row[i];
     }
 }
 extern "C" size_t hs_partition_ws_bytes(int64_t nrows, int32_t n_parts) {

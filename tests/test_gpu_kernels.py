@@ -451,3 +451,22 @@ def test_copy_segments_packs_and_unpacks_byte_ranges(dev):
         want[d: d + n] = src[s: s + n]
     assert np.array_equal(d_dst.cpu().numpy(), want)
     dev.copy_segments([])  # nothing to do
+
+
+@pytest.mark.parametrize("n,n_parts,skew", [(1, 1, False), (2047, 10, False), (2049, 10, True), (70_001, 32, False),
+                                            (1_000_003, 10, True), (300_000, 3, False)])
+def test_partition_perm_is_the_stable_counting_sort(n, n_parts, skew):
+    """hs_partition_perm (reference tasks.py:347-375: rows go to their shuffle partition in row order) against numpy's stable
+    argsort: the permutation and the partition starts; round 3 rewrote the scatter (striped rows, ballot ranks, LDS staging)."""
+    import torch
+
+    from minispark_amd.device import Device
+
+    dev = Device(0)
+    rng = np.random.default_rng(n + n_parts)
+    ids = (rng.integers(0, n_parts, n) if not skew else np.minimum(rng.geometric(0.4, n) - 1, n_parts - 1)).astype(np.uint8)
+    perm, start = dev.partition_by_ids(torch.from_numpy(ids).cuda(), n, n_parts)
+    torch.cuda.synchronize()
+    want = np.argsort(ids, kind="stable")
+    assert np.array_equal(perm[:n].cpu().numpy(), want)
+    assert start == [int(v) for v in np.concatenate([[0], np.cumsum(np.bincount(ids, minlength=n_parts))])]

@@ -41,7 +41,7 @@ lens = torch.randint(0, 16, (N,), dtype=torch.uint8, device="cuda", generator=g)
 # A1 string offsets scan
 offs = dev.empty(N + 1, torch.int64); mm = dev.empty(2, torch.int32); ws = dev.workspace(lib.hs_scan_ws_bytes(N))
 ms = timed(lambda: lib.hs_str_offsets(dev.stream, lens.data_ptr(), N, offs.data_ptr(), mm.data_ptr(), ws.data_ptr()))
-report("A1 hs_str_offsets (u8 lens -> i64 offsets)", ms, N * (1 + 1 + 1 + 8), "reads lens 3x (minmax, reduce, down), writes 8 B/row")
+report("A1 hs_str_offsets (u8 lens -> i64 offsets)", ms, N * (1 + 1 + 1 + 8), "reads lens twice (reduce with min/max, down), writes 8 B/row")
 
 # A3 compaction
 sel = dev.empty(N, torch.int64); cnt = dev.empty(1, torch.int64)
