@@ -219,6 +219,10 @@ def or_flags(dist: Any, flags: int, device: torch.device, group: Any = None) -> 
     return sum(int(v) << b for b, v in enumerate(bits.tolist()))
 
 
+class PeerSlabsUnavailable(RuntimeError):
+    """The peers' buffers cannot be mapped on some rank (raised on EVERY rank together): the caller keeps the all-gather."""
+
+
 class PeerSlabs:
     """Peer-to-peer exchange of the short tail's slabs (prototype, HIPSPARK_P2P_SLABS=1; csrc/hs_exchange.hip hs_slab_push /
     hs_slab_wait): every rank owns one device buffer that all peers map through hipIpc handles (exchanged ONCE here, over the
@@ -257,17 +261,29 @@ class PeerSlabs:
                 self._check(self.hip.hipIpcGetMemHandle(C.byref(handle), own), "hipIpcGetMemHandle")
                 handles: list = [None] * world
                 dist.all_gather_object(handles, C.string_at(C.byref(handle), 64), group=group)  # all 64 bytes (they contain NULs)
+                problem = None
                 for p in range(world):
                     if p == rank:
                         continue
                     h = PeerSlabs._Handle()
                     if len(handles[p]) != 64:
-                        raise RuntimeError("peer-to-peer slabs: a rank sent a malformed IPC handle")
+                        problem = f"rank {p} sent a malformed IPC handle"
+                        break
                     C.memmove(C.byref(h), handles[p], 64)
                     ptr = C.c_void_p()
-                    self._check(self.hip.hipIpcOpenMemHandle(C.byref(ptr), h, 1), f"hipIpcOpenMemHandle (rank {p})")  # lazy peer access
+                    rc = self.hip.hipIpcOpenMemHandle(C.byref(ptr), h, 1)  # 1: lazy peer access
+                    if rc != 0:
+                        problem = f"hipIpcOpenMemHandle of rank {p}'s buffer failed with hip error {rc}"
+                        break
                     peers[p] = ptr.value
                     self.opened.append(ptr.value)
+                # the mapping either works on EVERY rank or the exchange form is not used at all: a rank that raised alone
+                # would leave its peers waiting in the next collective
+                problems: list = [None] * world
+                dist.all_gather_object(problems, problem, group=group)
+                if any(problems):
+                    self.close()
+                    raise PeerSlabsUnavailable("; ".join(f"rank {r}: {m}" for r, m in enumerate(problems) if m))
             self.peers_dev = torch.tensor(peers, dtype=torch.int64, device=device)
             self.epochs = torch.zeros(2, dtype=torch.int64, device=device)
         if world > 1:

@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import math
 import os
+import sys
 import shutil
 import uuid
 from abc import ABC, abstractmethod
@@ -267,7 +268,7 @@ class HipExecutionEngine(ExecutionEngine):
     def __exit__(self, exc_type, exc_value, traceback) -> None:  # noqa: ANN001
         if self.tracer is not None:
             self.tracer.save(self.trace_file)
-        if self._p2p is not None:
+        if self._p2p:
             import torch  # noqa: PLC0415
 
             torch.cuda.synchronize(self.dev.device)  # no launch of ours still reads the mapped buffers
@@ -1557,9 +1558,15 @@ class HipExecutionEngine(ExecutionEngine):
         if os.environ.get("HIPSPARK_P2P_SLABS", "0") != "1" or self.dist is None:
             return None
         if self._p2p is None:
-            from .distributed import PeerSlabs  # noqa: PLC0415
+            from .distributed import PeerSlabs, PeerSlabsUnavailable  # noqa: PLC0415
 
-            self._p2p = PeerSlabs(self.dist, self.group, self.rank, self.world, self.dev.device, self.dev.lib)
+            try:
+                self._p2p = PeerSlabs(self.dist, self.group, self.rank, self.world, self.dev.device, self.dev.lib)
+            except PeerSlabsUnavailable as e:  # raised on every rank together: all of them keep the all-gather
+                print(f"[hipspark] peer-to-peer slabs unavailable, using the all-gather: {e}", file=sys.stderr, flush=True)
+                self._p2p = False
+        if self._p2p is False:
+            return None
         return self._p2p if self._p2p.fits(slab_bytes) and slab_bytes % 16 == 0 else None
 
     def _emit_result(self, raw: list, nrows: int, schema: Schema, stage_id: str) -> JobResult:
