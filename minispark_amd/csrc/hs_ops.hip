@@ -311,11 +311,28 @@ __global__ void __launch_bounds__(SCAN_WG) k_bytes_reduce(const uint8_t* p, int6
         sum = bytes_sum4(w[0]) + bytes_sum4(w[1]) + bytes_sum4(w[2]) + bytes_sum4(w[3]);
         if (minmax) {
             int mn = 256, mx = -1;
-            for (int k = 0; k < VT_U8; ++k) {
-                if (base + k < n) {
-                    const int v = (w[k >> 2] >> (8 * (k & 3))) & 0xff;
-                    mn = v < mn ? v : mn;
-                    mx = v > mx ? v : mx;
+            if (base + VT_U8 <= n) {
+                // a full lane: the sixteen bytes as eight pairs of 16-bit fields (even bytes, odd bytes of every word), min and
+                // max per field with the packed 16-bit instructions, then across the two fields (round 3; the byte loop below
+                // cost more than the sums it rides along with)
+                typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+                u16x2 lo2 = {255, 255}, hi2 = {0, 0};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t even = w[q] & 0x00ff00ffu, odd = (w[q] >> 8) & 0x00ff00ffu;
+                    const u16x2 e = __builtin_bit_cast(u16x2, even), o = __builtin_bit_cast(u16x2, odd);
+                    lo2 = __builtin_elementwise_min(lo2, __builtin_elementwise_min(e, o));
+                    hi2 = __builtin_elementwise_max(hi2, __builtin_elementwise_max(e, o));
+                }
+                mn = lo2.x < lo2.y ? lo2.x : lo2.y;
+                mx = hi2.x > hi2.y ? hi2.x : hi2.y;
+            } else {
+                for (int k = 0; k < VT_U8; ++k) {
+                    if (base + k < n) {
+                        const int v = (w[k >> 2] >> (8 * (k & 3))) & 0xff;
+                        mn = v < mn ? v : mn;
+                        mx = v > mx ? v : mx;
+                    }
                 }
             }
             for (int d = HS_WAVE / 2; d >= 1; d >>= 1) {
