@@ -42,7 +42,10 @@ with NativeEngine(0) as engine:
         aggs = [fn().alias(f"a{j}") if "count" not in repr(fn) else fn() for j, fn in enumerate(rng.sample(pool[:-1], rng.randint(1, 4)))]
         if rng.random() < 0.6:
             aggs.append(F.count())
-        q = df.group_by(Col(rng.choice(["k", "c", "k", "t"]))).agg(*aggs)
+        key = rng.choice(["k", "c", "k", "t", "m", "m"])
+        if key == "m":  # round 3: a SELECT with a computed INTEGER key in front of the GROUP BY (plan version 2)
+            df = df.select((Col("i") % rng.choice([7, 97, 700]) - 40).alias("m"), Col("f"), Col("g"), Col("i"))
+        q = df.group_by(Col(key)).agg(*aggs)
         want = run_query(q.task)
         try:
             stage = NativeStage(engine, q.task)
@@ -53,6 +56,12 @@ with NativeEngine(0) as engine:
             for _ in range(3):
                 got = stage.run()
                 assert_rows_match(got, want, max_ulps=1)
+        except HipSparkError as e:
+            if ("on-chip" in str(e) or "LDS" in str(e)) and len(want) > 256:
+                unsupported += 1  # more partial rows than the on-chip merge holds: the per-operator ABI's business
+            else:
+                bad += 1
+                print(f"seed {seed}: {type(e).__name__}: {str(e)[:300]}", flush=True)
         except Exception as e:  # noqa: BLE001
             bad += 1
             print(f"seed {seed}: {type(e).__name__}: {str(e)[:300]}", flush=True)
