@@ -420,3 +420,67 @@ def test_engine_takes_float_and_fixed_length_string_keys_to_the_hbm_tier(tmp_pat
         assert engine._global_partial
         if key != "s" or length <= 7 or sums_only:
             assert engine.dev.last_global_tier == "radix", engine.dev.last_global_tier
+
+
+_HS_FIRST = int(__import__("os").environ.get("HIPSPARK_HS_FIRST", "0"))
+
+
+@pytest.mark.parametrize("seed", list(range(_HS_FIRST, _HS_FIRST + int(__import__("os").environ.get("HIPSPARK_HS_SEEDS", "6")))))
+def test_random_high_cardinality_queries_on_string_and_float_keys(tmp_path, seed):
+    """The random high-cardinality queries again, grouped by a FLOAT column, a computed FLOAT or a STRING column of one fixed
+    length (3 ... 16 bytes): whatever HBM tier the shape gets (radix where it holds it, the hash table otherwise), the rows
+    must equal the Python oracle bit for bit."""
+    import random
+
+    from minispark_amd import constants
+    from minispark_amd.constants import ColumnType as T
+    from minispark_amd.dataframe import DataFrame
+    from minispark_amd.execution import HipExecutionEngine
+    from minispark_amd.io import BlockFile, StrCol
+    from minispark_amd.sql import Col, Functions as F, Lit
+    from oracle.py_engine import run_query
+    from tests.conftest import assert_rows_match
+
+    constants.SHUFFLE_FOLDER = tmp_path / "shuffle"
+    rng, nr = random.Random(9100 + seed), np.random.default_rng(9100 + seed)
+    n = rng.choice([20_000, 45_000])
+    distinct = rng.choice([5_000, 12_000, n])
+    length = rng.choice([3, 6, 8, 11, 12, 16])
+    alphabet = "abcdefghijklmnopqrstuvwxyz0123456789"
+    words = ["".join(alphabet[c] for c in nr.integers(0, len(alphabet), length)) for _ in range(distinct)]
+    pool = np.round(nr.normal(0, 1e3, distinct), 1).astype(np.float32)
+    pick = nr.integers(0, distinct, n)
+    cols = [pool[pick], StrCol.from_strings([words[p] for p in pick]), nr.normal(0, 1e3, n).astype(np.float32),
+            nr.uniform(0, 1, n).astype(np.float32), nr.integers(-10**5, 10**5, n).astype(np.int32)]
+    schema = [("x", T.FLOAT), ("s", T.STRING), ("f", T.FLOAT), ("g", T.FLOAT), ("i", T.INTEGER)]
+    bounds = sorted({0, n, *nr.integers(1, n, rng.choice([1, 3, 5]) - 1).tolist()})
+
+    def cut(c, lo, hi):
+        return StrCol.from_strings(c.to_list()[lo:hi]) if isinstance(c, StrCol) else c[lo:hi]
+
+    BlockFile(tmp_path / "t.bin").write_raw_blocks(schema, [[cut(c, lo, hi) for c in cols] for lo, hi in zip(bounds, bounds[1:])])
+
+    def query(engine):
+        qr = random.Random(seed)
+        df = DataFrame(engine).table(str(tmp_path / "t.bin"))
+        if qr.random() < 0.6:
+            df = df.filter(qr.choice([Col("g") > 0.3, Col("i") % 3 != 0, (Col("f") < 500.0) & (Col("g") <= 0.9)]))
+        key = qr.choice(["x", "s", "s", "q"])
+        if key == "q":
+            # a computed FLOAT key whose f64 values stay distinct after the f32 rounding of the shuffle write (powers of two
+            # scale exactly): keys that collapse there are a documented divergence (DESIGN.md section 2), not this test's subject
+            df = df.select((Col("x") * qr.choice([0.5, 2.0, -4.0])).alias("q"), Col("f"), Col("g"), Col("i"))
+        pool_ = [lambda: F.sum(Col("f")), lambda: F.sum(Col("i")), lambda: F.min(Col("f")), lambda: F.max(Col("i")),
+                 lambda: F.avg(Col("g")), lambda: F.sum(Col("f") * (Lit(1) - Col("g"))), lambda: F.avg(Col("i"))]
+        aggs = [fn().alias(f"a{k}") for k, fn in enumerate(qr.sample(pool_, qr.randint(1, 3)))]
+        if qr.random() < 0.7:
+            aggs.append(F.count())
+        return df.group_by(Col(key)).agg(*aggs)
+
+    want = run_query(query(object()).task)
+    with HipExecutionEngine(0) as engine:
+        frame = query(engine)
+        for _ in range(2):
+            assert_rows_match(frame.collect(), want, max_ulps=0)
+        if engine._global_partial:
+            assert engine.dev.last_global_tier in ("radix", "hash")
