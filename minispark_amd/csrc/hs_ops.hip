@@ -941,6 +941,43 @@ __device__ __forceinline__ uint32_t py_int_partition(int64_t v, int32_t n_parts)
     if (m < 0) m += n_parts;
     return (uint32_t)m;
 }
+// CPython's hash of a finite float (Python/pyhash.c _Py_HashDouble; not randomised, unlike str): the mantissa in 28-bit
+// chunks modulo the Mersenne prime 2^61 - 1, then a rotation by the exponent, the sign, and -1 -> -2.  The reference routes
+// a FLOAT key to shuffle partition hash(key) % P (tasks.py:362), so which JoinJob sums a row - and with it the f32 rounding
+// of that job's partial sums - depends on this function.  +-inf hash to +-314159; NaN (hashed by object identity since
+// Python 3.10) gets 0 here.
+__device__ __forceinline__ int64_t py_float_hash(double v) {
+    constexpr uint64_t MOD = (1ull << 61) - 1;
+    if (isinf(v)) return v > 0 ? 314159 : -314159;
+    if (isnan(v)) return 0;
+    int e;
+    double m = frexp(v, &e);
+    int sign = 1;
+    if (m < 0) {
+        sign = -1;
+        m = -m;
+    }
+    uint64_t x = 0;
+    while (m != 0.0) {
+        x = ((x << 28) & MOD) | (x >> (61 - 28));
+        m *= 268435456.0;  // 2^28
+        e -= 28;
+        const uint64_t y = (uint64_t)m;  // the integer part
+        m -= (double)y;
+        x += y;
+        if (x >= MOD) x -= MOD;
+    }
+    e = e >= 0 ? e % 61 : 61 - 1 - ((-1 - e) % 61);
+    x = ((x << e) & MOD) | (x >> (61 - e));
+    int64_t h = sign * (int64_t)x;
+    return h == -1 ? -2 : h;
+}
+__device__ __forceinline__ uint32_t py_hash_partition(int64_t h, int32_t n_parts) {  // Python's floor-mod
+    int64_t r = h % (int64_t)n_parts;
+    if (r < 0) r += n_parts;
+    return (uint32_t)r;
+}
+
 __global__ void __launch_bounds__(256) k_partition_ids(const hs_col key, const int64_t* sel, int64_t n, int32_t n_parts,
                                                        uint8_t* part) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -953,9 +990,7 @@ __global__ void __launch_bounds__(256) k_partition_ids(const hs_col key, const i
             p = py_int_partition((int64_t)hs_load_cell(key, r), n_parts);
         } else {
             const double d = hs_u2d(hs_load_cell(key, r));
-            // integral floats hash like the equal int in Python; others: any fixed hash is a valid outcome
-            if (d == floor(d) && fabs(d) < 9.0e15) p = py_int_partition((int64_t)d, n_parts);
-            else p = (uint32_t)(hs_mix64(hs_d2u(d)) % (uint64_t)n_parts);
+            p = py_hash_partition(py_float_hash(d), n_parts);  // (integral floats hash like the equal int: same function)
         }
         part[i] = (uint8_t)p;
     }

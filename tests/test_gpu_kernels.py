@@ -119,6 +119,34 @@ def test_partition_follows_python_hash_and_is_stable(dev, n_parts):
         assert np.array_equal(rows, np.nonzero(want_part == p)[0]), f"partition {p} not the stable selection"
 
 
+@pytest.mark.parametrize("n_parts", [7, 10])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_partition_of_float_keys_follows_pythons_float_hash(dev, n_parts, dtype):
+    """Round 3: FLOAT keys go to partition hash(float) % P with CPython's own (unrandomised) float hash - the partition decides
+    which JoinJob sums a row (reference tasks.py:362), so it has to be the reference's.  Round 2 used it for integral values
+    only and an arbitrary hash otherwise."""
+    import torch
+
+    from minispark_amd import hipspark as hs
+    from minispark_amd.device import DCol
+
+    rng = _rng(11)
+    vals = np.concatenate([rng.normal(0, 1e3, 20_000), rng.normal(0, 1e-6, 2_000), rng.integers(-10**6, 10**6, 2_000).astype(np.float64),
+                           rng.normal(0, 1, 2_000) * np.exp2(rng.integers(-200, 200, 2_000)),
+                           [0.0, -0.0, 1.0, -1.0, 0.5, -0.5, 1e300, -1e300, 5e-324, np.inf, -np.inf, 2.0**61, 2.0**61 - 1, -(2.0**62)]])
+    keys = vals.astype(dtype)
+    kind = hs.F32 if dtype == np.float32 else hs.F64
+    col = DCol(kind, torch.from_numpy(keys).cuda(), len(keys))
+    part = torch.empty(len(keys), dtype=torch.uint8, device="cuda")
+    k = col.as_hs()
+    import ctypes as C
+
+    hs.check(dev.lib.hs_partition_ids(dev.stream, C.byref(k), None, len(keys), n_parts, part.data_ptr()), "hs_partition_ids")
+    got = part.cpu().numpy()
+    want = np.array([hash(float(x)) % n_parts for x in keys], dtype=np.uint8)
+    assert np.array_equal(got, want), np.flatnonzero(got != want)[:10]
+
+
 def test_partition_strings_are_complete(dev):
     from minispark_amd.constants import ColumnType
     from minispark_amd.device import DBatch
