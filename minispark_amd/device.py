@@ -1662,7 +1662,7 @@ class Device:
         key = batch.cols[0]
         if sel is not None:  # values are read by POSITION: bring them into visiting order
             vals = [self.gather_col(v, sel, n) for v in vals]
-        if (self.radix_enabled and n > 0 and key.kind in (hs.I32, hs.I64) and key.dict is None
+        if (self.radix_enabled and n > 0 and self.radix_key_code(key) is not None
                 and all(v.kind in (hs.I32, hs.F32, hs.I64, hs.F64) and v.dict is None for v in vals)):
             # the partial rows in merge order (single GPU: as they are; multi-rank: through sel) are ONE unit of n rows
             bounds = self.to_device(np.asarray([0, n], dtype=np.int64))
