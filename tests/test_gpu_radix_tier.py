@@ -112,11 +112,12 @@ def test_radix_tier_matches_the_ordered_fold(dev, n, units, groups, seed, quanti
 
 
 @pytest.mark.parametrize("classes", ["f", "i", "c", "fc", "if", "cf", "ffc", "icf", "cii", "fif"])
-@pytest.mark.parametrize(("n", "units", "groups"), [(60_000, 4, 9_000), (3_000_000, 2, 400_000)])
+@pytest.mark.parametrize(("n", "units", "groups"), [(60_000, 4, 9_000), (3_000_000, 2, 400_000), (400_000, 3, 41)])
 def test_radix_sum_fold_in_every_class_combination(dev, classes, n, units, groups):
     """Round 3: SUMs over f32 / i32 columns and integer constants (what SUM, AVG and COUNT lower to) run a fold specialised
     at compile time per class combination (k_rx_fold_sum), INTEGER keys the 4-byte partition kernels - same order of
-    additions, so still bit for bit the reference's fold; one and two partition passes, ragged units."""
+    additions, so still bit for bit the reference's fold; one and two partition passes, ragged units; 41 groups: steps in
+    which dozens of the 64 rows share a group (the fold's register-chain form)."""
     from minispark_amd import hipspark as hs
 
     rng = np.random.default_rng(len(classes) * 7 + n % 13)
