@@ -226,6 +226,40 @@ def other_configs(local_rank: int, scratch: Path, steps: int, warmup: int) -> di
     return out
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` as a plain command: start the N ranks as a CHILD `python -m torch.distributed.run`
+    with the same arguments, let rank 0's JSON line through on stdout and hand the child's exit code back.  Called
+    before this process has imported torch or made any HIP call (a process that has touched the GPU must not be
+    replaced, and is not: the parent only waits)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:  # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
+        "HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env, check=False).returncode
+
+
+def launch_probe(rank: int, world: int) -> None:
+    """HIPSPARK_BENCH_LAUNCH_ONLY=1 (tests/test_distributed_cpu.py): the ranks rendezvous, agree on the world size
+    and leave - proves the launch path of `--gpus N` on a box without N GPUs; no kernel, no engine."""
+    import torch
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(os.environ.get("HIPSPARK_DIST_BACKEND", "nccl"))
+    t = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"launched_ranks": int(t.item()), "world": world}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -243,13 +277,18 @@ def main() -> None:
     if args.sf is None:
         args.sf = 100.0 if args.config == "q1" else 10.0
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus))  # nothing has touched the GPU (torch is not even imported yet)
+
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the two must agree")
+    if os.environ.get("HIPSPARK_BENCH_LAUNCH_ONLY") == "1":
+        return launch_probe(rank, world)
     # rehearsal knobs (one-GPU box): HIPSPARK_DIST_BACKEND=gloo HIPSPARK_FORCE_DEVICE=0 run N ranks on one GPU
     backend = os.environ.get("HIPSPARK_DIST_BACKEND", "nccl")
     if "HIPSPARK_FORCE_DEVICE" in os.environ:

@@ -138,3 +138,27 @@ def test_or_flags_reduces_the_whole_status_word_world2():
     result = manager.dict()
     mp.spawn(_flags_worker, args=(world, _free_port(), result), nprocs=world, join=True)
     assert result[0] == result[1] == [0x300, 0x100, 0x309, 0x80000000, 0]
+
+
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the shape of the driver's N=1 command) starts
+    its ranks itself as a child `torch.distributed.run` before anything touches a GPU, relays rank 0's line and its exit
+    code.  HIPSPARK_BENCH_LAUNCH_ONLY stops the ranks right after the rendezvous (no GPU here)."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(HIPSPARK_DIST_BACKEND="gloo", HIPSPARK_BENCH_LAUNCH_ONLY="1")
+    run = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"launched_ranks": 2, "world": 2}
+    # a failing rank's exit code comes back through the parent
+    env["HIPSPARK_DIST_BACKEND"] = "no-such-backend"
+    run = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                         text=True, timeout=300)
+    assert run.returncode != 0
