@@ -30,7 +30,9 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s)
-CUTOFF = "1998-12-01"  # the reference's query; --cutoff 1998-09-02 keeps ~97 % of the rows (predicate not vacuous)
+CUTOFF = "1998-12-01"  # the reference's query (README.md:141-158): TPC-H's last ship date, every row passes
+SELECTIVE_CUTOFF = "1998-09-02"  # SURVEY 8d's second cutoff: ~97 % of the rows pass (other_configs.q1_cutoff)
+Q1_TRAFFIC_FILE = "r04_pmc_hbm_traffic_q1_sf100.json"  # written by tools/pmc_traffic.py from this command's --pmc passes
 Q1_MOVED_BYTES_PER_ROW = 25  # the length bytes of the fixed-width l_returnflag are never read
 
 
@@ -158,10 +160,12 @@ def q1_full_check(rows, total_rows: int, cutoff: str) -> dict:
 
 def timed_steps(wl, engine, steps: int, warmup: int, dist):
     """W untimed + exactly K timed steps of one workload, bracketed by synchronise (+ barrier) on both sides; the MAX
-    over the ranks.  -> (seconds for the K steps, dominant kernel ms per step, exchange ms per step, last rows)."""
+    over the ranks.  -> (seconds for the K steps, dominant kernel ms per step, exchange ms per step, last rows).
+    A workload may hand over several equal `frames` over copies of its table (data that fits the 256 MiB Infinity Cache:
+    SURVEY 8d asks for >= 4 copies in rotation so that the cache does not serve the reads); step i runs frames[i % n]."""
     import torch
 
-    frame = wl.frame
+    frames = getattr(wl, "frames", None) or [wl.frame]
     engine.dev.time_scan_kernel(True)
     if dist is not None:
         engine.dev.time_exchange(True)
@@ -173,17 +177,29 @@ def timed_steps(wl, engine, steps: int, warmup: int, dist):
             torch.cuda.synchronize()
 
     # setup, not warm-up: the first runs of a query compile its kernels (hiprtc), fill the plan / launch caches and
-    # record the replayable launch sequence; whatever --warmup says, the timed steps are steady-state steps
-    for _ in range(3):
-        frame.collect()
+    # record the replayable launch sequence; whatever --warmup says, the timed steps are steady-state steps.  What the
+    # set-up costs is reported, not hidden: `cold`
+    lib = engine.dev._raw_lib
+    jit0, dict0 = lib.hs_jit_compile_seconds(), getattr(engine.dev, "dict_encode_seconds", 0.0)
+    setup_ms = []
+    for frame in frames:
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            frame.collect()
+            setup_ms.append((time.perf_counter() - t0) * 1e3)
+    wl.cold = {"first_collect_ms": setup_ms[0], "second_collect_ms (recorded)": setup_ms[1],
+               "third_collect_ms (first replay)": setup_ms[2],
+               "jit_ms": (lib.hs_jit_compile_seconds() - jit0) * 1e3, "jit_disk_hits": int(lib.hs_jit_disk_hits()),
+               "dict_code_ms": (getattr(engine.dev, "dict_encode_seconds", 0.0) - dict0) * 1e3}
     rows = None
-    for _ in range(warmup):
-        rows = frame.collect()
+    for i in range(warmup):
+        rows = frames[i % len(frames)].collect()
     fence()
     kernel_ms, exchange_ms = [], []
     t0 = time.perf_counter()
-    for _ in range(steps):
-        rows = frame.collect()
+    for i in range(steps):
+        rows = frames[i % len(frames)].collect()
         kernel_ms.append(wl.dominant_kernel_ms())  # the step ended with the result on the host: events are complete
         if dist is not None:
             exchange_ms.append(wl.exchange_ms())
@@ -198,32 +214,92 @@ def timed_steps(wl, engine, steps: int, warmup: int, dist):
     return elapsed, kernel_avg_ms, exchange_avg_ms, rows
 
 
-def other_configs(local_rank: int, scratch: Path, steps: int, warmup: int) -> dict:
-    """BASELINE configs 4 and 5 (sf=10) in the same process, AFTER the headline's timed region: the driver runs the
-    default command only, and these lines must not exist as builder-run files alone.  Each: its own engine and tables,
-    `steps` timed steps like the headline, the timed result checked against the C port over the whole tables."""
+def _other_line(wl, engine, steps: int, warmup: int) -> dict:
+    elapsed, kernel_avg_ms, _, rows = timed_steps(wl, engine, steps, warmup, None)
+    ms = elapsed / steps * 1e3
+    extra = wl.extra_split_ms() if hasattr(wl, "extra_split_ms") else {}
+    return {"metric": wl.metric, "value": wl.total_units / (elapsed / steps), "unit": "rows/s", "steps": steps,
+            "ms_per_step": ms, "config": wl.config(rows), "roofline": wl.roofline(kernel_avg_ms),
+            "time_split_ms": dict({"scan_partial": kernel_avg_ms, "exchange": 0.0,
+                                   "final": ms - kernel_avg_ms - sum(extra.values())}, **extra),
+            "cold": wl.cold, "full_check": wl.full_check(rows)}
+
+
+def other_configs(headline, local_rank: int, scratch: Path, steps: int, warmup: int) -> dict:
+    """What else the driver's line must carry, in the same process AFTER the headline's timed region (the driver runs the
+    default command only; these lines must not exist as builder-run files alone):
+      q1_cutoff  the headline's table under WHERE l_shipdate <= '1998-09-02' (~97 % of the rows: SURVEY 8d, the predicate
+                 is not vacuous);
+      q1_sf1     BASELINE config 2 (Q1 on sf=1): 156 MB - four copies of the table in rotation so that the Infinity Cache
+                 does not serve the reads, and the one-table (cache-resident) figure beside it;
+      join, strkey   BASELINE configs 4 and 5 (sf=10), each with its own engine and tables.
+    Each: `steps` timed steps like the headline, the timed result checked against the C port over the whole tables."""
     from types import SimpleNamespace
 
     from minispark_amd.execution import HipExecutionEngine
     from tools.bench_configs import JoinWorkload, StrKeyWorkload
 
     out = {}
+    engine = headline.engine
+    a = headline.args
+    wl = Q1Workload(engine, scratch, SimpleNamespace(sf=a.sf, cutoff=SELECTIVE_CUTOFF, sample_blocks=a.sample_blocks), 0, 1,
+                    table=(headline.table_path, headline.table))
+    out["q1_cutoff"] = _other_line(wl, engine, steps, warmup)
+    wl = Q1Workload(engine, scratch, SimpleNamespace(sf=1.0, cutoff=CUTOFF, sample_blocks=a.sample_blocks), 0, 1, copies=4)
+    line = _other_line(wl, engine, steps, warmup)
+    wl.frames = wl.frames[:1]
+    resident = timed_steps(wl, engine, steps, warmup, None)
+    line["cache_resident"] = {"ms_per_step": resident[0] / steps * 1e3, "kernel_ms": resident[1],
+                              "note": "the same query on ONE copy of the table (156 MB: served by the Infinity Cache)"}
+    out["q1_sf1"] = line
     for name, cls in (("join", JoinWorkload), ("strkey", StrKeyWorkload)):
         engine = HipExecutionEngine(device=local_rank)
         try:
             wl = cls(engine, scratch / f"other_{name}", SimpleNamespace(sf=10.0, config=name), 0, 1)
-            elapsed, kernel_avg_ms, _, rows = timed_steps(wl, engine, steps, warmup, None)
-            ms = elapsed / steps * 1e3
-            extra = wl.extra_split_ms()
-            out[name] = {"metric": wl.metric, "value": wl.total_units / (elapsed / steps), "unit": "rows/s", "steps": steps,
-                         "ms_per_step": ms, "config": wl.config(rows), "roofline": wl.roofline(kernel_avg_ms),
-                         "time_split_ms": dict({"scan_partial": kernel_avg_ms, "exchange": 0.0,
-                                                "final": ms - kernel_avg_ms - sum(extra.values())}, **extra),
-                         "full_check": wl.full_check(rows)}
+            out[name] = _other_line(wl, engine, steps, warmup)
         finally:
             engine.__exit__(None, None, None)
             del engine
     return out
+
+
+def second_process_cold(args) -> dict:
+    """A second process on the same box (code objects of the first on disk: HIPSPARK_JIT_CACHE): builds the same table and
+    times its FIRST collect().  A child started with subprocess - the parent keeps its tables; 2 processes on the GPU."""
+    import subprocess
+
+    cmd = [sys.executable, str(Path(__file__).resolve()), "--cold-child", "--sf", str(args.sf), "--cutoff", args.cutoff]
+    try:
+        run = subprocess.run(cmd, capture_output=True, text=True, timeout=300, check=False)
+        lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+        if run.returncode != 0 or not lines:
+            return {"error": f"rc {run.returncode}: {run.stderr[-300:]}"}
+        return json.loads(lines[-1])
+    except subprocess.TimeoutExpired:
+        return {"error": "timed out after 300 s"}
+
+
+def cold_child(args) -> None:
+    import torch
+
+    from minispark_amd import constants
+    from minispark_amd.execution import HipExecutionEngine
+
+    scratch = Path(tempfile.mkdtemp(prefix="hipspark_cold_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None))
+    constants.SHUFFLE_FOLDER = scratch / "shuffle"
+    engine = HipExecutionEngine(device=0)
+    wl = Q1Workload(engine, scratch, args, 0, 1)
+    lib = engine.dev._raw_lib
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rows = wl.frame.collect()
+    first = (time.perf_counter() - t0) * 1e3
+    print(json.dumps({"first_collect_ms": first, "jit_ms": lib.hs_jit_compile_seconds() * 1e3,
+                      "jit_disk_hits": int(lib.hs_jit_disk_hits()), "groups": len(rows)}), flush=True)
+    engine.__exit__(None, None, None)
+    import shutil
+
+    shutil.rmtree(scratch, ignore_errors=True)
 
 
 def launch_ranks(n: int) -> int:
@@ -273,9 +349,12 @@ def main() -> None:
     ap.add_argument("--no-other-configs", action="store_true",
                     help="q1 on one GPU: do not run BASELINE configs 4 / 5 (sf=10) after the timed region")
     ap.add_argument("--cutoff", default=CUTOFF, help="q1: WHERE l_shipdate <= CUTOFF")
+    ap.add_argument("--cold-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.sf is None:
         args.sf = 100.0 if args.config == "q1" else 10.0
+    if args.cold_child:
+        return cold_child(args)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args.gpus))  # nothing has touched the GPU (torch is not even imported yet)
@@ -338,12 +417,14 @@ def main() -> None:
                                   **extra_split),
             "whole_step_GBps_per_gpu": wl.algorithmic_bytes_per_launch() / (elapsed / args.steps) / 1e9,
         }
+        out["cold"] = dict(wl.cold)
         if not args.no_full_check:
             out["full_check"] = wl.full_check(rows)
         if world == 1 and dist is None and not args.no_cpu_baseline:
             out["cpu_baseline"] = wl.cpu_baseline()
         if world == 1 and dist is None and args.config == "q1" and not args.no_other_configs and not args.no_full_check:
-            out["other_configs"] = other_configs(local_rank, scratch, args.steps, args.warmup)
+            out["cold"]["second_process_first_collect_ms"] = second_process_cold(args)
+            out["other_configs"] = other_configs(wl, local_rank, scratch, args.steps, args.warmup)
         print(json.dumps(out), flush=True)
     engine.__exit__(None, None, None)
     if dist is not None:
@@ -359,15 +440,23 @@ class Q1Workload:
 
     metric = "TPC-H Q1 lineitem rows/sec"
 
-    def __init__(self, engine, scratch: Path, args, rank: int, world: int) -> None:
+    def __init__(self, engine, scratch: Path, args, rank: int, world: int, table=None, copies: int = 1) -> None:
         from minispark_amd import synth
 
         self.engine, self.scratch, self.args, self.world = engine, scratch, args, world
         self.total_units = synth.lineitem_rows(args.sf)
-        self.table_path = scratch / f"lineitem_sf{args.sf:g}.bin"
-        self.table = synth.make_lineitem(engine.dev, self.table_path, self.total_units, rank=rank, world=world)
-        engine.attach_device_table(self.table_path, self.table)
+        if table is not None:  # another query over a table that is already resident
+            self.table_path, self.table = table
+        else:
+            self.table_path = scratch / f"lineitem_sf{args.sf:g}.bin"
+            self.table = synth.make_lineitem(engine.dev, self.table_path, self.total_units, rank=rank, world=world)
+            engine.attach_device_table(self.table_path, self.table)
         self.frame = q1_frame(engine, str(self.table_path), args.cutoff)
+        self.frames = [self.frame]
+        for k in range(1, copies):  # equal tables at other addresses (timed_steps rotates among them)
+            path = scratch / f"lineitem_sf{args.sf:g}_copy{k}.bin"
+            engine.attach_device_table(path, synth.make_lineitem(engine.dev, path, self.total_units, rank=rank, world=world))
+            self.frames.append(q1_frame(engine, str(path), args.cutoff))
 
     def dominant_kernel_ms(self) -> float:
         return self.engine.dev.scan_kernel_ms()
@@ -395,7 +484,8 @@ class Q1Workload:
                         f"on synthetic lineitem sf={a.sf:g}",
             "rows": self.total_units, "blocks": len(synth.block_sizes(self.total_units)),
             "rows_per_block": constants.ROWS_PER_BLOCK, "bytes_per_row": synth.Q1_BYTES_PER_ROW,
-            "groups": len(rows or []),
+            "groups": len(rows or []), "rows_passing_the_predicate": sum(int(r["count_order"]) for r in rows or []),
+            "table_copies_in_rotation": len(self.frames),
         }
 
     def roofline(self, kernel_avg_ms: float) -> dict:
@@ -413,8 +503,8 @@ class Q1Workload:
             "moved_GBps": Q1_MOVED_BYTES_PER_ROW * local_rows / (kernel_avg_ms * 1e-3) / 1e9,
             "launch": self.engine.dev.last_scan,
         }
-        if self.world == 1 and self.total_units == 600_037_902:
-            out.update(pmc_traffic("r03_pmc_hbm_traffic_q1_sf100.json"))
+        if self.world == 1 and self.total_units == 600_037_902 and self.args.cutoff == CUTOFF:
+            out.update(pmc_traffic(Q1_TRAFFIC_FILE))
             if out["traffic"]:
                 out["hbm_frac"] = out["traffic"] / (kernel_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
         return out

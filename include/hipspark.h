@@ -54,6 +54,7 @@ extern "C" {
 #define HS_FLAG_JOIN_DUP 0x80u     /* hs_join_build_unique met a key twice: the caller takes the general (CSR) join */
 #define HS_FLAG_MERGE_ROWS 0x200u /* hs_agg_merge_small was given an upper bound of rows that does not fit LDS and
                                     ran with what fits; the device-side count turned out larger: use the HBM-tier merge */
+#define HS_FLAG_ROUTE_STALE 0x800u /* hs_join8_route: the build rows no longer route the way the cached split sizes say */
 #define HS_FLAG_PEER_TIMEOUT 0x400u /* hs_slab_wait: a peer's slab did not arrive within the time limit (peer-to-peer exchange) */
 #define HS_FLAG_MERGE_FULL 0x100u /* the FINAL merge met more distinct keys than merge_cap (hs_agg_merge_small /
                                     hs_agg_finish): grow that capacity, the per-unit one (HS_FLAG_DICT_FULL) is fine */
@@ -486,6 +487,30 @@ size_t hs_join8_table_bytes(int64_t slots);
 size_t hs_join8_ws_bytes(int64_t n_build, int64_t slots);
 int hs_join8_build(void* stream, const int32_t* build_keys, const uint8_t* payload, int64_t n_build, int64_t seg_len,
                    const int64_t* seg_counts, int32_t key_min, int64_t slots, uint8_t* table, void* ws, uint32_t* flags);
+/* ---- N ranks: the build side sharded by the probe side's key stripes (round 4).  Reference: both join inputs are
+ * shuffled on the key (plan.py:186-189), one JoinJob per partition (plan.py:99-109, tasks.py:201-240).  Here probe
+ * rows stay on the rank that owns their file block; a probe table clustered on the key gives every block a key stripe
+ * [min, max] (hs_minmax_i32_units: minmax[2u], minmax[2u + 1] per unit; a unit without rows: INT32_MAX, INT32_MIN), and
+ * a build row travels to the owner of every stripe that contains its key: none, one, or the two neighbours of a block
+ * boundary.  stripe_min / stripe_max / stripe_owner [n_stripes <= 4096] (device) list the non-empty blocks of ALL ranks in
+ * block order, min and max non-decreasing (the caller checks; otherwise it keeps the all-gathered build).
+ * hs_join8_route_count -> dest_start[world + 1] (device, caller-owned): where each destination's share of the routed
+ * (row, destination) pairs begins.  hs_join8_route (same ws and dest_start, after the count): out_keys / out_codes grouped by
+ * destination, ready for all_to_all_single with those split sizes; expect_start (optional, device): split sizes agreed in
+ * an earlier run - if the data routes differently now nothing is written and HS_FLAG_ROUTE_STALE is raised.
+ * hs_join8_build_windows: hs_join8_build over the received rows (no segments), assembling and writing ONLY the windows
+ * with window_mask[w] != 0 (device, one byte per HS_JOIN8_WINDOW slots) - those the rank's own stripes reach. */
+int hs_minmax_i32_units(void* stream, const int32_t* values, const int64_t* unit_rows_dev, int64_t n_units, int32_t* minmax);
+size_t hs_join8_route_ws_bytes(int64_t n_build, int32_t world);
+int hs_join8_route_count(void* stream, const int32_t* build_keys, int64_t n_build, const int32_t* stripe_min,
+                         const int32_t* stripe_max, const int32_t* stripe_owner, int32_t n_stripes, int32_t world, void* ws,
+                         uint32_t* dest_start);
+int hs_join8_route(void* stream, const int32_t* build_keys, const uint8_t* payload, int64_t n_build, const int32_t* stripe_min,
+                   const int32_t* stripe_max, const int32_t* stripe_owner, int32_t n_stripes, int32_t world, void* ws,
+                   const uint32_t* dest_start, const uint32_t* expect_start, int32_t* out_keys, uint8_t* out_codes, int64_t out_cap,
+                   uint32_t* flags);
+int hs_join8_build_windows(void* stream, const int32_t* build_keys, const uint8_t* payload, int64_t n_build, int32_t key_min,
+                           int64_t slots, const uint8_t* window_mask, uint8_t* table, void* ws, uint32_t* flags);
 /* out[i] = lut[codes[i]] (re-coding a dictionary-coded column after the ranks agreed on one dictionary). */
 int hs_remap_u8(void* stream, const uint8_t* codes, int64_t n, const uint8_t* lut256, uint8_t* out);
 
@@ -645,6 +670,9 @@ void hs_jit_stats(int32_t* counters);
  * "0" = off), one file per program named by a hash of everything the compiler sees; -> programs of this process that
  * were loaded from there instead of being compiled. */
 int hs_jit_disk_hits(void);
+/* Seconds this process has spent producing code objects (hiprtc compiles + cache reads) - the reference's counterpart is
+ * the wall time of its per-query `zig build` (codegen.py:239-245). */
+double hs_jit_compile_seconds(void);
 const char* hs_jit_last_log(void);
 /* Translate + compile only (needs no GPU): proves the generated source builds for `arch`
  * (NULL = "gfx950"); optionally returns the generated source text. */

@@ -422,13 +422,15 @@ struct ReaderPool {
         for (std::thread& th : threads) th.join();
     }
 
-    void worker(int w) {
+    // `seen0`: the id of the last job posted before this thread existed - a thread added to a pool that has already run
+    // jobs must wait for the NEXT post, not wake on the stale id with `job` reset to null
+    void worker(int w, uint64_t seen0) {
         const bool dev_ok = hipSetDevice(engine->device) == hipSuccess;
         hipStream_t stream = nullptr;
         hipEvent_t ev[HS_READ_SLOTS] = {};
         bool ok_setup = dev_ok && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess;
         for (int k = 0; ok_setup && k < HS_READ_SLOTS; ++k) ok_setup = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) == hipSuccess;
-        uint64_t seen = 0;
+        uint64_t seen = seen0;
         for (;;) {
             Job* j = nullptr;
             {
@@ -438,6 +440,7 @@ struct ReaderPool {
                 seen = job_id;
                 j = job;
             }
+            if (!j) continue;  // (never counted in `working`: nothing to report)
             bool ok = ok_setup;
             const int fd = ok ? open(j->path->c_str(), O_RDONLY) : -1;
             ok = ok && fd >= 0;
@@ -483,7 +486,8 @@ struct ReaderPool {
         engine = e;
         while ((int)threads.size() < n_threads) {
             const int w = (int)threads.size();
-            threads.emplace_back([this, w] { worker(w); });
+            const uint64_t posted = job_id;  // run() is the only writer and is not re-entered
+            threads.emplace_back([this, w, posted] { worker(w, posted); });
         }
         {
             std::lock_guard<std::mutex> lock(m);

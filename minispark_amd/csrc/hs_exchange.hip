@@ -152,7 +152,7 @@ extern "C" size_t hs_slab_p2p_bytes(int32_t world, int64_t slot_bytes) {
 extern "C" int hs_slab_push(void* stream, const void* slab, int64_t slab_bytes, void* const* peers_dev, int32_t world, int32_t rank,
                             int64_t slot_bytes, uint64_t* epochs_dev) {
     if (!slab || !peers_dev || !epochs_dev || world < 1 || world > 1024 || rank < 0 || rank >= world || slab_bytes < 16 ||
-        slab_bytes > slot_bytes || (slot_bytes & 15) || ((uintptr_t)slab & 15)) {
+        slab_bytes > slot_bytes || (slab_bytes & 15) || (slot_bytes & 15) || ((uintptr_t)slab & 15)) {
         hs_set_error("hs_slab_push: bad arguments (slab %lld B, slot %lld B, world %d)", (long long)slab_bytes, (long long)slot_bytes, (int)world);
         return HS_E_ARG;
     }
@@ -168,7 +168,7 @@ extern "C" int hs_slab_push(void* stream, const void* slab, int64_t slab_bytes, 
 extern "C" int hs_slab_wait(void* stream, void* own_buf, int32_t world, int64_t slot_bytes, int64_t slab_bytes, uint64_t* epochs_dev,
                             void* gathered, int64_t out_stride, uint32_t* flags, int64_t timeout_ms) {
     if (!own_buf || !epochs_dev || !gathered || !flags || world < 1 || world > 1024 || slab_bytes < 16 || slab_bytes > slot_bytes ||
-        (slot_bytes & 15) || out_stride < slab_bytes || (out_stride & 15) || ((uintptr_t)gathered & 15) || timeout_ms < 1) {
+        (slab_bytes & 15) || (slot_bytes & 15) || out_stride < slab_bytes || (out_stride & 15) || ((uintptr_t)gathered & 15) || timeout_ms < 1) {
         hs_set_error("hs_slab_wait: bad arguments");
         return HS_E_ARG;
     }

@@ -491,6 +491,7 @@ struct Join8Args {
     uint32_t* tuples;           // [n]: (offset in window) | payload << 24
     uint8_t* table;
     uint32_t* flags;
+    const uint8_t* window_mask;  // optional [n_win]: 0 = this rank never probes the window - it is neither assembled nor written
 };
 
 // window of row i's key, or -1 (padding row of a segment / key outside the table: flagged)
@@ -713,6 +714,10 @@ __global__ void __launch_bounds__(512) k_join8_fill(const Join8Args A) {
     extern __shared__ __align__(16) uint32_t s_win[];  // HS_JOIN8_WINDOW bytes
     __shared__ uint32_t s_occupied;
     const int tid = threadIdx.x, nthr = blockDim.x;
+    if (A.window_mask && !A.window_mask[blockIdx.x]) {  // (workgroup-uniform) a window outside this rank's key stripes
+        if (tid == 0 && A.win_start[blockIdx.x] != A.win_start[blockIdx.x + 1]) atomicOr(A.flags, HS_FLAG_BAD_PROGRAM);  // routed here by mistake
+        return;
+    }
     uint4* w4 = reinterpret_cast<uint4*>(s_win);
     for (int i = tid; i < HS_JOIN8_WINDOW / 16; i += nthr) w4[i] = make_uint4(~0u, ~0u, ~0u, ~0u);
     if (tid == 0) s_occupied = 0;
@@ -770,9 +775,9 @@ extern "C" size_t hs_join8_ws_bytes(int64_t n_build, int64_t slots) {
     hsj8_geometry(n_build, n_win, per, groups, staged);
     return (size_t)(2 * groups * n_win + n_win + 1 + n_build) * 4 + 64;
 }
-extern "C" int hs_join8_build(void* stream, const int32_t* build_keys, const uint8_t* payload, int64_t n_build,
-                              int64_t seg_len, const int64_t* seg_counts, int32_t key_min, int64_t slots, uint8_t* table,
-                              void* ws, uint32_t* flags) {
+static int join8_build_impl(void* stream, const int32_t* build_keys, const uint8_t* payload, int64_t n_build,
+                            int64_t seg_len, const int64_t* seg_counts, int32_t key_min, int64_t slots, uint8_t* table,
+                            void* ws, uint32_t* flags, const uint8_t* window_mask) {
     if (!build_keys || !table || !ws || !flags || n_build < 0 || n_build >= 0xffffffffll || slots < 1 ||
         slots > (1ll << 30) || ((uintptr_t)build_keys & 15) || ((uintptr_t)table & 15) || (payload && ((uintptr_t)payload & 3)) ||
         ((uintptr_t)ws & 3)) {
@@ -809,6 +814,7 @@ extern "C" int hs_join8_build(void* stream, const int32_t* build_keys, const uin
     A.tuples = A.win_start + n_win + 1;
     A.table = table;
     A.flags = flags;
+    A.window_mask = window_mask;
     hipStream_t s = (hipStream_t)stream;
     const size_t stage_lds = (size_t)(2 * n_win + 1 + HSJ8_STAGE_ROWS) * 4;
     static unsigned long long attr_set = 0;
@@ -834,6 +840,244 @@ extern "C" int hs_join8_build(void* stream, const int32_t* build_keys, const uin
     }
     hipLaunchKernelGGL(k_join8_fill, dim3((unsigned)n_win), dim3(512), HS_JOIN8_WINDOW, s, A);
     HSJ_CHECK_LAUNCH("hs_join8_build");
+    return HS_OK;
+}
+
+extern "C" int hs_join8_build(void* stream, const int32_t* build_keys, const uint8_t* payload, int64_t n_build,
+                              int64_t seg_len, const int64_t* seg_counts, int32_t key_min, int64_t slots, uint8_t* table,
+                              void* ws, uint32_t* flags) {
+    return join8_build_impl(stream, build_keys, payload, n_build, seg_len, seg_counts, key_min, slots, table, ws, flags, nullptr);
+}
+// The sharded form (N ranks): only the windows marked in window_mask[n_windows] (device) are assembled and written -
+// the ones this rank's own probe rows can reach; the rest of the table's address range is never touched.
+extern "C" int hs_join8_build_windows(void* stream, const int32_t* build_keys, const uint8_t* payload, int64_t n_build,
+                                      int32_t key_min, int64_t slots, const uint8_t* window_mask, uint8_t* table, void* ws,
+                                      uint32_t* flags) {
+    if (!window_mask) {
+        hs_set_error("hs_join8_build_windows: no window mask");
+        return HS_E_ARG;
+    }
+    return join8_build_impl(stream, build_keys, payload, n_build, 0, nullptr, key_min, slots, table, ws, flags, window_mask);
+}
+
+// =====================================================================================================
+// N ranks: the build side SHARDED by the probe side's key stripes (round 4)
+// =====================================================================================================
+// Reference: both join inputs are shuffled on the key (plan.py:186-189) and a JoinJob sees one partition of each
+// (plan.py:99-109).  Here the probe rows never move; what decides where a BUILD row is needed is which rank's probe
+// blocks can hold its key.  A probe table clustered on the key (TPC-H lineitem on l_orderkey) gives every block a key
+// STRIPE [min, max]; block b lives on rank b % world.  A build row travels to the owner(s) of the stripe(s) containing
+// its key - usually one, two when an order's lines straddle a block boundary, none when no probe block can match it.
+//   hs_minmax_i32_units   the stripes: (min, max) of a key column per unit (file block)
+//   hs_join8_route_count  per destination rank the number of (row, destination) pairs of this rank's build rows
+//   hs_join8_route        the pairs themselves, grouped by destination: keys and payload codes ready for all_to_all_single
+// Stripes arrive sorted by block id with non-decreasing min and max (the host checks that - otherwise the all-gather
+// form runs): the first stripe whose max reaches the key is found by binary search, the following ones are walked
+// while their min does not exceed it.
+
+__global__ void __launch_bounds__(256) k_minmax_i32_units(const int32_t* v, const int64_t* unit_rows, int32_t* out) {
+    __shared__ int32_t s_lo[4], s_hi[4];
+    const int64_t b = unit_rows[blockIdx.x], e = unit_rows[blockIdx.x + 1];
+    int32_t lo = 2147483647, hi = (-2147483647 - 1);
+    for (int64_t i = b + threadIdx.x; i < e; i += blockDim.x) {
+        const int32_t x = v[i];
+        lo = x < lo ? x : lo;
+        hi = x > hi ? x : hi;
+    }
+    for (int d = HS_WAVE / 2; d >= 1; d >>= 1) {
+        const int32_t l2 = __shfl_down(lo, d, HS_WAVE), h2 = __shfl_down(hi, d, HS_WAVE);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if ((threadIdx.x & (HS_WAVE - 1)) == 0) {
+        s_lo[threadIdx.x / HS_WAVE] = lo;
+        s_hi[threadIdx.x / HS_WAVE] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            lo = s_lo[w] < lo ? s_lo[w] : lo;
+            hi = s_hi[w] > hi ? s_hi[w] : hi;
+        }
+        out[2 * blockIdx.x] = lo;       // a unit without rows: (INT32_MAX, INT32_MIN)
+        out[2 * blockIdx.x + 1] = hi;
+    }
+}
+extern "C" int hs_minmax_i32_units(void* stream, const int32_t* values, const int64_t* unit_rows_dev, int64_t n_units,
+                                   int32_t* minmax) {
+    if (!values || !unit_rows_dev || !minmax || n_units < 0 || n_units > (1 << 24)) {
+        hs_set_error("hs_minmax_i32_units: bad arguments");
+        return HS_E_ARG;
+    }
+    if (n_units > 0)
+        hipLaunchKernelGGL(k_minmax_i32_units, dim3((unsigned)n_units), dim3(256), 0, (hipStream_t)stream, values, unit_rows_dev, minmax);
+    HSJ_CHECK_LAUNCH("hs_minmax_i32_units");
+    return HS_OK;
+}
+
+static constexpr int HSJ8_ROUTE_PER = 8192;      // build rows per workgroup of the two routing passes
+static constexpr int HSJ8_ROUTE_STRIPES = 4096;  // stripes staged in LDS (3 x 16 KiB)
+static constexpr int HSJ8_ROUTE_WORLD = 64;      // destinations are a 64-bit set
+
+struct Join8RouteArgs {
+    const int32_t* keys;
+    const uint8_t* payload;  // optional
+    int64_t n;
+    const int32_t* stripe_min;
+    const int32_t* stripe_max;
+    const int32_t* stripe_owner;
+    int32_t n_stripes, world;
+    uint32_t* hist;        // [n_groups][world]
+    uint32_t* offs;        // [n_groups][world]
+    uint32_t* dest_start;  // [world + 1]
+    const uint32_t* expect_start;  // optional [world + 1]: the sizes the host has agreed the collective on
+    int32_t* out_keys;
+    uint8_t* out_codes;
+    int64_t out_cap;
+    uint32_t* flags;
+};
+
+// the ranks that need build key k, as a bit set
+__device__ __forceinline__ uint64_t hsj8_route_set(const int32_t* s_min, const int32_t* s_max, const int32_t* s_own, int n, int32_t k) {
+    int lo = 0, hi = n;  // first stripe with max >= k
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (s_max[mid] < k) lo = mid + 1;
+        else hi = mid;
+    }
+    uint64_t set = 0;
+    for (int b = lo; b < n && s_min[b] <= k; ++b) set |= 1ull << s_own[b];
+    return set;
+}
+
+template <bool SCATTER>
+__global__ void __launch_bounds__(256) k_join8_route(const Join8RouteArgs A) {
+    extern __shared__ __align__(16) int32_t s_stripes[];  // min[n] | max[n] | owner[n]
+    __shared__ uint32_t s_cnt[HSJ8_ROUTE_WORLD];
+    const int NS = A.n_stripes, tid = threadIdx.x, nthr = blockDim.x;
+    int32_t *s_min = s_stripes, *s_max = s_stripes + NS, *s_own = s_stripes + 2 * NS;
+    for (int i = tid; i < NS; i += nthr) {
+        s_min[i] = A.stripe_min[i];
+        s_max[i] = A.stripe_max[i];
+        s_own[i] = A.stripe_owner[i];
+    }
+    if (tid < HSJ8_ROUTE_WORLD) {
+        // scatter pass: the next free position of this workgroup's pairs inside every destination's share
+        s_cnt[tid] = SCATTER && tid < A.world ? A.dest_start[tid] + A.offs[(int64_t)blockIdx.x * A.world + tid] : 0u;
+    }
+    __syncthreads();
+    if (SCATTER && A.expect_start) {  // (uniform) the data no longer routes the way the agreed split sizes say: nothing is written
+        bool stale = false;
+        for (int d = 0; d <= A.world; ++d) stale = stale || A.dest_start[d] != A.expect_start[d];
+        if (stale) {
+            if (tid == 0 && blockIdx.x == 0) atomicOr(A.flags, HS_FLAG_ROUTE_STALE);
+            return;
+        }
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * HSJ8_ROUTE_PER, r1 = r0 + HSJ8_ROUTE_PER < A.n ? r0 + HSJ8_ROUTE_PER : A.n;
+    uint32_t err = 0;
+    for (int64_t i = r0 + tid; i < r1; i += nthr) {
+        const int32_t k = A.keys[i];
+        uint64_t set = hsj8_route_set(s_min, s_max, s_own, NS, k);
+        const uint8_t code = SCATTER && A.payload ? A.payload[i] : (uint8_t)0;
+        while (set) {
+            const int d = __ffsll((unsigned long long)set) - 1;
+            set &= set - 1;
+            const uint32_t pos = atomicAdd(&s_cnt[d], 1u);
+            if constexpr (SCATTER) {
+                if ((int64_t)pos < A.out_cap) {
+                    A.out_keys[pos] = k;
+                    if (A.out_codes) A.out_codes[pos] = code;
+                } else {
+                    err |= HS_FLAG_ROUTE_STALE;
+                }
+            }
+        }
+    }
+    if constexpr (!SCATTER) {
+        __syncthreads();
+        if (tid < A.world) A.hist[(int64_t)blockIdx.x * A.world + tid] = s_cnt[tid];
+    }
+    if (err) atomicOr(A.flags, err);
+}
+
+extern "C" size_t hs_join8_route_ws_bytes(int64_t n_build, int32_t world) {
+    if (n_build < 0 || world < 1 || world > HSJ8_ROUTE_WORLD) return 0;
+    const int64_t groups = (n_build + HSJ8_ROUTE_PER - 1) / HSJ8_ROUTE_PER;
+    return (size_t)(2 * groups * world) * 4 + 64;
+}
+
+static int join8_route_args(const char* who, const int32_t* keys, int64_t n, const int32_t* stripe_min, const int32_t* stripe_max,
+                            const int32_t* stripe_owner, int32_t n_stripes, int32_t world, void* ws, uint32_t* dest_start,
+                            Join8RouteArgs& A, int64_t& groups) {
+    if (!keys || !ws || !dest_start || ((uintptr_t)dest_start & 3) || n < 0 || n >= 0xffffffffll || world < 1 || world > HSJ8_ROUTE_WORLD || n_stripes < 0 ||
+        n_stripes > HSJ8_ROUTE_STRIPES || (n_stripes > 0 && (!stripe_min || !stripe_max || !stripe_owner)) || ((uintptr_t)ws & 3)) {
+        hs_set_error("%s: bad arguments (world <= %d, at most %d stripes)", who, HSJ8_ROUTE_WORLD, HSJ8_ROUTE_STRIPES);
+        return HS_E_ARG;
+    }
+    groups = (n + HSJ8_ROUTE_PER - 1) / HSJ8_ROUTE_PER;
+    A = Join8RouteArgs{};
+    A.keys = keys;
+    A.n = n;
+    A.stripe_min = stripe_min;
+    A.stripe_max = stripe_max;
+    A.stripe_owner = stripe_owner;
+    A.n_stripes = n_stripes;
+    A.world = world;
+    A.hist = (uint32_t*)ws;
+    A.offs = A.hist + groups * world;
+    A.dest_start = dest_start;
+    return HS_OK;
+}
+
+// dest_start[world + 1] (device, caller-owned): where every destination's share of the routed pairs starts;
+// dest_start[world] = all pairs.
+extern "C" int hs_join8_route_count(void* stream, const int32_t* build_keys, int64_t n_build, const int32_t* stripe_min,
+                                    const int32_t* stripe_max, const int32_t* stripe_owner, int32_t n_stripes, int32_t world,
+                                    void* ws, uint32_t* dest_start) {
+    Join8RouteArgs A;
+    int64_t groups;
+    const int rc = join8_route_args("hs_join8_route_count", build_keys, n_build, stripe_min, stripe_max, stripe_owner, n_stripes,
+                                    world, ws, dest_start, A, groups);
+    if (rc != HS_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (groups > 0) {
+        hipLaunchKernelGGL(k_join8_route<false>, dim3((unsigned)groups), dim3(256), (size_t)n_stripes * 12, s, A);
+        hipLaunchKernelGGL(k_join8_scan_groups, dim3((unsigned)((world + 15) / 16)), dim3(1024), 0, s, A.hist, A.offs, (int32_t)groups,
+                           world, A.dest_start);
+    } else {
+        hs_memset_async(A.dest_start, 0, (size_t)(world + 1) * 4, s);
+    }
+    hipLaunchKernelGGL(k_join8_scan_windows, dim3(1), dim3(1024), 0, s, A.dest_start, world);
+    HSJ_CHECK_LAUNCH("hs_join8_route_count");
+    return HS_OK;
+}
+
+// after hs_join8_route_count on the same ws: the pairs, destination-major.  expect_start (optional, device): the split
+// sizes the ranks agreed on in an earlier run - when the data routes differently now, HS_FLAG_ROUTE_STALE is raised and
+// nothing is written (the collective that follows still has its agreed sizes; the query is then repeated from scratch).
+extern "C" int hs_join8_route(void* stream, const int32_t* build_keys, const uint8_t* payload, int64_t n_build,
+                              const int32_t* stripe_min, const int32_t* stripe_max, const int32_t* stripe_owner, int32_t n_stripes,
+                              int32_t world, void* ws, const uint32_t* dest_start, const uint32_t* expect_start, int32_t* out_keys,
+                              uint8_t* out_codes, int64_t out_cap, uint32_t* flags) {
+    Join8RouteArgs A;
+    int64_t groups;
+    const int rc = join8_route_args("hs_join8_route", build_keys, n_build, stripe_min, stripe_max, stripe_owner, n_stripes, world,
+                                    ws, const_cast<uint32_t*>(dest_start), A, groups);
+    if (rc != HS_OK) return rc;
+    if (!out_keys || !flags || out_cap < 0 || (payload && !out_codes)) {
+        hs_set_error("hs_join8_route: no output buffers");
+        return HS_E_ARG;
+    }
+    A.payload = payload;
+    A.expect_start = expect_start;
+    A.out_keys = out_keys;
+    A.out_codes = out_codes;
+    A.out_cap = out_cap;
+    A.flags = flags;
+    if (groups > 0)
+        hipLaunchKernelGGL(k_join8_route<true>, dim3((unsigned)groups), dim3(256), (size_t)n_stripes * 12, (hipStream_t)stream, A);
+    HSJ_CHECK_LAUNCH("hs_join8_route");
     return HS_OK;
 }
 

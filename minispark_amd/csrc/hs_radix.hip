@@ -929,6 +929,16 @@ __global__ void __launch_bounds__(256) k_rx_fold(const RxAgg A_kernarg) {
     }
 }
 
+// Cross-lane read-after-write through LDS inside ONE wave (the rank rounds and the wide key's second word below): the
+// hardware runs a wave's LDS instructions in order, but the COMPILER must be told not to move the plain loads / stores
+// across the hand-over - __builtin_amdgcn_wave_barrier alone is a scheduling barrier, not a memory fence.  Wavefront-scope
+// fences cost no instruction (no s_waitcnt at this scope); they pin the order in the source instead of in today's codegen.
+__device__ __forceinline__ void rx_wave_handover() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---- the fold, specialised for SUMs (round 3) ---------------------------------------------------------------------
 // What SUM / AVG / COUNT lower to: every aggregate is a SUM whose argument is an f32 column (class 0: f64 cell), an i32
 // column (class 1: i64 cell) or an integer constant (class 2: COUNT).  Same tables, same launches (small table first,
@@ -1043,7 +1053,7 @@ __global__ void __launch_bounds__(256) k_rx_fold_sum(const RxAgg A_kernarg) {
                             // the lane that claimed the slot completes it before any lane of the wave - this probe round or a
                             // later one - compares the second word (LDS executes the wave's instructions in order)
                             if (cur == HS_EMPTY_KEY) keys1[h] = k1;
-                            __builtin_amdgcn_wave_barrier();
+                            rx_wave_handover();
                             if (cur == HS_EMPTY_KEY || (cur == k && keys1[h] == k1)) {
                                 inserted = cur == HS_EMPTY_KEY;
                                 slot = (int)h;
@@ -1088,7 +1098,7 @@ __global__ void __launch_bounds__(256) k_rx_fold_sum(const RxAgg A_kernarg) {
                                 *cell = hs_d2u(hs_u2d(*cell) + (double)__uint_as_float(cx[j][col_of(a)]));
                             }
                         }
-                        __builtin_amdgcn_wave_barrier();
+                        rx_wave_handover();
                     }
                 }
             }

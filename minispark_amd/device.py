@@ -15,6 +15,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import struct
+import time
 from dataclasses import dataclass, field
 from typing import Any, Sequence
 
@@ -660,6 +661,15 @@ class Device:
     DICT_SLOTS = 4096  # slots of the string set built on the device (a column with <= 256 distinct strings is coded)
 
     def dict_encode(self, col: DCol) -> DCol | None:
+        """`_dict_encode` with its wall time added to ``dict_encode_seconds`` (it ends on a read-back, so the clock sees the
+        kernels too): the table-open share of a cold query (bench.py `cold`)."""
+        t0 = time.perf_counter()
+        try:
+            return self._dict_encode(col)
+        finally:
+            self.dict_encode_seconds = getattr(self, "dict_encode_seconds", 0.0) + time.perf_counter() - t0
+
+    def _dict_encode(self, col: DCol) -> DCol | None:
         """Try to re-code a STRING column as one byte per row + dictionary (at most 256 distinct strings; sorted, so
         the codes do not depend on row order).  None = the column stays as it is.  Two passes over the column
         (hs_dict_build / hs_dict_assign) and one small read-back: done once, when a table column is loaded."""
@@ -1919,6 +1929,132 @@ class Device:
             self.op(self.join_events[1].record)
         self.last_join = {"mode": "byte table", "slots": slots, "n_build": shape["total"], "table_bytes": int(table.numel())}
         return {"table": table, "key_min": key_min, "slots": slots, "n_parts": n_parts, "keep": (keys, codes, counts, ws)}
+
+    # ---- N ranks: the byte table sharded by the probe side's key stripes (round 4) -----------------------
+    JOIN8_MAX_STRIPES = 4096
+
+    def join8_stripes(self, probe_key: DCol, unit_rows: Sequence[int], unit_ids: Sequence[int] | None, shape: dict,
+                      dist_ctx: tuple) -> dict | None:
+        """The key stripe [min, max] of every probe-side block on every rank - or None when the probe table is not clustered
+        on the key (stripes of consecutive blocks must not step backwards), in which case the caller keeps the all-gathered
+        build.  Learnt once per probe column (one launch + one small read-back + one object all-gather: a collective moment,
+        like the plan exchange of join8_plan; the answer is the same on every rank because it is computed from the gathered
+        list)."""
+        dist, group, world = dist_ctx
+        cached = probe_key.__dict__.get("_hs_join8_stripes")
+        stamp = (world, tuple(unit_rows), tuple(unit_ids or ()), shape["key_min"], shape["slots"])
+        if cached is not None and cached["stamp"] == stamp:
+            return cached["stripes"]
+        n_units = len(unit_rows) - 1
+        ids = list(unit_ids) if unit_ids is not None else list(range(n_units))
+        mine: list[tuple[int, int, int]] = []
+        if n_units > 0 and probe_key.n > 0:
+            bounds = self.to_device_const(np.asarray(unit_rows, dtype=np.int64))
+            minmax = self.empty(2 * n_units, torch.int32)
+            hs.check(self._raw_lib.hs_minmax_i32_units(self.stream, probe_key.data.data_ptr(), bounds.data_ptr(), n_units,
+                                                       minmax.data_ptr()), "hs_minmax_i32_units")
+            vals = minmax.tolist()
+            mine = [(int(ids[u]), int(vals[2 * u]), int(vals[2 * u + 1])) for u in range(n_units)
+                    if unit_rows[u + 1] > unit_rows[u]]
+        if self.rec is not None:
+            self.rec.poisoned = True  # this run learnt the stripes on the way; the next one finds them cached
+        everyone: list = [None] * world
+        dist.all_gather_object(everyone, mine, group=group)
+        blocks = sorted((b, lo, hi, r) for r, part in enumerate(everyone) for b, lo, hi in part)
+        stripes = None
+        clustered = all(blocks[i][1] <= blocks[i + 1][1] and blocks[i][2] <= blocks[i + 1][2] for i in range(len(blocks) - 1))
+        if clustered and 0 < len(blocks) <= self.JOIN8_MAX_STRIPES and world <= 64:
+            key_min, slots = shape["key_min"], shape["slots"]
+            n_win = (slots + hs.JOIN8_WINDOW - 1) // hs.JOIN8_WINDOW
+            mask = np.zeros(n_win, dtype=np.uint8)
+            rank = dist.get_rank(group)
+            for _b, lo, hi, r in blocks:
+                if r == rank:
+                    w0, w1 = max(lo - key_min, 0) // hs.JOIN8_WINDOW, min(hi - key_min, slots - 1) // hs.JOIN8_WINDOW
+                    if w1 >= w0:
+                        mask[w0: w1 + 1] = 1
+            arr = np.asarray(blocks, dtype=np.int64)
+            stripes = {"n": len(blocks), "min": self.to_device_const(arr[:, 1].astype(np.int32)),
+                       "max": self.to_device_const(arr[:, 2].astype(np.int32)),
+                       "owner": self.to_device_const(arr[:, 3].astype(np.int32)),
+                       "window_mask": self.to_device_const(mask), "windows": int(mask.sum()), "n_windows": int(n_win)}
+        probe_key.__dict__["_hs_join8_stripes"] = {"stamp": stamp, "stripes": stripes}
+        return stripes
+
+    def join8_table_sharded(self, shape: dict, stripes: dict, build_key: DCol, payload: DCol | None, n_parts: int,
+                            dist_ctx: tuple) -> dict:
+        """The byte table on N ranks WITHOUT replicating the build (reference: both inputs shuffled on the key,
+        plan.py:186-189; one JoinJob per partition, plan.py:99-109).  Every rank routes its build rows (key + payload code)
+        to the rank(s) whose probe blocks' key stripes contain the key - two all_to_all_single calls of ~1/world of the
+        build side each way instead of all-gathering all of it -, builds only the windows of the table its own stripes
+        reach and probes in place.  The split sizes are data: the first run reads them back and agrees the receive sizes
+        (one small collective); later runs - recorded and replayed - pass the same sizes while the routing kernel verifies
+        on the device that the data still routes that way (HS_FLAG_ROUTE_STALE -> the engine forgets the sizes and repeats
+        the query)."""
+        from .distributed import _a2a, exchange_size_matrix  # noqa: PLC0415
+
+        dist, group, world = dist_ctx
+        slots, key_min, n = shape["slots"], shape["key_min"], build_key.n
+        table = self.workspace(self.lib.hs_join8_table_bytes(slots))
+        route_ws = self.workspace(self.lib.hs_join8_route_ws_bytes(n, world))
+        timed = self.exchange_events
+        if timed is not None:
+            self.op(timed[0].record)
+        sizes = build_key.__dict__.get("_hs_join8_route")
+        stamp = (world, id(stripes), payload is not None)
+        dest_start = self.empty(world + 1, torch.int32)
+        hs.check(self.lib.hs_join8_route_count(self.stream, build_key.data.data_ptr(), n, stripes["min"].data_ptr(),
+                                               stripes["max"].data_ptr(), stripes["owner"].data_ptr(), stripes["n"], world,
+                                               route_ws.data_ptr(), dest_start.data_ptr()), "hs_join8_route_count")
+        if sizes is None or sizes["stamp"] != stamp:
+            starts = [int(v) & 0xFFFFFFFF for v in dest_start.tolist()]
+            if self.rec is not None:
+                self.rec.poisoned = True  # sizes learnt on the host + a collective of its own: never part of a replay
+            send = [starts[d + 1] - starts[d] for d in range(world)]
+            recv = [row[0] for row in exchange_size_matrix(dist, [[c] for c in send], self.device, group)]
+            expect = torch.tensor(starts, dtype=torch.int64).to(torch.int32).to(self.device)
+            sizes = {"stamp": stamp, "send": send, "recv": recv, "expect": expect, "stripes": stripes}
+            build_key.__dict__["_hs_join8_route"] = sizes
+            self.__dict__.setdefault("_route_caches", []).append(build_key)
+        send, recv = sizes["send"], sizes["recv"]
+        n_out, n_in = sum(send), sum(recv)
+        out_keys = self.empty(n_out, torch.int32)
+        out_codes = self.empty(n_out, torch.uint8) if payload is not None else None
+        hs.check(self.lib.hs_join8_route(self.stream, build_key.data.data_ptr(), payload.data.data_ptr() if payload is not None else None,
+                                         n, stripes["min"].data_ptr(), stripes["max"].data_ptr(), stripes["owner"].data_ptr(),
+                                         stripes["n"], world, route_ws.data_ptr(), dest_start.data_ptr(), sizes["expect"].data_ptr(),
+                                         out_keys.data_ptr(),
+                                         out_codes.data_ptr() if out_codes is not None else None, n_out, self.flags.data_ptr()),
+                 "hs_join8_route")
+        keys = self.empty(n_in, torch.int32)
+        self.op(_a2a, dist, keys, out_keys, recv, send, group)
+        codes = None
+        if out_codes is not None:
+            codes = self.empty(n_in, torch.uint8)
+            self.op(_a2a, dist, codes, out_codes, recv, send, group)
+        if timed is not None:
+            self.op(timed[1].record)
+        ws = self.workspace(self.lib.hs_join8_ws_bytes(n_in, slots))
+        if self.join_events is not None:
+            self.op(self.join_events[0].record)
+        hs.check(self.lib.hs_join8_build_windows(self.stream, keys.data_ptr(), codes.data_ptr() if codes is not None else None, n_in,
+                                                 key_min, slots, stripes["window_mask"].data_ptr(), table.data_ptr(), ws.data_ptr(),
+                                                 self.flags.data_ptr()), "hs_join8_build_windows")
+        if self.join_events is not None:
+            self.op(self.join_events[1].record)
+        row_bytes = 4 + (1 if payload is not None else 0)
+        self.last_join = {"mode": "byte table", "sharded": True, "slots": slots, "n_build": shape["total"],
+                          "build_rows_local": n, "build_rows_received": n_in, "bytes_sent": (n_out - send[dist.get_rank(group)]) * row_bytes,
+                          "bytes_received": (n_in - recv[dist.get_rank(group)]) * row_bytes,
+                          "table_bytes": stripes["windows"] * hs.JOIN8_WINDOW, "table_address_range": int(table.numel()),
+                          "windows": f"{stripes['windows']} of {stripes['n_windows']}"}
+        return {"table": table, "key_min": key_min, "slots": slots, "n_parts": n_parts,
+                "keep": (keys, codes, out_keys, out_codes, route_ws, dest_start, ws, sizes)}
+
+    def forget_routes(self) -> None:
+        """HS_FLAG_ROUTE_STALE: the cached split sizes of every sharded build are dropped (the next run agrees them anew)."""
+        for col in self.__dict__.pop("_route_caches", []):
+            col.__dict__.pop("_hs_join8_route", None)
 
     def to_device_const(self, arr: np.ndarray) -> torch.Tensor:
         """A small constant of the query SHAPE (not of this run's data): uploading it does not poison a recording."""

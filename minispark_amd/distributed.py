@@ -21,6 +21,8 @@ plain torch tensor plumbing and device-agnostic: tests/test_distributed_cpu.py r
 
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass, field
 from typing import Any
 
@@ -232,7 +234,12 @@ class PeerSlabs:
     and with 2 - 3 processes sharing the test box's GPU - the 8-GPU xGMI case has not run anywhere."""
 
     SLOT = 256 * 1024
-    TIMEOUT_MS = 20_000
+    # bound of the device-side wait (HS_FLAG_PEER_TIMEOUT).  The decision is RANK-LOCAL by design - reducing the status word
+    # over the ranks would put back the collective this form removes: a rank whose wait ran out raises DeviceError while its
+    # peers may still return that query's result; they run out on their next query (the raising rank pushes no more).  A
+    # timeout therefore means "a peer is lost", never "a peer is slow": runs that are not yet recorded (a peer may still be
+    # in its first-run hiprtc compile) wait ten times as long.
+    TIMEOUT_MS = int(os.environ.get("HIPSPARK_P2P_TIMEOUT_MS", "20000"))
 
     class _Handle(__import__("ctypes").Structure):
         _fields_ = [("reserved", __import__("ctypes").c_char * 64)]
@@ -249,25 +256,36 @@ class PeerSlabs:
             # fine-grained device memory: a peer's stores and flag writes arrive over the fabric, not through this GPU's L2 -
             # the waiting kernel's system-scope loads must see them while it runs (what RCCL does for its own flags)
             self.fine_grained = self.hip.hipExtMallocWithFlags(C.byref(own), C.c_size_t(self.nbytes), C.c_uint(0x1)) == 0
+            problem = None
             if not self.fine_grained:
-                self._check(self.hip.hipMalloc(C.byref(own), C.c_size_t(self.nbytes)), "hipMalloc")
-            self._check(self.hip.hipMemset(own, 0, C.c_size_t(self.nbytes)), "hipMemset")
-            self._check(self.hip.hipDeviceSynchronize(), "hipDeviceSynchronize")
-            self.own = own.value
+                # a coarse-grained buffer would let k_slab_wait spin on a flag its L2 never refreshes, or copy stale slab bytes:
+                # across ranks that is a `problem` like a failed mapping (every rank then keeps the all-gather together); at
+                # world 1 the only writer is this GPU itself and ordinary device memory is sound
+                own = C.c_void_p()
+                if world > 1:
+                    problem = "hipExtMallocWithFlags(fine-grained) failed: no peer-visible buffer on this rank"
+                else:
+                    self._check(self.hip.hipMalloc(C.byref(own), C.c_size_t(self.nbytes)), "hipMalloc")
+            if own.value:
+                self._check(self.hip.hipMemset(own, 0, C.c_size_t(self.nbytes)), "hipMemset")
+                self._check(self.hip.hipDeviceSynchronize(), "hipDeviceSynchronize")
+            self.own = own.value or 0
             self.opened: list[int] = []
             peers = [self.own] * world
             if world > 1:
                 handle = PeerSlabs._Handle()
-                self._check(self.hip.hipIpcGetMemHandle(C.byref(handle), own), "hipIpcGetMemHandle")
+                sent = b""  # a rank without a buffer sends a handle its peers reject: all of them then report a problem
+                if problem is None:
+                    self._check(self.hip.hipIpcGetMemHandle(C.byref(handle), own), "hipIpcGetMemHandle")
+                    sent = C.string_at(C.byref(handle), 64)  # all 64 bytes (they contain NULs)
                 handles: list = [None] * world
-                dist.all_gather_object(handles, C.string_at(C.byref(handle), 64), group=group)  # all 64 bytes (they contain NULs)
-                problem = None
+                dist.all_gather_object(handles, sent, group=group)
                 for p in range(world):
-                    if p == rank:
+                    if p == rank or problem is not None:
                         continue
                     h = PeerSlabs._Handle()
                     if len(handles[p]) != 64:
-                        problem = f"rank {p} sent a malformed IPC handle"
+                        problem = f"rank {p} has no mappable buffer (IPC handle of {len(handles[p])} bytes)"
                         break
                     C.memmove(C.byref(h), handles[p], 64)
                     ptr = C.c_void_p()
@@ -303,11 +321,12 @@ class PeerSlabs:
         hs.check(self.lib.hs_slab_push(stream, slab.data_ptr(), slab.numel(), self.peers_dev.data_ptr(), self.world, self.rank,
                                        self.SLOT, self.epochs.data_ptr()), "hs_slab_push")
 
-    def wait_into(self, stream: Any, slab_bytes: int, gathered: torch.Tensor, flags_ptr: int) -> None:
+    def wait_into(self, stream: Any, slab_bytes: int, gathered: torch.Tensor, flags_ptr: int, recorded: bool = True) -> None:
         from . import hipspark as hs  # noqa: PLC0415
 
         hs.check(self.lib.hs_slab_wait(stream, self.own, self.world, self.SLOT, slab_bytes, self.epochs.data_ptr(),
-                                       gathered.data_ptr(), slab_bytes, flags_ptr, self.TIMEOUT_MS), "hs_slab_wait")
+                                       gathered.data_ptr(), slab_bytes, flags_ptr, self.TIMEOUT_MS * (1 if recorded else 10)),
+                 "hs_slab_wait")
 
     def close(self) -> None:
         import ctypes as C  # noqa: PLC0415

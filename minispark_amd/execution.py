@@ -162,6 +162,10 @@ class HipExecutionEngine(ExecutionEngine):
         self.fused_join_enabled = os.environ.get("HIPSPARK_FUSED_JOIN", "1") != "0"
         self.fused_probe_enabled = os.environ.get("HIPSPARK_FUSED_PROBE", "1") != "0"  # round 3: probe inside the aggregate
         self.fused_probes = 0
+        # N ranks, round 4: the join's byte table built from ROUTED build rows, only where the rank's own probe blocks reach
+        # (0: every rank all-gathers the build side and builds the whole table - also the form for unclustered probe tables)
+        self.sharded_build_enabled = os.environ.get("HIPSPARK_SHARDED_BUILD", "1") != "0"
+        self.sharded_builds = 0
         self._no_join8: set[Any] = set()  # join task ids the fused probe turned out not to hold
         self._no_fused_join: set[Any] = set()  # join task ids whose build side turned out to hold duplicate keys
         self._fused_join_tasks: set[Any] = set()  # join task ids the running query took the in-place path for
@@ -440,7 +444,7 @@ class HipExecutionEngine(ExecutionEngine):
     def _switches(self) -> tuple:
         """The run-time switches a recording was made under (tests flip them between runs of one query)."""
         return (self.replay_enabled, self.short_tail_enabled, self.shared_tier_enabled, self.dict_enabled,
-                self.fused_join_enabled, self.fused_probe_enabled, self.dev.zero_copy_results)
+                self.fused_join_enabled, self.fused_probe_enabled, self.sharded_build_enabled, self.dev.zero_copy_results)
 
     @staticmethod
     def _stamp_of(path: str) -> tuple:
@@ -991,7 +995,17 @@ class HipExecutionEngine(ExecutionEngine):
             return None
         if right.cols[rkey].data.data_ptr() % 16 or left.cols[lkey].data.data_ptr() % 16:
             raise ExecutionError("join key columns must be 16-byte aligned")
-        j = dev.join8_table(shape, left.cols[lkey], payload, constants.SHUFFLE_PARTITIONS, self._dist_ctx())
+        ctx = self._dist_ctx()
+        stripes = None
+        if ctx is not None and self.sharded_build_enabled and ctx[2] <= 64:
+            # N ranks: a probe table clustered on the key (every block a key stripe) lets every rank build only the part of
+            # the table its own blocks can reach, from build rows routed to it; otherwise the whole build side is gathered
+            stripes = dev.join8_stripes(right.cols[rkey], right.unit_rows, right.unit_ids, shape, ctx)
+        if stripes is not None:
+            j = dev.join8_table_sharded(shape, stripes, left.cols[lkey], payload, constants.SHUFFLE_PARTITIONS, ctx)
+            self.sharded_builds += 1
+        else:
+            j = dev.join8_table(shape, left.cols[lkey], payload, constants.SHUFFLE_PARTITIONS, ctx)
         j["probe_key"] = right.cols[rkey]
         n = right.nrows
         schema, cols = [], []
@@ -1480,6 +1494,11 @@ class HipExecutionEngine(ExecutionEngine):
 
         if not flags:
             return
+        if flags & hs.FLAG_ROUTE_STALE:
+            # a sharded join build met other data than the split sizes it had agreed on (raised on every rank: the status
+            # words meet before this decision): forget the sizes, run again - the next run agrees them anew
+            self.dev.forget_routes()
+            raise RestartQuery
         if flags & hs.FLAG_JOIN_DUP:
             # the in-place join met a build key twice: every join of this query takes the general path from now on
             self._no_fused_join.update(self._fused_join_tasks)
@@ -1522,7 +1541,8 @@ class HipExecutionEngine(ExecutionEngine):
                 # prototype (HIPSPARK_P2P_SLABS=1): stores into every peer's mapped buffer + device-side flags, no collective
                 # (two library launches: recorded and replayed like every other launch of the query, arguments unchanged)
                 peers.push(self.dev.stream, slab)
-                peers.wait_into(self.dev.stream, tail["layout"].nbytes, gathered, self.dev.flags.data_ptr())
+                peers.wait_into(self.dev.stream, tail["layout"].nbytes, gathered, self.dev.flags.data_ptr(),
+                                recorded=self.dev.rec is not None)
                 if self.dev.rec is not None:
                     self.dev.rec.keep.append((slab, gathered))
                 self.p2p_exchanges += 1
@@ -1561,7 +1581,9 @@ class HipExecutionEngine(ExecutionEngine):
             from .distributed import PeerSlabs, PeerSlabsUnavailable  # noqa: PLC0415
 
             try:
-                self._p2p = PeerSlabs(self.dist, self.group, self.rank, self.world, self.dev.device, self.dev.lib)
+                # the library itself, never the recording proxy of whichever run happens to be first: PeerSlabs lives as long as
+                # the engine and a stale proxy would keep appending its arguments to that old recording
+                self._p2p = PeerSlabs(self.dist, self.group, self.rank, self.world, self.dev.device, self.dev._raw_lib)
             except PeerSlabsUnavailable as e:  # raised on every rank together: all of them keep the all-gather
                 print(f"[hipspark] peer-to-peer slabs unavailable, using the all-gather: {e}", file=sys.stderr, flush=True)
                 self._p2p = False

@@ -38,7 +38,8 @@ FLAG_STR_TOO_LONG = 0x20
 FLAG_TYPE_ASSERT = 0x40
 FLAG_JOIN_DUP = 0x80
 FLAG_PEER_TIMEOUT = 0x400
-FLAG_KNOWN = 0x7FF  # every HS_FLAG_* bit include/hipspark.h defines
+FLAG_ROUTE_STALE = 0x800
+FLAG_KNOWN = 0xFFF  # every HS_FLAG_* bit include/hipspark.h defines
 
 AGG_SUM, AGG_MIN, AGG_MAX = 0, 1, 2
 
@@ -306,6 +307,11 @@ SIGNATURES: dict[str, tuple] = {
     "hs_join8_table_bytes": (C.c_size_t, [_I64]),
     "hs_join8_ws_bytes": (C.c_size_t, [_I64, _I64]),
     "hs_join8_build": (C.c_int, [_P, _P, _P, _I64, _I64, _P, _I32, _I64, _P, _P, _P]),
+    "hs_minmax_i32_units": (C.c_int, [_P, _P, _P, _I64, _P]),
+    "hs_join8_route_ws_bytes": (C.c_size_t, [_I64, _I32]),
+    "hs_join8_route_count": (C.c_int, [_P, _P, _I64, _P, _P, _P, _I32, _I32, _P, _P]),
+    "hs_join8_route": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _I64, _P]),
+    "hs_join8_build_windows": (C.c_int, [_P, _P, _P, _I64, _I32, _I64, _P, _P, _P, _P]),
     "hs_remap_u8": (C.c_int, [_P, _P, _I64, _P, _P]),
     "hs_dict_build": (C.c_int, [_P, _COLP, _I64, _I32, _P, _P, _P, _P]),
     "hs_dict_assign": (C.c_int, [_P, _COLP, _I64, _I32, _P, _P, _P, _P, _P]),
@@ -322,6 +328,7 @@ SIGNATURES: dict[str, tuple] = {
     "hs_jit_get_enabled": (C.c_int, []),
     "hs_jit_stats": (None, [C.POINTER(_I32)]),
     "hs_jit_disk_hits": (C.c_int, []),
+    "hs_jit_compile_seconds": (C.c_double, []),
     "hs_jit_last_log": (C.c_char_p, []),
     "hs_jit_compile_check": (C.c_int, [_COLP, _I32, _I32, _PROGP, _SPECP, C.c_char_p, C.POINTER(_I64), C.c_char_p, _I64]),
     "hs_jit_compile_check_shared": (C.c_int, [_COLP, _I32, _I32, _I32, _PROGP, _SPECP, C.c_char_p, C.POINTER(_I64),

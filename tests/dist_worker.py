@@ -74,7 +74,10 @@ def main() -> None:
             for _ in range(5):
                 rows = wl.frame.collect()
             report = {"replays": engine.replays, "fused_probes": engine.fused_probes, "rows": len(rows),
-                      "join": getattr(engine.dev, "last_join", None)}
+                      "join": getattr(engine.dev, "last_join", None), "sharded_builds": engine.sharded_builds}
+            joins: list = [None] * world
+            dist.all_gather_object(joins, report["join"])
+            report["joins"] = joins
             if rank == 0:
                 report["check"] = wl.full_check(rows)
                 report["n"] = sum(r.get("n", r.get("count", 0)) for r in rows)

@@ -199,12 +199,12 @@ def test_final_merge_outgrowing_its_capacity_is_retried_on_every_rank(tmp_path, 
 
 
 # ---- BASELINE config 4 as stated: hash-join + GROUP BY on N GPUs, at size ---------------------------------------------
-def _run_config_ranks(case: str, world: int, out, backend: str = "gloo") -> dict:
+def _run_config_ranks(case: str, world: int, out, backend: str = "gloo", extra_env: dict | None = None) -> dict:
     port = _free_port()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
+                   MASTER_PORT=str(port), **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, str(ROOT / "tests" / "dist_worker.py"), case, str(out), backend],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = [p.communicate(timeout=600)[0].decode() for p in procs]
@@ -214,19 +214,39 @@ def _run_config_ranks(case: str, world: int, out, backend: str = "gloo") -> dict
     return json.loads(out.read_text())
 
 
-@pytest.mark.parametrize("world,backend,sf", [(2, "gloo", 10), (3, "gloo", 10), (1, "nccl", 10), (4, "gloo", 1)])
-def test_config4_on_n_ranks_matches_the_c_port(tmp_path, world, backend, sf):
+@pytest.mark.parametrize("world,backend,sf,build", [(2, "gloo", 10, "sharded"), (3, "gloo", 10, "sharded"), (4, "gloo", 10, "sharded"),
+                                                    (1, "nccl", 10, "sharded"), (4, "gloo", 1, "sharded"), (2, "gloo", 1, "gathered")])
+def test_config4_on_n_ranks_matches_the_c_port(tmp_path, world, backend, sf, build):
     """orders JOIN lineitem GROUP BY o_orderpriority with both tables spread over the ranks (block b on rank b % N):
-    dictionaries agreed across ranks, the build side all-gathered (key + code bytes), the byte table built on every
-    rank, the probe inside each rank's aggregate scan over its OWN lineitem blocks, raw unit tables added up over the
-    ranks before the one rounding per JoinJob, finish launch on every rank - equal to q4_run (the C port of the
-    reference's algorithm, pinned to its goldens) over the whole sf=10 tables.  RCCL itself at world 1."""
-    report = _run_config_ranks(f"config4:{sf}", world, tmp_path / "report.json", backend)
+    dictionaries agreed across ranks, the probe inside each rank's aggregate scan over its OWN lineitem blocks, raw unit
+    tables added up over the ranks before the one rounding per JoinJob, finish launch on every rank - equal to q4_run (the C
+    port of the reference's algorithm, pinned to its goldens) over the whole tables.  RCCL itself at world 1.
+    Round 4, "sharded": lineitem is clustered on the order key, so every rank builds only the windows of the byte table its
+    own blocks' key stripes reach, from build rows ROUTED to it (two all_to_all_single calls of about 1/N of the build side)
+    - table bytes written and build rows per rank are about 1/N; the split sizes are agreed in the first run and verified
+    on the device in the recorded / replayed ones.  "gathered": the fallback for unclustered probe tables (every rank
+    all-gathers the build side and builds the whole table), forced here."""
+    env = {"HIPSPARK_SHARDED_BUILD": "0"} if build == "gathered" else None
+    report = _run_config_ranks(f"config4:{sf}", world, tmp_path / "report.json", backend, env)
     assert report["check"]["gpu_matches_oracle_full"], report
     assert report["check"]["f32_ulp_flips_full"] <= 2
     assert report["fused_probes"] >= 1 and report["join"]["mode"] == "byte table", "N ranks must not fall back to the general join"
     assert report["replays"] >= 1, "recorded and replayed, collectives included"
     assert report["rows"] == 5 and report["n"] > 0
+    joins = report["joins"]  # every rank's last build
+    if build == "gathered":
+        assert not any(j.get("sharded") for j in joins)
+        return
+    assert all(j.get("sharded") for j in joins) and report["sharded_builds"] >= 1
+    n_build, full = joins[0]["n_build"], joins[0]["table_address_range"]
+    # every build row whose key some block can match arrives once, plus once more per block boundary its lines straddle
+    received = sum(j["build_rows_received"] for j in joins)
+    assert n_build - 16 <= received <= n_build + 64 * world, (received, n_build)
+    if sf >= 10:  # 29 lineitem blocks: every rank owns several stripes; its share of table and build rows is about 1/N
+        for j in joins:
+            assert j["table_bytes"] <= full / world * 1.25 + 4 * 65536, (j, world)
+            assert j["build_rows_received"] <= n_build / world * 1.25 + 1024, (j, world)
+        assert sum(j["table_bytes"] for j in joins) <= full + (29 + world) * 65536
 
 
 @pytest.mark.parametrize("world", [2, 3])
