@@ -389,6 +389,10 @@ def main() -> None:
 
     scratch = Path(tempfile.mkdtemp(prefix=f"hipspark_bench_r{rank}_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None))
     constants.SHUFFLE_FOLDER = scratch / "shuffle"
+    if "HIPSPARK_JIT_CACHE" not in os.environ:
+        # a code-object cache of this run's own: `cold.jit_ms` is then a real hiprtc compile, not a hit on what an earlier
+        # process of the box left behind; the second process of `cold` (and the other configs' engines) find it warm
+        os.environ["HIPSPARK_JIT_CACHE"] = str(scratch / "jit-cache")
     engine = HipExecutionEngine(device=local_rank)
     if dist is not None:
         engine.enable_distributed(dist)

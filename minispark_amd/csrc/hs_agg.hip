@@ -27,9 +27,14 @@ __global__ void __launch_bounds__(256) k_agg_main(const AggMainArgs A_kernarg) {
     hs_agg_main_body<InterpProg<HASHED, D>>(A);
 }
 
-// shared-dictionary tier (hs_agg_kernel.h): interpreter instantiations
+// shared-dictionary tier (hs_agg_kernel.h): interpreter instantiations.  512 lanes, not the compiled programs' 1024: the
+// interpreter's operand stack (D x 4 rows x 64 bits) does not fit 128 VGPRs - at 1024 lanes it lived in scratch memory
+// (440-712 bytes per lane, ~5 400 scratch instructions).  A stack of depth 4 fits the 256 VGPRs of a 512-lane workgroup,
+// depth 8 needs the accumulation registers as well: 256 lanes.  Chunks are whole steps of 1024 x 4 rows, so any of these
+// widths walks them exactly.
+static constexpr int hs_shared_interp_wg(int depth) { return depth > 4 ? 256 : 512; }
 template <bool HASHED, int D>
-__global__ void __launch_bounds__(1024) k_agg_shared(const AggMainArgs A_kernarg) {
+__global__ void __launch_bounds__(hs_shared_interp_wg(D)) k_agg_shared(const AggMainArgs A_kernarg) {
     HS_KERNARG(AggMainArgs, A);
     hs_agg_shared_body<InterpProg<HASHED, D>>(A);
 }
@@ -114,7 +119,7 @@ __global__ void __launch_bounds__(256) k_agg_shared_finish(const SharedFinishArg
 
 // --------------------------------------------------------------------------------------------------
 // One workgroup per unit: the stand-alone form of the unit combine (body: hs_agg_kernel.h).  Used when the combine is
-// not fused into the scan kernel's epilogue (HIPSPARK_FUSE_UNIT=0, a unit without rows, tables too small to stage it).
+// not fused into the scan kernel's epilogue (a unit without rows, tables too small to stage it).
 __global__ void __launch_bounds__(256) k_agg_unit(const AggUnitArgs A_kernarg) {
     HS_KERNARG(AggUnitArgs, A);
     extern __shared__ __align__(16) uint64_t lds[];
@@ -1355,9 +1360,8 @@ static int agg_partial_impl(void* stream, const hs_col* cols, int32_t n_cols, in
     A.unit_col = -1;
     A.pad3 = 0;
     A.chunk_acc = nullptr;
-    static const bool fuse_env = !(getenv("HIPSPARK_FUSE_UNIT") && getenv("HIPSPARK_FUSE_UNIT")[0] == '0');
     bool fused = false;
-    if (fuse_env && geom->pad == HS_GEOM_FUSABLE && spec->n_acc > 0) {
+    if (geom->pad == HS_GEOM_FUSABLE && spec->n_acc > 0) {
         int fbatch = ubatch;
         while (fbatch > 1 && ubase + (size_t)fbatch * uper > geom->lds_bytes) fbatch /= 2;
         if (ubase + (size_t)fbatch * uper <= geom->lds_bytes) {
@@ -1613,8 +1617,7 @@ extern "C" int hs_agg_finish(void* stream, const uint8_t* gathered, int32_t worl
                 ++n_simple;
                 pc += 2;
             }
-            static const bool simple_env = !(getenv("HIPSPARK_SIMPLE_PROJECTION") && getenv("HIPSPARK_SIMPLE_PROJECTION")[0] == '0');
-            A.n_simple = ok && simple_env ? n_simple : 0;
+            A.n_simple = ok ? n_simple : 0;
         }
     } else if (n_prog_out) {
         hs_set_error("hs_agg_finish: program outputs without a program");
@@ -1908,11 +1911,11 @@ static int agg_shared_impl(void* stream, const hs_col* cols, int32_t n_cols, int
         hs_set_error("hs_agg_shared_join8: needs the run-time compiler (hiprtc): %s", hs_jit_last_log());
         return HS_E_LIMIT;
     } else if (hashed) {
-        hipLaunchKernelGGL((k_agg_shared<true, 8>), grid, block, geom->lds_bytes, s, A);
+        hipLaunchKernelGGL((k_agg_shared<true, 8>), grid, dim3(hs_shared_interp_wg(8)), geom->lds_bytes, s, A);
     } else if (depth <= 4) {
-        hipLaunchKernelGGL((k_agg_shared<false, 4>), grid, block, geom->lds_bytes, s, A);
+        hipLaunchKernelGGL((k_agg_shared<false, 4>), grid, dim3(hs_shared_interp_wg(4)), geom->lds_bytes, s, A);
     } else {
-        hipLaunchKernelGGL((k_agg_shared<false, 8>), grid, block, geom->lds_bytes, s, A);
+        hipLaunchKernelGGL((k_agg_shared<false, 8>), grid, dim3(hs_shared_interp_wg(8)), geom->lds_bytes, s, A);
     }
     if (A.chunk_acc && spec->n_acc > 0) {
         SharedFoldArgs G;

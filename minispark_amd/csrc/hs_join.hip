@@ -753,10 +753,9 @@ __global__ void __launch_bounds__(512) k_join8_fill(const Join8Args A) {
 static int64_t hsj8_windows(int64_t slots) { return (slots + HS_JOIN8_WINDOW - 1) >> HSJ8_WSHIFT; }
 // rows per workgroup of the two passes over the build rows; staged = the scatter's LDS form applies
 static void hsj8_geometry(int64_t n, int64_t n_win, int64_t& per, int64_t& groups, bool& staged) {
-    static const bool allow = !(getenv("HIPSPARK_JOIN8_STAGED") && getenv("HIPSPARK_JOIN8_STAGED")[0] == '0');
     per = HSJ8_STAGE_ROWS;
     groups = n > 0 ? (n + per - 1) / per : 0;
-    staged = allow && n_win <= HSJ8_STAGE_WINDOWS && (size_t)groups * (size_t)n_win * 8 <= ((size_t)256 << 20);
+    staged = n_win <= HSJ8_STAGE_WINDOWS && (size_t)groups * (size_t)n_win * 8 <= ((size_t)256 << 20);
     if (!staged) {  // big inputs: at most 1024 workgroups, tuples go straight to their place
         per = (n + 1023) / 1024;
         if (per < 8192) per = 8192;
@@ -1010,7 +1009,7 @@ extern "C" size_t hs_join8_route_ws_bytes(int64_t n_build, int32_t world) {
 static int join8_route_args(const char* who, const int32_t* keys, int64_t n, const int32_t* stripe_min, const int32_t* stripe_max,
                             const int32_t* stripe_owner, int32_t n_stripes, int32_t world, void* ws, uint32_t* dest_start,
                             Join8RouteArgs& A, int64_t& groups) {
-    if (!keys || !ws || !dest_start || ((uintptr_t)dest_start & 3) || n < 0 || n >= 0xffffffffll || world < 1 || world > HSJ8_ROUTE_WORLD || n_stripes < 0 ||
+    if ((!keys && n > 0) || !ws || !dest_start || ((uintptr_t)dest_start & 3) || n < 0 || n >= 0xffffffffll || world < 1 || world > HSJ8_ROUTE_WORLD || n_stripes < 0 ||
         n_stripes > HSJ8_ROUTE_STRIPES || (n_stripes > 0 && (!stripe_min || !stripe_max || !stripe_owner)) || ((uintptr_t)ws & 3)) {
         hs_set_error("%s: bad arguments (world <= %d, at most %d stripes)", who, HSJ8_ROUTE_WORLD, HSJ8_ROUTE_STRIPES);
         return HS_E_ARG;

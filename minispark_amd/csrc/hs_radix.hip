@@ -95,6 +95,8 @@ struct RxPass {
     int64_t n_seg;
     int32_t shift, bits;       // bin = (mix(key word) >> shift) & (2^bits - 1); raw: ((key + 1) >> shift) & ... (hs_sort_by_order)
     int32_t n_cols, first;     // columns that travel (0 = key); first pass reads the key through `key` / `sel`
+    int32_t range, range_bias; // range (4-byte keys only): bin = ((key - range_bias) >> shift) & (2^bits - 1) - partitions are KEY RANGES,
+                               // most significant bits first (the dense join build); else a mix of the key's bits
     int32_t wide, pad_w;       // wide: a STRING key of one fixed length 8 .. 16 travels as this many 4-byte word columns (2 .. 4), round 3
     int32_t raw, key4;         // key4: the key is a 4-byte integer (bins from a 32-bit mix: a quarter of hs_mix64's multiplies)
     hs_col key;
@@ -124,8 +126,12 @@ __device__ __forceinline__ uint32_t rx_mix32(uint32_t k) {
     return h ^ (h >> 16);
 }
 __device__ __forceinline__ uint32_t rx_bin4(uint32_t key, int shift, int bits) { return (rx_mix32(key) >> shift) & ((1u << bits) - 1u); }
+// ... or, for range partitions (RxPass.range; wave-uniform choice), bits of the key's offset itself
+__device__ __forceinline__ uint32_t rx_bin4r(const RxPass& A, uint32_t key, int shift, int bits) {
+    return A.range ? ((key - (uint32_t)A.range_bias) >> shift) & ((1u << bits) - 1u) : rx_bin4(key, shift, bits);
+}
 __device__ __forceinline__ uint32_t rx_bin_of(const RxPass& A, uint64_t word) {
-    return A.key4 ? rx_bin4((uint32_t)word, A.shift, A.bits) : rx_bin(word, A.shift, A.bits, A.raw);
+    return A.key4 ? rx_bin4r(A, (uint32_t)word, A.shift, A.bits) : rx_bin(word, A.shift, A.bits, A.raw);
 }
 __device__ __forceinline__ void rx_move(const void* src, void* dst, int esize, int64_t from, int64_t to) {
     if (esize == 4) ((uint32_t*)dst)[to] = ((const uint32_t*)src)[from];
@@ -166,17 +172,16 @@ __global__ void __launch_bounds__(RX_THREADS) k_rx_hist(const RxPass A_kernarg) 
 // rank among the rows of its bin = the wave's running count of the bin + its rank among this step's equal-bin lanes
 // (the AND of one ballot per bin bit).  A scan over the waves per bin and the tile's scanned counter finish the address.
 //
-// STAGED: the tile is first put in bin order in LDS, one column at a time, and written out by consecutive threads:
-// the rows of a bin (32 on average at fan-out 256) leave as one or two contiguous segments instead of one 4-8 B store
-// per row and bin - the store path of a CU takes a request per distinct line, not per byte.
-template <bool STAGED>
+// The tile is first put in bin order in LDS, one column at a time, and written out by consecutive threads: the rows of
+// a bin (32 on average at fan-out 256) leave as one or two contiguous segments instead of one 4-8 B store per row and
+// bin - the store path of a CU takes a request per distinct line, not per byte.
 // two workgroups per CU (<= 64 VGPRs, a few spilled) beat one at 94 VGPRs: 560 us against 840 us per pass of 64 M rows
 __global__ void __launch_bounds__(RX_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) k_rx_scatter(const RxPass A_kernarg) {
     HS_KERNARG(RxPass, A);
     __shared__ uint32_t whist[RX_WAVES][1 << RX_MAX_BITS];
     __shared__ int64_t gbase[1 << RX_MAX_BITS];
     __shared__ uint32_t s_wave_tot[4];
-    extern __shared__ __align__(16) uint8_t rx_stage[];  // STAGED: sbin[RX_TILE] u8, then stage[RX_TILE] of the widest column
+    extern __shared__ __align__(16) uint8_t rx_stage[];  // sbin[RX_TILE] u8, then stage[RX_TILE] of the widest column
     int64_t seg, t;
     if (!rx_find_tile(A.tile_base, A.n_seg, blockIdx.x, seg, t)) return;
     const int tid = threadIdx.x, lane = tid & (HS_WAVE - 1), w = tid / HS_WAVE, F = 1 << A.bits;
@@ -225,7 +230,7 @@ __global__ void __launch_bounds__(RX_THREADS) __attribute__((amdgpu_waves_per_eu
         bin_total = run;
         gbase[tid] = A.counters[(A.tile_base[seg] << A.bits) + (int64_t)tid * nt + t];
     }
-    if constexpr (STAGED) {
+    {
         // tile-local start of every bin: exclusive scan of the bin totals (threads 0 .. 255 = waves 0 .. 3);
         // gbase becomes "global position minus tile-local position"
         uint32_t x = bin_total;
@@ -296,40 +301,12 @@ __global__ void __launch_bounds__(RX_THREADS) __attribute__((amdgpu_waves_per_eu
             }
             write_out(A.dst[c], es);
         }
-        return;
-    }
-    __syncthreads();
-    int64_t to[RX_PER];
-#pragma unroll
-    for (int j = 0; j < RX_PER; ++j) {
-        to[j] = first + j * HS_WAVE < e ? gbase[bin[j]] + whist[w][bin[j]] + local[j] : -1;
-        if (to[j] < 0) continue;
-        if (A.esize[0] == 4) ((int32_t*)A.dst[0])[to[j]] = (int32_t)word[j];
-        else ((uint64_t*)A.dst[0])[to[j]] = word[j];
-    }
-    for (int c = 1; c < A.n_cols; ++c) {
-        const int es = A.esize[c];
-        const void* src = A.src[c];
-        void* dst = A.dst[c];
-        uint64_t v[RX_PER];
-#pragma unroll
-        for (int j = 0; j < RX_PER; ++j) {
-            const int64_t i = first + j * HS_WAVE;
-            v[j] = to[j] < 0 ? 0 : (es == 4 ? (uint64_t)((const uint32_t*)src)[i] : es == 8 ? ((const uint64_t*)src)[i] : (uint64_t)((const uint8_t*)src)[i]);
-        }
-#pragma unroll
-        for (int j = 0; j < RX_PER; ++j) {
-            if (to[j] < 0) continue;
-            if (es == 4) ((uint32_t*)dst)[to[j]] = (uint32_t)v[j];
-            else if (es == 8) ((uint64_t*)dst)[to[j]] = v[j];
-            else ((uint8_t*)dst)[to[j]] = (uint8_t)v[j];
-        }
     }
 }
 
 // ---- the pass for 4-byte tuples (round 3) --------------------------------------------------------------------------
 // INTEGER key + up to three 4-byte value columns (f32 / i32: what SUM, AVG, COUNT over stored columns carry): the same
-// tile, ranking and staging as k_rx_hist / k_rx_scatter<true> with everything that was decided per element at run time
+// tile, ranking and staging as k_rx_hist / k_rx_scatter with everything that was decided per element at run time
 // (element size, first pass or later, selection, key kind) decided at compile time, tile-local 32-bit indexing and the
 // 32-bit bin mix.  FIRST: the key is read from the table's INTEGER column at row0 + position, or through the row list.
 template <bool FIRST>
@@ -363,7 +340,7 @@ __global__ void __launch_bounds__(RX_H4_THREADS) k_rx_hist4(const RxPass A_kerna
     const int shift = A.shift, bits = A.bits;
 #pragma unroll
     for (int j = 0; j < RX_H4_PER; ++j)
-        if (tid + j * RX_H4_THREADS < rows) atomicAdd(&hist[w][rx_bin4(key[j], shift, bits)], 1u);
+        if (tid + j * RX_H4_THREADS < rows) atomicAdd(&hist[w][rx_bin4r(A, key[j], shift, bits)], 1u);
     __syncthreads();
     const int64_t nt = A.tile_base[seg + 1] - A.tile_base[seg];
     if (tid < F) {
@@ -400,6 +377,11 @@ __global__ void __launch_bounds__(RX_THREADS) __attribute__((amdgpu_waves_per_eu
     }
 #pragma unroll
     for (int c = 0; c < NV; ++c) {
+        if (FIRST && A.src[1 + c] == nullptr) {  // (uniform) a first pass without this column: it carries the row's POSITION
+#pragma unroll
+            for (int j = 0; j < RX_PER; ++j) val[c][j] = (uint32_t)(b + first + j * HS_WAVE);
+            continue;
+        }
         const uint32_t* src = (const uint32_t*)A.src[1 + c] + b;
 #pragma unroll
         for (int j = 0; j < RX_PER; ++j) val[c][j] = first + j * HS_WAVE < rows ? src[first + j * HS_WAVE] : 0u;
@@ -412,7 +394,7 @@ __global__ void __launch_bounds__(RX_THREADS) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
     for (int j = 0; j < RX_PER; ++j) {
         const bool valid = first + j * HS_WAVE < rows;
-        const uint32_t bin = valid ? rx_bin4(key[j], shift, bits) : 0u;
+        const uint32_t bin = valid ? rx_bin4r(A, key[j], shift, bits) : 0u;
         uint64_t peers = __ballot(valid);
         for (int bit = 0; bit < bits; ++bit) {
             const bool on = (bin >> bit) & 1u;
@@ -1209,10 +1191,7 @@ static int rx_pass(hipStream_t stream, RxPass& P, int64_t max_tiles, int64_t* co
     hs_memset_async(counters, 0, (size_t)ncnt * 8, stream);
     P.counters = counters;
     // 4-byte tuples (INTEGER key, f32 / i32 values): the specialised kernels
-    static const bool generic = getenv("HIPSPARK_RADIX_GENERIC") != nullptr;
-    static const bool direct = getenv("HIPSPARK_RADIX_DIRECT") != nullptr;
-    bool four = !generic && !direct && !P.raw && P.n_cols <= 4 &&
-                (P.first ? P.key.kind == HS_I32 : P.esize[0] == 4);
+    bool four = !P.raw && P.n_cols <= 4 && (P.first ? P.key.kind == HS_I32 : P.esize[0] == 4);
     for (int c = 1; c < P.n_cols; ++c) four = four && P.esize[c] == 4;
     P.key4 = four ? 1 : 0;
 #define RX_WIDE(KERNEL, THREADS)                                                                                          \
@@ -1240,7 +1219,7 @@ static int rx_pass(hipStream_t stream, RxPass& P, int64_t max_tiles, int64_t* co
     for (int c = 0; c < P.n_cols; ++c) widest = P.esize[c] > widest ? P.esize[c] : widest;
     static unsigned long long attr_set = 0;
     if (hs_first_on_device(attr_set))  // 8-byte columns stage 72 KB + 18 KB static: above the 64 KB a launch gets unasked
-        (void)hipFuncSetAttribute((const void*)k_rx_scatter<true>, hipFuncAttributeMaxDynamicSharedMemorySize, RX_TILE * 9);
+        (void)hipFuncSetAttribute((const void*)k_rx_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, RX_TILE * 9);
     if (P.wide) {
         RX_WIDE(k_rx_scatterw, RX_THREADS)
     } else if (four) {
@@ -1255,8 +1234,7 @@ static int rx_pass(hipStream_t stream, RxPass& P, int64_t max_tiles, int64_t* co
         }
 #undef RX_S4
 #undef RX_WIDE
-    } else if (direct) hipLaunchKernelGGL(k_rx_scatter<false>, dim3((unsigned)max_tiles), dim3(RX_THREADS), 0, stream, P);
-    else hipLaunchKernelGGL(k_rx_scatter<true>, dim3((unsigned)max_tiles), dim3(RX_THREADS), (size_t)RX_TILE * (1 + widest), stream, P);
+    } else hipLaunchKernelGGL(k_rx_scatter, dim3((unsigned)max_tiles), dim3(RX_THREADS), (size_t)RX_TILE * (1 + widest), stream, P);
     RX_CHECK_LAUNCH("radix pass (scatter)");
     if (next_seg) {
         const int64_t nout = (P.n_seg << P.bits) + 1;
@@ -1304,20 +1282,12 @@ extern "C" int hs_group_radix_plan(int32_t key_kind, int64_t n, int32_t n_units,
     int cap = 2048;
     while (cap > 64 && ((size_t)cap * (1 + (wide ? 1 : 0) + NA) + (size_t)cap / 4) * 8 > 65536) cap >>= 1;
     // rows per partition: half the slots of the LARGE table.  Partitions that turn out to hold few distinct keys - the
-    // usual case - are folded by the 512-slot launch anyway.  HIPSPARK_RADIX_FINE=1 cuts down to half the slots of the
-    // small table where two passes can (units of file-block size): measured at 600 M rows / 287 units, it makes
-    // all-distinct keys 2.2x faster (78 -> 35 ms: no partition needs the large-table launch) but ~100 rows per group 65 %
-    // slower (34 -> 57 ms: a finer cut puts more rows of a group into every 64-row step, and those fold one after the
-    // other) and 4 rows per group 10 % slower - so it is not the default.
+    // usual case - are folded by the 512-slot launch anyway.  (Cutting down to half the slots of the SMALL table where two
+    // passes can was measured at 600 M rows / 287 units: all-distinct keys 2.2x faster - no partition needs the large-table
+    // launch -, but ~100 rows per group 65 % slower - a finer cut puts more rows of a group into every 64-row step, and
+    // those fold one after the other - and 4 rows per group 10 % slower: not taken.)
     int bits = 0;
-    if (getenv("HIPSPARK_RADIX_FINE")) {
-        const int small = cap < 512 ? cap : 512;
-        while (bits <= 2 * RX_MAX_BITS && ((int64_t)(small / 2) << bits) < max_unit_rows) ++bits;
-    }
-    if (bits == 0 || bits > 2 * RX_MAX_BITS) {
-        bits = 0;
-        while (bits < 2 * RX_MAX_BITS && ((int64_t)(cap / 2) << bits) < max_unit_rows) ++bits;
-    }
+    while (bits < 2 * RX_MAX_BITS && ((int64_t)(cap / 2) << bits) < max_unit_rows) ++bits;
     const int bits1 = bits <= RX_MAX_BITS ? bits : (bits + 1) / 2, bits2 = bits - bits1;
     f[PL_N] = n;
     f[PL_UNITS] = n_units;
@@ -1491,7 +1461,6 @@ extern "C" int hs_group_radix_run(void* stream_, const hs_radix_plan* plan, cons
     hs_memset_async(overflow, 0, 8, stream);
     // every aggregate a SUM over an f32 / i32 column or an integer constant: the specialised fold (k_rx_fold_sum)
     int sum_cls = NA >= 1 && NA <= 3 ? 0 : -1;
-    static const bool lean_off = getenv("HIPSPARK_RADIX_LEAN") != nullptr && getenv("HIPSPARK_RADIX_LEAN")[0] == '0';
     for (int a = 0; a < NA && sum_cls >= 0; ++a) {
         const bool is_int = spec->is_int[a] != 0;
         int c = -1;
@@ -1501,7 +1470,7 @@ extern "C" int hs_group_radix_run(void* stream_, const hs_radix_plan* plan, cons
         else if (!G.carried[a] && is_int) c = 2;
         sum_cls = c < 0 ? -1 : (sum_cls | (c << (2 * a)));
     }
-    if ((lean_off || stamps) && !wide) sum_cls = -1;
+    if (stamps && !wide) sum_cls = -1;  // (the phase stamps live in the general fold)
     if (wide && sum_cls < 0) {
         hs_set_error("hs_group_radix_run: a wide STRING key needs the SUM-specialised fold");
         return HS_E_LIMIT;
@@ -1581,8 +1550,7 @@ extern "C" int hs_group_radix_run(void* stream_, const hs_radix_plan* plan, cons
 #undef RX_FOLD
     };
     const int big = (int)f[PL_CAP], small = big > 512 ? 512 : big;
-    static const bool one_table = getenv("HIPSPARK_RADIX_ONE_TABLE") != nullptr;
-    if (small < big && !one_table) {
+    if (small < big) {
         fold(small, false);
         RX_CHECK_LAUNCH("hs_group_radix_run (fold)");
         fold(big, true);
@@ -1737,5 +1705,379 @@ extern "C" int hs_expand_by_bounds(void* stream, const int64_t* bounds, const in
     hipLaunchKernelGGL(k_expand_by_bounds, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, bounds, values, n_seg, n, out);
     RX_CHECK_LAUNCH("hs_expand_by_bounds");
+    return HS_OK;
+}
+
+// =====================================================================================================
+// The general inner join on INTEGER keys over a dense key range (round 4; include/hipspark.h hs_join_dense_*)
+// =====================================================================================================
+// Reference: BroadcastHashJoinTask.generate_chunks tasks.py:201-240 - a hash map key -> build rows (in row order), every
+// probe row emits its matches in that order; duplicates on either side multiply (zig twin: tasks.zig:70-194, 258-326).
+// Round 1-3 built one open-addressing table over all build keys with a 64-bit atomic per row scattered over 800 MB
+// (8.6 G keys/s, 5.6 % of the HBM roofline).  Here the build side is MOVED instead, like the radix tier of GROUP BY:
+//   1. two stable partition passes (the kernels above, RxPass.range) on the most significant bits of slot = key - key_min
+//      bring the (key, row) tuples into partitions of 2^L consecutive slots, still in row order;
+//   2. one wave per partition (k_jd_assemble): slot counts in LDS, a scan, then the rows are placed IN ORDER - lanes of a
+//      64-tuple step that share a slot rank themselves with ballots - so every slot's rows come out ascending without a
+//      sort and without a global atomic; the partition's slice of starts[] (CSR offsets, one per SLOT, absent keys
+//      included) leaves with coalesced stores.
+// The probe is then one or two adjacent 4-byte reads per row (starts[s], starts[s + 1]) instead of a hash probe over
+// three arrays: count -> exclusive scan -> fill, pairs ordered by probe row, then build row (tasks.py:224-240).
+constexpr int JD_MAX_L = 14;  // slots of one partition: 2^L u32 cursors in LDS per wave (64 KB at most)
+
+struct JdAssemble {
+    const int64_t* seg_start;  // [parts + 1] tuple ranges of the partitions
+    int64_t parts;
+    const int32_t* keys;       // tuples, partitioned
+    const uint32_t* rows;
+    int64_t slots;
+    int32_t key_min, L;
+    uint32_t* starts;          // [slots + 1]
+    uint32_t* out_rows;        // [n]
+    int64_t n;
+    uint32_t* flags;
+};
+
+__global__ void __launch_bounds__(256) k_jd_assemble(const JdAssemble A) {
+    extern __shared__ __align__(16) uint32_t jd_lds[];
+    const int lane = threadIdx.x & (HS_WAVE - 1), w = threadIdx.x / HS_WAVE, wpb = blockDim.x / HS_WAVE;
+    const int W = 1 << A.L;
+    uint32_t* cur = jd_lds + (size_t)w * W;
+    const uint64_t below = (1ull << lane) - 1ull;
+    const int per = W / HS_WAVE;  // consecutive slots of a lane in the scan (W >= 64)
+    uint32_t err = 0;
+    for (int64_t p = (int64_t)blockIdx.x * wpb + w; p < A.parts; p += (int64_t)gridDim.x * wpb) {
+        const int64_t b = A.seg_start[p], e = A.seg_start[p + 1];
+        const int64_t slot0 = p << A.L;
+        if (slot0 >= A.slots) {
+            if (e > b) err |= HS_FLAG_BAD_PROGRAM;  // a key past the declared range
+            continue;
+        }
+        for (int s = lane; s < W; s += HS_WAVE) cur[s] = 0;
+        rx_wave_handover();
+        for (int64_t i = b + lane; i < e; i += HS_WAVE) {
+            const uint32_t s = ((uint32_t)A.keys[i] - (uint32_t)A.key_min) & (uint32_t)(W - 1);
+            atomicAdd(&cur[s], 1u);  // LDS; counting is order-free
+        }
+        rx_wave_handover();
+        // exclusive scan of the W counts: a lane's consecutive slots, then a scan over the lanes
+        uint32_t sum = 0;
+        for (int k = 0; k < per; ++k) sum += cur[lane * per + k];
+        uint32_t x = sum;
+        for (int d = 1; d < HS_WAVE; d <<= 1) {
+            const uint32_t up = __shfl_up(x, d, HS_WAVE);
+            if (lane >= d) x += up;
+        }
+        uint32_t run = x - sum;
+        for (int k = 0; k < per; ++k) {
+            const uint32_t c = cur[lane * per + k];
+            cur[lane * per + k] = run;
+            run += c;
+        }
+        rx_wave_handover();
+        // the partition's slice of the CSR offsets: coalesced
+        const int64_t live = A.slots - slot0 < W ? A.slots - slot0 : W;
+        for (int s = lane; s < live; s += HS_WAVE) A.starts[slot0 + s] = (uint32_t)b + cur[s];
+        // ordered placement: tuples arrive in row order; within a step, equal slots take consecutive places in lane order
+        for (int64_t base = b; base < e; base += HS_WAVE) {
+            const int64_t i = base + lane;
+            const bool valid = i < e;
+            const uint32_t s = valid ? ((uint32_t)A.keys[i] - (uint32_t)A.key_min) & (uint32_t)(W - 1) : 0u;
+            const uint32_t row = valid ? A.rows[i] : 0u;
+            uint64_t peers = __ballot(valid);
+            for (int bit = 0; bit < A.L; ++bit) {
+                const bool on = (s >> bit) & 1u;
+                const uint64_t bal = __ballot(valid && on);
+                peers &= on ? bal : ~bal;
+            }
+            const uint32_t rank = (uint32_t)__popcll(peers & below);
+            const uint32_t at = valid ? cur[s] : 0u;
+            rx_wave_handover();  // every lane has read its slot's cursor before a leader moves it
+            if (valid) {
+                A.out_rows[b + at + rank] = row;
+                if (rank == 0) cur[s] = at + (uint32_t)__popcll(peers);
+            }
+            rx_wave_handover();
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) A.starts[A.slots] = (uint32_t)A.n;
+    if (err) atomicOr(A.flags, err);
+}
+
+// the one segment [0, n) of the first pass; without passes (a key range of one partition) the tuples are the build column
+// itself and the row ids 0 .. n-1
+__global__ void __launch_bounds__(256) k_jd_setup(uint32_t* iota, int64_t n_iota, int64_t n, int64_t* seg0) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_iota; i += (int64_t)gridDim.x * blockDim.x) iota[i] = (uint32_t)i;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        seg0[0] = 0;
+        seg0[1] = n;
+    }
+}
+
+// the passes' geometry for a key range of `slots` slots: L = slots per partition (log2), bits1 + bits2 = partition bits
+static void jd_geometry(int64_t slots, int& L, int& bits1, int& bits2) {
+    int S = 0;
+    while (S < 31 && ((int64_t)1 << S) < slots) ++S;
+    L = 10;
+    if (S - L > 2 * RX_MAX_BITS) L = S - 2 * RX_MAX_BITS;
+    const int bits = S > L ? S - L : 0;
+    bits1 = bits <= RX_MAX_BITS ? bits : (bits + 1) / 2;
+    bits2 = bits - bits1;
+}
+struct JdLayout {
+    size_t keys_a, rows_a, keys_b, rows_b, iota, seg0, seg1, seg2, tb0, tb1, cnt, scan, scan_ws, total;
+    int64_t tiles1, tiles2, nseg1, parts, counters;
+    int L, bits1, bits2;
+};
+static bool jd_layout(int64_t n, int64_t slots, JdLayout& Y) {
+    if (n < 0 || n >= 0xffffffffll || slots < 1 || slots > ((int64_t)1 << 30)) return false;
+    jd_geometry(slots, Y.L, Y.bits1, Y.bits2);
+    if (Y.L > JD_MAX_L) return false;
+    Y.nseg1 = (int64_t)1 << Y.bits1;
+    Y.parts = (int64_t)1 << (Y.bits1 + Y.bits2);
+    Y.tiles1 = n / RX_TILE + 2;
+    Y.tiles2 = Y.bits2 ? n / RX_TILE + Y.nseg1 + 1 : 0;
+    const int64_t c1 = Y.tiles1 << Y.bits1, c2 = Y.tiles2 << Y.bits2;
+    Y.counters = c1 > c2 ? c1 : c2;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = off;
+        off += rx_align(bytes);
+        return at;
+    };
+    Y.keys_a = take((size_t)n * 4 + 64);
+    Y.rows_a = take((size_t)n * 4 + 64);
+    Y.keys_b = take(Y.bits2 ? (size_t)n * 4 + 64 : 0);
+    Y.rows_b = take(Y.bits2 ? (size_t)n * 4 + 64 : 0);
+    Y.iota = take(Y.bits1 ? 64 : (size_t)n * 4 + 64);  // row ids travel from the first pass on; needed as an array only without passes
+    Y.seg0 = take(16);
+    Y.seg1 = take((size_t)(Y.nseg1 + 1) * 8);
+    Y.seg2 = take((size_t)(Y.parts + 1) * 8);
+    Y.tb0 = take(16);
+    Y.tb1 = take((size_t)(Y.nseg1 + 1) * 8);
+    Y.cnt = take((size_t)Y.counters * 8);
+    Y.scan = take((size_t)(Y.counters + 1) * 8);
+    Y.scan_ws = take(hs_scan_ws_bytes(Y.counters > 1 ? Y.counters : 1));
+    Y.total = off;
+    return true;
+}
+
+extern "C" size_t hs_join_dense_ws_bytes(int64_t n_build, int64_t slots) {
+    JdLayout Y;
+    return jd_layout(n_build, slots, Y) ? Y.total : 0;
+}
+
+extern "C" int hs_join_dense_build(void* stream_, const int32_t* build_keys, int64_t n_build, int32_t key_min, int64_t slots,
+                                   uint32_t* starts, uint32_t* rows, void* ws_, uint32_t* flags) {
+    JdLayout Y;
+    if ((!build_keys && n_build > 0) || !starts || !rows || !ws_ || !flags || !jd_layout(n_build, slots, Y)) {
+        hs_set_error("hs_join_dense_build: bad arguments (n_build < 2^32, 1 <= slots <= 2^30)");
+        return HS_E_ARG;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    uint8_t* ws = (uint8_t*)ws_;
+    const int64_t n = n_build;
+    uint32_t* iota = (uint32_t*)(ws + Y.iota);
+    int64_t* seg0 = (int64_t*)(ws + Y.seg0);
+    int64_t* seg1 = (int64_t*)(ws + Y.seg1);
+    int64_t* seg2 = (int64_t*)(ws + Y.seg2);
+    const int64_t n_iota = Y.bits1 ? 0 : n;
+    int64_t grid = (n_iota + 255) / 256;
+    grid = grid < 1 ? 1 : (grid > 4096 ? 4096 : grid);
+    hipLaunchKernelGGL(k_jd_setup, dim3((unsigned)grid), dim3(256), 0, stream, iota, n_iota, n, seg0);
+    RX_CHECK_LAUNCH("hs_join_dense_build (row ids)");
+    const int32_t* t_keys = build_keys;
+    const uint32_t* t_rows = iota;
+    const int64_t* seg = seg0;
+    if (Y.bits1 > 0 && n > 0) {
+        RxPass P;
+        std::memset(&P, 0, sizeof(P));
+        P.n_cols = 2;
+        P.esize[0] = P.esize[1] = 4;
+        P.range = 1;
+        P.range_bias = key_min;
+        P.key = hs_col{HS_I32, -1, build_keys, nullptr, nullptr};
+        P.row0 = 0;
+        // pass 1: the top bits1 bits of the slot over the one segment [0, n)
+        P.seg_start = seg0;
+        P.tile_base = (int64_t*)(ws + Y.tb0);
+        P.n_seg = 1;
+        P.shift = Y.L + Y.bits2;
+        P.bits = Y.bits1;
+        P.first = 1;
+        P.src[1] = nullptr;  // the row id column is the position (k_rx_scatter4)
+        P.dst[0] = ws + Y.keys_a;
+        P.dst[1] = ws + Y.rows_a;
+        int rc = rx_pass(stream, P, Y.tiles1, (int64_t*)(ws + Y.cnt), (int64_t*)(ws + Y.scan), ws + Y.scan_ws, n, Y.bits2 ? seg1 : seg2);
+        if (rc != HS_OK) return rc;
+        t_keys = (const int32_t*)(ws + Y.keys_a);
+        t_rows = (const uint32_t*)(ws + Y.rows_a);
+        seg = seg2;
+        if (Y.bits2) {  // pass 2: the next bits2 bits inside every segment of pass 1
+            P.seg_start = seg1;
+            P.tile_base = (int64_t*)(ws + Y.tb1);
+            P.n_seg = Y.nseg1;
+            P.shift = Y.L;
+            P.bits = Y.bits2;
+            P.first = 0;
+            P.src[0] = ws + Y.keys_a;
+            P.src[1] = ws + Y.rows_a;
+            P.dst[0] = ws + Y.keys_b;
+            P.dst[1] = ws + Y.rows_b;
+            rc = rx_pass(stream, P, Y.tiles2, (int64_t*)(ws + Y.cnt), (int64_t*)(ws + Y.scan), ws + Y.scan_ws, n, seg2);
+            if (rc != HS_OK) return rc;
+            t_keys = (const int32_t*)(ws + Y.keys_b);
+            t_rows = (const uint32_t*)(ws + Y.rows_b);
+        }
+    } else if (Y.bits1 > 0) {  // no rows: every partition is empty
+        hs_memset_async(seg2, 0, (size_t)(Y.parts + 1) * 8, stream);
+        seg = seg2;
+    }
+    JdAssemble A;
+    A.seg_start = seg;
+    A.parts = Y.bits1 > 0 ? Y.parts : 1;
+    A.keys = t_keys;
+    A.rows = t_rows;
+    A.slots = slots;
+    A.key_min = key_min;
+    A.L = Y.L;
+    A.starts = starts;
+    A.out_rows = rows;
+    A.n = n;
+    A.flags = flags;
+    const size_t per_wave = (size_t)4 << Y.L;
+    int wpb = (int)(65536 / per_wave);
+    wpb = wpb < 1 ? 1 : (wpb > 4 ? 4 : wpb);
+    int64_t g = (A.parts + wpb - 1) / wpb;
+    if (g > 256 * 32) g = 256 * 32;
+    static unsigned long long attr_set = 0;
+    if (hs_first_on_device(attr_set)) (void)hipFuncSetAttribute((const void*)k_jd_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipLaunchKernelGGL(k_jd_assemble, dim3((unsigned)g), dim3(HS_WAVE * wpb), per_wave * wpb, stream, A);
+    RX_CHECK_LAUNCH("hs_join_dense_build (assemble)");
+    return HS_OK;
+}
+
+struct JdProbe {
+    const int32_t* keys;
+    int64_t n, slots;
+    int32_t key_min, pad;
+    const uint32_t* starts;
+    const uint32_t* rows;
+    int64_t* counts;
+    uint32_t* aux;  // [2 n]: first matching build row | start of the probe row's list in `rows`
+    const int64_t* out_start;
+    int64_t* out_left;
+    int64_t* out_right;
+};
+typedef int jd_i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned jd_u32x4 __attribute__((ext_vector_type(4)));
+typedef long long jd_i64x2 __attribute__((ext_vector_type(2)));
+
+// Probe, pass 1: four keys per lane (one 16-byte load; buffers carry slack past n); per key the two adjacent offsets of its
+// slot, then the first row of its list - all four lookups of a lane in flight together.  What the fill pass needs again is
+// written down sequentially (the first build row and the list's start: 8 bytes per probe row) so that it never returns
+// to the scattered arrays for a key with one partner - the usual case.
+__global__ void __launch_bounds__(256) k_jd_count(const JdProbe A) {
+    const int64_t nq = (A.n + 3) / 4;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+        const jd_i32x4 kv = __builtin_nontemporal_load(reinterpret_cast<const jd_i32x4*>(A.keys) + q);
+        const int32_t k[4] = {kv.x, kv.y, kv.z, kv.w};
+        uint32_t st[4], en[4], first[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t o = (int64_t)k[j] - (int64_t)A.key_min;
+            const bool in = q * 4 + j < A.n && (uint64_t)o < (uint64_t)A.slots;
+            st[j] = in ? A.starts[o] : 0u;
+            en[j] = in ? A.starts[o + 1] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) first[j] = en[j] > st[j] ? A.rows[st[j]] : 0u;
+        if (q * 4 + 3 < A.n) {
+            int64_t* c = A.counts + q * 4;
+            __builtin_nontemporal_store(jd_i64x2{(long long)(en[0] - st[0]), (long long)(en[1] - st[1])}, reinterpret_cast<jd_i64x2*>(c));
+            __builtin_nontemporal_store(jd_i64x2{(long long)(en[2] - st[2]), (long long)(en[3] - st[3])}, reinterpret_cast<jd_i64x2*>(c + 2));
+            __builtin_nontemporal_store(jd_u32x4{first[0], first[1], first[2], first[3]}, reinterpret_cast<jd_u32x4*>(A.aux) + q);
+            __builtin_nontemporal_store(jd_u32x4{st[0], st[1], st[2], st[3]}, reinterpret_cast<jd_u32x4*>(A.aux + ((A.n + 3) & ~(int64_t)3)) + q);
+        } else {
+            for (int j = 0; j < 4 && q * 4 + j < A.n; ++j) {
+                A.counts[q * 4 + j] = (int64_t)(en[j] - st[j]);
+                A.aux[q * 4 + j] = first[j];
+                A.aux[((A.n + 3) & ~(int64_t)3) + q * 4 + j] = st[j];
+            }
+        }
+    }
+}
+
+// Probe, pass 2: pairs ordered by probe row, then build row.  A stream: output offsets (their differences are the match
+// counts), the first build rows, the pairs; only a probe row with several partners reads the rest of its list.
+__global__ void __launch_bounds__(256) k_jd_fill(const JdProbe A) {
+    const int64_t nq = (A.n + 3) / 4;
+    const int64_t second = (A.n + 3) & ~(int64_t)3;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+        int64_t at[5];
+        uint32_t first[4];
+        if (q * 4 + 3 < A.n) {
+            const jd_u32x4 f = __builtin_nontemporal_load(reinterpret_cast<const jd_u32x4*>(A.aux) + q);
+            first[0] = f.x; first[1] = f.y; first[2] = f.z; first[3] = f.w;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) at[j] = A.out_start[q * 4 + j];  // out_start has n + 1 entries
+        } else {
+            for (int j = 0; j < 5; ++j) at[j] = q * 4 + j <= A.n ? A.out_start[q * 4 + j] : A.out_start[A.n];
+            for (int j = 0; j < 4; ++j) first[j] = q * 4 + j < A.n ? A.aux[q * 4 + j] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t cnt = at[j + 1] - at[j];
+            if (cnt <= 0) continue;
+            const int64_t i = q * 4 + j;
+            A.out_left[at[j]] = (int64_t)first[j];
+            A.out_right[at[j]] = i;
+            if (cnt > 1) {
+                const uint32_t st = A.aux[second + i];
+                for (int64_t r = 1; r < cnt; ++r) {
+                    A.out_left[at[j] + r] = (int64_t)A.rows[st + r];
+                    A.out_right[at[j] + r] = i;
+                }
+            }
+        }
+    }
+}
+
+static int jd_probe_args(const char* who, const int32_t* probe_keys, int64_t n_probe, int64_t slots, const uint32_t* starts) {
+    if ((!probe_keys && n_probe > 0) || !starts || n_probe < 0 || slots < 1 || ((uintptr_t)probe_keys & 15)) {
+        hs_set_error("%s: bad arguments (probe keys 16-byte aligned)", who);
+        return HS_E_ARG;
+    }
+    return HS_OK;
+}
+extern "C" size_t hs_join_dense_aux_bytes(int64_t n_probe) { return n_probe < 0 ? 0 : (size_t)(((n_probe + 3) & ~(int64_t)3) * 2) * 4 + 64; }
+extern "C" int hs_join_dense_count(void* stream, const int32_t* probe_keys, int64_t n_probe, int32_t key_min, int64_t slots,
+                                   const uint32_t* starts, const uint32_t* rows, int64_t* counts, void* aux) {
+    int rc = jd_probe_args("hs_join_dense_count", probe_keys, n_probe, slots, starts);
+    if (rc != HS_OK) return rc;
+    if (!rows || !counts || !aux || ((uintptr_t)counts & 15) || ((uintptr_t)aux & 15)) {
+        hs_set_error("hs_join_dense_count: counts and aux must be 16-byte aligned");
+        return HS_E_ARG;
+    }
+    if (n_probe == 0) return HS_OK;
+    JdProbe A{probe_keys, n_probe, slots, key_min, 0, starts, rows, counts, (uint32_t*)aux, nullptr, nullptr, nullptr};
+    int64_t g = ((n_probe + 3) / 4 + 255) / 256;
+    if (g > 256 * 64) g = 256 * 64;
+    hipLaunchKernelGGL(k_jd_count, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, A);
+    RX_CHECK_LAUNCH("hs_join_dense_count");
+    return HS_OK;
+}
+extern "C" int hs_join_dense_fill(void* stream, int64_t n_probe, const uint32_t* rows, const void* aux, const int64_t* out_start,
+                                  int64_t* out_left, int64_t* out_right) {
+    if (n_probe < 0 || !rows || !aux || !out_start || !out_left || !out_right || ((uintptr_t)aux & 15)) {
+        hs_set_error("hs_join_dense_fill: bad arguments");
+        return HS_E_ARG;
+    }
+    if (n_probe == 0) return HS_OK;
+    JdProbe A{nullptr, n_probe, 0, 0, 0, nullptr, rows, nullptr, (uint32_t*)const_cast<void*>(aux), out_start, out_left, out_right};
+    int64_t g = ((n_probe + 3) / 4 + 255) / 256;
+    if (g > 256 * 64) g = 256 * 64;
+    hipLaunchKernelGGL(k_jd_fill, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, A);
+    RX_CHECK_LAUNCH("hs_join_dense_fill");
     return HS_OK;
 }

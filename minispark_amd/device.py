@@ -1104,8 +1104,7 @@ class Device:
             small = 16
             while small < 4 * per_unit:
                 small *= 2
-            if os.environ.get("HIPSPARK_SMALL_UNIT_TABLES", "1") != "0":
-                geom.pad = min(int(geom.pad), small)
+            geom.pad = min(int(geom.pad), small)
         unit_cap = int(geom.pad) if shared else cap  # slots per unit of the kernels' output arrays
         if computed:
             n_units = batch.n_unit_ids  # from here on: the unit tables
@@ -1444,7 +1443,7 @@ class Device:
         return out
 
     # ---- HBM tier by radix partition (csrc/hs_radix.hip) ------------------------------------------------------
-    radix_enabled = os.environ.get("HIPSPARK_RADIX", "1") != "0"
+    radix_enabled = True  # (tests switch it off to hold the hash-table tier - the form STRING / computed keys keep - to the same rows)
 
     def _radix_values(self, batch: DBatch, args: Sequence[Any], sel: torch.Tensor | None, n: int):
         """Aggregate arguments for the radix tier -> per argument (value column | None, constant cell, is_int).
@@ -2018,20 +2017,20 @@ class Device:
             self.__dict__.setdefault("_route_caches", []).append(build_key)
         send, recv = sizes["send"], sizes["recv"]
         n_out, n_in = sum(send), sum(recv)
-        out_keys = self.empty(n_out, torch.int32)
-        out_codes = self.empty(n_out, torch.uint8) if payload is not None else None
+        out_keys = self.empty(max(n_out, 1), torch.int32)  # (torch hands out a null pointer for an empty tensor)
+        out_codes = self.empty(max(n_out, 1), torch.uint8) if payload is not None else None
         hs.check(self.lib.hs_join8_route(self.stream, build_key.data.data_ptr(), payload.data.data_ptr() if payload is not None else None,
                                          n, stripes["min"].data_ptr(), stripes["max"].data_ptr(), stripes["owner"].data_ptr(),
                                          stripes["n"], world, route_ws.data_ptr(), dest_start.data_ptr(), sizes["expect"].data_ptr(),
                                          out_keys.data_ptr(),
                                          out_codes.data_ptr() if out_codes is not None else None, n_out, self.flags.data_ptr()),
                  "hs_join8_route")
-        keys = self.empty(n_in, torch.int32)
-        self.op(_a2a, dist, keys, out_keys, recv, send, group)
+        keys = self.empty(max(n_in, 1), torch.int32)
+        self.op(_a2a, dist, keys[:n_in], out_keys[:n_out], recv, send, group)
         codes = None
         if out_codes is not None:
-            codes = self.empty(n_in, torch.uint8)
-            self.op(_a2a, dist, codes, out_codes, recv, send, group)
+            codes = self.empty(max(n_in, 1), torch.uint8)
+            self.op(_a2a, dist, codes[:n_in], out_codes[:n_out], recv, send, group)
         if timed is not None:
             self.op(timed[1].record)
         ws = self.workspace(self.lib.hs_join8_ws_bytes(n_in, slots))
@@ -2182,10 +2181,53 @@ class Device:
                       slab_layout=p["layout"], tail=p["tail"])
 
     # ---- hash join (A8) --------------------------------------------------------------------------------
+    JOIN_DENSE_SPREAD = 32  # slots per build row at most (TPC-H order keys use 8 of every 32 values) ...
+    JOIN_DENSE_CROWD = 4    # ... and build rows per slot at most on average: a few hot keys would leave the assembly to single waves
+
+    def _join_indices_dense(self, left_key: DCol, right_key: DCol) -> tuple | None:
+        """INTEGER keys over a dense range (round 4, hs_join_dense_*): the build rows are range-partitioned and assembled
+        into a CSR over key slots - no hash table, no global atomics; the probe reads two adjacent offsets per row.  None:
+        this shape keeps the hash-table join (other key kinds, a sparse or a crowded key range)."""
+        n_left, n_right = left_key.n, right_key.n
+        if (left_key.kind != hs.I32 or right_key.kind != hs.I32 or n_left == 0 or n_right == 0 or n_left >= 0xFFFFFFFF
+                or left_key.data.data_ptr() % 16 or right_key.data.data_ptr() % 16):
+            return None
+        lo, hi, _ = self.key_range(left_key)
+        slots = hi - lo + 1
+        if slots > min(1 << 30, self.JOIN_DENSE_SPREAD * n_left + 65536) or slots * self.JOIN_DENSE_CROWD < n_left:
+            return None
+        ws_bytes = int(self.lib.hs_join_dense_ws_bytes(n_left, slots))
+        if ws_bytes == 0:
+            return None
+        starts = self.empty(slots + 1, torch.int32)
+        rows = self.empty(n_left, torch.int32)
+        ws = self.workspace(ws_bytes)
+        hs.check(self.lib.hs_join_dense_build(self.stream, left_key.data.data_ptr(), n_left, lo, slots, starts.data_ptr(),
+                                              rows.data_ptr(), ws.data_ptr(), self.flags.data_ptr()), "hs_join_dense_build")
+        counts = self.empty(max(n_right, 1), torch.int64)
+        aux = self.workspace(self.lib.hs_join_dense_aux_bytes(n_right))
+        hs.check(self.lib.hs_join_dense_count(self.stream, right_key.data.data_ptr(), n_right, lo, slots, starts.data_ptr(),
+                                              rows.data_ptr(), counts.data_ptr(), aux.data_ptr()), "hs_join_dense_count")
+        out_start = self.empty(n_right + 1, torch.int64)
+        ws2 = self.workspace(self.lib.hs_scan_ws_bytes(n_right))
+        hs.check(self.lib.hs_exclusive_scan_i64(self.stream, counts.data_ptr(), n_right, out_start.data_ptr(), ws2.data_ptr()),
+                 "hs_exclusive_scan_i64")
+        n_out = self.host_int(out_start[n_right])  # sizes the pair lists: the run is data-dependent (not replayable)
+        out_left = self.empty(max(n_out, 1), torch.int64)
+        out_right = self.empty(max(n_out, 1), torch.int64)
+        hs.check(self.lib.hs_join_dense_fill(self.stream, n_right, rows.data_ptr(), aux.data_ptr(), out_start.data_ptr(),
+                                             out_left.data_ptr(), out_right.data_ptr()), "hs_join_dense_fill")
+        self.last_join = {"mode": "dense csr", "slots": slots, "n_build": n_left}
+        self.dense_joins = getattr(self, "dense_joins", 0) + 1
+        return out_left, out_right, out_start, n_out
+
     def join_indices(self, left_key: DCol, right_key: DCol) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, int]:
         """Inner equi-join -> (left_rows, right_rows, out_start, n_out): pairs ordered by right row,
         then by left row (the reference's emission order, tasks.py:224-240)."""
         n_left, n_right = left_key.n, right_key.n
+        dense = self._join_indices_dense(left_key, right_key)
+        if dense is not None:
+            return dense
         cap = 16
         while cap < 2 * max(n_left, 1):
             cap *= 2

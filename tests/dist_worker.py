@@ -16,6 +16,10 @@ sys.path.insert(0, str(ROOT))
 
 
 def main() -> None:
+    """`dist_worker.py <case> <out> <backend>` - or `batch:<jobs.json>` as the case: a list of [case, out] pairs run one
+    after the other inside ONE process group (one interpreter + torch import + rendezvous per world instead of per case:
+    the spawns were half of the GPU suite's wall time).  A job that raises ends the batch: its error is written where its
+    rows would have gone, the jobs behind it are not run (a rank that went on alone would hang in the next collective)."""
     case_name, out_path, backend = sys.argv[1], sys.argv[2], sys.argv[3]
     if os.environ.get("HIPSPARK_WORKER_DUMP_AFTER"):  # a hung collective: every thread's stack after N seconds, then exit
         import faulthandler
@@ -32,6 +36,32 @@ def main() -> None:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     else:
         dist.init_process_group(backend, rank=rank, world_size=world)
+    jobs = json.loads(Path(case_name[len("batch:"):]).read_text()) if case_name.startswith("batch:") else [[case_name, out_path]]
+    failed = None
+    for job_case, job_out in jobs:
+        if failed is not None:
+            if rank == 0:
+                Path(job_out).write_text(json.dumps({"error": f"not run: the batch ended at {failed}"}))
+            continue
+        try:
+            run_case(job_case, job_out, dist, rank, world)
+        except BaseException:  # noqa: BLE001
+            import traceback
+
+            failed = job_case
+            if len(jobs) == 1:
+                raise
+            print(f"[rank {rank}] job {job_case} failed:\n{traceback.format_exc()}", file=sys.stderr, flush=True)
+            Path(str(job_out) + f".rank{rank}.error").write_text(traceback.format_exc())
+            if rank == 0:
+                Path(job_out).write_text(json.dumps({"error": traceback.format_exc()[-3000:]}))
+    if failed is not None:
+        os._exit(3)  # peers may be parked in a collective of the failed job: no barrier, no teardown
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def run_case(case_name: str, out_path: str, dist, rank: int, world: int) -> None:
     from minispark_amd import constants
     from minispark_amd.dataframe import DataFrame
     from minispark_amd.execution import HipExecutionEngine
@@ -84,8 +114,6 @@ def main() -> None:
                 Path(out_path).write_text(json.dumps(report))
             else:
                 assert rows == [], f"rank {rank} must not own result rows"
-        dist.barrier()
-        dist.destroy_process_group()
         return
     elif case_name.startswith("width:"):
         # GROUP BY a string key whose fixed width the ranks see differently (tests/test_gpu_distributed.py)
@@ -113,8 +141,6 @@ def main() -> None:
             Path(out_path).write_text(json.dumps(enc))
         else:
             assert rows == [], f"rank {rank} must not own result rows"
-    dist.barrier()
-    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -320,3 +320,18 @@ def test_scan_stage_lowering_inlines_a_projection_and_hands_over_a_computed_key(
                 Col("l_orderkey") * Col("l_orderkey")):
         with pytest.raises(StageUnsupported):
             lower_stage_plan(frame(bad).task)
+
+
+def test_no_kernel_of_the_library_lives_in_scratch_memory():
+    """Register budget of the built library (tools/register_report.py reads the code objects' metadata, no GPU): the
+    interpreter kernels of the fused aggregate - the fallback when hiprtc is unavailable - used to spill 440-712 bytes per
+    lane at 1024 lanes; they now run 512 / 256 lanes wide and nothing spills.  The only
+    kernels allowed a few spilled dwords are the radix partition's scatter kernels, which pin 8 waves per SIMD (two
+    1024-lane workgroups per CU) on purpose."""
+    from tools.register_report import kernels
+
+    rows = kernels()
+    assert len(rows) > 200
+    spilling = {r["name"]: r["scratch"] for r in rows if r["scratch"]}
+    assert all("k_rx_scatter" in name and size <= 64 for name, size in spilling.items()), spilling
+    assert not any("k_agg" in name or "k_eval" in name or "k_join" in name for name in spilling)

@@ -25,33 +25,78 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("case_name,world", [("many_groups", 2), ("q1_multiblock", 2), ("q1_ragged_blocks", 3), ("q1_selective", 2),
-                                              ("edge_int_key", 2), ("fruit", 2), ("join_group", 2), ("join_group", 3),
-                                              ("concat_like", 2), ("e2e_join_select", 2), ("e2e_join_group_sum", 3),
-                                              ("fruits5_filter", 2), ("e2e_group_avg_float", 2)])
-def test_world_n_matches_reference(tmp_path, case_name, world):
+# ---- one spawn per (world, backend, environment), not per case -------------------------------------------------------
+# Every case used to start its own `world` interpreters (torch import, engine, rendezvous: ~3 s each, half of the GPU
+# suite's wall time).  Cases that share world / backend / environment now run as ONE batch of tests/dist_worker.py; the
+# first test of a group that needs a result runs the whole group, the others read theirs.
+_BATCHES: dict = {}
+
+
+def _spawn_ranks(case: str, out, world: int, backend: str, extra_env: dict | None, timeout: int = 600) -> None:
     port = _free_port()
-    out = tmp_path / "rows.json"
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, str(ROOT / "tests" / "dist_worker.py"), case_name, str(out), "gloo"],
+                   MASTER_PORT=str(port), **(extra_env or {}))
+        procs.append(subprocess.Popen([sys.executable, str(ROOT / "tests" / "dist_worker.py"), case, str(out), backend],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    logs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    logs = [p.communicate(timeout=timeout)[0].decode() for p in procs]
     if any(p.returncode != 0 for p in procs):
-        report = "\n".join(f"--- rank {r} (exit {p.returncode}) ---\n{log[-2500:]}" for r, (p, log) in enumerate(zip(procs, logs)))
-        raise AssertionError(report)
-    rows = [{k: (float.fromhex(v) if isinstance(v, str) and v.startswith(("0x", "-0x")) else v) for k, v in r.items()}
-            for r in json.loads(out.read_text())]
+        return "\n".join(f"--- rank {r} (exit {p.returncode}) ---\n{log[-2500:]}" for r, (p, log) in enumerate(zip(procs, logs)))
+    return None
+
+
+def _batch(tmp_path_factory, group: str, world: int, backend: str, jobs: list, extra_env: dict | None = None) -> dict:
+    """jobs: [(case, folder the case's tables live in or None)] -> {case: decoded JSON the worker wrote, or {"error": ...}}."""
+    key = (group, world, backend, tuple(sorted((extra_env or {}).items())))
+    if key not in _BATCHES:
+        base = tmp_path_factory.mktemp(f"dist_{group}_{world}")
+        plan, outs = [], {}
+        for i, (case, folder) in enumerate(jobs):
+            folder = Path(folder) if folder is not None else base / f"job{i}"
+            folder.mkdir(parents=True, exist_ok=True)
+            outs[case] = folder / "rows.json"
+            plan.append([case, str(outs[case])])
+        (base / "jobs.json").write_text(json.dumps(plan))
+        log = _spawn_ranks(f"batch:{base / 'jobs.json'}", base / "unused.json", world, backend, extra_env, timeout=900)
+        results = {}
+        for case, out in outs.items():
+            if out.exists():
+                results[case] = json.loads(out.read_text())
+            else:
+                results[case] = {"error": f"no result written\n{log or ''}"}
+            if isinstance(results[case], dict) and "error" in results[case] and log:
+                results[case]["error"] += "\n" + log
+        _BATCHES[key] = results
+    return _BATCHES[key]
+
+
+def _decode_rows(result, want: list) -> list:
+    """The worker's JSON rows -> Python values (floats travel as hex, datetimes as ISO strings)."""
     from datetime import datetime
 
+    if isinstance(result, dict) and "error" in result:
+        raise AssertionError(result["error"])
+    for row in result:
+        for k, v in row.items():
+            if isinstance(v, str) and v.startswith(("0x", "-0x")):
+                row[k] = float.fromhex(v)
+            elif want and isinstance(want[0].get(k), datetime):
+                row[k] = datetime.fromisoformat(v)
+    return result
+
+
+_GOLDEN_CASES = [("many_groups", 2), ("q1_multiblock", 2), ("q1_ragged_blocks", 3), ("q1_selective", 2),
+                 ("edge_int_key", 2), ("fruit", 2), ("join_group", 2), ("join_group", 3),
+                 ("concat_like", 2), ("e2e_join_select", 2), ("e2e_join_group_sum", 3),
+                 ("fruits5_filter", 2), ("e2e_group_avg_float", 2)]
+
+
+@pytest.mark.parametrize("case_name,world", _GOLDEN_CASES)
+def test_world_n_matches_reference(tmp_path_factory, case_name, world):
+    jobs = [(c, None) for c, w in _GOLDEN_CASES if w == world]
     golden = load_golden(case_name)["rows"]
-    for r, g in zip(rows, golden[:1]):  # datetimes travel as ISO strings through the worker's JSON
-        for k, v in g.items():
-            if isinstance(v, datetime):
-                for row in rows:
-                    row[k] = datetime.fromisoformat(row[k])
+    rows = _decode_rows(_batch(tmp_path_factory, "golden", world, "gloo", jobs)[case_name], golden)
     flips = assert_rows_match(rows, golden, max_ulps=1)
     assert flips <= (2 if case_name == "many_groups" else 0)  # shared tier: hardware-order additions
 
@@ -63,52 +108,47 @@ if os.environ.get("HIPSPARK_DIST_FUZZ"):  # "first:last" - a wider hunt than the
     _DIST_FUZZ = [(s, 2 + s % 2) for s in range(_lo, _hi)]
 
 
+def _fuzz_jobs(tmp_path_factory, world: int) -> tuple[list, dict]:
+    """Tables + oracle rows of every fuzz seed of this world (seeds whose query must raise are the single-process fuzz
+    test's business: no job)."""
+    key = ("fuzz-prep", world)
+    if key not in _BATCHES:
+        import random
+
+        from minispark_amd.dataframe import DataFrame
+        from minispark_amd.sql import Col, Functions, Lit
+        from oracle.py_engine import run_query
+        from tests.queries import api_namespace
+        from tests.test_gpu_fuzz import make_table, random_query
+
+        jobs, wants = [], {}
+        for seed, w in _DIST_FUZZ:
+            if w != world:
+                continue
+            folder = tmp_path_factory.mktemp(f"fuzz{seed}")
+            rng = random.Random(7000 + seed)
+            make_table(folder / "a.bin", rng, 4000, blocks=5)
+            make_table(folder / "b.bin", rng, 200, blocks=3)
+            api = api_namespace(lambda: DataFrame(object()), Col, Functions, Lit)
+            try:
+                wants[seed] = run_query(random_query(random.Random(seed), api, str(folder / "a.bin"), str(folder / "b.bin")).task)
+            except Exception:  # noqa: BLE001
+                wants[seed] = None
+                continue
+            jobs.append((f"fuzz:{seed}", folder))
+        _BATCHES[key] = (jobs, wants)
+    return _BATCHES[key]
+
+
 @pytest.mark.parametrize("seed,world", _DIST_FUZZ)
-def test_random_queries_on_n_ranks_match_the_oracle(tmp_path, seed, world):
+def test_random_queries_on_n_ranks_match_the_oracle(tmp_path_factory, seed, world):
     """Random queries of the fuzz generator (joins, filters, projections, GROUP BY on int / string / computed keys)
     over 5-block tables, N ranks over gloo on the one GPU: every exchange form against the CPU oracle."""
-    import random
-
-    from minispark_amd.dataframe import DataFrame
-    from minispark_amd.sql import Col, Functions, Lit
-    from oracle.py_engine import run_query
-    from tests.queries import api_namespace
-    from tests.test_gpu_fuzz import make_table, random_query
-
-    rng = random.Random(7000 + seed)
-    make_table(tmp_path / "a.bin", rng, 4000, blocks=5)
-    make_table(tmp_path / "b.bin", rng, 200, blocks=3)
-    api = api_namespace(lambda: DataFrame(object()), Col, Functions, Lit)
-    try:
-        want = run_query(random_query(random.Random(seed), api, str(tmp_path / "a.bin"), str(tmp_path / "b.bin")).task)
-    except Exception:  # noqa: BLE001 - queries that must raise are the single-process fuzz test's business
+    jobs, wants = _fuzz_jobs(tmp_path_factory, world)
+    if wants[seed] is None:
         pytest.skip("the oracle raises for this seed")
-    port = _free_port()
-    out = tmp_path / "rows.json"
-    assert_rows_match(_run_ranks(f"fuzz:{seed}", world, out, port, want), want, max_ulps=1)
-
-
-def _run_ranks(case: str, world: int, out, port: int, want: list, backend: str = "gloo", extra_env: dict | None = None) -> list:
-    procs = []
-    for rank in range(world):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), **(extra_env or {}))
-        procs.append(subprocess.Popen([sys.executable, str(ROOT / "tests" / "dist_worker.py"), case, str(out), backend],
-                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    logs = [p.communicate(timeout=300)[0].decode() for p in procs]
-    if any(p.returncode != 0 for p in procs):
-        report = "\n".join(f"--- rank {r} (exit {p.returncode}) ---\n{log[-2500:]}" for r, (p, log) in enumerate(zip(procs, logs)))
-        raise AssertionError(report)
-    from datetime import datetime
-
-    rows = json.loads(out.read_text())
-    for row in rows:
-        for k, v in row.items():
-            if isinstance(v, str) and v.startswith(("0x", "-0x")):
-                row[k] = float.fromhex(v)
-            elif want and isinstance(want[0].get(k), datetime):
-                row[k] = datetime.fromisoformat(v)
-    return rows
+    rows = _decode_rows(_batch(tmp_path_factory, "fuzz", world, "gloo", jobs)[f"fuzz:{seed}"], wants[seed])
+    assert_rows_match(rows, wants[seed], max_ulps=1)
 
 
 _DIST_WIDE = [(0, 2), (3, 3), (5, 2), (8, 2)]
@@ -117,24 +157,38 @@ if os.environ.get("HIPSPARK_DIST_WIDE"):
     _DIST_WIDE = [(s, 2 + s % 2) for s in range(_lo, _hi)]
 
 
+def _wide_jobs(tmp_path_factory, world: int) -> tuple[list, dict]:
+    key = ("wide-prep", world)
+    if key not in _BATCHES:
+        import random
+
+        from minispark_amd.dataframe import DataFrame
+        from minispark_amd.sql import Col, Functions, Lit
+        from oracle.py_engine import run_query
+        from tests.queries import api_namespace
+        from tests.test_gpu_shared_tier import _wide_query, _wide_table
+
+        jobs, wants = [], {}
+        for seed, w in _DIST_WIDE:
+            if w != world:
+                continue
+            folder = tmp_path_factory.mktemp(f"wide{seed}")
+            rng = random.Random(900 + seed)
+            _wide_table(folder / "w.bin", rng.choice([5_000, 20_000]), rng.choice([3, 5, 7]), seed)
+            api = api_namespace(lambda: DataFrame(object()), Col, Functions, Lit)
+            wants[seed] = run_query(_wide_query(random.Random(seed), api, str(folder / "w.bin")).task)
+            jobs.append((f"wide:{seed}", folder))
+        _BATCHES[key] = (jobs, wants)
+    return _BATCHES[key]
+
+
 @pytest.mark.parametrize("seed,world", _DIST_WIDE)
-def test_random_many_group_queries_on_n_ranks_match_the_oracle(tmp_path, seed, world):
+def test_random_many_group_queries_on_n_ranks_match_the_oracle(tmp_path_factory, seed, world):
     """Random GROUP BY queries with tens to thousands of groups (tests/test_gpu_shared_tier.py's generator) on N ranks
     over gloo: shared-dictionary and HBM-tier partials through the all-to-all exchange against the CPU oracle."""
-    import random
-
-    from minispark_amd.dataframe import DataFrame
-    from minispark_amd.sql import Col, Functions, Lit
-    from oracle.py_engine import run_query
-    from tests.queries import api_namespace
-    from tests.test_gpu_shared_tier import _wide_query, _wide_table
-
-    rng = random.Random(900 + seed)
-    _wide_table(tmp_path / "w.bin", rng.choice([5_000, 20_000]), rng.choice([3, 5, 7]), seed)
-    api = api_namespace(lambda: DataFrame(object()), Col, Functions, Lit)
-    want = run_query(_wide_query(random.Random(seed), api, str(tmp_path / "w.bin")).task)
-    rows = _run_ranks(f"wide:{seed}", world, tmp_path / "rows.json", _free_port(), want)
-    assert assert_rows_match(rows, want, max_ulps=1) <= 3
+    jobs, wants = _wide_jobs(tmp_path_factory, world)
+    rows = _decode_rows(_batch(tmp_path_factory, "wide", world, "gloo", jobs)[f"wide:{seed}"], wants[seed])
+    assert assert_rows_match(rows, wants[seed], max_ulps=1) <= 3
 
 
 # ---- the exchange form must not depend on what a rank's own rows look like (ADVICE round 1, high) -----------------
@@ -157,45 +211,54 @@ def _width_table(path, blocks: list[list[str]]):
     BlockFile(path).write_raw_blocks(schema, out)
 
 
+_WIDTH_BLOCKS = {
+    # a 1-block table with a 1-char key: the ranks without a block see fixed_len 0
+    "oneblock": [[("A", "N", "R")[i % 3] for i in range(50)]],
+    # block 0 holds only 2-char keys, the other blocks mixed lengths: fixed-width on one rank, variable on the others
+    "disagree": [[("ab", "cd")[i % 2] for i in range(40)], ["ab", "x", "cd", "long-key", ""] * 8, ["cd", "yy", "zzz"] * 5],
+    # 6 blocks x 14 disjoint variable-length keys: the units' dictionaries fit, their union does not
+    "union": [[f"k{b}-{'x' * (i % 5)}{i}" for i in range(14)] * 3 for b in range(6)],
+}
+
+
+def _width_jobs(tmp_path_factory) -> tuple[list, dict]:
+    if "width-prep" not in _BATCHES:
+        from minispark_amd.dataframe import DataFrame
+        from minispark_amd.sql import Col, Functions, Lit
+        from minispark_amd.workloads import api_namespace
+        from oracle.py_engine import run_query
+
+        jobs, wants = [], {}
+        for variant, blocks in _WIDTH_BLOCKS.items():
+            folder = tmp_path_factory.mktemp(f"width_{variant}")
+            _width_table(folder / "w.bin", blocks)
+            api = api_namespace(lambda: DataFrame(object()), Col, Functions, Lit)
+            wants[variant] = run_query(width_query(api, str(folder / "w.bin")).task)
+            jobs.append((f"width:{variant}", folder))
+        _BATCHES["width-prep"] = (jobs, wants)
+    return _BATCHES["width-prep"]
+
+
 @pytest.mark.parametrize("variant,world", [("oneblock", 2), ("oneblock", 3), ("disagree", 2), ("disagree", 3)])
-def test_ranks_agree_on_the_exchange_form(tmp_path, variant, world):
+def test_ranks_agree_on_the_exchange_form(tmp_path_factory, variant, world):
     """oneblock: a 1-block table with a 1-char key - the ranks without a block see fixed_len 0 and used to pick the
     all-to-all while rank 0 picked the all-gather (hang).  disagree: block 0 holds only 2-char keys, the other blocks
     mixed lengths - locally fixed-width on one rank, variable on the others."""
-    from minispark_amd.dataframe import DataFrame
-    from minispark_amd.sql import Col, Functions, Lit
-    from minispark_amd.workloads import api_namespace
-    from oracle.py_engine import run_query
-
-    if variant == "oneblock":
-        blocks = [[("A", "N", "R")[i % 3] for i in range(50)]]
-    else:
-        blocks = [[("ab", "cd")[i % 2] for i in range(40)], ["ab", "x", "cd", "long-key", ""] * 8, ["cd", "yy", "zzz"] * 5]
-    _width_table(tmp_path / "w.bin", blocks)
-    api = api_namespace(lambda: DataFrame(object()), Col, Functions, Lit)
-    want = run_query(width_query(api, str(tmp_path / "w.bin")).task)
-    rows = _run_ranks(f"width:{variant}", world, tmp_path / "rows.json", _free_port(), want)
-    assert assert_rows_match(rows, want) == 0
+    jobs, wants = _width_jobs(tmp_path_factory)
+    rows = _decode_rows(_batch(tmp_path_factory, "width", world, "gloo", jobs)[f"width:{variant}"], wants[variant])
+    assert assert_rows_match(rows, wants[variant]) == 0
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_final_merge_outgrowing_its_capacity_is_retried_on_every_rank(tmp_path, world):
+def test_final_merge_outgrowing_its_capacity_is_retried_on_every_rank(tmp_path_factory, world):
     """6 blocks x 14 disjoint variable-length keys: every unit's dictionary fits (14 <= 16, HS_FLAG_DICT_FULL stays
     down), the final merge's first capacity (16) does not hold the union of 84 keys -> HS_FLAG_MERGE_FULL (bit 8).
     Round 2's or_flags reduced bits 0-7 only and erased it - on the rank that raised it too - so the query was not
     repeated with a larger merge dictionary and came back short, silently (VERDICT round 2, weak #1)."""
-    from minispark_amd.dataframe import DataFrame
-    from minispark_amd.sql import Col, Functions, Lit
-    from minispark_amd.workloads import api_namespace
-    from oracle.py_engine import run_query
-
-    blocks = [[f"k{b}-{'x' * (i % 5)}{i}" for i in range(14)] * 3 for b in range(6)]
-    _width_table(tmp_path / "w.bin", blocks)
-    api = api_namespace(lambda: DataFrame(object()), Col, Functions, Lit)
-    want = run_query(width_query(api, str(tmp_path / "w.bin")).task)
-    assert len(want) == 84
-    rows = _run_ranks("width:union", world, tmp_path / "rows.json", _free_port(), want)
-    assert assert_rows_match(rows, want) == 0
+    jobs, wants = _width_jobs(tmp_path_factory)
+    assert len(wants["union"]) == 84
+    rows = _decode_rows(_batch(tmp_path_factory, "width", world, "gloo", jobs)["width:union"], wants["union"])
+    assert assert_rows_match(rows, wants["union"]) == 0
 
 
 # ---- BASELINE config 4 as stated: hash-join + GROUP BY on N GPUs, at size ---------------------------------------------
@@ -259,29 +322,35 @@ def test_config5_on_n_ranks_matches_the_c_port(tmp_path, world):
 
 
 # ---- RCCL itself (backend "nccl"): one rank per device, so world 1 on the one-GPU test box ----------------------------
-@pytest.mark.parametrize("case_name", ["q1_multiblock", "q1_ragged_blocks", "join_group", "concat_like", "many_groups",
-                                       "e2e_join_select", "fruit"])
-def test_rccl_world1_matches_reference(tmp_path, case_name):
+_RCCL_CASES = ["q1_multiblock", "q1_ragged_blocks", "join_group", "concat_like", "many_groups", "e2e_join_select", "fruit"]
+
+
+@pytest.mark.parametrize("case_name", _RCCL_CASES)
+def test_rccl_world1_matches_reference(tmp_path_factory, case_name):
     """The collectives the 8-GPU run uses - all_gather_into_tensor of the slabs, all_to_all_single of rows, the
     device-side count exchange and flag reduction - executed by RCCL in a fresh child process (world 1: RCCL refuses
     two ranks per device).  Rows must equal the reference's goldens like on every other path."""
     golden = load_golden(case_name)["rows"]
-    rows = _run_ranks(case_name, 1, tmp_path / "rows.json", _free_port(), golden, backend="nccl")
+    rows = _decode_rows(_batch(tmp_path_factory, "rccl", 1, "nccl", [(c, None) for c in _RCCL_CASES])[case_name], golden)
     flips = assert_rows_match(rows, golden, max_ulps=1)
     assert flips <= (2 if case_name == "many_groups" else 0)
 
 
-@pytest.mark.parametrize("case_name,world,backend", [("q1_multiblock", 1, "nccl"), ("q1_multiblock", 2, "gloo"),
-                                                     ("q1_ragged_blocks", 3, "gloo"), ("edge_int_key", 2, "gloo"),
-                                                     ("q1_selective", 3, "gloo")])
-def test_peer_to_peer_slab_exchange_matches_reference(tmp_path, case_name, world, backend):
+_P2P_CASES = [("q1_multiblock", 1, "nccl"), ("q1_multiblock", 2, "gloo"), ("q1_ragged_blocks", 3, "gloo"), ("edge_int_key", 2, "gloo"),
+              ("q1_selective", 3, "gloo")]
+
+
+@pytest.mark.parametrize("case_name,world,backend", _P2P_CASES)
+def test_peer_to_peer_slab_exchange_matches_reference(tmp_path_factory, case_name, world, backend):
     """Round 3 prototype (HIPSPARK_P2P_SLABS=1): the short tail's slabs travel as stores into buffers the peers map through
     hipIpc handles, with device-side flags instead of a collective (csrc/hs_exchange.hip hs_slab_push / hs_slab_wait).  World 1
     under RCCL's process group, and 2 - 3 PROCESSES sharing the test box's GPU (real hipIpc mappings between processes; the
-    xGMI hop itself needs a multi-GPU node).  Four runs per rank: first, recorded, replays - the epochs must stay in step."""
+    xGMI hop itself needs a multi-GPU node).  Four runs per rank: first, recorded, replays - the epochs must stay in step
+    (also from one query to the next: the cases of a world share their processes and so their peer buffers)."""
     golden = load_golden(case_name)["rows"]
-    rows = _run_ranks(case_name, world, tmp_path / "rows.json", _free_port(), golden, backend=backend,
-                      extra_env={"HIPSPARK_P2P_SLABS": "1", "HIPSPARK_WORKER_EXPECT_P2P": "1"})
+    jobs = [(c, None) for c, w, b in _P2P_CASES if (w, b) == (world, backend)]
+    rows = _decode_rows(_batch(tmp_path_factory, "p2p", world, backend, jobs,
+                               {"HIPSPARK_P2P_SLABS": "1", "HIPSPARK_WORKER_EXPECT_P2P": "1"})[case_name], golden)
     assert assert_rows_match(rows, golden, max_ulps=1) == 0
 
 

@@ -180,6 +180,41 @@ def test_join_matches_reference_order(dev):
     assert got == want
 
 
+@pytest.mark.parametrize("n_left,n_right,spread,seed", [(1, 5, 1, 0), (3000, 5000, 2, 1), (70_000, 200_000, 4, 2),
+                                                        (2_000_000, 3_000_000, 10, 3), (300_000, 100_000, 30, 4)])
+def test_dense_integer_join_matches_reference_order(dev, n_left, n_right, spread, seed):
+    """Round 4: INTEGER keys over a dense range take hs_join_dense_* - two stable range-partition passes over the build
+    rows, a CSR over key SLOTS assembled per partition in LDS (rows of a slot ascending, no sort, no global atomic), probe by
+    two adjacent offsets.  Duplicates on both sides, keys without a partner on both sides, a negative key_min, zero / one /
+    two partition passes: pairs must come out ordered by right row, then left row ascending (reference tasks.py:224-240)."""
+    from minispark_amd.constants import ColumnType
+
+    rng = _rng(100 + seed)
+    span = max(1, n_left * spread // 2)
+    base = -span // 3
+    left = (base + rng.integers(0, span, n_left)).astype(np.int32)       # duplicates happen (birthday), gaps too
+    if n_left > 1:
+        left[rng.integers(0, n_left, max(1, n_left // 50))] = left[0]    # ... and one key many times
+    right = (base - 5 + rng.integers(0, span + 10, n_right)).astype(np.int32)  # some probe keys fall outside the range
+    lcol, rcol = dev.upload_raw(left, ColumnType.INTEGER), dev.upload_raw(right, ColumnType.INTEGER)
+    before = getattr(dev, "dense_joins", 0)
+    out_left, out_right, out_start, n_out = dev.join_indices(lcol, rcol)
+    assert getattr(dev, "dense_joins", 0) == before + 1 and dev.last_join["mode"] == "dense csr"
+    assert dev.read_flags() == 0
+    order = np.argsort(left, kind="stable")
+    keys_sorted = left[order]
+    lo, hi = np.searchsorted(keys_sorted, right, "left"), np.searchsorted(keys_sorted, right, "right")
+    counts = hi - lo
+    want_right = np.repeat(np.arange(n_right, dtype=np.int64), counts)
+    starts = np.concatenate([[0], np.cumsum(counts)])
+    within = np.arange(int(counts.sum()), dtype=np.int64) - np.repeat(starts[:-1], counts)
+    want_left = order[np.repeat(lo, counts) + within].astype(np.int64)
+    assert n_out == len(want_right)
+    assert np.array_equal(out_start[: n_right + 1].cpu().numpy(), starts)
+    assert np.array_equal(out_right[:n_out].cpu().numpy(), want_right)
+    assert np.array_equal(out_left[:n_out].cpu().numpy(), want_left)
+
+
 def test_join_on_strings_including_long_ones(dev):
     from minispark_amd.constants import ColumnType
     from minispark_amd.io import StrCol

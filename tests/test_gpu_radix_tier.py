@@ -20,7 +20,7 @@ def dev():
 
 
 def _expected(keys, vals, ops, is_int, bounds, quantise):
-    """-> per unit {key: tuple of accumulators}"""
+    """-> per unit (sorted distinct keys, one accumulator array per aggregate in that order)"""
     from minispark_amd import hipspark as hs
 
     out = []
@@ -41,7 +41,7 @@ def _expected(keys, vals, ops, is_int, bounds, quantise):
             if quantise:
                 acc = acc.astype(np.int32 if integer else np.float32)
             accs.append(acc)
-        out.append({int(k): tuple(a[i].item() for a in accs) for i, k in enumerate(uniq)})
+        out.append((uniq.astype(np.int64), accs))
     return out
 
 
@@ -70,23 +70,32 @@ def _run(dev, keys, key_kind, sel, bounds, values, ops, quantise):
     key_col, accs, unit_rows = done
     torch.cuda.synchronize()
     assert dev.read_flags() == 0
-    k = key_col.data[: key_col.n].cpu().numpy()
+    k = key_col.data[: key_col.n].cpu().numpy().astype(np.int64)
     a = [c.data[: c.n].cpu().numpy() for c in accs]
     got = []
     for lo, hi in zip(unit_rows, unit_rows[1:]):
-        unit = {int(k[i]): tuple(x[i].item() for x in a) for i in range(lo, hi)}
-        assert len(unit) == hi - lo, "a key twice in one unit"
-        got.append(unit)
+        order = np.argsort(k[lo:hi], kind="stable")
+        got.append((k[lo:hi][order], [x[lo:hi][order] for x in a]))
     return got
 
 
+def _bits(x):
+    return x.view({4: np.int32, 8: np.int64}[x.dtype.itemsize])
+
+
 def _same(got, want):
+    """Bit for bit (signed zeros included), group for group - as arrays: these tests hold millions of groups."""
     assert len(got) == len(want)
-    for u, (g, w) in enumerate(zip(got, want)):
-        assert g.keys() == w.keys(), f"unit {u}: {len(g)} groups, expected {len(w)}"
-        for key, accs in w.items():
-            for x, y in zip(g[key], accs):
-                assert x == y and np.signbit(x) == np.signbit(y), (u, key, g[key], accs)
+    for u, ((gk, ga), (wk, wa)) in enumerate(zip(got, want)):
+        assert len(gk) == len(wk), f"unit {u}: {len(gk)} groups, expected {len(wk)}"
+        assert len(gk) < 2 or (gk[1:] != gk[:-1]).all(), f"unit {u}: a key twice in one unit"
+        assert np.array_equal(gk, wk), f"unit {u}: other keys"
+        for j, (x, y) in enumerate(zip(ga, wa)):
+            if x.dtype != y.dtype and x.dtype.kind in "iu" and y.dtype.kind in "iu":
+                x, y = x.astype(np.int64), y.astype(np.int64)
+            assert x.dtype == y.dtype, (u, j, x.dtype, y.dtype)
+            bad = np.nonzero(_bits(x) != _bits(y))[0]
+            assert len(bad) == 0, (u, j, int(gk[bad[0]]), x[bad[0]].item(), y[bad[0]].item())
 
 
 @pytest.mark.parametrize(("n", "units", "groups", "seed"), [
@@ -247,7 +256,7 @@ def test_radix_tier_reports_an_outgrown_dictionary(dev):
 
 def test_engine_takes_the_radix_tier_for_integer_keys(tmp_path):
     """Through the engine: the high-cardinality GROUP BY of test_gpu_q1_large runs on the radix tier and still equals
-    the Python oracle bit for bit; with HIPSPARK_RADIX=0 the hash-table tier gives the same rows."""
+    the Python oracle bit for bit; with `Device.radix_enabled` off the hash-table tier gives the same rows."""
     from minispark_amd import constants
     from minispark_amd.constants import ColumnType as T
     from minispark_amd.dataframe import DataFrame

@@ -5,6 +5,7 @@ sums at an f32 rounding boundary: at most one ulp, and rarely (the test bounds t
 from __future__ import annotations
 
 import random
+from ctypes import c_int32 as C_int32
 
 import numpy as np
 import pytest
@@ -74,6 +75,38 @@ def test_many_group_queries_match_the_oracle(engine, tmp_path):
             assert flips <= 3, f"{name}: {flips} values moved across an f32 rounding boundary"
         assert engine.dev.last_scan["tier"] == "shared", name
         assert engine.dev.last_scan["wg_threads"] == 1024
+
+
+def test_the_interpreter_kernels_of_the_shared_tier_match_the_oracle(tmp_path):
+    """Without the run-time compiler (HIPSPARK_JIT=0, or hiprtc missing) the shared tier runs its ahead-of-time
+    interpreter kernels k_agg_shared<...>: 512 lanes wide for expression stacks of depth <= 4, 256 lanes for depth 8 and for
+    long string keys ("hashed") - round 3 ran them at 1024 lanes with the stack in scratch memory.  Same chunks, same
+    results: the three query shapes (packed INTEGER key, 8-16 byte string key, computed key) against the oracle."""
+    from minispark_amd.dataframe import DataFrame
+    from minispark_amd.execution import HipExecutionEngine
+    from minispark_amd.sql import Col, Functions, Lit
+    from oracle.py_engine import run_query
+    from tests.queries import api_namespace
+
+    path = tmp_path / "t.bin"
+    _table(path, 60_000, 4, 12)
+    oracle = _queries(api_namespace(lambda: DataFrame(object()), Col, Functions, Lit), str(path))
+    with HipExecutionEngine(0) as e:
+        e.dev.lib.hs_jit_set_enabled(0)
+        try:
+            ours = _queries(api_namespace(lambda: DataFrame(e), Col, Functions, Lit), str(path))
+            stats = (C_int32 * 3)()
+            e.dev.lib.hs_jit_stats(stats)
+            launches_before = stats[1]
+            for name in ours:
+                want = run_query(oracle[name].task)
+                for _run in range(2):
+                    assert assert_rows_match(ours[name].collect(), want, max_ulps=1) <= 3, name
+                assert e.dev.last_scan["tier"] == "shared", name
+            e.dev.lib.hs_jit_stats(stats)
+            assert stats[1] == launches_before, "no compiled program may have run"
+        finally:
+            e.dev.lib.hs_jit_set_enabled(1)
 
 
 def test_counts_and_integer_sums_are_exact_at_scale(engine, tmp_path):

@@ -93,6 +93,27 @@ nout = int(ost[N].item()); ol = dev.empty(nout, torch.int64); orr = dev.empty(no
 ms = timed(lambda: lib.hs_join_fill(dev.stream, C.byref(b_hs), C.byref(p_hs), N, cap, tk.data_ptr(), tr.data_ptr(), ss.data_ptr(), rows.data_ptr(), ost.data_ptr(), ol.data_ptr(), orr.data_ptr()))
 report("A8 hs_join_fill (emit pairs)", ms, N * (4 + 16 + 8 + 16 + 8) + nout * 16, f"{nout} pairs")
 
+# A8, round 4: the same join through the dense-range CSR (hs_join_dense_*: range partition passes + per-partition assembly in
+# LDS; probe = two adjacent offsets per row).  Keys 0 .. nb-1 (every slot used) and TPC-H-like sparse keys (8 of every 32).
+for label, bkeys, pkeys in (("dense", build, probe),
+                            ("sparse 8/32", (32 * (build // 8) + build % 8 + 1).to(torch.int32), (32 * (probe // 8) + probe % 8 + 1).to(torch.int32))):
+    lo, hi = int(bkeys.min().item()), int(bkeys.max().item())
+    slots = hi - lo + 1
+    starts = dev.empty(slots + 1, torch.int32); drows = dev.empty(nb, torch.int32)
+    dws = dev.workspace(lib.hs_join_dense_ws_bytes(nb, slots))
+    bk = dev.empty(nb, torch.int32); bk.copy_(bkeys); pk = dev.empty(N, torch.int32); pk.copy_(pkeys)
+    ms_b = timed(lambda: lib.hs_join_dense_build(dev.stream, bk.data_ptr(), nb, lo, slots, starts.data_ptr(), drows.data_ptr(), dws.data_ptr(), dev.flags.data_ptr()))
+    report(f"A8 hs_join_dense_build ({label}, {slots} slots)", ms_b, nb * (4 + 4) + (slots + 1) * 4, f"{nb / ms_b / 1e3:.0f} M keys/s; keys in, rows + one offset per slot out")
+    aux = dev.workspace(lib.hs_join_dense_aux_bytes(N))
+    ms_c = timed(lambda: lib.hs_join_dense_count(dev.stream, pk.data_ptr(), N, lo, slots, starts.data_ptr(), drows.data_ptr(), counts.data_ptr(), aux.data_ptr()))
+    report(f"A8 hs_join_dense_count ({label})", ms_c, N * (4 + 8 + 8), f"{N / ms_c / 1e3:.0f} M probes/s; random 8 B reads of a {slots * 4 / 1e6:.0f} MB offset array + the first row; counts + 8 B aux out")
+    lib.hs_exclusive_scan_i64(dev.stream, counts.data_ptr(), N, ost.data_ptr(), sws.data_ptr())
+    nout2 = int(ost[N].item()); assert nout2 == nout, (nout2, nout)
+    ms_f = timed(lambda: lib.hs_join_dense_fill(dev.stream, N, drows.data_ptr(), aux.data_ptr(), ost.data_ptr(), ol.data_ptr(), orr.data_ptr()))
+    report(f"A8 hs_join_dense_fill ({label})", ms_f, N * (8 + 4) + nout * 16, f"{nout} pairs; a stream: offsets + first rows in, pairs out")
+    report(f"A8 dense count + fill ({label})", ms_c + ms_f, N * (4 + 8 + 8) + N * (8 + 4) + nout * 16)
+    assert dev.read_flags() == 0
+
 # A5 global-tier group build + fold (high cardinality)
 ng_keys = torch.randint(0, N // 16, (N,), dtype=torch.int32, device="cuda", generator=g)
 gcol = DCol(hs.I32, ng_keys, N)
