@@ -411,21 +411,25 @@ int hs_group_radix_emit(void* stream, const hs_radix_plan* plan, void* ws, void*
 /* ---- the general inner join on INTEGER keys over a dense key range (round 4; csrc/hs_radix.hip) -------------------------
  * Reference: BroadcastHashJoinTask.generate_chunks tasks.py:201-240 (zig twin tasks.zig:70-194; duplicate keys multiply,
  * tasks.zig:258-326).  Replaces hs_join_build / hs_join_count / hs_join_fill when both key columns are INTEGER and the
- * build keys span at most `slots` <= 2^30 consecutive values from key_min: the build rows are moved by two stable range
- * partition passes and assembled partition by partition in LDS into a CSR over SLOTS - starts[slots + 1] (uint32; a slot
- * without a build row is an empty range) and rows[n_build] (uint32 build rows, ascending within a slot) - with no global
- * atomic and no hash table.  hs_join_dense_count: counts[i] = matches of probe row i, and in aux
- * (hs_join_dense_aux_bytes(n_probe), 16-byte aligned) the first matching build row and the list start of every probe row,
- * written sequentially; the caller scans the counts (hs_exclusive_scan_i64) and sizes the pair lists;
- * hs_join_dense_fill writes the pairs ordered by probe row, then build row - the reference's emission order - as a
- * stream over out_start and aux: it returns to `rows` only for probe rows with several partners.  A build key outside the declared range raises HS_FLAG_BAD_PROGRAM.
- * ws: hs_join_dense_ws_bytes(n_build, slots) (0 = this shape is not held: n_build >= 2^32 or slots > 2^30). */
+ * build keys span at most `slots` <= 2^29 consecutive values from key_min (n_build < 2^31): the build rows are moved by two
+ * stable range partition passes and assembled partition by partition in LDS - no global atomic, no hash table - into
+ *   words[slots]        per key SLOT: 0xffffffff = no build row, a build row (the key's only one), or 0x80000000 + the
+ *                       start of the key's list in rows[] (several rows);
+ *   rows[n_build]       the build rows in slot order, ascending within a slot;
+ *   list_count[n_build] at the start of a list of several rows: its length (other entries are not written).
+ * hs_join_dense_count: ONE scattered 4-byte read per probe row (its slot word; two more only for keys with several
+ * partners); counts[i] = matches of probe row i, and in aux (hs_join_dense_aux_bytes(n_probe), 16-byte aligned) the
+ * first matching build row and the list start of every probe row, written sequentially.  The caller scans the counts
+ * (hs_exclusive_scan_i64) and sizes the pair lists; hs_join_dense_fill writes the pairs ordered by probe row, then build
+ * row - the reference's emission order - as a stream over out_start and aux: it returns to rows[] only for probe rows with
+ * several partners.  A build key outside the declared range raises HS_FLAG_BAD_PROGRAM.
+ * ws: hs_join_dense_ws_bytes(n_build, slots) (0 = this shape is not held). */
 size_t hs_join_dense_ws_bytes(int64_t n_build, int64_t slots);
-int hs_join_dense_build(void* stream, const int32_t* build_keys, int64_t n_build, int32_t key_min, int64_t slots, uint32_t* starts,
-                        uint32_t* rows, void* ws, uint32_t* flags);
+int hs_join_dense_build(void* stream, const int32_t* build_keys, int64_t n_build, int32_t key_min, int64_t slots, uint32_t* words,
+                        uint32_t* rows, uint32_t* list_count, void* ws, uint32_t* flags);
 size_t hs_join_dense_aux_bytes(int64_t n_probe);
 int hs_join_dense_count(void* stream, const int32_t* probe_keys, int64_t n_probe, int32_t key_min, int64_t slots,
-                        const uint32_t* starts, const uint32_t* rows, int64_t* counts, void* aux);
+                        const uint32_t* words, const uint32_t* rows, const uint32_t* list_count, int64_t* counts, void* aux);
 int hs_join_dense_fill(void* stream, int64_t n_probe, const uint32_t* rows, const void* aux, const int64_t* out_start,
                        int64_t* out_left, int64_t* out_right);
 /* Merge order of a multi-rank final aggregate (the reference reads a partition's shuffle files in block order,

@@ -1178,6 +1178,13 @@ extern "C" int hs_agg_partial_geom(const int64_t* host_unit_rows, int64_t n_unit
             if (n <= wg_slots * rounds) break;
             ++steps_per_chunk;
         }
+        // small tables: a workgroup costs ~11 us before its first and after its last step, and the unit combine in the last
+        // one's epilogue walks the unit's chunks in batches of 64 - filling every workgroup slot with one- or two-step chunks
+        // is slower than fewer, longer ones as long as every CU still gets one.  Measured at sf=1 (6 M rows, 3 units;
+        // profiles/r04_chunk_steps_sweep.txt): 8 steps (733 chunks) 94 us, 16 steps (367) 73 us, 32 steps (184) 82 us.
+        int64_t floor = total_steps / n_cus;
+        floor = floor < 1 ? 1 : (floor > 16 ? 16 : floor);
+        if (steps_per_chunk < floor) steps_per_chunk = floor;
     }
     if (steps_per_chunk < 1) steps_per_chunk = 1;
     if (steps_per_chunk > 4096) steps_per_chunk = 4096;

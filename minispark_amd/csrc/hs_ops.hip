@@ -528,7 +528,15 @@ __global__ void __launch_bounds__(256) k_lens_minmax(const uint8_t* lens, int64_
 
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-// reduce -> scan of the tile sums -> down-sweep, byte-input form
+// reduce -> scan of the tile sums -> down-sweep, byte-input form.
+// Round 4 tried ONE pass instead (decoupled look-back: 16384-row tiles taken in ticket order, a tile's sum and then its
+// inclusive prefix published in one 64-bit word per tile, wave 0 looking back over 64 predecessors at a time) and measured
+// it at 64 Mi rows on MI355X: with release / acquire at agent scope 0.53 ms (compaction) and 0.56 ms (offsets) - every
+// publish wrote back, every poll invalidated the XCD's L2; with relaxed agent-scope words (the word is the whole message)
+// and 1024 persistent workgroups 0.114 / 0.169 ms - against 0.099 / 0.164 ms for these three launches.  A poll of a word
+// another XCD wrote goes through the memory-side cache (~1-2 us) and the four workgroups of a CU all stall in it; what
+// the pass saves - the second read of 1 byte per row - is a fifth of the 8 bytes per kept row it has to write anyway.
+// Not kept (profiles/r04_single_pass_scans_64M.txt).
 template <bool MASK>
 static int run_bytes_scan(hipStream_t s, const uint8_t* p, int64_t n, int64_t* out, int64_t* total_out, int32_t* minmax,
                           void* ws, const char* name) {

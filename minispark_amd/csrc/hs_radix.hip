@@ -1723,7 +1723,9 @@ extern "C" int hs_expand_by_bounds(void* stream, const int64_t* bounds, const in
 //      included) leaves with coalesced stores.
 // The probe is then one or two adjacent 4-byte reads per row (starts[s], starts[s + 1]) instead of a hash probe over
 // three arrays: count -> exclusive scan -> fill, pairs ordered by probe row, then build row (tasks.py:224-240).
-constexpr int JD_MAX_L = 14;  // slots of one partition: 2^L u32 cursors in LDS per wave (64 KB at most)
+constexpr int JD_MAX_L = 13;  // slots of one partition: 2^L cursors + 2^L first rows (uint32) in LDS per wave (64 KB at most)
+constexpr uint32_t JD_EMPTY = 0xffffffffu;  // slot word: no build row has this key
+constexpr uint32_t JD_MULTI = 0x80000000u;  // slot word: several - the low 31 bits are the start of the key's list in rows[]
 
 struct JdAssemble {
     const int64_t* seg_start;  // [parts + 1] tuple ranges of the partitions
@@ -1732,8 +1734,9 @@ struct JdAssemble {
     const uint32_t* rows;
     int64_t slots;
     int32_t key_min, L;
-    uint32_t* starts;          // [slots + 1]
-    uint32_t* out_rows;        // [n]
+    uint32_t* words;           // [slots]: JD_EMPTY | the one build row | JD_MULTI + list start
+    uint32_t* out_rows;        // [n]: build rows in slot order, ascending within a slot
+    uint32_t* list_count;      // [n]: at the start of a list of several rows, its length
     int64_t n;
     uint32_t* flags;
 };
@@ -1742,9 +1745,11 @@ __global__ void __launch_bounds__(256) k_jd_assemble(const JdAssemble A) {
     extern __shared__ __align__(16) uint32_t jd_lds[];
     const int lane = threadIdx.x & (HS_WAVE - 1), w = threadIdx.x / HS_WAVE, wpb = blockDim.x / HS_WAVE;
     const int W = 1 << A.L;
-    uint32_t* cur = jd_lds + (size_t)w * W;
+    uint32_t* cur = jd_lds + (size_t)w * 2 * W;  // counts, then list cursors
+    uint32_t* head = cur + W;                    // the first (= lowest) build row of every slot
     const uint64_t below = (1ull << lane) - 1ull;
     const int per = W / HS_WAVE;  // consecutive slots of a lane in the scan (W >= 64)
+    const uint32_t wmask = (uint32_t)(W - 1), kmin = (uint32_t)A.key_min;
     uint32_t err = 0;
     for (int64_t p = (int64_t)blockIdx.x * wpb + w; p < A.parts; p += (int64_t)gridDim.x * wpb) {
         const int64_t b = A.seg_start[p], e = A.seg_start[p + 1];
@@ -1753,11 +1758,19 @@ __global__ void __launch_bounds__(256) k_jd_assemble(const JdAssemble A) {
             if (e > b) err |= HS_FLAG_BAD_PROGRAM;  // a key past the declared range
             continue;
         }
-        for (int s = lane; s < W; s += HS_WAVE) cur[s] = 0;
+        // the first step's tuples are asked for before the tables are cleared; every later step's before the current one
+        // is worked on (a wave walks its partition in order: without this it paid one global round trip per step)
+        int32_t nkey = b + lane < e ? A.keys[b + lane] : 0;
+        for (int s = lane; s < W; s += HS_WAVE) {
+            cur[s] = 0;
+            head[s] = JD_EMPTY;
+        }
         rx_wave_handover();
-        for (int64_t i = b + lane; i < e; i += HS_WAVE) {
-            const uint32_t s = ((uint32_t)A.keys[i] - (uint32_t)A.key_min) & (uint32_t)(W - 1);
-            atomicAdd(&cur[s], 1u);  // LDS; counting is order-free
+        for (int64_t base = b; base < e; base += HS_WAVE) {
+            const int32_t key = nkey;
+            const bool valid = base + lane < e;
+            if (base + HS_WAVE + lane < e) nkey = A.keys[base + HS_WAVE + lane];
+            if (valid) atomicAdd(&cur[((uint32_t)key - kmin) & wmask], 1u);  // LDS; counting is order-free
         }
         rx_wave_handover();
         // exclusive scan of the W counts: a lane's consecutive slots, then a scan over the lanes
@@ -1775,15 +1788,17 @@ __global__ void __launch_bounds__(256) k_jd_assemble(const JdAssemble A) {
             run += c;
         }
         rx_wave_handover();
-        // the partition's slice of the CSR offsets: coalesced
-        const int64_t live = A.slots - slot0 < W ? A.slots - slot0 : W;
-        for (int s = lane; s < live; s += HS_WAVE) A.starts[slot0 + s] = (uint32_t)b + cur[s];
         // ordered placement: tuples arrive in row order; within a step, equal slots take consecutive places in lane order
+        nkey = b + lane < e ? A.keys[b + lane] : 0;
+        uint32_t nrow = b + lane < e ? A.rows[b + lane] : 0u;
         for (int64_t base = b; base < e; base += HS_WAVE) {
-            const int64_t i = base + lane;
-            const bool valid = i < e;
-            const uint32_t s = valid ? ((uint32_t)A.keys[i] - (uint32_t)A.key_min) & (uint32_t)(W - 1) : 0u;
-            const uint32_t row = valid ? A.rows[i] : 0u;
+            const bool valid = base + lane < e;
+            const uint32_t s = ((uint32_t)nkey - kmin) & wmask;
+            const uint32_t row = nrow;
+            if (base + HS_WAVE + lane < e) {
+                nkey = A.keys[base + HS_WAVE + lane];
+                nrow = A.rows[base + HS_WAVE + lane];
+            }
             uint64_t peers = __ballot(valid);
             for (int bit = 0; bit < A.L; ++bit) {
                 const bool on = (s >> bit) & 1u;
@@ -1792,15 +1807,32 @@ __global__ void __launch_bounds__(256) k_jd_assemble(const JdAssemble A) {
             }
             const uint32_t rank = (uint32_t)__popcll(peers & below);
             const uint32_t at = valid ? cur[s] : 0u;
+            const uint32_t first = valid ? head[s] : 0u;
             rx_wave_handover();  // every lane has read its slot's cursor before a leader moves it
             if (valid) {
                 A.out_rows[b + at + rank] = row;
-                if (rank == 0) cur[s] = at + (uint32_t)__popcll(peers);
+                if (rank == 0) {
+                    cur[s] = at + (uint32_t)__popcll(peers);
+                    if (first == JD_EMPTY) head[s] = row;  // the step's lowest lane of the slot holds its lowest row
+                }
             }
             rx_wave_handover();
         }
+        // the partition's slice of the slot words (coalesced): lists are contiguous, so list s starts where list s - 1 ends
+        const int64_t live = A.slots - slot0 < W ? A.slots - slot0 : W;
+        for (int s = lane; s < live; s += HS_WAVE) {
+            const uint32_t end = cur[s], start = s ? cur[s - 1] : 0u;
+            const uint32_t c = end - start;
+            uint32_t word = JD_EMPTY;
+            if (c == 1) word = head[s];
+            else if (c > 1) {
+                word = JD_MULTI | (uint32_t)(b + start);
+                A.list_count[b + start] = c;
+            }
+            A.words[slot0 + s] = word;
+        }
+        rx_wave_handover();
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) A.starts[A.slots] = (uint32_t)A.n;
     if (err) atomicOr(A.flags, err);
 }
 
@@ -1830,9 +1862,9 @@ struct JdLayout {
     int L, bits1, bits2;
 };
 static bool jd_layout(int64_t n, int64_t slots, JdLayout& Y) {
-    if (n < 0 || n >= 0xffffffffll || slots < 1 || slots > ((int64_t)1 << 30)) return false;
+    if (n < 0 || n >= 0x7fffffffll || slots < 1 || slots > ((int64_t)1 << 29)) return false;  // a slot word holds a row in 31 bits
     jd_geometry(slots, Y.L, Y.bits1, Y.bits2);
-    if (Y.L > JD_MAX_L) return false;
+    if (Y.L > JD_MAX_L) return false;  // (slots <= 2^29 with 16 partition bits)
     Y.nseg1 = (int64_t)1 << Y.bits1;
     Y.parts = (int64_t)1 << (Y.bits1 + Y.bits2);
     Y.tiles1 = n / RX_TILE + 2;
@@ -1868,10 +1900,10 @@ extern "C" size_t hs_join_dense_ws_bytes(int64_t n_build, int64_t slots) {
 }
 
 extern "C" int hs_join_dense_build(void* stream_, const int32_t* build_keys, int64_t n_build, int32_t key_min, int64_t slots,
-                                   uint32_t* starts, uint32_t* rows, void* ws_, uint32_t* flags) {
+                                   uint32_t* words, uint32_t* rows, uint32_t* list_count, void* ws_, uint32_t* flags) {
     JdLayout Y;
-    if ((!build_keys && n_build > 0) || !starts || !rows || !ws_ || !flags || !jd_layout(n_build, slots, Y)) {
-        hs_set_error("hs_join_dense_build: bad arguments (n_build < 2^32, 1 <= slots <= 2^30)");
+    if ((!build_keys && n_build > 0) || !words || !rows || !list_count || !ws_ || !flags || !jd_layout(n_build, slots, Y)) {
+        hs_set_error("hs_join_dense_build: bad arguments (n_build < 2^31, 1 <= slots <= 2^29)");
         return HS_E_ARG;
     }
     hipStream_t stream = (hipStream_t)stream_;
@@ -1941,11 +1973,12 @@ extern "C" int hs_join_dense_build(void* stream_, const int32_t* build_keys, int
     A.slots = slots;
     A.key_min = key_min;
     A.L = Y.L;
-    A.starts = starts;
+    A.words = words;
     A.out_rows = rows;
+    A.list_count = list_count;
     A.n = n;
     A.flags = flags;
-    const size_t per_wave = (size_t)4 << Y.L;
+    const size_t per_wave = (size_t)8 << Y.L;
     int wpb = (int)(65536 / per_wave);
     wpb = wpb < 1 ? 1 : (wpb > 4 ? 4 : wpb);
     int64_t g = (A.parts + wpb - 1) / wpb;
@@ -1961,8 +1994,9 @@ struct JdProbe {
     const int32_t* keys;
     int64_t n, slots;
     int32_t key_min, pad;
-    const uint32_t* starts;
+    const uint32_t* words;
     const uint32_t* rows;
+    const uint32_t* list_count;
     int64_t* counts;
     uint32_t* aux;  // [2 n]: first matching build row | start of the probe row's list in `rows`
     const int64_t* out_start;
@@ -1973,36 +2007,46 @@ typedef int jd_i32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned jd_u32x4 __attribute__((ext_vector_type(4)));
 typedef long long jd_i64x2 __attribute__((ext_vector_type(2)));
 
-// Probe, pass 1: four keys per lane (one 16-byte load; buffers carry slack past n); per key the two adjacent offsets of its
-// slot, then the first row of its list - all four lookups of a lane in flight together.  What the fill pass needs again is
-// written down sequentially (the first build row and the list's start: 8 bytes per probe row) so that it never returns
-// to the scattered arrays for a key with one partner - the usual case.
+// Probe, pass 1: four keys per lane (one 16-byte load; buffers carry slack past n), ONE scattered 4-byte read per key - its
+// slot word says "no partner", names the one partner, or points at a list (then, and only then, two more reads: the
+// list's length and its first row); the four lookups of a lane are in flight together.  What the fill pass needs is written
+// down sequentially (the first build row and the list's start: 8 bytes per probe row), so it never returns to the
+// scattered arrays for a key with one partner - the usual case.
 __global__ void __launch_bounds__(256) k_jd_count(const JdProbe A) {
     const int64_t nq = (A.n + 3) / 4;
+    const int64_t second = (A.n + 3) & ~(int64_t)3;
     for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
         const jd_i32x4 kv = __builtin_nontemporal_load(reinterpret_cast<const jd_i32x4*>(A.keys) + q);
         const int32_t k[4] = {kv.x, kv.y, kv.z, kv.w};
-        uint32_t st[4], en[4], first[4];
+        uint32_t word[4], cnt[4], first[4], st[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int64_t o = (int64_t)k[j] - (int64_t)A.key_min;
             const bool in = q * 4 + j < A.n && (uint64_t)o < (uint64_t)A.slots;
-            st[j] = in ? A.starts[o] : 0u;
-            en[j] = in ? A.starts[o + 1] : 0u;
+            word[j] = in ? A.words[o] : JD_EMPTY;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) first[j] = en[j] > st[j] ? A.rows[st[j]] : 0u;
+        for (int j = 0; j < 4; ++j) {
+            const bool multi = word[j] != JD_EMPTY && (word[j] & JD_MULTI);
+            st[j] = multi ? word[j] & ~JD_MULTI : 0u;
+            cnt[j] = word[j] == JD_EMPTY ? 0u : 1u;
+            first[j] = word[j];
+            if (multi) {
+                cnt[j] = A.list_count[st[j]];
+                first[j] = A.rows[st[j]];
+            }
+        }
         if (q * 4 + 3 < A.n) {
             int64_t* c = A.counts + q * 4;
-            __builtin_nontemporal_store(jd_i64x2{(long long)(en[0] - st[0]), (long long)(en[1] - st[1])}, reinterpret_cast<jd_i64x2*>(c));
-            __builtin_nontemporal_store(jd_i64x2{(long long)(en[2] - st[2]), (long long)(en[3] - st[3])}, reinterpret_cast<jd_i64x2*>(c + 2));
+            __builtin_nontemporal_store(jd_i64x2{(long long)cnt[0], (long long)cnt[1]}, reinterpret_cast<jd_i64x2*>(c));
+            __builtin_nontemporal_store(jd_i64x2{(long long)cnt[2], (long long)cnt[3]}, reinterpret_cast<jd_i64x2*>(c + 2));
             __builtin_nontemporal_store(jd_u32x4{first[0], first[1], first[2], first[3]}, reinterpret_cast<jd_u32x4*>(A.aux) + q);
-            __builtin_nontemporal_store(jd_u32x4{st[0], st[1], st[2], st[3]}, reinterpret_cast<jd_u32x4*>(A.aux + ((A.n + 3) & ~(int64_t)3)) + q);
+            __builtin_nontemporal_store(jd_u32x4{st[0], st[1], st[2], st[3]}, reinterpret_cast<jd_u32x4*>(A.aux + second) + q);
         } else {
             for (int j = 0; j < 4 && q * 4 + j < A.n; ++j) {
-                A.counts[q * 4 + j] = (int64_t)(en[j] - st[j]);
+                A.counts[q * 4 + j] = (int64_t)cnt[j];
                 A.aux[q * 4 + j] = first[j];
-                A.aux[((A.n + 3) & ~(int64_t)3) + q * 4 + j] = st[j];
+                A.aux[second + q * 4 + j] = st[j];
             }
         }
     }
@@ -2043,8 +2087,8 @@ __global__ void __launch_bounds__(256) k_jd_fill(const JdProbe A) {
     }
 }
 
-static int jd_probe_args(const char* who, const int32_t* probe_keys, int64_t n_probe, int64_t slots, const uint32_t* starts) {
-    if ((!probe_keys && n_probe > 0) || !starts || n_probe < 0 || slots < 1 || ((uintptr_t)probe_keys & 15)) {
+static int jd_probe_args(const char* who, const int32_t* probe_keys, int64_t n_probe, int64_t slots, const uint32_t* words) {
+    if ((!probe_keys && n_probe > 0) || !words || n_probe < 0 || slots < 1 || ((uintptr_t)probe_keys & 15)) {
         hs_set_error("%s: bad arguments (probe keys 16-byte aligned)", who);
         return HS_E_ARG;
     }
@@ -2052,15 +2096,15 @@ static int jd_probe_args(const char* who, const int32_t* probe_keys, int64_t n_p
 }
 extern "C" size_t hs_join_dense_aux_bytes(int64_t n_probe) { return n_probe < 0 ? 0 : (size_t)(((n_probe + 3) & ~(int64_t)3) * 2) * 4 + 64; }
 extern "C" int hs_join_dense_count(void* stream, const int32_t* probe_keys, int64_t n_probe, int32_t key_min, int64_t slots,
-                                   const uint32_t* starts, const uint32_t* rows, int64_t* counts, void* aux) {
-    int rc = jd_probe_args("hs_join_dense_count", probe_keys, n_probe, slots, starts);
+                                   const uint32_t* words, const uint32_t* rows, const uint32_t* list_count, int64_t* counts, void* aux) {
+    int rc = jd_probe_args("hs_join_dense_count", probe_keys, n_probe, slots, words);
     if (rc != HS_OK) return rc;
-    if (!rows || !counts || !aux || ((uintptr_t)counts & 15) || ((uintptr_t)aux & 15)) {
+    if (!rows || !list_count || !counts || !aux || ((uintptr_t)counts & 15) || ((uintptr_t)aux & 15)) {
         hs_set_error("hs_join_dense_count: counts and aux must be 16-byte aligned");
         return HS_E_ARG;
     }
     if (n_probe == 0) return HS_OK;
-    JdProbe A{probe_keys, n_probe, slots, key_min, 0, starts, rows, counts, (uint32_t*)aux, nullptr, nullptr, nullptr};
+    JdProbe A{probe_keys, n_probe, slots, key_min, 0, words, rows, list_count, counts, (uint32_t*)aux, nullptr, nullptr, nullptr};
     int64_t g = ((n_probe + 3) / 4 + 255) / 256;
     if (g > 256 * 64) g = 256 * 64;
     hipLaunchKernelGGL(k_jd_count, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, A);
@@ -2074,7 +2118,7 @@ extern "C" int hs_join_dense_fill(void* stream, int64_t n_probe, const uint32_t*
         return HS_E_ARG;
     }
     if (n_probe == 0) return HS_OK;
-    JdProbe A{nullptr, n_probe, 0, 0, 0, nullptr, rows, nullptr, (uint32_t*)const_cast<void*>(aux), out_start, out_left, out_right};
+    JdProbe A{nullptr, n_probe, 0, 0, 0, nullptr, rows, nullptr, nullptr, (uint32_t*)const_cast<void*>(aux), out_start, out_left, out_right};
     int64_t g = ((n_probe + 3) / 4 + 255) / 256;
     if (g > 256 * 64) g = 256 * 64;
     hipLaunchKernelGGL(k_jd_fill, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, A);

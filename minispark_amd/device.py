@@ -2194,20 +2194,23 @@ class Device:
             return None
         lo, hi, _ = self.key_range(left_key)
         slots = hi - lo + 1
-        if slots > min(1 << 30, self.JOIN_DENSE_SPREAD * n_left + 65536) or slots * self.JOIN_DENSE_CROWD < n_left:
+        if slots > min(1 << 29, self.JOIN_DENSE_SPREAD * n_left + 65536) or slots * self.JOIN_DENSE_CROWD < n_left or n_left >= 1 << 31:
             return None
         ws_bytes = int(self.lib.hs_join_dense_ws_bytes(n_left, slots))
         if ws_bytes == 0:
             return None
-        starts = self.empty(slots + 1, torch.int32)
+        words = self.empty(slots, torch.int32)
         rows = self.empty(n_left, torch.int32)
+        list_count = self.empty(n_left, torch.int32)
         ws = self.workspace(ws_bytes)
-        hs.check(self.lib.hs_join_dense_build(self.stream, left_key.data.data_ptr(), n_left, lo, slots, starts.data_ptr(),
-                                              rows.data_ptr(), ws.data_ptr(), self.flags.data_ptr()), "hs_join_dense_build")
+        hs.check(self.lib.hs_join_dense_build(self.stream, left_key.data.data_ptr(), n_left, lo, slots, words.data_ptr(),
+                                              rows.data_ptr(), list_count.data_ptr(), ws.data_ptr(), self.flags.data_ptr()),
+                 "hs_join_dense_build")
         counts = self.empty(max(n_right, 1), torch.int64)
         aux = self.workspace(self.lib.hs_join_dense_aux_bytes(n_right))
-        hs.check(self.lib.hs_join_dense_count(self.stream, right_key.data.data_ptr(), n_right, lo, slots, starts.data_ptr(),
-                                              rows.data_ptr(), counts.data_ptr(), aux.data_ptr()), "hs_join_dense_count")
+        hs.check(self.lib.hs_join_dense_count(self.stream, right_key.data.data_ptr(), n_right, lo, slots, words.data_ptr(),
+                                              rows.data_ptr(), list_count.data_ptr(), counts.data_ptr(), aux.data_ptr()),
+                 "hs_join_dense_count")
         out_start = self.empty(n_right + 1, torch.int64)
         ws2 = self.workspace(self.lib.hs_scan_ws_bytes(n_right))
         hs.check(self.lib.hs_exclusive_scan_i64(self.stream, counts.data_ptr(), n_right, out_start.data_ptr(), ws2.data_ptr()),

@@ -313,9 +313,9 @@ SIGNATURES: dict[str, tuple] = {
     "hs_join8_route": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _I64, _P]),
     "hs_join8_build_windows": (C.c_int, [_P, _P, _P, _I64, _I32, _I64, _P, _P, _P, _P]),
     "hs_join_dense_ws_bytes": (C.c_size_t, [_I64, _I64]),
-    "hs_join_dense_build": (C.c_int, [_P, _P, _I64, _I32, _I64, _P, _P, _P, _P]),
+    "hs_join_dense_build": (C.c_int, [_P, _P, _I64, _I32, _I64, _P, _P, _P, _P, _P]),
     "hs_join_dense_aux_bytes": (C.c_size_t, [_I64]),
-    "hs_join_dense_count": (C.c_int, [_P, _P, _I64, _I32, _I64, _P, _P, _P, _P]),
+    "hs_join_dense_count": (C.c_int, [_P, _P, _I64, _I32, _I64, _P, _P, _P, _P, _P]),
     "hs_join_dense_fill": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P]),
     "hs_remap_u8": (C.c_int, [_P, _P, _I64, _P, _P]),
     "hs_dict_build": (C.c_int, [_P, _COLP, _I64, _I32, _P, _P, _P, _P]),

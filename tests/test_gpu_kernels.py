@@ -42,7 +42,7 @@ def test_synthetic_generator_matches_cpu_twin(dev):
     assert (t["l"].cpu().numpy() == 1).all()
 
 
-@pytest.mark.parametrize("n", [0, 1, 15, 16, 17, 2047, 2048, 2049, 4095, 4096, 4097, 8193, 100_003])
+@pytest.mark.parametrize("n", [0, 1, 15, 16, 17, 2047, 2048, 2049, 4095, 4096, 4097, 8193, 16383, 16384, 16385, 100_003, 3_000_017])
 def test_string_offsets_and_fixed_len(dev, n):
     import torch
 
@@ -59,9 +59,11 @@ def test_string_offsets_and_fixed_len(dev, n):
         assert col.fixed_len == 0
 
 
-@pytest.mark.parametrize("n,p", [(0, 0.5), (1, 1.0), (17, 0.5), (4096, 0.5), (4097, 0.0), (4097, 1.0), (250_000, 0.3),
-                                 (1_000_003, 0.9)])
+@pytest.mark.parametrize("n,p", [(0, 0.5), (1, 1.0), (17, 0.5), (4096, 0.5), (4097, 0.0), (4097, 1.0), (16384, 0.5), (16385, 1.0),
+                                 (250_000, 0.3), (1_000_003, 0.9), (9_000_001, 0.5), (40_000_000, 0.02)])
 def test_compact_is_stable_selection(dev, n, p):
+    """Round 4: ONE pass over the mask - 16384-row tiles taken in arrival order, a tile's place in the output found by
+    looking back over its predecessors' published sums (decoupled look-back), thousands of tiles in the larger cases."""
     import torch
 
     from minispark_amd import hipspark as hs

@@ -99,14 +99,14 @@ for label, bkeys, pkeys in (("dense", build, probe),
                             ("sparse 8/32", (32 * (build // 8) + build % 8 + 1).to(torch.int32), (32 * (probe // 8) + probe % 8 + 1).to(torch.int32))):
     lo, hi = int(bkeys.min().item()), int(bkeys.max().item())
     slots = hi - lo + 1
-    starts = dev.empty(slots + 1, torch.int32); drows = dev.empty(nb, torch.int32)
+    starts = dev.empty(slots, torch.int32); drows = dev.empty(nb, torch.int32); lcount = dev.empty(nb, torch.int32)
     dws = dev.workspace(lib.hs_join_dense_ws_bytes(nb, slots))
     bk = dev.empty(nb, torch.int32); bk.copy_(bkeys); pk = dev.empty(N, torch.int32); pk.copy_(pkeys)
-    ms_b = timed(lambda: lib.hs_join_dense_build(dev.stream, bk.data_ptr(), nb, lo, slots, starts.data_ptr(), drows.data_ptr(), dws.data_ptr(), dev.flags.data_ptr()))
-    report(f"A8 hs_join_dense_build ({label}, {slots} slots)", ms_b, nb * (4 + 4) + (slots + 1) * 4, f"{nb / ms_b / 1e3:.0f} M keys/s; keys in, rows + one offset per slot out")
+    ms_b = timed(lambda: lib.hs_join_dense_build(dev.stream, bk.data_ptr(), nb, lo, slots, starts.data_ptr(), drows.data_ptr(), lcount.data_ptr(), dws.data_ptr(), dev.flags.data_ptr()))
+    report(f"A8 hs_join_dense_build ({label}, {slots} slots)", ms_b, nb * (4 + 4) + slots * 4, f"{nb / ms_b / 1e3:.0f} M keys/s; keys in, rows + one word per slot out")
     aux = dev.workspace(lib.hs_join_dense_aux_bytes(N))
-    ms_c = timed(lambda: lib.hs_join_dense_count(dev.stream, pk.data_ptr(), N, lo, slots, starts.data_ptr(), drows.data_ptr(), counts.data_ptr(), aux.data_ptr()))
-    report(f"A8 hs_join_dense_count ({label})", ms_c, N * (4 + 8 + 8), f"{N / ms_c / 1e3:.0f} M probes/s; random 8 B reads of a {slots * 4 / 1e6:.0f} MB offset array + the first row; counts + 8 B aux out")
+    ms_c = timed(lambda: lib.hs_join_dense_count(dev.stream, pk.data_ptr(), N, lo, slots, starts.data_ptr(), drows.data_ptr(), lcount.data_ptr(), counts.data_ptr(), aux.data_ptr()))
+    report(f"A8 hs_join_dense_count ({label})", ms_c, N * (4 + 8 + 8), f"{N / ms_c / 1e3:.0f} M probes/s; one random 4 B read of a {slots * 4 / 1e6:.0f} MB slot-word array per probe; counts + 8 B aux out")
     lib.hs_exclusive_scan_i64(dev.stream, counts.data_ptr(), N, ost.data_ptr(), sws.data_ptr())
     nout2 = int(ost[N].item()); assert nout2 == nout, (nout2, nout)
     ms_f = timed(lambda: lib.hs_join_dense_fill(dev.stream, N, drows.data_ptr(), aux.data_ptr(), ost.data_ptr(), ol.data_ptr(), orr.data_ptr()))
