@@ -2068,7 +2068,7 @@ class Device:
 
     def aggregate_join8(self, batch: DBatch, filters: Sequence[Any], group_by: Any, agg_columns: Sequence[Any],
                         out_schema: Schema, group_cap_hint: int, cache_key: Any = None,
-                        dist_ctx: tuple | None = None) -> DBatch:
+                        dist_ctx: tuple | None = None, raw_tables: list | None = None) -> Any:
         """Partial aggregate per JoinJob (plan.py:99-109) of a join whose rows were never produced: the scan looks every
         probe key up in the join's byte table (`batch.join8`), takes the unit from python_hash(key) % partitions and
         the GROUP BY key / nothing from the table byte, and folds the probe side's columns into per-(unit, key) cells
@@ -2157,6 +2157,14 @@ class Device:
                                               self._event_handle(1)), "hs_agg_shared_join8")
         self.last_scan = p["info"]
         self.last_group_cap = cap
+        if raw_tables is not None:
+            # a streamed probe side (the engine's _run_join_stage_streamed): this range's raw per-JoinJob tables are set
+            # aside; join8_finish_ranges adds the ranges up BEFORE the one rounding per JoinJob, like ranks are added up
+            nb = p["table_bytes"]
+            copy = self.empty(nb, torch.uint8)
+            self.op(copy.copy_, xbuf[:nb])
+            raw_tables.append(copy)
+            return p
         if world > 1:
             from .distributed import all_gather_into  # noqa: PLC0415
 
@@ -2174,11 +2182,32 @@ class Device:
             hs.check(self.lib.hs_agg_units_merge(self.stream, p["gathered"].data_ptr(), world, p["n_units"], p["unit_cap"],
                                                  C.byref(p["spec"]), keys_ptr, acc_ptr, self.flags.data_ptr()),
                      "hs_agg_units_merge")
+        return self._join8_tables_to_batch(p, keys_ptr, acc_ptr, out_schema)
+
+    def _join8_tables_to_batch(self, p: dict, keys_ptr: int, acc_ptr: int, out_schema: Schema) -> DBatch:
+        """Raw per-JoinJob tables -> rounded like a shuffle-file write into the exchange slab -> the short tail's batch."""
+        slots = p["slots"]
         hs.check(self.lib.hs_agg_units_to_slab(self.stream, keys_ptr, acc_ptr, p["n_units"], p["unit_cap"], C.byref(p["spec"]),
                                                p["slab"].data_ptr(), C.byref(p["desc"]), self.flags.data_ptr()),
                  "hs_agg_units_to_slab")
         return DBatch(list(out_schema), [], slots, [0, slots], None, total_units=p["n_units"], slab=p["slab"],
                       slab_layout=p["layout"], tail=p["tail"])
+
+    def join8_finish_ranges(self, p: dict, raw_tables: Sequence[torch.Tensor], out_schema: Schema) -> DBatch:
+        """The raw unit tables of a streamed probe side's ranges, added up in range order (hs_agg_units_merge: the same
+        launch that adds up ranks) BEFORE the one rounding the reference applies per JoinJob (tasks.py:373 -> io.py:87-94),
+        then the short tail's batch.  Every range ran with the same capacities (same query, same hints)."""
+        nb, slots, n = p["table_bytes"], p["slots"], len(raw_tables)
+        gathered = self.empty(n * nb, torch.uint8)
+        for r, t in enumerate(raw_tables):
+            self.op(gathered[r * nb: (r + 1) * nb].copy_, t[:nb])
+        merged = torch.zeros(nb + PAD, dtype=torch.uint8, device=self.device)
+        keys_ptr, acc_ptr = merged.data_ptr() + 16, merged.data_ptr() + 16 + slots * 8
+        hs.check(self.lib.hs_agg_units_merge(self.stream, gathered.data_ptr(), n, p["n_units"], p["unit_cap"], C.byref(p["spec"]),
+                                             keys_ptr, acc_ptr, self.flags.data_ptr()), "hs_agg_units_merge")
+        batch = self._join8_tables_to_batch(p, keys_ptr, acc_ptr, out_schema)
+        batch.keep = (gathered, merged)
+        return batch
 
     # ---- hash join (A8) --------------------------------------------------------------------------------
     JOIN_DENSE_SPREAD = 32  # slots per build row at most (TPC-H order keys use 8 of every 32 values) ...

@@ -138,6 +138,14 @@ def _plain_names(expr: Any) -> list[str]:
     return [c.name for c in expr.all_nested_columns if _cls(c) in ("Col", "SchemaCol")]
 
 
+class _DeferredScan:
+    """Output of a scan stage that was NOT run: the probe side of a join, larger than the HBM budget.  The join stage
+    reads it block range by block range (HipExecutionEngine._run_join_stage_streamed)."""
+
+    def __init__(self, stage: Any, ranges: list[list[int]]) -> None:
+        self.stage, self.ranges = stage, ranges
+
+
 class HipExecutionEngine(ExecutionEngine):
     """Runs query stages on an MI355X.  Zero-argument constructible like the reference's engines."""
 
@@ -391,6 +399,10 @@ class HipExecutionEngine(ExecutionEngine):
             self._lds_merges: list[int] = []
             outputs: dict[int, Any] = {}
             results: list[JobResult] = []
+            # scan stages that feed a join's probe (right) side: one that does not fit HBM is not materialised - the join
+            # stage streams it block range by block range (the reference's right side is streamed too: tasks.py:224-240)
+            self._probe_stages = {id(st.dependencies[1]) for st in plan.stages
+                                  if _cls(st.producer) == "BroadcastHashJoinTask" and len(st.dependencies) == 2}
             # record the second (cache-warm) run of a plan: by then every buffer it needs is prepared
             want_record = self.replay_enabled and self._plan_runs.get(rec_key, 0) >= 1
             recording = self.dev.start_recording() if want_record else None
@@ -559,6 +571,10 @@ class HipExecutionEngine(ExecutionEngine):
         if kind == "LoadTableBlockTask":
             ranges = self._stream_ranges(producer, consumers)
             if ranges is not None:
+                if id(stage) in getattr(self, "_probe_stages", ()) and _cls(writer) == "WriteToShufflePartitions":
+                    outputs[id(stage)] = _DeferredScan(stage, ranges)  # read by the join stage, range by range
+                    self._job_seq += 1
+                    return [JobResult(f"{self._job_prefix}-{self._job_seq}", self._executor_id, [])]
                 return self._run_scan_stage_streamed(stage, outputs, ranges)
             batch = self._scan(producer, consumers, writer)
         elif kind == "LoadShuffleFilesTask":
@@ -570,6 +586,8 @@ class HipExecutionEngine(ExecutionEngine):
         elif kind == "BroadcastHashJoinTask":
             first_real = next((t for t in consumers if _cls(t) != "FilterTask"), None)
             feeds_aggregate = first_real is not None and _cls(first_real) == "AggregateTask" and first_real.before_shuffle
+            if isinstance(outputs[id(stage.dependencies[1])], _DeferredScan):
+                return self._run_join_stage_streamed(stage, outputs, feeds_aggregate)
             batch = self._join(producer, outputs[id(stage.dependencies[0])], outputs[id(stage.dependencies[1])],
                                self._needed_names(consumers), feeds_aggregate, consumers)
         else:
@@ -834,6 +852,90 @@ class HipExecutionEngine(ExecutionEngine):
         outputs[id(stage)] = merged
         return [JobResult(job_id, self._executor_id, [])]
 
+    def _run_join_stage_streamed(self, stage: Any, outputs: dict[int, Any], feeds_aggregate: bool) -> list[JobResult]:
+        """A join whose probe (right) side does not fit HBM (reference: the right side is streamed block by
+        block through the build side's hash map, tasks.py:224-240).  The build side is resident; the probe side's scan
+        stage was deferred and runs here range by range: read (pruned, pipelined) -> its own consumers -> join ->
+        * join feeding a GROUP BY (the byte-table join with the probe inside the aggregate): the table is
+          built ONCE; every range leaves the RAW per-JoinJob tables; they are added up in range order before the one
+          rounding the reference applies per JoinJob, then the short tail runs as for a resident table;
+        * join feeding the result file: the joined rows of every range go through the stage's consumers and are appended
+          to the result BlockFile with the reference's append-merge rule (io.py:231-252).
+        One rank only (a streamed stage is a per-rank decision, see _stream_ranges)."""
+        from . import table as tbl  # noqa: PLC0415
+        from .device import SlabUnsupported, TierExceeded  # noqa: PLC0415
+        from .hipspark import HipSparkLimit  # noqa: PLC0415
+
+        producer, consumers, writer = stage.producer, list(stage.consumers), stage.writer
+        left = outputs[id(stage.dependencies[0])]
+        deferred = outputs[id(stage.dependencies[1])]
+        scan = deferred.stage
+        table = self._table(scan.producer.file_path)
+        scan_consumers = list(scan.consumers)
+        col_ids = self._scan_columns(table, scan.producer.alias, scan_consumers)
+        needed = self._needed_names(consumers)
+        if self.dev.rec is not None:
+            self.dev.rec.poisoned = True  # host data flows in on every run
+        to_file = _cls(writer) == "WriteToLocalFileTask"
+        if not feeds_aggregate and not to_file:
+            raise ExecutionError("a join over a probe side larger than the HBM budget must feed a GROUP BY or the result file")
+        self.streamed_ranges += len(deferred.ranges)
+        agg = next((t for t in consumers if _cls(t) == "AggregateTask"), None)
+        raw_tables: list = []
+        prepared = None
+        out_path, rows_written = None, 0
+        schema = writer.inferred_schema
+        self._join8_reuse = {}
+        left = self.dev.resolve(left)
+        for blocks in deferred.ranges:
+            sub = tbl.sub_table(table, blocks)
+            tbl.load_columns(self.dev, sub, col_ids)
+            if self.dict_enabled:
+                self._encode_string_columns(sub, col_ids)
+            right = tbl.table_batch(sub, col_ids, scan.producer.alias)
+            right = self.dev.resolve(self._quantise_batch(self.dev.resolve(self._consume(right, scan_consumers)), scan.writer.inferred_schema))
+            joined = self._join(producer, left, right, needed, feeds_aggregate, consumers)
+            if feeds_aggregate:
+                if joined.join8 is None:
+                    raise ExecutionError("this join shape cannot stream its probe side: only the byte-table join (unique dense "
+                                         "INTEGER build keys, at most one dictionary-coded build column) adds partial "
+                                         "aggregates up across block ranges before the per-JoinJob rounding")
+                pending = [t.condition for t in consumers[: consumers.index(agg)] if _cls(t) == "FilterTask"]
+                if any(_cls(t) not in ("FilterTask",) for t in consumers[: consumers.index(agg)]):
+                    raise ExecutionError("a projection between a streamed join and its GROUP BY is not supported")
+                try:
+                    p = self.dev.aggregate_join8(joined, pending, agg.group_by_column, agg.agg_columns, agg.inferred_schema,
+                                                 self.group_cap_hint, cache_key=None, raw_tables=raw_tables)
+                except (TierExceeded, SlabUnsupported, HipSparkLimit) as e:
+                    raise ExecutionError(f"streamed join: {e}") from e
+                if prepared is not None and (p["unit_cap"], p["slots"], p["table_bytes"]) != (
+                        prepared["unit_cap"], prepared["slots"], prepared["table_bytes"]):
+                    raise ExecutionError("streamed join: the ranges' unit tables differ in shape")
+                prepared = p
+            else:
+                batch = self.dev.resolve(self._consume(joined, consumers))
+                raw, nrows, flags = self.dev.download_batch(self.dev.resolve(self._quantise_batch(batch, schema)), schema, None)
+                self._act_on_flags(flags)
+                if nrows:
+                    if out_path is None:
+                        out_path = self._result_path(stage.stage_id)
+                        out_path.parent.mkdir(parents=True, exist_ok=True)
+                        out_path.unlink(missing_ok=True)
+                    BlockFile(out_path, list(schema)).append_raw(raw)
+                    rows_written += nrows
+            del sub, right, joined
+        self._join8_reuse = None
+        self._job_seq += 1
+        job_id = f"{self._job_prefix}-{self._job_seq}"
+        if not feeds_aggregate:
+            from .jobs import OutputFile  # noqa: PLC0415
+
+            return [JobResult(job_id, self._executor_id, [OutputFile(out_path)] if rows_written else [])]
+        batch = self.dev.join8_finish_ranges(prepared, raw_tables, agg.inferred_schema)
+        batch.tail["task_id"] = _uid(agg)
+        outputs[id(stage)] = batch
+        return [JobResult(job_id, self._executor_id, [])]
+
     def _result_path(self, stage_id: str) -> Path:
         if self._result_root is None:
             base = Path(self._work_folder) if self._work_folder else constants.SHUFFLE_FOLDER
@@ -1001,11 +1103,16 @@ class HipExecutionEngine(ExecutionEngine):
             # N ranks: a probe table clustered on the key (every block a key stripe) lets every rank build only the part of
             # the table its own blocks can reach, from build rows routed to it; otherwise the whole build side is gathered
             stripes = dev.join8_stripes(right.cols[rkey], right.unit_rows, right.unit_ids, shape, ctx)
-        if stripes is not None:
+        reuse = getattr(self, "_join8_reuse", None)  # a streamed probe side: the table is built for the first range only
+        if reuse is not None and reuse.get("for") is left.cols[lkey]:
+            j = dict(reuse["table"])
+        elif stripes is not None:
             j = dev.join8_table_sharded(shape, stripes, left.cols[lkey], payload, constants.SHUFFLE_PARTITIONS, ctx)
             self.sharded_builds += 1
         else:
             j = dev.join8_table(shape, left.cols[lkey], payload, constants.SHUFFLE_PARTITIONS, ctx)
+        if reuse is not None and reuse.get("for") is None:
+            reuse["for"], reuse["table"] = left.cols[lkey], dict(j)
         j["probe_key"] = right.cols[rkey]
         n = right.nrows
         schema, cols = [], []

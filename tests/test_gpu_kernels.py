@@ -62,8 +62,7 @@ def test_string_offsets_and_fixed_len(dev, n):
 @pytest.mark.parametrize("n,p", [(0, 0.5), (1, 1.0), (17, 0.5), (4096, 0.5), (4097, 0.0), (4097, 1.0), (16384, 0.5), (16385, 1.0),
                                  (250_000, 0.3), (1_000_003, 0.9), (9_000_001, 0.5), (40_000_000, 0.02)])
 def test_compact_is_stable_selection(dev, n, p):
-    """Round 4: ONE pass over the mask - 16384-row tiles taken in arrival order, a tile's place in the output found by
-    looking back over its predecessors' published sums (decoupled look-back), thousands of tiles in the larger cases."""
+    """Stable compaction of a byte mask (any non-zero byte keeps the row) against numpy.nonzero, up to thousands of tiles."""
     import torch
 
     from minispark_amd import hipspark as hs

@@ -68,3 +68,49 @@ def test_streamed_result_file_follows_the_append_merge_rule(tmp_path):
     assert ranges_r == 0 and ranges_s >= 4
     assert rows_s == rows_r and len(rows_s) > 4000
     assert all(sz == 1500 for sz in sizes_s[:-1]) and 0 < sizes_s[-1] <= 1500  # append-merge: full blocks, then the rest
+
+
+@pytest.mark.parametrize("name", ["config4", "filtered_on_the_probe_side", "count_only"])
+def test_join_streams_a_probe_side_that_does_not_fit(tmp_path, name):
+    """Round 4: a join whose probe (right) side exceeds the HBM budget.  The reference streams the right side block by
+    block through the build side's hash map (tasks.py:224-240); here the probe side's scan stage is deferred and the join
+    stage reads it block range by block range: the byte table is built once, every range leaves RAW per-JoinJob tables,
+    and they are added up before the one rounding per JoinJob - so the rows equal the oracle's like a resident run."""
+    from minispark_amd.execution import HipExecutionEngine
+    from oracle.py_engine import run_query
+    from tests.test_gpu_join_dict import _api, _join_queries, _join_tables, _oracle_api
+
+    orders, lineitem = _join_tables(tmp_path, 3000, 24_000, seed=33)
+    want = run_query(_join_queries(_oracle_api(), orders, lineitem)[name].task)
+    with HipExecutionEngine(device=0) as engine:
+        engine.hbm_budget = 150_000  # lineitem's three blocks (96 KB each): two ranges; orders streams through its scan stage
+        frame = _join_queries(_api(engine), orders, lineitem)[name]
+        for _ in range(2):
+            assert assert_rows_match(frame.collect(), want, max_ulps=1) <= 2
+        assert engine.streamed_ranges >= 4 and engine.fused_probes >= 2
+        assert engine.dev.last_join["mode"] == "byte table"
+
+
+def test_join_to_the_result_file_streams_its_probe_side(tmp_path):
+    """orders JOIN lineitem -> SELECT ... with a probe side beyond the budget: every range's joined rows are appended to
+    the result BlockFile (append-merge rule, io.py:231-252); the row multiset equals the oracle's."""
+    from minispark_amd.execution import HipExecutionEngine
+    from oracle.py_engine import run_query
+    from tests.test_gpu_join_dict import _api, _join_tables, _oracle_api
+
+    orders, lineitem = _join_tables(tmp_path, 2000, 9000, seed=34)
+
+    def query(api):
+        C = api.Col
+        o = api.DataFrame().table(orders).select(C("o_orderkey"), C("o_orderpriority"))
+        li = api.DataFrame().table(lineitem).select(C("l_orderkey"), C("l_quantity"), C("l_extendedprice"))
+        return (o.join(li, on=C("o_orderkey") == C("l_orderkey"), how="inner").filter(C("l_quantity") > 25)
+                .select(C("o_orderpriority"), C("l_orderkey"), (C("l_extendedprice") * 2).alias("twice")))
+
+    want = run_query(query(_oracle_api()).task)
+    with HipExecutionEngine(device=0) as engine:
+        engine.hbm_budget = 60_000
+        rows = query(_api(engine)).collect()
+        assert engine.streamed_ranges >= 3
+    assert len(rows) == len(want) > 1000
+    assert assert_rows_match(rows, want, max_ulps=0) == 0
