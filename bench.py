@@ -32,7 +32,6 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s)
 CUTOFF = "1998-12-01"  # the reference's query (README.md:141-158): TPC-H's last ship date, every row passes
 SELECTIVE_CUTOFF = "1998-09-02"  # SURVEY 8d's second cutoff: ~97 % of the rows pass (other_configs.q1_cutoff)
-Q1_TRAFFIC_FILE = "r04_pmc_hbm_traffic_q1_sf100.json"  # written by tools/pmc_traffic.py from this command's --pmc passes
 Q1_MOVED_BYTES_PER_ROW = 25  # the length bytes of the fixed-width l_returnflag are never read
 
 
@@ -43,31 +42,45 @@ def q1_frame(engine, table_path: str, cutoff: str = CUTOFF):
 
 
 SCAN_KERNEL_SOURCES = ("hs_device.h", "hs_agg_kernel.h", "hs_capture.h", "hs_agg.hip", "hs_jit.hip")
+# per bench config: the dominant kernel whose PMC traffic is quoted, the other kernels of a step worth a line, the sources
+# whose hash stamps the measurement, the committed file (tools/pmc_traffic.py writes it from this command's --pmc passes)
+TRAFFIC_KERNELS = {
+    "q1": {"dominant": "k_agg_jit", "others": ("k_agg_finish",), "sources": SCAN_KERNEL_SOURCES,
+           "file": "r04_pmc_hbm_traffic_q1_sf100.json"},
+    "strkey": {"dominant": "k_agg_jit", "others": ("k_dict_combine", "k_agg_finish"), "sources": SCAN_KERNEL_SOURCES + ("hs_join.hip",),
+               "file": "r04_pmc_hbm_traffic_strkey_sf10.json"},
+    "join": {"dominant": "k_agg_shared_jit", "others": ("k_join8_", "k_agg_shared_fold_chunks", "k_agg_units_to_slab", "k_agg_finish"),
+             "sources": SCAN_KERNEL_SOURCES + ("hs_join.hip",), "file": "r04_pmc_hbm_traffic_join_sf10.json"},
+}
 
 
-def kernel_sources_sha() -> str:
-    """Identity of the scan kernel's code: PMC traffic figures under profiles/ are only quoted while it is unchanged.
-    Covers what k_agg_jit is compiled from and launched by - the embedded headers, the code generator, the launch
-    geometry (csrc/hs_agg.hip) and the public header they all include; operators the Q1 step never launches (join,
-    radix tier, stage engine) are not part of it."""
+def kernel_sources_sha(sources=SCAN_KERNEL_SOURCES) -> str:
+    """Identity of a scan kernel's code: PMC traffic figures under profiles/ are only quoted while it is unchanged.
+    Covers what the kernel is compiled from and launched by - the embedded headers, the code generator, the launch
+    geometry (csrc/hs_agg.hip), for the join and dictionary configs csrc/hs_join.hip, and the public header they all
+    include; operators the step never launches (radix tier, stage engine) are not part of it."""
     h = hashlib.sha256()
-    for p in [*(ROOT / "minispark_amd" / "csrc" / name for name in SCAN_KERNEL_SOURCES), ROOT / "include" / "hipspark.h"]:
+    for p in [*(ROOT / "minispark_amd" / "csrc" / name for name in sources), ROOT / "include" / "hipspark.h"]:
         h.update(p.name.encode())
         h.update(p.read_bytes())
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(name: str) -> dict:
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 counter passes of THIS command
-    (profiles/<name>; rocprofv3 cannot run inside the process) - refused when the kernels changed since."""
+def pmc_traffic(config: str) -> dict:
+    """HBM bytes per launch of the config's dominant kernel from the committed rocprofv3 counter passes of THIS command
+    (profiles/<file>; rocprofv3 cannot run inside the process) - refused when the kernels changed since."""
+    spec = TRAFFIC_KERNELS[config]
+    name = spec["file"]
     path = ROOT / "profiles" / name
     if not path.exists():
         return {"traffic": None, "traffic_source": f"profiles/{name} not collected yet"}
     t = json.loads(path.read_text())
-    if t.get("kernel_sources_sha") != kernel_sources_sha():
+    now = kernel_sources_sha(spec["sources"])
+    if t.get("kernel_sources_sha") != now:
         return {"traffic": None, "traffic_source": f"profiles/{name} is stale: measured at kernel sources "
-                                                   f"{t.get('kernel_sources_sha')}, now {kernel_sources_sha()}"}
+                                                   f"{t.get('kernel_sources_sha')}, now {now}"}
     return {"traffic": t["hbm_read_bytes_per_launch (FETCH_SIZE*1024*2)"] + t["hbm_write_bytes_per_launch"],
+            "traffic_other_kernels": t.get("other_kernels") or None,
             "traffic_source": f"profiles/{name} (separate --pmc FETCH_SIZE / WRITE_SIZE passes at kernel sources "
                               f"{t['kernel_sources_sha']}, commit {t.get('commit', '?')})"}
 
@@ -508,7 +521,7 @@ class Q1Workload:
             "launch": self.engine.dev.last_scan,
         }
         if self.world == 1 and self.total_units == 600_037_902 and self.args.cutoff == CUTOFF:
-            out.update(pmc_traffic(Q1_TRAFFIC_FILE))
+            out.update(pmc_traffic("q1"))
             if out["traffic"]:
                 out["hbm_frac"] = out["traffic"] / (kernel_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
         return out

@@ -484,10 +484,10 @@ static int run_scan(hipStream_t s, In in, int64_t n, Emit emit, int64_t* total_o
     const int64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
     int64_t* tiles = (int64_t*)ws;
     if (ntiles == 0) {
-        // empty input: total = 0
-        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_WG), 0, s, tiles, (int64_t)0);
-        hipLaunchKernelGGL((k_scan_down<In, Emit>), dim3(1), dim3(SCAN_WG), 0, s, in, (int64_t)0, tiles, emit,
-                           total_out);
+        // empty input: total = 0.  (Until round 4 this launched the two kernels over zero tiles, and the down-sweep read
+        // its total from tile_sums[gridDim.x] = word 1 of a workspace only word 0 of which had been written: whatever the
+        // allocator had left there came back as the row count - zero in a fresh process, garbage in a long-lived one.)
+        if (total_out) hs_memset_async(total_out, 0, sizeof(int64_t), s);
         HS_CHECK_LAUNCH(name);
         return HS_OK;
     }

@@ -20,6 +20,18 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBPS = 8000.0
 
 
+def _with_traffic(out: dict, config: str, world: int, sf: float, kernel_ms: float) -> dict:
+    """`traffic` (PMC bytes per launch of the dominant kernel, stamped with the kernel sources' hash like Q1's) and the HBM
+    utilisation on those bytes - only for the configuration the passes were collected on (one GPU, sf=10)."""
+    from bench import pmc_traffic  # noqa: PLC0415
+
+    if world == 1 and sf == 10.0:
+        out.update(pmc_traffic(config))
+        if out.get("traffic"):
+            out["hbm_frac"] = out["traffic"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
+    return out
+
+
 class _EventPair:
     """HIP events on the launch stream around one operator call (the library launches on torch's current stream)."""
 
@@ -132,7 +144,7 @@ class JoinWorkload(_Workload):
             achieved = algo / (kernel_avg_ms * 1e-3) / 1e9
             build_ms = self.engine.dev.join_ms()
             build_algo = self.n_ord * 5 + self.n_ord * 4 * 2 + table_bytes  # keys + codes read, tuples written + read, table written
-            return {"bound": "hbm", "kernel": "k_agg_shared_jit with the join's probe inside (byte table lookup per key, unit = "
+            out = {"bound": "hbm", "kernel": "k_agg_shared_jit with the join's probe inside (byte table lookup per key, unit = "
                                               "python_hash(key) % 10, LDS dictionary of (unit, code) cells)",
                     "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                     "kernel_ms": kernel_avg_ms, "rows_per_launch": n_local, "algorithmic_bytes_per_launch": algo,
@@ -144,6 +156,7 @@ class JoinWorkload(_Workload):
                                   "(probe keys arrive clustered: the table is streamed, not sampled); SURVEY 8d's own accounting "
                                   "(64 B per probe as a random access) is the sector_accounting figure; build: keys + codes in, "
                                   "4-byte tuples out and in, table out"}
+            return _with_traffic(out, "join", self.world, self.args.sf, kernel_avg_ms)
         # round 2's materialising form (table fill + scatter + occupied-slot count + probe), priced on the bytes it must
         # move when every access were perfectly coalesced
         slots = last.get("slots", 4 * self.n_ord)
@@ -236,15 +249,20 @@ class StrKeyWorkload(_Workload):
         algo = n_local * (4 + 4 + 2 + 1 + self.mode_bytes)
         achieved = algo / (kernel_avg_ms * 1e-3) / 1e9
         moved = n_local * (4 + 4 + 1 + 1)
-        return {"bound": "hbm", "kernel": "k_agg_jit: fused scan + WHERE (bit test on the l_shipmode code) + GROUP BY the coded "
+        out = {"bound": "hbm", "kernel": "k_agg_jit: fused scan + WHERE (bit test on the l_shipmode code) + GROUP BY the coded "
                                           "CONCAT key + partial aggregate (after one pass over code bytes that builds the key)",
+                # `frac` prices SURVEY 8d's ALGORITHMIC bytes (strings as stored); the kernel moves the dictionary-coded form:
+                # `hbm_frac_moved` is the utilisation of the bytes that really leave HBM
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "hbm_frac_moved": moved / (kernel_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                 "kernel_ms": kernel_avg_ms, "rows_per_launch": n_local,
                 "algorithmic_bytes_per_row": algo / max(n_local, 1), "moved_bytes_per_row": moved / max(n_local, 1),
                 "moved_GBps": moved / (kernel_avg_ms * 1e-3) / 1e9, "launch": self.engine.dev.last_scan,
                 "accounting": "algorithmic (SURVEY 8d) = 4 (qty) + 4 (discount) + (1 + len) of l_returnflag and l_shipmode; moved = "
                               "the two f32 columns + one key-code byte + one shipmode-code byte (both string columns are "
-                              "dictionary-coded at table open)"}
+                              "dictionary-coded at table open); LIKE is evaluated once per dictionary entry (<= 256), never per "
+                              "row, in the timed step"}
+        return _with_traffic(out, "strkey", self.world, self.args.sf, kernel_avg_ms)
 
     def _host_columns(self):
         from minispark_amd import synth
