@@ -445,6 +445,11 @@ int hs_expand_by_bounds(void* stream, const int64_t* bounds, const int64_t* valu
 /* Debug aid: with HIPSPARK_RADIX_STAMPS=1 in the environment the fold kernel sums the cycles its waves spend per phase;
  * out8 = {clear tables, wait for loads, slot lookup, ranking, fold, emit, waves, 0} since the last call. */
 int hs_group_radix_debug_stamps(uint64_t* out8);
+/* Debug aid: with HIPSPARK_SCAN_STAMPS=1 in the environment every workgroup of the private-table scan (hs_agg_partial*)
+ * leaves eight words: wall_clock64() (100 MHz) at entry, after the early-exit check, after the table initialisation, after
+ * its last step, after the table reduction, after the arrival count, at exit, and (XCC_ID << 32 | HW_ID).  Copies the
+ * last launch's words of up to max_chunks workgroups to host_out; returns the number of workgroups copied (0: stamps off). */
+int64_t hs_agg_debug_scan_stamps(int64_t* host_out, int64_t max_chunks);
 /* mask[s] = 1 for non-empty slots (compact it with hs_compact to get the dense slot list). */
 int hs_group_mask(void* stream, const int64_t* slot_start, int64_t table_cap, uint8_t* mask);
 /* One lane per group folds val_cols[a][position] over the group's positions front to back - the reference's

@@ -1242,6 +1242,32 @@ static void allow_big_lds(K kernel) {
     (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HS_LDS_HARD);
 }
 
+// debug: per-workgroup phase stamps of the private-table scan (HIPSPARK_SCAN_STAMPS=1, tools/scan_stamps.py).  The
+// buffer belongs to the library and is only ever grown, so a captured launch keeps a valid pointer.
+static int64_t* g_scan_stamps = nullptr;
+static int64_t g_scan_stamps_cap = 0, g_scan_stamps_chunks = 0;
+static int64_t* hs_scan_stamps_for(int64_t n_chunks) {
+    static const bool want = getenv("HIPSPARK_SCAN_STAMPS") && getenv("HIPSPARK_SCAN_STAMPS")[0] == '1';
+    if (!want) return nullptr;
+    if (n_chunks > g_scan_stamps_cap) {
+        int64_t* fresh = nullptr;
+        if (hipMalloc((void**)&fresh, (size_t)n_chunks * 64) != hipSuccess) return nullptr;
+        g_scan_stamps = fresh;  // (the old block stays allocated: an earlier captured launch may still name it)
+        g_scan_stamps_cap = n_chunks;
+    }
+    g_scan_stamps_chunks = n_chunks;
+    return g_scan_stamps;
+}
+extern "C" int64_t hs_agg_debug_scan_stamps(int64_t* host_out, int64_t max_chunks) {
+    if (!g_scan_stamps || !host_out) return 0;
+    const int64_t n = g_scan_stamps_chunks < max_chunks ? g_scan_stamps_chunks : max_chunks;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host_out, g_scan_stamps, (size_t)n * 64, hipMemcpyDeviceToHost) != hipSuccess) {
+        hs_set_error("hs_agg_debug_scan_stamps: copy failed");
+        return -1;
+    }
+    return n;
+}
+
 static int agg_partial_impl(void* stream, const hs_col* cols, int32_t n_cols, int32_t key_col, const hs_program* prog,
                             const hs_agg_spec* spec, const hs_chunk* chunks, const int64_t* unit_chunk0,
                             int64_t n_units, const hs_agg_geom* geom, int64_t* out_rep, uint64_t* out_acc,
@@ -1367,6 +1393,7 @@ static int agg_partial_impl(void* stream, const hs_col* cols, int32_t n_cols, in
     A.unit_col = -1;
     A.pad3 = 0;
     A.chunk_acc = nullptr;
+    A.stamps = hs_scan_stamps_for(geom->n_chunks);
     bool fused = false;
     if (geom->pad == HS_GEOM_FUSABLE && spec->n_acc > 0) {
         int fbatch = ubatch;
@@ -1872,6 +1899,7 @@ static int agg_shared_impl(void* stream, const hs_col* cols, int32_t n_cols, int
                 : (uint64_t*)((char*)ws + (((size_t)n_units * (size_t)geom->pad * 8 + 256 + 15) & ~(size_t)15));
     if (join) A.join = *join;
     else memset(&A.join, 0, sizeof(A.join));
+    A.stamps = nullptr;
     {  // the replica count the geometry sized the LDS block for
         const size_t per_replica = (size_t)geom->group_cap * (size_t)(spec->n_acc > 0 ? spec->n_acc : 1) * 8;
         const size_t r = (geom->lds_bytes - (size_t)geom->group_cap * 16) / per_replica;

@@ -228,7 +228,11 @@ struct AggMainArgs {
     // round 3: the join's byte table when cols hold HS_JOIN8_CODE / HS_JOIN8_UNIT columns (the probe runs inside the
     // scan: include/hipspark.h hs_agg_shared_join8); table NULL otherwise
     hs_join8 join;
+    // debug (HIPSPARK_SCAN_STAMPS=1; tools/scan_stamps.py): [n_chunks][8] wall_clock64() at the phase boundaries of every
+    // workgroup of the private-table scan + the hardware id; NULL otherwise
+    int64_t* stamps;
 };
+#define HS_SCAN_STAMP(i) do { if (A.stamps && threadIdx.x == 0) A.stamps[(int64_t)blockIdx.x * 8 + (i)] = (int64_t)wall_clock64(); } while (0)
 
 // key word of (unit, key): valid for key words that carry their information in the low 56 bits - INTEGER keys
 // (32 significant bits), packed strings of a FIXED length <= 6 (the length byte is the same for every row)
@@ -530,6 +534,7 @@ __device__ __forceinline__ void hs_agg_main_arrive(const AggMainArgs& A, const i
         if (s_last) __hip_atomic_store(&A.unit_arrivals[unit], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
+    HS_SCAN_STAMP(5);
     if (s_last) hs_agg_unit_body<true>(A.unit, unit, lds);
 }
 
@@ -546,6 +551,10 @@ __device__ __forceinline__ void hs_agg_main_body(const AggMainArgs& A) {
 
     // this workgroup's row range: one 32-byte descriptor (a wave-uniform scalar load)
     const int64_t chunk = blockIdx.x;
+    HS_SCAN_STAMP(0);
+    if (A.stamps && threadIdx.x == 0)  // XCC_ID (hwreg 20) << 32 | HW_ID (hwreg 4): which XCD / SE / CU ran the chunk
+        A.stamps[chunk * 8 + 7] = ((int64_t)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 20) << 32) |
+                                  (int64_t)(uint32_t)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 4);
     const hs_chunk desc = A.chunks[chunk];
     const int64_t us = desc.unit_begin, c0 = desc.row_begin, c1 = desc.row_end;
     // a run that has already overflowed a dictionary is going to be repeated with larger tables: later rounds of
@@ -564,6 +573,7 @@ __device__ __forceinline__ void hs_agg_main_body(const AggMainArgs& A) {
         return;
     }
 
+    HS_SCAN_STAMP(1);
     // the first quad's loads go out before the LDS tables are initialised: their latency hides the init
     const int64_t stride = (int64_t)nthr * HS_V;
     int64_t base = c0 + (int64_t)tid * HS_V;
@@ -590,6 +600,7 @@ __device__ __forceinline__ void hs_agg_main_body(const AggMainArgs& A) {
     ctx.mask = (uint32_t)GC - 1;
     ctx.n_acc = NA;
     ctx.err = 0;
+    HS_SCAN_STAMP(2);
 
     // software pipeline: the loads of step i+1 are in flight while step i is evaluated
     while (base < c1) {
@@ -606,6 +617,7 @@ __device__ __forceinline__ void hs_agg_main_body(const AggMainArgs& A) {
         Prog::run(A, cur, ctx);
         base = next_base;
     }
+    HS_SCAN_STAMP(3);
     __syncthreads();
 
     // Fixed-order reduction of the private tables.  A wave owns cells wave, wave+nwaves, ...; it folds
@@ -647,7 +659,9 @@ __device__ __forceinline__ void hs_agg_main_body(const AggMainArgs& A) {
         hs_st_part(&A.part_rep[chunk * GC + i], dreps[i]);
     }
     if (ctx.err) atomicOr(A.flags, ctx.err);
+    HS_SCAN_STAMP(4);
     hs_agg_main_arrive(A, desc.unit, hs_lds);
+    HS_SCAN_STAMP(6);
 }
 
 // ======================================================================================================

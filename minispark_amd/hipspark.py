@@ -293,6 +293,7 @@ SIGNATURES: dict[str, tuple] = {
     "hs_group_radix_run": (C.c_int, [_P, _P, _COLP, _P, _I64, _P, _COLP, _P, _SPECP, _P, _P, _P]),
     "hs_group_radix_emit": (C.c_int, [_P, _P, _P, _P, _P]),
     "hs_group_radix_debug_stamps": (C.c_int, [_P]),
+    "hs_agg_debug_scan_stamps": (C.c_int64, [_P, C.c_int64]),
     "hs_sort_by_order_ws_bytes": (C.c_size_t, [_I64]),
     "hs_sort_by_order": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P]),
     "hs_expand_by_bounds": (C.c_int, [_P, _P, _P, _I64, _I64, _P]),

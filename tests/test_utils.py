@@ -63,14 +63,16 @@ def test_tracer_writes_chrome_trace_json(tmp_path):
 
 
 def test_committed_pmc_traffic_belongs_to_the_current_scan_kernel_sources():
-    """bench.py quotes profiles/r03_pmc_hbm_traffic_q1_sf100.json only while the scan kernel's sources hash to the
+    """bench.py quotes the committed PMC file of a config (bench.TRAFFIC_KERNELS) only while the scan kernel's sources hash to the
     measured ones (otherwise `roofline.traffic` is null).  Stale after a kernel change is a reminder to re-run the two
     --pmc passes (tools/pmc_traffic.py), not an error: the test then skips with that message."""
     import pytest
 
     import bench
 
-    got = bench.pmc_traffic("r03_pmc_hbm_traffic_q1_sf100.json")
+    for config in bench.TRAFFIC_KERNELS:
+        assert set(bench.pmc_traffic(config)) >= {"traffic", "traffic_source"}
+    got = bench.pmc_traffic("q1")
     if got["traffic"] is None:
         pytest.skip(got["traffic_source"])
     assert 0.9 * 26 * 600_037_902 < got["traffic"] < 1.1 * 26 * 600_037_902
