@@ -432,6 +432,23 @@ int hs_join_dense_count(void* stream, const int32_t* probe_keys, int64_t n_probe
                         const uint32_t* words, const uint32_t* rows, const uint32_t* list_count, int64_t* counts, void* aux);
 int hs_join_dense_fill(void* stream, int64_t n_probe, const uint32_t* rows, const void* aux, const int64_t* out_start,
                        int64_t* out_left, int64_t* out_right);
+/* ---- the general inner join on ANY INTEGER keys (round 4; csrc/hs_radix.hip) -------------------------------------------
+ * The same reference loop (tasks.py:201-240) for keys the dense form does not hold: a sparse or huge key range, negative
+ * keys.  table = hs_join_hash_slots(n_build) 8-byte slots {key, word} (word as in the dense form), cut into windows of 1024
+ * slots; a key hashes to ONE window and probes linearly inside it.  Build: two stable partition passes bring the (key, row)
+ * tuples into window order, one wave per window inserts / counts / scans / places them in LDS and stores the finished window
+ * with coalesced stores - no global atomic, no scattered store, lists ascending without a sort.  hs_join_hash_count: one
+ * scattered 8-byte read per probe row in the usual case (~1.7 slots from the start at the table's load of 0.57, nearly always
+ * the same 64-byte line); counts / aux exactly as hs_join_dense_count leaves them, so the second pass IS
+ * hs_join_dense_fill(rows, aux, ...).  n_build <= ~38 M rows per call (hs_join_hash_slots returns 0 beyond); a window with
+ * more distinct keys than slots (a degenerate hash) is left empty and raises HS_FLAG_DICT_FULL - the caller takes
+ * hs_join_build instead.  rows / list_count: n_build entries each; ws: hs_join_hash_ws_bytes(n_build). */
+size_t hs_join_hash_ws_bytes(int64_t n_build);
+int64_t hs_join_hash_slots(int64_t n_build);
+int hs_join_hash_build(void* stream, const int32_t* build_keys, int64_t n_build, void* table, uint32_t* rows,
+                       uint32_t* list_count, void* ws, uint32_t* flags);
+int hs_join_hash_count(void* stream, const int32_t* probe_keys, int64_t n_probe, int64_t n_build, const void* table,
+                       const uint32_t* rows, const uint32_t* list_count, int64_t* counts, void* aux);
 /* Merge order of a multi-rank final aggregate (the reference reads a partition's shuffle files in block order,
  * tasks.py:117-133): STABLE sort of positions 0 .. n-1 by order[i] in [-1, n_order) (global block id; -1 = padding,
  * sorted first) with the radix tier's partition passes, least significant byte first.  out_perm[j] = position of the
@@ -446,8 +463,10 @@ int hs_expand_by_bounds(void* stream, const int64_t* bounds, const int64_t* valu
  * out8 = {clear tables, wait for loads, slot lookup, ranking, fold, emit, waves, 0} since the last call. */
 int hs_group_radix_debug_stamps(uint64_t* out8);
 /* Debug aid: with HIPSPARK_SCAN_STAMPS=1 in the environment every workgroup of the private-table scan (hs_agg_partial*)
- * leaves eight words: wall_clock64() (100 MHz) at entry, after the early-exit check, after the table initialisation, after
- * its last step, after the table reduction, after the arrival count, at exit, and (XCC_ID << 32 | HW_ID).  Copies the
+ * leaves sixteen words: wall_clock64() (100 MHz) at [0] entry, [1] after the early-exit check, [2] after the table initialisation,
+ * [3] after its last step, [4] after the table reduction, [5] after the arrival count, [6] at exit, [7] (XCC_ID << 32 | HW_ID),
+ * [8..13] inside the unit combine of a last arriver (initialised, first batch's entries filed, its partials staged, folded,
+ * all batches folded, rows written), [14] all waves past their last step.  Copies the
  * last launch's words of up to max_chunks workgroups to host_out; returns the number of workgroups copied (0: stamps off). */
 int64_t hs_agg_debug_scan_stamps(int64_t* host_out, int64_t max_chunks);
 /* mask[s] = 1 for non-empty slots (compact it with hs_compact to get the dense slot list). */

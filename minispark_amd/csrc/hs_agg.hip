@@ -1251,7 +1251,7 @@ static int64_t* hs_scan_stamps_for(int64_t n_chunks) {
     if (!want) return nullptr;
     if (n_chunks > g_scan_stamps_cap) {
         int64_t* fresh = nullptr;
-        if (hipMalloc((void**)&fresh, (size_t)n_chunks * 64) != hipSuccess) return nullptr;
+        if (hipMalloc((void**)&fresh, (size_t)n_chunks * 128) != hipSuccess) return nullptr;
         g_scan_stamps = fresh;  // (the old block stays allocated: an earlier captured launch may still name it)
         g_scan_stamps_cap = n_chunks;
     }
@@ -1261,7 +1261,7 @@ static int64_t* hs_scan_stamps_for(int64_t n_chunks) {
 extern "C" int64_t hs_agg_debug_scan_stamps(int64_t* host_out, int64_t max_chunks) {
     if (!g_scan_stamps || !host_out) return 0;
     const int64_t n = g_scan_stamps_chunks < max_chunks ? g_scan_stamps_chunks : max_chunks;
-    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host_out, g_scan_stamps, (size_t)n * 64, hipMemcpyDeviceToHost) != hipSuccess) {
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host_out, g_scan_stamps, (size_t)n * 128, hipMemcpyDeviceToHost) != hipSuccess) {
         hs_set_error("hs_agg_debug_scan_stamps: copy failed");
         return -1;
     }
@@ -1373,7 +1373,7 @@ static int agg_partial_impl(void* stream, const hs_col* cols, int32_t n_cols, in
         U.key_off = desc->key_off;
         for (int a = 0; a < spec->n_acc; ++a) U.acc_off[a] = desc->acc_off[a];
     }
-    const size_t ubase = (size_t)geom->group_cap * 16 + (size_t)geom->group_cap * spec->n_acc * 8;
+    const size_t ubase = (size_t)geom->group_cap * 16 + (size_t)geom->group_cap * spec->n_acc * 16;  // (+ the staged batch's spare column)
     const size_t uper = (size_t)geom->group_cap * spec->n_acc * 8 + (size_t)geom->group_cap * 4;  // per staged chunk
     int ubatch = HS_UNIT_BATCH;
     while (ubatch > 1 && ubase + (size_t)ubatch * uper > HS_LDS_SOFT) ubatch /= 2;

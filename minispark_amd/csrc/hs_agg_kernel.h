@@ -72,63 +72,139 @@ __device__ __forceinline__ void hs_st_part(T* p, T v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// One (unit slot, accumulator) cell over the staged chunks of a batch, in ascending chunk order.  The batch is staged
+// CELL-major (x[cell][chunk], a chunk without the key holds the aggregate's identity - a no-op for every kind: +0.0 never
+// changes a sum that started from +0.0, MIN / MAX never pass their identity), so the lane reads consecutive LDS words and
+// the only dependent chain is the folds themselves; the kind is a template argument (lanes of different kinds take their
+// loops one after the other).  (Round 4 history, profiles/r04_scan_stamps_*.txt: the run-time-kind loop through the
+// slot map took ~160 ns per chunk - 10 us per 64-chunk batch, most of the combine at sf=1; kind as a template argument
+// and eight map / partial reads in flight: 84 ns; this form: the reads are a stream.)
+template <int OP, bool IS_INT>
+__device__ __forceinline__ void hs_fold_staged_cell(uint64_t* cell, const uint64_t* x, int nb) {
+    uint64_t v = *cell;
+    int c = 0;
+    for (; c + 8 <= nb; c += 8) {
+        uint64_t t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = x[c + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v = hs_acc_fold(OP, IS_INT, v, t[k]);
+    }
+    for (; c < nb; ++c) v = hs_acc_fold(OP, IS_INT, v, x[c]);
+    *cell = v;
+}
+
 // Phase 1: every (chunk, slot) entry of the unit is inserted into the unit's dictionary in parallel (the SET of keys
 // does not depend on insertion races) and remembers its unit slot.  Phase 2: one lane per (unit slot, accumulator)
 // folds that key's chunk partials in ascending chunk order = row order, without barriers.  Chunks are staged through
-// LDS in batches.  `lds`: GC * 16 + GC * NA * 8 + batch * (GC * NA * 8 + GC * 4) bytes.  All lanes of the workgroup.
+// LDS in batches.  `lds`: GC * 16 + 2 * GC * NA * 8 + batch * (GC * NA * 8 + GC * 4) bytes.  All lanes of the workgroup.
+// `bounds`: the unit's first and one-past-last chunk when the caller has read them already (LDS), else NULL.
 template <bool HANDOFF>
-__device__ __forceinline__ void hs_agg_unit_body(const AggUnitArgs& A, const int64_t u, uint64_t* lds) {
+__device__ __forceinline__ void hs_agg_unit_body(const AggUnitArgs& A, const int64_t u, uint64_t* lds, const int64_t* bounds = nullptr,
+                                                 int64_t* st = nullptr) {
+#define HS_UNIT_STAMP(i) do { if (st && threadIdx.x == 0) st[i] = (int64_t)wall_clock64(); } while (0)
     const int GC = A.group_cap, NA = A.spec.n_acc;
+    const HsSpecBits sb = hs_spec_bits(A.spec);
     uint64_t* ukeys = lds;                                  // [GC]
     int64_t* ureps = (int64_t*)(lds + GC);                  // [GC]
     uint64_t* uacc = lds + 2 * GC;                          // [GC][NA]
-    uint64_t* pacc = uacc + GC * NA;                        // [BATCH][GC][NA] staged chunk partials
+    uint64_t* pacc = uacc + GC * NA;                        // [GC * NA][BATCH + 1] staged chunk partials, cell-major
     const int BATCH = A.batch;
-    int* inv = (int*)(pacc + (size_t)BATCH * GC * NA);  // [BATCH][GC] unit slot -> chunk slot (or -1)
+    int* inv = (int*)(pacc + (size_t)(BATCH + 1) * GC * NA);  // [BATCH][GC] chunk slot -> unit slot (or -1)
     __shared__ int s_count;
     const int tid = threadIdx.x, nthr = blockDim.x;
     uint32_t err = 0;
+    // the scan's status so far (fused: every chunk of THIS unit has OR-ed its bits in before arriving); asked for here,
+    // used when the rows are written - a round trip that used to sit at the very end of the launch
+    uint32_t scan_flags = 0;
+    if (A.slab && tid == 0) scan_flags = __hip_atomic_load(A.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     for (int i = tid; i < GC; i += nthr) {
         ukeys[i] = HS_EMPTY_KEY;
         ureps[i] = -1;
     }
-    for (int i = tid; i < GC * NA; i += nthr) uacc[i] = hs_acc_identity(A.spec.op[i % NA], A.spec.is_int[i % NA] != 0);
+    for (int i = tid; i < GC * NA; i += nthr) uacc[i] = hs_acc_identity(hs_spec_op(sb, i % NA), hs_spec_int(sb, i % NA));
     if (tid == 0) s_count = 0;
     __syncthreads();
+    HS_UNIT_STAMP(8);
 
     const uint32_t mask = (uint32_t)GC - 1;
-    const int64_t cbeg = A.unit_chunk0[u], cend = A.unit_chunk0[u + 1];
+    const int64_t cbeg = bounds ? bounds[0] : A.unit_chunk0[u], cend = bounds ? bounds[1] : A.unit_chunk0[u + 1];
+    constexpr int HS_UNIT_MLP = 8;  // global loads a lane keeps in flight while staging (one wait per group, not per load)
+    const int XS = BATCH + 1;       // cell stride of the staged batch (odd: the folding lanes start in different banks)
     for (int64_t b0 = cbeg; b0 < cend; b0 += BATCH) {
         const int nb = (int)((cend - b0) < BATCH ? (cend - b0) : BATCH);
-        for (int i = tid; i < nb * GC; i += nthr) inv[i] = -1;
+        const int nent = nb * GC, ncell = nb * GC * NA;
+        // every global word of the batch is asked for up front: the first pass's dictionary entries and the first
+        // HS_UNIT_MLP partials of every lane travel together (one round trip; a load -> wait -> ds_write loop cost one per
+        // element: 6 per batch for Q1, 12 at sf=1 = most of the combine's 30 us there)
+        int64_t rep0 = -1;
+        uint64_t kw0 = 0;
+        if (tid < nent) {
+            rep0 = hs_ld_part<HANDOFF>(&A.part_rep[b0 * GC + tid]);
+            if (!A.hashed) kw0 = hs_ld_part<HANDOFF>(&A.part_keys[b0 * GC + tid]);
+        }
+        uint64_t v0[HS_UNIT_MLP];
+#pragma unroll
+        for (int k = 0; k < HS_UNIT_MLP; ++k) {
+            const int i = tid + k * nthr;
+            v0[k] = i < ncell ? hs_ld_part<HANDOFF>(&A.part_acc[b0 * GC * NA + i]) : 0ull;
+        }
+        for (int i = tid; i < nent; i += nthr) inv[i] = -1;  // chunk slot -> unit slot
+        for (int i = tid; i < GC * NA * nb; i += nthr) {     // x[cell][chunk] = identity until a chunk brings the key
+            const int cellid = i / nb, c = i - cellid * nb;
+            pacc[cellid * XS + c] = hs_acc_identity(hs_spec_op(sb, cellid % NA), hs_spec_int(sb, cellid % NA));
+        }
         __syncthreads();
-        for (int i = tid; i < nb * GC; i += nthr) {
-            const int64_t c = b0 + i / GC;
-            const int sl = i % GC;
-            const int64_t rep = hs_ld_part<HANDOFF>(&A.part_rep[c * GC + sl]);
+        for (int i = tid; i < nent; i += nthr) {
+            // both words of the entry in one round trip (the key word is only meaningful next to a valid row id)
+            const int64_t rep = i == tid ? rep0 : hs_ld_part<HANDOFF>(&A.part_rep[b0 * GC + i]);
+            const uint64_t kw = i == tid ? kw0 : A.hashed ? 0ull : hs_ld_part<HANDOFF>(&A.part_keys[b0 * GC + i]);
             if (rep >= 0) {
                 const int m = A.hashed ? hs_dict_upsert_rows(ureps, mask, A.key, hs_key_at(A.key, rep), rep)
-                                       : hs_dict_upsert_word(ukeys, ureps, mask, hs_ld_part<HANDOFF>(&A.part_keys[c * GC + sl]), rep);
+                                       : hs_dict_upsert_word(ukeys, ureps, mask, kw, rep);
                 if (m < 0) err |= HS_FLAG_DICT_FULL;
-                else inv[(i / GC) * GC + m] = sl;  // keys are distinct within a chunk: one writer per cell
+                else inv[i] = m;
             }
         }
-        for (int i = tid; i < nb * GC * NA; i += nthr) pacc[i] = hs_ld_part<HANDOFF>(&A.part_acc[b0 * GC * NA + i]);
         __syncthreads();
+        if (b0 == cbeg) HS_UNIT_STAMP(9);
+        // the partials go to their unit slot's row (keys are distinct within a chunk: one writer per word)
+#pragma unroll
+        for (int k = 0; k < HS_UNIT_MLP; ++k) {
+            const int i = tid + k * nthr;
+            if (i < ncell) {
+                const int c = i / (GC * NA), r = i - c * (GC * NA), sl = r / NA, a = r - sl * NA;
+                const int m = inv[c * GC + sl];
+                if (m >= 0) pacc[(m * NA + a) * XS + c] = v0[k];
+            }
+        }
+        for (int i = tid + HS_UNIT_MLP * nthr; i < ncell; i += nthr) {  // (wider tables: the rest, one round trip each)
+            const int c = i / (GC * NA), r = i - c * (GC * NA), sl = r / NA, a = r - sl * NA;
+            const int m = inv[c * GC + sl];
+            if (m >= 0) pacc[(m * NA + a) * XS + c] = hs_ld_part<HANDOFF>(&A.part_acc[b0 * GC * NA + i]);
+        }
+        __syncthreads();
+        if (b0 == cbeg) HS_UNIT_STAMP(10);
         for (int i = tid; i < GC * NA; i += nthr) {
-            const int us = i / NA, a = i % NA;
-            const uint32_t op = A.spec.op[a];
-            const bool is_int = A.spec.is_int[a] != 0;
-            uint64_t v = uacc[i];
-            for (int c = 0; c < nb; ++c) {  // ascending chunk order = row order
-                const int sl = inv[c * GC + us];
-                if (sl >= 0) v = hs_acc_fold(op, is_int, v, pacc[(c * GC + sl) * NA + a]);
+            const int a = i % NA;
+            const uint32_t op = hs_spec_op(sb, a);
+            const bool is_int = hs_spec_int(sb, a);
+            const uint64_t* x = pacc + i * XS;
+            if (is_int) {
+                if (op == HS_AGG_SUM) hs_fold_staged_cell<HS_AGG_SUM, true>(&uacc[i], x, nb);
+                else if (op == HS_AGG_MIN) hs_fold_staged_cell<HS_AGG_MIN, true>(&uacc[i], x, nb);
+                else hs_fold_staged_cell<HS_AGG_MAX, true>(&uacc[i], x, nb);
+            } else {
+                if (op == HS_AGG_SUM) hs_fold_staged_cell<HS_AGG_SUM, false>(&uacc[i], x, nb);
+                else if (op == HS_AGG_MIN) hs_fold_staged_cell<HS_AGG_MIN, false>(&uacc[i], x, nb);
+                else hs_fold_staged_cell<HS_AGG_MAX, false>(&uacc[i], x, nb);
             }
-            uacc[i] = v;
         }
         __syncthreads();
+        if (b0 == cbeg) HS_UNIT_STAMP(11);
     }
+    HS_UNIT_STAMP(12);
     if (A.slab) {
         // the unit's groups, dense from slab row u * GC, in the stored kinds (what the reference's shuffle file
         // holds); dense position of a slot = number of occupied slots before it (wave 0, ballot prefix)
@@ -154,26 +230,31 @@ __device__ __forceinline__ void hs_agg_unit_body(const AggUnitArgs& A, const int
         for (int sl = tid; sl < GC; sl += nthr) {
             const int64_t rep = ureps[sl];
             if (rep < 0) continue;
-            const uint8_t* src = (const uint8_t*)A.key.data + rep * kb;
             uint8_t* dst = A.slab + A.key_off + (row0 + dpos[sl]) * kb;
+            if (!A.hashed && A.key.kind == HS_STR) {  // a packed string's key word holds its bytes: no trip back to the column
+                const uint64_t w = ukeys[sl];
+                for (int b = 0; b < kb; ++b) dst[b] = (uint8_t)(w >> (8 * b));
+                continue;
+            }
+            const uint8_t* src = (const uint8_t*)A.key.data + rep * kb;
             for (int b = 0; b < kb; ++b) dst[b] = src[b];
         }
         for (int i = tid; i < GC * NA; i += nthr) {
             const int sl = i / NA, a = i % NA;
             if (ureps[sl] < 0) continue;
-            const bool is_int = A.spec.is_int[a] != 0;
-            if (hs_float_identity_left(A.spec.op[a], is_int, uacc[i])) err |= HS_FLAG_TYPE_ASSERT;
+            const bool is_int = hs_spec_int(sb, a);
+            if (hs_float_identity_left(hs_spec_op(sb, a), is_int, uacc[i])) err |= HS_FLAG_TYPE_ASSERT;
             const uint64_t v = hs_quantise_cell(is_int, uacc[i], err);
             uint8_t* col = A.slab + A.acc_off[a];
             if (is_int) ((int32_t*)col)[row0 + dpos[sl]] = (int32_t)(int64_t)v;
             else ((float*)col)[row0 + dpos[sl]] = (float)hs_u2d(v);
         }
-        // the scan's status so far (fused: at least every chunk of THIS unit has OR-ed its bits in before arriving)
-        if (tid == 0) err |= __hip_atomic_load(A.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        err |= scan_flags;
         if (err) {
             atomicOr(A.flags, err);
             atomicOr((uint32_t*)A.slab, err);  // slab header: reaches every rank with the rows
         }
+        HS_UNIT_STAMP(13);
         return;
     }
     for (int sl = tid; sl < GC; sl += nthr) {
@@ -185,9 +266,9 @@ __device__ __forceinline__ void hs_agg_unit_body(const AggUnitArgs& A, const int
     }
     for (int i = tid; i < GC * NA; i += nthr) {
         const int a = i % NA;
-        if (ureps[i / NA] >= 0 && hs_float_identity_left(A.spec.op[a], A.spec.is_int[a] != 0, uacc[i]))
+        if (ureps[i / NA] >= 0 && hs_float_identity_left(hs_spec_op(sb, a), hs_spec_int(sb, a), uacc[i]))
             err |= HS_FLAG_TYPE_ASSERT;
-        A.out_acc[u * (int64_t)GC * NA + i] = hs_quantise_cell(A.spec.is_int[a] != 0, uacc[i], err);
+        A.out_acc[u * (int64_t)GC * NA + i] = hs_quantise_cell(hs_spec_int(sb, a), uacc[i], err);
     }
     __syncthreads();
     if (tid == 0) A.out_ngroups[u] = s_count;
@@ -228,11 +309,11 @@ struct AggMainArgs {
     // round 3: the join's byte table when cols hold HS_JOIN8_CODE / HS_JOIN8_UNIT columns (the probe runs inside the
     // scan: include/hipspark.h hs_agg_shared_join8); table NULL otherwise
     hs_join8 join;
-    // debug (HIPSPARK_SCAN_STAMPS=1; tools/scan_stamps.py): [n_chunks][8] wall_clock64() at the phase boundaries of every
+    // debug (HIPSPARK_SCAN_STAMPS=1; tools/scan_stamps.py): [n_chunks][16] wall_clock64() at the phase boundaries of every
     // workgroup of the private-table scan + the hardware id; NULL otherwise
     int64_t* stamps;
 };
-#define HS_SCAN_STAMP(i) do { if (A.stamps && threadIdx.x == 0) A.stamps[(int64_t)blockIdx.x * 8 + (i)] = (int64_t)wall_clock64(); } while (0)
+#define HS_SCAN_STAMP(i) do { if (A.stamps && threadIdx.x == 0) A.stamps[(int64_t)blockIdx.x * 16 + (i)] = (int64_t)wall_clock64(); } while (0)
 
 // key word of (unit, key): valid for key words that carry their information in the low 56 bits - INTEGER keys
 // (32 significant bits), packed strings of a FIXED length <= 6 (the length byte is the same for every row)
@@ -336,6 +417,7 @@ struct AggCtx {
     uint32_t tid, nthr, mask;
     int32_t n_acc;
     uint32_t err;
+    HsSpecBits sb;  // the aggregate description in two scalars (hs_spec_bits)
 
     // One-byte string keys (TPC-H flags): the byte indexes a 256-entry LDS map straight to its slot - one
     // ds_read_u8 instead of hash + probe loop; the dictionary is only walked the first time a lane meets a byte.
@@ -380,7 +462,8 @@ struct AggCtx {
     __device__ __forceinline__ void fold(const hs_agg_spec& spec, uint32_t a, int s, bool live, uint64_t x) {
         if (live) {
             const uint32_t idx = ((uint32_t)s * (uint32_t)n_acc + a) * nthr + tid;
-            tbl[idx] = hs_acc_fold(spec.op[a], spec.is_int[a] != 0, tbl[idx], x);
+            (void)spec;
+            tbl[idx] = hs_acc_fold(hs_spec_op(sb, a), hs_spec_int(sb, a), tbl[idx], x);
         }
     }
 
@@ -399,6 +482,10 @@ template <bool HASHED_, int D>
 struct InterpProg {
     static constexpr bool HASHED = HASHED_;
     static constexpr bool TWO_STAGE = false;  // (compiled programs with the join's probe inside load in two stages)
+    static constexpr bool STATIC_SPEC = false;  // (compiled programs know their aggregates' kinds at compile time)
+    static constexpr int NA = 0;
+    static __device__ constexpr uint32_t acc_op(int) { return 0; }
+    static __device__ constexpr bool acc_int(int) { return false; }
     struct Cells {
         uint64_t cell[HS_FUSED_COLS][HS_V];
     };
@@ -527,15 +614,19 @@ __device__ __forceinline__ void hs_agg_main_arrive(const AggMainArgs& A, const i
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave, before the barrier
     __syncthreads();                                  // ... which also frees the LDS tables for the combine
     __shared__ int s_last;
+    __shared__ int64_t s_bounds[2];
     if (threadIdx.x == 0) {
-        const uint32_t need = (uint32_t)(A.unit_chunk0[unit + 1] - A.unit_chunk0[unit]);
+        const int64_t cb = A.unit_chunk0[unit], ce = A.unit_chunk0[unit + 1];
+        s_bounds[0] = cb;
+        s_bounds[1] = ce;
+        const uint32_t need = (uint32_t)(ce - cb);
         const uint32_t prev = __hip_atomic_fetch_add(&A.unit_arrivals[unit], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = prev + 1 == need;
         if (s_last) __hip_atomic_store(&A.unit_arrivals[unit], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     HS_SCAN_STAMP(5);
-    if (s_last) hs_agg_unit_body<true>(A.unit, unit, lds);
+    if (s_last) hs_agg_unit_body<true>(A.unit, unit, lds, s_bounds, A.stamps ? A.stamps + (int64_t)blockIdx.x * 16 : nullptr);
 }
 
 // ---- the kernel body ---------------------------------------------------------------------------------
@@ -553,33 +644,24 @@ __device__ __forceinline__ void hs_agg_main_body(const AggMainArgs& A) {
     const int64_t chunk = blockIdx.x;
     HS_SCAN_STAMP(0);
     if (A.stamps && threadIdx.x == 0)  // XCC_ID (hwreg 20) << 32 | HW_ID (hwreg 4): which XCD / SE / CU ran the chunk
-        A.stamps[chunk * 8 + 7] = ((int64_t)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 20) << 32) |
+        A.stamps[chunk * 16 + 7] = ((int64_t)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 20) << 32) |
                                   (int64_t)(uint32_t)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 4);
     const hs_chunk desc = A.chunks[chunk];
     const int64_t us = desc.unit_begin, c0 = desc.row_begin, c1 = desc.row_end;
+    // the first quad's loads go out first of all: their latency hides the early-exit check and the LDS initialisation
+    const int64_t stride = (int64_t)nthr * HS_V;
+    int64_t base = c0 + (int64_t)tid * HS_V;
+    typename Prog::Cells cur, nxt;
+    if (base < c1) Prog::load(A, base, nxt);
+    const HsSpecBits sb = hs_spec_bits(A.spec);
+
     // a run that has already overflowed a dictionary is going to be repeated with larger tables: later rounds of
     // workgroups only mark their chunk empty and leave
     // (the decision must be the SAME for every lane of the workgroup - one lane reads the flag, LDS hands it round:
     // lanes leaving on their own would let the others run on half-initialised tables and emit garbage row ids)
     __shared__ uint32_t s_overflowed;
     if (threadIdx.x == 0) s_overflowed = __hip_atomic_load(A.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & HS_FLAG_DICT_FULL;
-    __syncthreads();
-    if (s_overflowed) {
-        for (int i = threadIdx.x; i < A.group_cap; i += blockDim.x) {
-            hs_st_part(&A.part_keys[chunk * A.group_cap + i], HS_EMPTY_KEY);
-            hs_st_part(&A.part_rep[chunk * A.group_cap + i], (int64_t)-1);
-        }
-        hs_agg_main_arrive(A, desc.unit, hs_lds);
-        return;
-    }
-
-    HS_SCAN_STAMP(1);
-    // the first quad's loads go out before the LDS tables are initialised: their latency hides the init
-    const int64_t stride = (int64_t)nthr * HS_V;
-    int64_t base = c0 + (int64_t)tid * HS_V;
-    typename Prog::Cells cur, nxt;
-    if (base < c1) Prog::load(A, base, nxt);
-
+    // the tables are initialised on this side of the barrier the check needs anyway (a workgroup that leaves does not care)
     for (int i = tid; i < GC; i += nthr) {
         dkeys[i] = HS_EMPTY_KEY;
         dreps[i] = -1;
@@ -587,9 +669,15 @@ __device__ __forceinline__ void hs_agg_main_body(const AggMainArgs& A) {
     __shared__ uint8_t s_dmap[256];
     for (int i = tid; i < 256; i += nthr) s_dmap[i] = 0xff;
     for (int cellid = 0; cellid < GC * NA; ++cellid)
-        tbl[(uint32_t)cellid * nthr + tid] = hs_acc_identity(A.spec.op[cellid % NA], A.spec.is_int[cellid % NA] != 0);
+        tbl[(uint32_t)cellid * nthr + tid] = hs_acc_identity(hs_spec_op(sb, cellid % NA), hs_spec_int(sb, cellid % NA));
     __syncthreads();
-
+    HS_SCAN_STAMP(1);
+    if (s_overflowed) {
+        for (int i = threadIdx.x; i < A.group_cap; i += blockDim.x) {
+            hs_st_part(&A.part_keys[chunk * A.group_cap + i], HS_EMPTY_KEY);
+            hs_st_part(&A.part_rep[chunk * A.group_cap + i], (int64_t)-1);
+        }
+    } else {  // (one call site of the arrival / unit combine below: it is inlined, and long)
     AggCtx ctx;
     ctx.dkeys = dkeys;
     ctx.dreps = dreps;
@@ -600,6 +688,7 @@ __device__ __forceinline__ void hs_agg_main_body(const AggMainArgs& A) {
     ctx.mask = (uint32_t)GC - 1;
     ctx.n_acc = NA;
     ctx.err = 0;
+    ctx.sb = sb;
     HS_SCAN_STAMP(2);
 
     // software pipeline: the loads of step i+1 are in flight while step i is evaluated
@@ -619,32 +708,72 @@ __device__ __forceinline__ void hs_agg_main_body(const AggMainArgs& A) {
     }
     HS_SCAN_STAMP(3);
     __syncthreads();
+    HS_SCAN_STAMP(14);
 
     // Fixed-order reduction of the private tables.  A wave owns cells wave, wave+nwaves, ...; it folds
     // each cell's lanes (stride 64), then a shuffle tree.  HS_RED cells are reduced together so that
     // their shuffle chains (each ~6 dependent cross-lane hops) overlap instead of running back to back.
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid / HS_WAVE)), lane = tid % HS_WAVE, nwaves = nthr / HS_WAVE;
+    if constexpr (Prog::STATIC_SPEC && (Prog::NA > 0)) {
+        // Compiled programs: a wave takes whole SLOTS, and a slot's accumulators are a compile-time list - the folds below
+        // are straight-line code of the right kind, all of a slot's cross-lane reads are in flight together.  (With the
+        // kinds as run-time values every fold was a tree of branches: ~5 us of this epilogue on an idle chip,
+        // profiles/r04_scan_stamps_*.txt.)  Per cell the order of the folds is the generic form's: same bits.
+        constexpr int SNA = Prog::NA;
+        for (uint32_t sl = wave; sl < (uint32_t)GC; sl += nwaves) {
+            if (__builtin_amdgcn_readfirstlane((int)(dreps[sl] >= 0)) == 0) continue;  // wave-uniform
+            uint64_t v[SNA], t[SNA];
+#pragma unroll
+            for (int a = 0; a < SNA; ++a) v[a] = hs_acc_identity(Prog::acc_op(a), Prog::acc_int(a));
+            for (uint32_t t0 = lane; t0 < nthr; t0 += HS_WAVE) {
+#pragma unroll
+                for (int a = 0; a < SNA; ++a) t[a] = tbl[(sl * (uint32_t)SNA + (uint32_t)a) * nthr + t0];
+#pragma unroll
+                for (int a = 0; a < SNA; ++a) v[a] = hs_acc_fold(Prog::acc_op(a), Prog::acc_int(a), v[a], t[a]);
+            }
+#pragma unroll
+            for (int d = HS_WAVE / 2; d >= 1; d >>= 1) {
+#pragma unroll
+                for (int a = 0; a < SNA; ++a) t[a] = hs_shfl_down64(v[a], d);
+#pragma unroll
+                for (int a = 0; a < SNA; ++a) v[a] = hs_acc_fold(Prog::acc_op(a), Prog::acc_int(a), v[a], t[a]);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int a = 0; a < SNA; ++a) hs_st_part(&A.part_acc[((int64_t)chunk * GC + sl) * SNA + a], v[a]);
+            }
+        }
+    } else {
+    // Everything that selects code here is wave-uniform and is kept in SGPRs on purpose (readfirstlane): with the wave
+    // number in a VGPR the aggregate kinds were per-lane values and every fold became a tree of exec-mask branches.
     constexpr int HS_RED = 6;
-    const uint32_t wave = tid / HS_WAVE, lane = tid % HS_WAVE, nwaves = nthr / HS_WAVE;
     const uint32_t ncells = (uint32_t)(GC * NA);
     for (uint32_t c0id = wave; c0id < ncells; c0id += nwaves * HS_RED) {
-        uint64_t v[HS_RED];
+        uint64_t v[HS_RED], t[HS_RED];
         uint32_t ops[HS_RED];
         bool ints[HS_RED], on[HS_RED];
 #pragma unroll
         for (int k = 0; k < HS_RED; ++k) {
             const uint32_t cellid = c0id + (uint32_t)k * nwaves;
-            on[k] = cellid < ncells && dreps[cellid / NA] >= 0;  // wave-uniform
+            on[k] = cellid < ncells && __builtin_amdgcn_readfirstlane((int)(dreps[cellid < ncells ? cellid / NA : 0] >= 0)) != 0;
             const uint32_t a = on[k] ? cellid % NA : 0;
-            ops[k] = A.spec.op[a];
-            ints[k] = A.spec.is_int[a] != 0;
+            ops[k] = hs_spec_op(sb, a);
+            ints[k] = hs_spec_int(sb, a);
             v[k] = hs_acc_identity(ops[k], ints[k]);
-            if (on[k])
-                for (uint32_t t = lane; t < nthr; t += HS_WAVE) v[k] = hs_acc_fold(ops[k], ints[k], v[k], tbl[cellid * nthr + t]);
+        }
+        for (uint32_t t0 = lane; t0 < nthr; t0 += HS_WAVE) {
+#pragma unroll
+            for (int k = 0; k < HS_RED; ++k) t[k] = on[k] ? tbl[(c0id + (uint32_t)k * nwaves) * nthr + t0] : 0ull;
+#pragma unroll
+            for (int k = 0; k < HS_RED; ++k)
+                if (on[k]) v[k] = hs_acc_fold(ops[k], ints[k], v[k], t[k]);
         }
 #pragma unroll
         for (int d = HS_WAVE / 2; d >= 1; d >>= 1) {
 #pragma unroll
-            for (int k = 0; k < HS_RED; ++k) v[k] = hs_acc_fold(ops[k], ints[k], v[k], hs_shfl_down64(v[k], d));
+            for (int k = 0; k < HS_RED; ++k) t[k] = hs_shfl_down64(v[k], d);
+#pragma unroll
+            for (int k = 0; k < HS_RED; ++k) v[k] = hs_acc_fold(ops[k], ints[k], v[k], t[k]);
         }
         if (lane == 0) {
 #pragma unroll
@@ -654,11 +783,13 @@ __device__ __forceinline__ void hs_agg_main_body(const AggMainArgs& A) {
             }
         }
     }
+    }
     for (int i = tid; i < GC; i += nthr) {
         hs_st_part(&A.part_keys[chunk * GC + i], dkeys[i]);
         hs_st_part(&A.part_rep[chunk * GC + i], dreps[i]);
     }
     if (ctx.err) atomicOr(A.flags, ctx.err);
+    }
     HS_SCAN_STAMP(4);
     hs_agg_main_arrive(A, desc.unit, hs_lds);
     HS_SCAN_STAMP(6);
@@ -838,7 +969,8 @@ __device__ __forceinline__ void hs_agg_shared_body(const AggMainArgs& A) {
         dreps[i] = -1;
     }
     const int R = A.replicas > 0 ? A.replicas : 1;
-    for (int i = tid; i < GC * R * NA; i += nthr) acc[i] = hs_acc_identity(A.spec.op[i % NA], A.spec.is_int[i % NA] != 0);
+    const HsSpecBits sb = hs_spec_bits(A.spec);
+    for (int i = tid; i < GC * R * NA; i += nthr) acc[i] = hs_acc_identity(hs_spec_op(sb, i % NA), hs_spec_int(sb, i % NA));
     __shared__ int s_full, s_count;
     if (tid == 0) {
         s_full = 0;
@@ -893,7 +1025,7 @@ __device__ __forceinline__ void hs_agg_shared_body(const AggMainArgs& A) {
     if (A.chunk_acc) {  // this chunk's cells start as identities (most (unit, slot) pairs stay that way)
         uint64_t* mine = A.chunk_acc + (int64_t)blockIdx.x * A.n_units * (int64_t)UC * NA;
         const int cells = (int)A.n_units * UC * NA;
-        for (int i = tid; i < cells; i += nthr) mine[i] = hs_acc_identity(A.spec.op[i % NA], A.spec.is_int[i % NA] != 0);
+        for (int i = tid; i < cells; i += nthr) mine[i] = hs_acc_identity(hs_spec_op(sb, i % NA), hs_spec_int(sb, i % NA));
         __syncthreads();  // (drains the stores: a cell overwritten below must not be overtaken by its identity)
     }
     for (int sl = tid; sl < GC; sl += nthr) {
@@ -912,8 +1044,8 @@ __device__ __forceinline__ void hs_agg_shared_body(const AggMainArgs& A) {
         }
         uint64_t* mine = A.chunk_acc ? A.chunk_acc + ((int64_t)blockIdx.x * A.n_units + unit) * (int64_t)UC * NA : nullptr;
         for (int a = 0; a < NA; ++a) {
-            const uint32_t op = A.spec.op[a];
-            const bool is_int = A.spec.is_int[a] != 0;
+            const uint32_t op = hs_spec_op(sb, a);
+            const bool is_int = hs_spec_int(sb, a);
             uint64_t v = acc[(sl * R) * NA + a];
             for (int r = 1; r < R; ++r) v = hs_acc_fold(op, is_int, v, acc[(sl * R + r) * NA + a]);  // replicas, in order
             if (mine) mine[u * NA + a] = v;  // this chunk's own cell: no contention (k_agg_shared_fold_chunks adds them up)

@@ -668,6 +668,33 @@ __device__ __forceinline__ int hs_dict_upsert_rows(int64_t* reps, uint32_t mask,
 }
 
 // ---- accumulator folding -----------------------------------------------------------------------------
+// The aggregate description as two scalars: an op nibble and an "integer accumulator" bit per accumulator.  Kernels index
+// the description with run-time values, and gfx9 has no scalar byte load: `spec.op[a]` read from the kernarg segment is a
+// VECTOR load + s_waitcnt vmcnt(0) at every use.  In the scan's table initialisation that wait drained the first step's
+// column loads 24 times per workgroup (5-8 us on an idle chip, 40+ us next to streaming workgroups:
+// profiles/r04_scan_stamps_before.txt).  Built once per kernel from nine s_load_dword; every later use is SALU / VALU.
+struct HsSpecBits {
+    uint64_t ops;   // 4 bits per accumulator: HS_AGG_*
+    uint32_t ints;  // bit a: accumulator a is an i64
+};
+__device__ __forceinline__ HsSpecBits hs_spec_bits(const hs_agg_spec& s) {
+    static_assert(HS_MAX_ACC == 16 && sizeof(hs_agg_spec) == 36, "hs_spec_bits packs 16 accumulators");
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(&s);  // [0] n_acc, [1..4] op bytes, [5..8] is_int bytes
+    HsSpecBits b{0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t o = w[1 + i], t = w[5 + i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            b.ops |= (uint64_t)((o >> (8 * k)) & 0xfu) << (4 * (4 * i + k));
+            b.ints |= (((t >> (8 * k)) & 0xffu) != 0 ? 1u : 0u) << (4 * i + k);
+        }
+    }
+    return b;
+}
+__device__ __forceinline__ uint32_t hs_spec_op(const HsSpecBits& b, uint32_t a) { return (uint32_t)(b.ops >> (4 * a)) & 0xfu; }
+__device__ __forceinline__ bool hs_spec_int(const HsSpecBits& b, uint32_t a) { return (b.ints >> a) & 1u; }
+
 __device__ __forceinline__ uint64_t hs_acc_identity(uint32_t op, bool is_int) {
     if (op == HS_AGG_SUM) return is_int ? 0ull : hs_d2u(0.0);
     const int64_t id = (op == HS_AGG_MIN) ? 2147483647ll : -2147483648ll;  // MAX_INT / MIN_INT, constants.py:14-15

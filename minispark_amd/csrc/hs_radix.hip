@@ -95,8 +95,9 @@ struct RxPass {
     int64_t n_seg;
     int32_t shift, bits;       // bin = (mix(key word) >> shift) & (2^bits - 1); raw: ((key + 1) >> shift) & ... (hs_sort_by_order)
     int32_t n_cols, first;     // columns that travel (0 = key); first pass reads the key through `key` / `sel`
-    int32_t range, range_bias; // range (4-byte keys only): bin = ((key - range_bias) >> shift) & (2^bits - 1) - partitions are KEY RANGES,
-                               // most significant bits first (the dense join build); else a mix of the key's bits
+    int32_t range, range_bias; // range (4-byte keys only): 1: bin = ((key - range_bias) >> shift) & (2^bits - 1) - partitions are KEY RANGES,
+                               // most significant bits first (the dense join build); 2: bin = bits of the key's hash WINDOW
+                               // jh_window(key, range_bias) (the hashed join build); 0: a mix of the key's bits
     int32_t wide, pad_w;       // wide: a STRING key of one fixed length 8 .. 16 travels as this many 4-byte word columns (2 .. 4), round 3
     int32_t raw, key4;         // key4: the key is a 4-byte integer (bins from a 32-bit mix: a quarter of hs_mix64's multiplies)
     hs_col key;
@@ -127,7 +128,12 @@ __device__ __forceinline__ uint32_t rx_mix32(uint32_t k) {
 }
 __device__ __forceinline__ uint32_t rx_bin4(uint32_t key, int shift, int bits) { return (rx_mix32(key) >> shift) & ((1u << bits) - 1u); }
 // ... or, for range partitions (RxPass.range; wave-uniform choice), bits of the key's offset itself
+// the hashed join (hs_join_hash_*): a key's window of the table, 0 .. windows - 1 (multiply-shift: no power of two needed)
+__device__ __forceinline__ uint32_t jh_window(uint32_t key, uint32_t windows) {
+    return (uint32_t)(((uint64_t)rx_mix32(key) * windows) >> 32);
+}
 __device__ __forceinline__ uint32_t rx_bin4r(const RxPass& A, uint32_t key, int shift, int bits) {
+    if (A.range == 2) return (jh_window(key, (uint32_t)A.range_bias) >> shift) & ((1u << bits) - 1u);
     return A.range ? ((key - (uint32_t)A.range_bias) >> shift) & ((1u << bits) - 1u) : rx_bin4(key, shift, bits);
 }
 __device__ __forceinline__ uint32_t rx_bin_of(const RxPass& A, uint64_t word) {
@@ -2123,5 +2129,375 @@ extern "C" int hs_join_dense_fill(void* stream, int64_t n_probe, const uint32_t*
     if (g > 256 * 64) g = 256 * 64;
     hipLaunchKernelGGL(k_jd_fill, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, A);
     RX_CHECK_LAUNCH("hs_join_dense_fill");
+    return HS_OK;
+}
+
+// =====================================================================================================
+// The general inner join on ANY INTEGER keys (round 4; include/hipspark.h hs_join_hash_*)
+// =====================================================================================================
+// Same reference loop as above (tasks.py:201-240), for keys the dense form does not hold: a sparse or huge key range,
+// negative keys, a few hot values.  The table is an open-addressing table of 8-byte slots {key, word} cut into WINDOWS of
+// 2^JH_L slots; a key belongs to window jh_window(key) and probes linearly INSIDE it (wrapping at the window's end), so
+//   * the build never leaves LDS: the (key, row) tuples are brought into window order by the two stable partition passes
+//     (RxPass.range = 2), one wave per window inserts its keys into an LDS copy of the window (ds_cmpst on a 64-bit cell),
+//     counts, scans and places the rows in order exactly like the dense form, and stores the finished window with coalesced
+//     8-byte stores - no global atomic, no scattered store, every list ascending without a sort;
+//   * a probe is ONE scattered 8-byte read in the usual case (the slot holds key and word together; at a load of ~0.57 a
+//     present key sits 1.7 slots from its start on average - the same 64-byte line nearly always).
+// The slot word is the dense form's (JD_EMPTY / the one build row / JD_MULTI + list start), rows[] and list_count[] too, so
+// the probe's second pass IS hs_join_dense_fill.
+constexpr int JH_L = 10;                       // slots per window: 8 KB of keys + 8 KB of cursors / first rows in LDS per wave
+constexpr uint64_t JH_FREE = ~0ull;            // LDS key cell: nobody here yet (a key occupies the low 32 bits only)
+
+static int64_t jh_windows(int64_t n_build) {   // ~1.75 slots per build row: distinct keys <= rows
+    const int64_t w = (n_build * 7 / 4 + (1 << JH_L) - 1) >> JH_L;
+    return w < 1 ? 1 : w;
+}
+
+struct JhAssemble {
+    const int64_t* seg_start;  // [parts + 1] tuple ranges of the partitions = windows (parts >= windows; the rest are empty)
+    int64_t parts, windows;
+    const int32_t* keys;       // tuples, window by window, in row order inside a window
+    const uint32_t* rows;
+    uint2* table;              // [windows << JH_L] {key, word}
+    uint32_t* out_rows;        // [n]: build rows window by window, slot by slot, ascending within a slot
+    uint32_t* list_count;      // [n]: at the start of a list of several rows, its length
+    uint32_t* flags;
+};
+
+// slot of `key` in the wave's LDS window, claiming a free cell on the way when INSERT; -1: the window is full (more
+// distinct keys than slots - jh_windows leaves 1.75x room over the AVERAGE window; the caller falls back)
+template <bool INSERT>
+__device__ __forceinline__ int jh_slot(uint64_t* cell, uint32_t key, uint32_t start) {
+    constexpr uint32_t wmask = (1u << JH_L) - 1u;
+    uint32_t s = start & wmask;
+    for (int probe = 0; probe <= (int)wmask; ++probe) {
+        uint64_t cur = __hip_atomic_load(&cell[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (INSERT && cur == JH_FREE) {
+            cur = atomicCAS((unsigned long long*)&cell[s], (unsigned long long)JH_FREE, (unsigned long long)key);
+            if (cur == JH_FREE) return (int)s;
+        }
+        if (cur == (uint64_t)key) return (int)s;
+        if (!INSERT && cur == JH_FREE) return -1;
+        s = (s + 1) & wmask;
+    }
+    return -1;
+}
+
+__global__ void __launch_bounds__(256) k_jh_assemble(const JhAssemble A) {
+    extern __shared__ __align__(16) uint64_t jh_lds[];
+    constexpr int W = 1 << JH_L, per = W / HS_WAVE;
+    const int lane = threadIdx.x & (HS_WAVE - 1), w = threadIdx.x / HS_WAVE, wpb = blockDim.x / HS_WAVE;
+    uint64_t* cell = jh_lds + (size_t)w * 2 * W;   // key cells
+    uint32_t* cur = (uint32_t*)(cell + W);         // counts, then list cursors
+    uint32_t* head = cur + W;                      // the first (= lowest) build row of every slot
+    const uint64_t below = (1ull << lane) - 1ull;
+    uint32_t err = 0;
+    for (int64_t p = (int64_t)blockIdx.x * wpb + w; p < A.parts; p += (int64_t)gridDim.x * wpb) {
+        const int64_t b = A.seg_start[p], e = A.seg_start[p + 1];
+        if (p >= A.windows) {
+            if (e > b) err |= HS_FLAG_BAD_PROGRAM;  // a tuple past the last window: the passes and the table disagree
+            continue;
+        }
+        int32_t nkey = b + lane < e ? A.keys[b + lane] : 0;
+        for (int s = lane; s < W; s += HS_WAVE) {
+            cell[s] = JH_FREE;
+            cur[s] = 0;
+            head[s] = JD_EMPTY;
+        }
+        rx_wave_handover();
+        bool full = false;
+        for (int64_t base = b; base < e; base += HS_WAVE) {  // claim slots, count rows per slot
+            const uint32_t key = (uint32_t)nkey;
+            const bool valid = base + lane < e;
+            if (base + HS_WAVE + lane < e) nkey = A.keys[base + HS_WAVE + lane];
+            if (valid) {
+                const int s = jh_slot<true>(cell, key, rx_mix32(key));
+                if (s < 0) full = true;
+                else atomicAdd(&cur[s], 1u);
+            }
+        }
+        rx_wave_handover();
+        if (__ballot(full)) {  // (wave-uniform) leave the window empty and say so
+            err |= HS_FLAG_DICT_FULL;
+            for (int s = lane; s < W; s += HS_WAVE) A.table[(p << JH_L) + s] = make_uint2(0u, JD_EMPTY);
+            continue;
+        }
+        uint32_t sum = 0;
+        for (int k = 0; k < per; ++k) sum += cur[lane * per + k];
+        uint32_t x = sum;
+        for (int d = 1; d < HS_WAVE; d <<= 1) {
+            const uint32_t up = __shfl_up(x, d, HS_WAVE);
+            if (lane >= d) x += up;
+        }
+        uint32_t run = x - sum;
+        for (int k = 0; k < per; ++k) {
+            const uint32_t c = cur[lane * per + k];
+            cur[lane * per + k] = run;
+            run += c;
+        }
+        rx_wave_handover();
+        nkey = b + lane < e ? A.keys[b + lane] : 0;
+        uint32_t nrow = b + lane < e ? A.rows[b + lane] : 0u;
+        for (int64_t base = b; base < e; base += HS_WAVE) {  // ordered placement (see k_jd_assemble)
+            const bool valid = base + lane < e;
+            const uint32_t key = (uint32_t)nkey, row = nrow;
+            if (base + HS_WAVE + lane < e) {
+                nkey = A.keys[base + HS_WAVE + lane];
+                nrow = A.rows[base + HS_WAVE + lane];
+            }
+            const uint32_t s = valid ? (uint32_t)jh_slot<false>(cell, key, rx_mix32(key)) : 0u;
+            uint64_t peers = __ballot(valid);
+            for (int bit = 0; bit < JH_L; ++bit) {
+                const bool on = (s >> bit) & 1u;
+                const uint64_t bal = __ballot(valid && on);
+                peers &= on ? bal : ~bal;
+            }
+            const uint32_t rank = (uint32_t)__popcll(peers & below);
+            const uint32_t at = valid ? cur[s] : 0u;
+            const uint32_t first = valid ? head[s] : 0u;
+            rx_wave_handover();
+            if (valid) {
+                A.out_rows[b + at + rank] = row;
+                if (rank == 0) {
+                    cur[s] = at + (uint32_t)__popcll(peers);
+                    if (first == JD_EMPTY) head[s] = row;
+                }
+            }
+            rx_wave_handover();
+        }
+        // the finished window (coalesced).  Lists lie in SLOT order, so list s starts where the previous slot's ends.
+        for (int s = lane; s < W; s += HS_WAVE) {
+            const uint32_t end = cur[s], start = s ? cur[s - 1] : 0u;
+            const uint32_t c = end - start;
+            uint32_t word = JD_EMPTY;
+            if (c == 1) word = head[s];
+            else if (c > 1) {
+                word = JD_MULTI | (uint32_t)(b + start);
+                A.list_count[b + start] = c;
+            }
+            A.table[(p << JH_L) + s] = make_uint2((uint32_t)cell[s], word);
+        }
+        rx_wave_handover();
+    }
+    if (err) atomicOr(A.flags, err);
+}
+
+struct JhLayout {
+    size_t keys_a, rows_a, keys_b, rows_b, iota, seg0, seg1, seg2, tb0, tb1, cnt, scan, scan_ws, total;
+    int64_t tiles1, tiles2, nseg1, parts, counters, windows;
+    int bits1, bits2;
+};
+static bool jh_layout(int64_t n, JhLayout& Y) {
+    if (n < 0 || n >= 0x7fffffffll) return false;  // a slot word holds a row in 31 bits
+    Y.windows = jh_windows(n);
+    int bits = 0;
+    while (((int64_t)1 << bits) < Y.windows) ++bits;
+    if (bits > 2 * RX_MAX_BITS) return false;  // 65 536 windows = 38 M build rows per call
+    Y.bits1 = bits <= RX_MAX_BITS ? bits : (bits + 1) / 2;
+    Y.bits2 = bits - Y.bits1;
+    Y.nseg1 = (int64_t)1 << Y.bits1;
+    Y.parts = (int64_t)1 << bits;
+    Y.tiles1 = n / RX_TILE + 2;
+    Y.tiles2 = Y.bits2 ? n / RX_TILE + Y.nseg1 + 1 : 0;
+    const int64_t c1 = Y.tiles1 << Y.bits1, c2 = Y.tiles2 << Y.bits2;
+    Y.counters = c1 > c2 ? c1 : c2;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = off;
+        off += rx_align(bytes);
+        return at;
+    };
+    Y.keys_a = take((size_t)n * 4 + 64);
+    Y.rows_a = take((size_t)n * 4 + 64);
+    Y.keys_b = take(Y.bits2 ? (size_t)n * 4 + 64 : 0);
+    Y.rows_b = take(Y.bits2 ? (size_t)n * 4 + 64 : 0);
+    Y.iota = take(Y.bits1 ? 64 : (size_t)n * 4 + 64);
+    Y.seg0 = take(16);
+    Y.seg1 = take((size_t)(Y.nseg1 + 1) * 8);
+    Y.seg2 = take((size_t)(Y.parts + 1) * 8);
+    Y.tb0 = take(16);
+    Y.tb1 = take((size_t)(Y.nseg1 + 1) * 8);
+    Y.cnt = take((size_t)Y.counters * 8);
+    Y.scan = take((size_t)(Y.counters + 1) * 8);
+    Y.scan_ws = take(hs_scan_ws_bytes(Y.counters > 1 ? Y.counters : 1));
+    Y.total = off;
+    return true;
+}
+
+extern "C" size_t hs_join_hash_ws_bytes(int64_t n_build) {
+    JhLayout Y;
+    return jh_layout(n_build, Y) ? Y.total : 0;
+}
+extern "C" int64_t hs_join_hash_slots(int64_t n_build) {
+    JhLayout Y;
+    return jh_layout(n_build, Y) ? Y.windows << JH_L : 0;
+}
+
+extern "C" int hs_join_hash_build(void* stream_, const int32_t* build_keys, int64_t n_build, void* table, uint32_t* rows,
+                                  uint32_t* list_count, void* ws_, uint32_t* flags) {
+    JhLayout Y;
+    if ((!build_keys && n_build > 0) || !table || !rows || !list_count || !ws_ || !flags || ((uintptr_t)table & 7) || !jh_layout(n_build, Y)) {
+        hs_set_error("hs_join_hash_build: bad arguments (n_build <= 38 M rows, table 8-byte aligned)");
+        return HS_E_ARG;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    uint8_t* ws = (uint8_t*)ws_;
+    const int64_t n = n_build;
+    uint32_t* iota = (uint32_t*)(ws + Y.iota);
+    int64_t* seg0 = (int64_t*)(ws + Y.seg0);
+    int64_t* seg1 = (int64_t*)(ws + Y.seg1);
+    int64_t* seg2 = (int64_t*)(ws + Y.seg2);
+    const int64_t n_iota = Y.bits1 ? 0 : n;
+    int64_t grid = (n_iota + 255) / 256;
+    grid = grid < 1 ? 1 : (grid > 4096 ? 4096 : grid);
+    hipLaunchKernelGGL(k_jd_setup, dim3((unsigned)grid), dim3(256), 0, stream, iota, n_iota, n, seg0);
+    RX_CHECK_LAUNCH("hs_join_hash_build (row ids)");
+    const int32_t* t_keys = build_keys;
+    const uint32_t* t_rows = iota;
+    const int64_t* seg = seg0;
+    if (Y.bits1 > 0 && n > 0) {
+        RxPass P;
+        std::memset(&P, 0, sizeof(P));
+        P.n_cols = 2;
+        P.esize[0] = P.esize[1] = 4;
+        P.range = 2;
+        P.range_bias = (int32_t)Y.windows;
+        P.key = hs_col{HS_I32, -1, build_keys, nullptr, nullptr};
+        P.row0 = 0;
+        P.seg_start = seg0;  // pass 1: the top bits1 bits of the window number over the one segment [0, n)
+        P.tile_base = (int64_t*)(ws + Y.tb0);
+        P.n_seg = 1;
+        P.shift = Y.bits2;
+        P.bits = Y.bits1;
+        P.first = 1;
+        P.src[1] = nullptr;  // the row id column is the position (k_rx_scatter4)
+        P.dst[0] = ws + Y.keys_a;
+        P.dst[1] = ws + Y.rows_a;
+        int rc = rx_pass(stream, P, Y.tiles1, (int64_t*)(ws + Y.cnt), (int64_t*)(ws + Y.scan), ws + Y.scan_ws, n, Y.bits2 ? seg1 : seg2);
+        if (rc != HS_OK) return rc;
+        t_keys = (const int32_t*)(ws + Y.keys_a);
+        t_rows = (const uint32_t*)(ws + Y.rows_a);
+        seg = seg2;
+        if (Y.bits2) {  // pass 2: the low bits2 bits inside every segment of pass 1
+            P.seg_start = seg1;
+            P.tile_base = (int64_t*)(ws + Y.tb1);
+            P.n_seg = Y.nseg1;
+            P.shift = 0;
+            P.bits = Y.bits2;
+            P.first = 0;
+            P.src[0] = ws + Y.keys_a;
+            P.src[1] = ws + Y.rows_a;
+            P.dst[0] = ws + Y.keys_b;
+            P.dst[1] = ws + Y.rows_b;
+            rc = rx_pass(stream, P, Y.tiles2, (int64_t*)(ws + Y.cnt), (int64_t*)(ws + Y.scan), ws + Y.scan_ws, n, seg2);
+            if (rc != HS_OK) return rc;
+            t_keys = (const int32_t*)(ws + Y.keys_b);
+            t_rows = (const uint32_t*)(ws + Y.rows_b);
+        }
+    } else if (Y.bits1 > 0) {  // no rows: every window is empty
+        hs_memset_async(seg2, 0, (size_t)(Y.parts + 1) * 8, stream);
+        seg = seg2;
+    }
+    JhAssemble A;
+    A.seg_start = seg;
+    A.parts = Y.bits1 > 0 ? Y.parts : 1;
+    A.windows = Y.windows;
+    A.keys = t_keys;
+    A.rows = t_rows;
+    A.table = (uint2*)table;
+    A.out_rows = rows;
+    A.list_count = list_count;
+    A.flags = flags;
+    constexpr size_t per_wave = (size_t)16 << JH_L;
+    constexpr int wpb = 4;
+    int64_t g = (A.parts + wpb - 1) / wpb;
+    if (g > 256 * 32) g = 256 * 32;
+    static unsigned long long attr_set = 0;
+    if (hs_first_on_device(attr_set)) (void)hipFuncSetAttribute((const void*)k_jh_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(per_wave * wpb));
+    hipLaunchKernelGGL(k_jh_assemble, dim3((unsigned)g), dim3(HS_WAVE * wpb), per_wave * wpb, stream, A);
+    RX_CHECK_LAUNCH("hs_join_hash_build (assemble)");
+    return HS_OK;
+}
+
+struct JhProbe {
+    const int32_t* keys;
+    int64_t n;
+    uint32_t windows, pad;
+    const uint2* table;
+    const uint32_t* rows;
+    const uint32_t* list_count;
+    int64_t* counts;
+    uint32_t* aux;
+};
+
+// Probe, pass 1 (the hashed twin of k_jd_count): four keys per lane, their first slots in flight together; a slot that
+// holds another key sends the lane to the next one of the window.  counts / aux as hs_join_dense_count writes them.
+__global__ void __launch_bounds__(256) k_jh_count(const JhProbe A) {
+    constexpr uint32_t wmask = (1u << JH_L) - 1u;
+    const int64_t nq = (A.n + 3) / 4;
+    const int64_t second = (A.n + 3) & ~(int64_t)3;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (int64_t)gridDim.x * blockDim.x) {
+        const jd_i32x4 kv = __builtin_nontemporal_load(reinterpret_cast<const jd_i32x4*>(A.keys) + q);
+        const uint32_t k[4] = {(uint32_t)kv.x, (uint32_t)kv.y, (uint32_t)kv.z, (uint32_t)kv.w};
+        uint32_t word[4], cnt[4], first[4], st[4], at[4];
+        const uint2* win[4];
+        uint2 slot[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t h = rx_mix32(k[j]);
+            win[j] = A.table + ((int64_t)(((uint64_t)h * A.windows) >> 32) << JH_L);
+            at[j] = h & wmask;
+            slot[j] = win[j][at[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            for (int probe = 0; probe < (int)wmask && slot[j].y != JD_EMPTY && slot[j].x != k[j]; ++probe) {
+                at[j] = (at[j] + 1) & wmask;
+                slot[j] = win[j][at[j]];
+            }
+            word[j] = q * 4 + j < A.n && slot[j].x == k[j] ? slot[j].y : JD_EMPTY;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool multi = word[j] != JD_EMPTY && (word[j] & JD_MULTI);
+            st[j] = multi ? word[j] & ~JD_MULTI : 0u;
+            cnt[j] = word[j] == JD_EMPTY ? 0u : 1u;
+            first[j] = word[j];
+            if (multi) {
+                cnt[j] = A.list_count[st[j]];
+                first[j] = A.rows[st[j]];
+            }
+        }
+        if (q * 4 + 3 < A.n) {
+            int64_t* c = A.counts + q * 4;
+            __builtin_nontemporal_store(jd_i64x2{(long long)cnt[0], (long long)cnt[1]}, reinterpret_cast<jd_i64x2*>(c));
+            __builtin_nontemporal_store(jd_i64x2{(long long)cnt[2], (long long)cnt[3]}, reinterpret_cast<jd_i64x2*>(c + 2));
+            __builtin_nontemporal_store(jd_u32x4{first[0], first[1], first[2], first[3]}, reinterpret_cast<jd_u32x4*>(A.aux) + q);
+            __builtin_nontemporal_store(jd_u32x4{st[0], st[1], st[2], st[3]}, reinterpret_cast<jd_u32x4*>(A.aux + second) + q);
+        } else {
+            for (int j = 0; j < 4 && q * 4 + j < A.n; ++j) {
+                A.counts[q * 4 + j] = (int64_t)cnt[j];
+                A.aux[q * 4 + j] = first[j];
+                A.aux[second + q * 4 + j] = st[j];
+            }
+        }
+    }
+}
+
+extern "C" int hs_join_hash_count(void* stream, const int32_t* probe_keys, int64_t n_probe, int64_t n_build, const void* table,
+                                  const uint32_t* rows, const uint32_t* list_count, int64_t* counts, void* aux) {
+    JhLayout Y;
+    if ((!probe_keys && n_probe > 0) || n_probe < 0 || !table || !rows || !list_count || !counts || !aux || ((uintptr_t)probe_keys & 15) ||
+        ((uintptr_t)counts & 15) || ((uintptr_t)aux & 15) || !jh_layout(n_build, Y)) {
+        hs_set_error("hs_join_hash_count: bad arguments (probe keys, counts and aux 16-byte aligned; n_build as given to the build)");
+        return HS_E_ARG;
+    }
+    if (n_probe == 0) return HS_OK;
+    JhProbe A{probe_keys, n_probe, (uint32_t)Y.windows, 0, (const uint2*)table, rows, list_count, counts, (uint32_t*)aux};
+    int64_t g = ((n_probe + 3) / 4 + 255) / 256;
+    if (g > 256 * 64) g = 256 * 64;
+    hipLaunchKernelGGL(k_jh_count, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, A);
+    RX_CHECK_LAUNCH("hs_join_hash_count");
     return HS_OK;
 }

@@ -2253,13 +2253,54 @@ class Device:
         self.dense_joins = getattr(self, "dense_joins", 0) + 1
         return out_left, out_right, out_start, n_out
 
+    def _join_indices_hashed(self, left_key: DCol, right_key: DCol) -> tuple | None:
+        """Any INTEGER keys (round 4, hs_join_hash_*): the build rows are moved into the order of their hash windows and every
+        window of the {key, word} table is assembled in LDS - no global atomics; the probe reads one 8-byte slot per row in
+        the usual case and shares the dense form's second pass.  None: other key kinds, more than ~38 M build rows, or a
+        window that overflowed (a degenerate key set) - the hash table in global memory takes those."""
+        n_left, n_right = left_key.n, right_key.n
+        if (left_key.kind != hs.I32 or right_key.kind != hs.I32 or n_left == 0 or n_right == 0
+                or left_key.data.data_ptr() % 16 or right_key.data.data_ptr() % 16):
+            return None
+        slots = int(self.lib.hs_join_hash_slots(n_left))
+        if slots == 0:
+            return None
+        table = self.empty(slots, torch.int64)
+        rows = self.empty(n_left, torch.int32)
+        list_count = self.empty(n_left, torch.int32)
+        ws = self.workspace(int(self.lib.hs_join_hash_ws_bytes(n_left)))
+        overflowed = self.empty(1, torch.int32)  # a status word of this build's own: "a window overflowed" is not an error
+        overflowed.zero_()
+        hs.check(self.lib.hs_join_hash_build(self.stream, left_key.data.data_ptr(), n_left, table.data_ptr(), rows.data_ptr(),
+                                             list_count.data_ptr(), ws.data_ptr(), overflowed.data_ptr()), "hs_join_hash_build")
+        counts = self.empty(max(n_right, 1), torch.int64)
+        aux = self.workspace(self.lib.hs_join_dense_aux_bytes(n_right))
+        hs.check(self.lib.hs_join_hash_count(self.stream, right_key.data.data_ptr(), n_right, n_left, table.data_ptr(),
+                                             rows.data_ptr(), list_count.data_ptr(), counts.data_ptr(), aux.data_ptr()),
+                 "hs_join_hash_count")
+        out_start = self.empty(n_right + 1, torch.int64)
+        ws2 = self.workspace(self.lib.hs_scan_ws_bytes(n_right))
+        hs.check(self.lib.hs_exclusive_scan_i64(self.stream, counts.data_ptr(), n_right, out_start.data_ptr(), ws2.data_ptr()),
+                 "hs_exclusive_scan_i64")
+        n_out = self.host_int(out_start[n_right])  # sizes the pair lists: the run is data-dependent (not replayable)
+        if int(overflowed.item()) != 0:  # (the stream is idle after the read above: this one costs no second wait)
+            return None
+        out_left = self.empty(max(n_out, 1), torch.int64)
+        out_right = self.empty(max(n_out, 1), torch.int64)
+        hs.check(self.lib.hs_join_dense_fill(self.stream, n_right, rows.data_ptr(), aux.data_ptr(), out_start.data_ptr(),
+                                             out_left.data_ptr(), out_right.data_ptr()), "hs_join_dense_fill")
+        self.last_join = {"mode": "hashed windows", "slots": slots, "n_build": n_left}
+        self.hashed_joins = getattr(self, "hashed_joins", 0) + 1
+        return out_left, out_right, out_start, n_out
+
     def join_indices(self, left_key: DCol, right_key: DCol) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, int]:
         """Inner equi-join -> (left_rows, right_rows, out_start, n_out): pairs ordered by right row,
         then by left row (the reference's emission order, tasks.py:224-240)."""
         n_left, n_right = left_key.n, right_key.n
-        dense = self._join_indices_dense(left_key, right_key)
+        dense = self._join_indices_dense(left_key, right_key) or self._join_indices_hashed(left_key, right_key)
         if dense is not None:
             return dense
+        self.last_join = {"mode": "global hash table", "n_build": n_left}
         cap = 16
         while cap < 2 * max(n_left, 1):
             cap *= 2

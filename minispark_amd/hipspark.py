@@ -318,6 +318,10 @@ SIGNATURES: dict[str, tuple] = {
     "hs_join_dense_aux_bytes": (C.c_size_t, [_I64]),
     "hs_join_dense_count": (C.c_int, [_P, _P, _I64, _I32, _I64, _P, _P, _P, _P, _P]),
     "hs_join_dense_fill": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P]),
+    "hs_join_hash_ws_bytes": (C.c_size_t, [_I64]),
+    "hs_join_hash_slots": (C.c_int64, [_I64]),
+    "hs_join_hash_build": (C.c_int, [_P, _P, _I64, _P, _P, _P, _P, _P]),
+    "hs_join_hash_count": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P]),
     "hs_remap_u8": (C.c_int, [_P, _P, _I64, _P, _P]),
     "hs_dict_build": (C.c_int, [_P, _COLP, _I64, _I32, _P, _P, _P, _P]),
     "hs_dict_assign": (C.c_int, [_P, _COLP, _I64, _I32, _P, _P, _P, _P, _P]),

@@ -216,6 +216,78 @@ def test_dense_integer_join_matches_reference_order(dev, n_left, n_right, spread
     assert np.array_equal(out_left[:n_out].cpu().numpy(), want_left)
 
 
+@pytest.mark.parametrize("n_left,n_right,seed", [(1, 5, 0), (700, 5000, 1), (3000, 900, 2), (70_000, 200_000, 3),
+                                                 (2_000_000, 3_000_000, 4), (9_000_000, 1_000_000, 5)])
+def test_sparse_integer_join_takes_the_hash_windows_and_matches_reference_order(dev, n_left, n_right, seed):
+    """Round 4: INTEGER keys that are NOT dense (the whole int32 range, negative values) take hs_join_hash_* - the build
+    rows moved into hash-window order by zero / one / two stable partition passes, every 1024-slot window of the {key, word}
+    table assembled in LDS, probe by one 8-byte slot read, second pass shared with the dense form.  Duplicates on both sides
+    (one key many times), probe keys without a partner, INT32_MIN / INT32_MAX / 0 / -1 as keys: pairs must come out ordered by
+    right row, then left row ascending (reference tasks.py:224-240)."""
+    from minispark_amd.constants import ColumnType
+
+    rng = _rng(200 + seed)
+    pool = rng.integers(-2**31, 2**31 - 1, max(2, n_left * 3 // 4), dtype=np.int64).astype(np.int32)
+    pool[:4] = np.array([-2**31, 2**31 - 1, 0, -1], dtype=np.int32)[: len(pool[:4])]
+    left = pool[rng.integers(0, len(pool), n_left)]                       # duplicates happen, most pool keys appear
+    if n_left > 1:
+        left[rng.integers(0, n_left, max(1, n_left // 50))] = left[0]     # ... and one key many times
+    right = pool[rng.integers(0, len(pool), n_right)]
+    miss = rng.random(n_right) < 0.2
+    right[miss] = rng.integers(-2**31, 2**31 - 1, int(miss.sum()), dtype=np.int64).astype(np.int32)  # (almost surely) no partner
+    lcol, rcol = dev.upload_raw(left, ColumnType.INTEGER), dev.upload_raw(right, ColumnType.INTEGER)
+    before = getattr(dev, "hashed_joins", 0)
+    out_left, out_right, out_start, n_out = dev.join_indices(lcol, rcol)
+    if n_left > 1:  # (a single build row spans one slot: the dense form holds it)
+        assert getattr(dev, "hashed_joins", 0) == before + 1 and dev.last_join["mode"] == "hashed windows"
+    assert dev.read_flags() == 0
+    order = np.argsort(left, kind="stable")
+    keys_sorted = left[order]
+    lo, hi = np.searchsorted(keys_sorted, right, "left"), np.searchsorted(keys_sorted, right, "right")
+    counts = hi - lo
+    want_right = np.repeat(np.arange(n_right, dtype=np.int64), counts)
+    starts = np.concatenate([[0], np.cumsum(counts)])
+    within = np.arange(int(counts.sum()), dtype=np.int64) - np.repeat(starts[:-1], counts)
+    want_left = order[np.repeat(lo, counts) + within].astype(np.int64)
+    assert n_out == len(want_right)
+    assert np.array_equal(out_start[: n_right + 1].cpu().numpy(), starts)
+    assert np.array_equal(out_right[:n_out].cpu().numpy(), want_right)
+    assert np.array_equal(out_left[:n_out].cpu().numpy(), want_left)
+
+
+def test_a_hash_window_that_overflows_hands_the_join_to_the_global_table(dev):
+    """More distinct keys in ONE 1024-slot window than it has slots (keys picked by brute force to share a window - a
+    degenerate hash, not a data pattern): the build leaves that window empty and says so, the engine's join falls back to
+    hs_join_build and the pairs are still the reference's."""
+    from minispark_amd.constants import ColumnType
+
+    def mix32(k):
+        k = k.astype(np.uint64)
+        h = (k * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)
+        h ^= h >> np.uint64(15)
+        h = (h * np.uint64(0x85EBCA77)) & np.uint64(0xFFFFFFFF)
+        return h ^ (h >> np.uint64(16))
+
+    n_left = 4000
+    windows = (n_left * 7 // 4 + 1023) >> 10
+    cand = np.arange(0, 4_000_000, dtype=np.int64)
+    in_window_0 = cand[((mix32(cand) * np.uint64(windows)) >> np.uint64(32)) == 0]
+    assert len(in_window_0) >= 1100
+    left = np.concatenate([in_window_0[:1100], cand[:n_left - 1100] + 5_000_000]).astype(np.int32)
+    # spread the keys far apart so that the dense form refuses them (a range of more than 32 slots per build row)
+    left[-1] = 2_000_000_000
+    right = np.concatenate([left[::3], np.array([7, -9], dtype=np.int32)])
+    lcol, rcol = dev.upload_raw(left, ColumnType.INTEGER), dev.upload_raw(right, ColumnType.INTEGER)
+    before = getattr(dev, "hashed_joins", 0)
+    out_left, out_right, _, n_out = dev.join_indices(lcol, rcol)
+    assert getattr(dev, "hashed_joins", 0) == before and dev.last_join["mode"] == "global hash table"
+    assert dev.read_flags() == 0
+    pos = {int(k): i for i, k in enumerate(left.tolist())}
+    want = [(pos[int(k)], ri) for ri, k in enumerate(right.tolist()) if int(k) in pos]
+    got = list(zip(out_left[:n_out].cpu().numpy().tolist(), out_right[:n_out].cpu().numpy().tolist()))
+    assert got == want
+
+
 def test_join_on_strings_including_long_ones(dev):
     from minispark_amd.constants import ColumnType
     from minispark_amd.io import StrCol

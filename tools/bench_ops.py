@@ -114,6 +114,27 @@ for label, bkeys, pkeys in (("dense", build, probe),
     report(f"A8 dense count + fill ({label})", ms_c + ms_f, N * (4 + 8 + 8) + N * (8 + 4) + nout * 16)
     assert dev.read_flags() == 0
 
+# A8, round 4: ANY INTEGER keys through the hashed windows (hs_join_hash_*): the build keys scattered over the whole int32 range
+# (a multiplicative scramble of 0 .. nb-1: unique, no structure the window hash could profit from)
+hk = ((build.to(torch.int64) * 2654435761 + 12345) & 0xFFFFFFFF).to(torch.int64)
+hbk = dev.empty(nb, torch.int32); hbk.copy_(torch.where(hk >= 2**31, hk - 2**32, hk).to(torch.int32))
+hp = ((probe.to(torch.int64) * 2654435761 + 12345) & 0xFFFFFFFF).to(torch.int64)
+hpk = dev.empty(N, torch.int32); hpk.copy_(torch.where(hp >= 2**31, hp - 2**32, hp).to(torch.int32))
+hslots = int(lib.hs_join_hash_slots(nb))
+htable = dev.empty(hslots, torch.int64); hrows = dev.empty(nb, torch.int32); hlc = dev.empty(nb, torch.int32)
+hws = dev.workspace(lib.hs_join_hash_ws_bytes(nb))
+ms_b = timed(lambda: lib.hs_join_hash_build(dev.stream, hbk.data_ptr(), nb, htable.data_ptr(), hrows.data_ptr(), hlc.data_ptr(), hws.data_ptr(), dev.flags.data_ptr()))
+report(f"A8 hs_join_hash_build (any int32 keys, {hslots} slots)", ms_b, nb * (4 + 4) + hslots * 8, f"{nb / ms_b / 1e3:.0f} M keys/s; keys in, rows + the 8-byte slots out")
+aux = dev.workspace(lib.hs_join_dense_aux_bytes(N))
+ms_c = timed(lambda: lib.hs_join_hash_count(dev.stream, hpk.data_ptr(), N, nb, htable.data_ptr(), hrows.data_ptr(), hlc.data_ptr(), counts.data_ptr(), aux.data_ptr()))
+report("A8 hs_join_hash_count (any int32 keys)", ms_c, N * (4 + 8 + 8 + 8), f"{N / ms_c / 1e3:.0f} M probes/s; random 8 B reads of a {hslots * 8 / 1e6:.0f} MB table; counts + 8 B aux out")
+lib.hs_exclusive_scan_i64(dev.stream, counts.data_ptr(), N, ost.data_ptr(), sws.data_ptr())
+nout3 = int(ost[N].item()); assert nout3 == nout, (nout3, nout)
+ms_f = timed(lambda: lib.hs_join_dense_fill(dev.stream, N, hrows.data_ptr(), aux.data_ptr(), ost.data_ptr(), ol.data_ptr(), orr.data_ptr()))
+report("A8 hs_join_dense_fill (after the hashed count)", ms_f, N * (8 + 4) + nout * 16, f"{nout} pairs")
+report("A8 hashed count + fill", ms_c + ms_f, N * (4 + 8 + 8 + 8) + N * (8 + 4) + nout * 16)
+assert dev.read_flags() == 0
+
 # A5 global-tier group build + fold (high cardinality)
 ng_keys = torch.randint(0, N // 16, (N,), dtype=torch.int32, device="cuda", generator=g)
 gcol = DCol(hs.I32, ng_keys, N)

@@ -27,7 +27,7 @@ for _ in range(8):
     frame.collect()
 torch.cuda.synchronize()
 lib = engine.dev._raw_lib
-buf = np.zeros((1 << 16, 8), dtype=np.int64)
+buf = np.zeros((1 << 16, 16), dtype=np.int64)
 n = int(lib.hs_agg_debug_scan_stamps(buf.ctypes.data, buf.shape[0]))
 st = buf[:n]
 print(f"sf={sf:g}: {n} workgroups, scan kernel (events) {engine.dev.scan_kernel_ms() * 1e3:.1f} us, launch {engine.dev.last_scan}")
@@ -48,9 +48,22 @@ print(f"entry -> early-exit check done    {q(t[:, 1] - t[:, 0])}")
 print(f"check -> tables initialised       {q(t[:, 2] - t[:, 1])}")
 print(f"streaming loop                    {q(t[:, 3] - t[:, 2])}")
 print(f"loop end (since first entry)      {q(t[:, 3])}")
-print(f"table reduction + partial stores  {q(t[:, 4] - t[:, 3])}")
+t14 = st[:, 14].astype(np.float64) / 100.0 - t0
+print(f"wave 0 done -> all waves done     {q(t14 - t[:, 3])}")
+print(f"table reduction + partial stores  {q(t[:, 4] - t14)}")
 print(f"drain + arrival count             {q(t[:, 5] - t[:, 4])}")
 print(f"unit combine (last arrivers only) {q((t[:, 6] - t[:, 5])[(t[:, 6] - t[:, 5]) > 0.5]) if ((t[:, 6] - t[:, 5]) > 0.5).any() else '-'}")
+last = (t[:, 6] - t[:, 5]) > 0.5
+if last.any():
+    c = st[last][:, 8:14].astype(np.float64) / 100.0 - t0
+    e5 = t[last, 5]
+    print(f"  combine: tables initialised     {q(c[:, 0] - e5)}")
+    print(f"  combine: loads + entries filed  {q(c[:, 1] - c[:, 0])}")
+    print(f"  combine: partials staged        {q(c[:, 2] - c[:, 1])}")
+    print(f"  combine: first batch folded     {q(c[:, 3] - c[:, 2])}")
+    print(f"  combine: further batches        {q(c[:, 4] - c[:, 3])}")
+    print(f"  combine: rows written           {q(c[:, 5] - c[:, 4])}")
+    print(f"  combine: to exit                {q(t[last, 6] - c[:, 5])}")
 print(f"exit (since first entry)          {q(t[:, 6])}")
 print(f"tail: last loop end -> last exit  {end - t[:, 3].max():7.1f}")
 xcc = (st[:, 7] >> 32) & 0xF
