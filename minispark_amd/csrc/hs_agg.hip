@@ -312,6 +312,18 @@ struct MergeFlatIn {
     __device__ __forceinline__ int handle(int r) const { return r; }
     __device__ __forceinline__ int row_of(int h) const { return h; }
     __device__ __forceinline__ uint64_t cell_h(int a, int h) const { return cell(a, h); }
+    // the stored kind of fold a's partials, decided once per fold (0: i32, 1: f32, 2: ask per cell), and the typed read
+    __device__ __forceinline__ int kind_of(int a) const {
+        const int k = A.acc_cols[a].kind;
+        return k == HS_I32 ? 0 : k == HS_F32 ? 1 : 2;
+    }
+    __device__ __forceinline__ const void* cell_base(int a) const { return A.acc_cols[a].data; }
+    template <int KIND>
+    __device__ __forceinline__ uint64_t cell_hk(const void* base, int a, int h) const {
+        if constexpr (KIND == 0) return (uint64_t)(int64_t)((const int32_t*)base)[h];
+        else if constexpr (KIND == 1) return hs_d2u((double)((const float*)base)[h]);
+        else return cell(a, h);
+    }
 };
 
 struct AggFinishArgs {
@@ -394,6 +406,13 @@ struct MergeSlabIn {
         const uint8_t* base = V.slabs + A.desc.acc_off[src];
         if (A.desc.acc_kind[src] == HS_I32) return (uint64_t)(int64_t)((const int32_t*)base)[h];
         return hs_d2u((double)((const float*)base)[h]);
+    }
+    __device__ __forceinline__ int kind_of(int a) const { return A.desc.acc_kind[A.fin.fold_src[a]] == HS_I32 ? 0 : 1; }
+    __device__ __forceinline__ const void* cell_base(int a) const { return V.slabs + A.desc.acc_off[A.fin.fold_src[a]]; }
+    template <int KIND>
+    __device__ __forceinline__ uint64_t cell_hk(const void* base, int, int h) const {
+        if constexpr (KIND == 0) return (uint64_t)(int64_t)((const int32_t*)base)[h];
+        else return hs_d2u((double)((const float*)base)[h]);
     }
 };
 
@@ -479,6 +498,44 @@ __device__ __forceinline__ uint64_t hs_fold_bucket_wave(uint32_t op, bool is_int
     exact = __all(ok);
     return hs_d2u(__shfl(incl, HS_WAVE - 1, HS_WAVE));
 }
+
+// One (group, aggregate) of the sort-free merge by ONE lane: the reference's own chain 0 + p(unit 0) + p(unit 1) + ... in unit
+// order (tasks.py:290-292), so there is nothing to verify - the cost is the chain's latency.  The aggregate kind is a template
+// argument and eight units' row handles, then their cells, are read together, which leaves one dependent fold per unit
+// per unit.  Measured (profiles/r04_finish_kernel_phases.txt, fold phase): 3 units 2.0 us, 36 units 6.4 us, 287 units 11.5 us -
+// against 4.6 / 7.0-7.4 / 7.7 us for the lane-group protocol below, whose price is its instruction count (a cold
+// one-workgroup launch pays per instruction fetched), not its length: the chain wins for few units only.
+// A unit without the key contributes the identity (see hs_fold_group_indexed).
+template <uint32_t OP, bool IS_INT, int KIND, class In>
+__device__ __forceinline__ uint64_t hs_fold_units_seq_k(const In& in, const int32_t* M, int cap, int sl, int nord, int a) {
+    const uint64_t ident = hs_acc_identity(OP, IS_INT);
+    const void* base = in.cell_base(a);  // (read once: the argument block lives in LDS, every field is a round trip)
+    const int32_t* Ms = M + sl;
+    uint64_t v = ident;
+    for (int o0 = 0; o0 < nord; o0 += 8) {
+        int h[8];
+        uint64_t x[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int o = o0 + k < nord ? o0 + k : nord - 1;
+            const int got = Ms[o * cap];
+            h[k] = o0 + k < nord ? got : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = in.template cell_hk<KIND>(base, a, h[k] < 0 ? 0 : h[k]);  // (handle 0 = row 0 of slab 0: always there)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v = hs_acc_fold(OP, IS_INT, v, h[k] >= 0 ? x[k] : ident);
+    }
+    return v;
+}
+// (the partials' stored kind picks the loop once: a per-cell kind test kept the eight reads from travelling together)
+template <uint32_t OP, bool IS_INT, class In>
+__device__ __forceinline__ uint64_t hs_fold_units_seq(const In& in, const int32_t* M, int cap, int sl, int nord, int a, int kind) {
+    if (kind == 0) return hs_fold_units_seq_k<OP, IS_INT, 0>(in, M, cap, sl, nord, a);
+    if (kind == 1) return hs_fold_units_seq_k<OP, IS_INT, 1>(in, M, cap, sl, nord, a);
+    return hs_fold_units_seq_k<OP, IS_INT, 2>(in, M, cap, sl, nord, a);
+}
+constexpr int HS_SEQ_FOLD_MAX = 64;  // units up to which a lane's chain beats the lane-group protocol
 
 // The same fold over a sequence given by a functor, by a GROUP of `width` lanes (16, 32 or 64: several folds share a
 // wave when there are more (group, aggregate) pairs than waves, or few positions per fold).  get(i) = cell i of the
@@ -637,6 +694,40 @@ __device__ __forceinline__ int hs_merge_small_core(const In& in, const hs_agg_sp
             HS_STAMP(5);
             HS_STAMP(6);
             const int lane = tid & (HS_WAVE - 1), wv = tid / HS_WAVE, nwv = nthr / HS_WAVE;
+            if (nord <= HS_SEQ_FOLD_MAX) {
+                // round 4: a wave per aggregate (its kind is then wave-uniform: scalar dispatch, no divergence), a lane per
+                // group, the reference's chain; one more wave finds every group's first row (the key's representative)
+                for (int a = wv; a <= NA; a += nwv) {
+                    if (a == NA) {
+                        for (int g = lane; g < ngroups; g += HS_WAVE) {
+                            const int sl = run[g];
+                            int first = -1;
+                            for (int o = 0; o < nord && first < 0; ++o) first = M[o * cap + sl];
+                            out_rep[g] = first >= 0 ? in.row_of(first) : -1;
+                        }
+                        continue;
+                    }
+                    const uint32_t op = (uint32_t)__builtin_amdgcn_readfirstlane((int)spec.op[a]);
+                    const bool is_int = __builtin_amdgcn_readfirstlane((int)spec.is_int[a]) != 0;
+                    const int kind = __builtin_amdgcn_readfirstlane(in.kind_of(a));
+                    for (int g = lane; g < ngroups; g += HS_WAVE) {
+                        const int sl = run[g];
+                        uint64_t v;
+                        if (is_int) {
+                            if (op == HS_AGG_SUM) v = hs_fold_units_seq<HS_AGG_SUM, true>(in, M, cap, sl, nord, a, kind);
+                            else if (op == HS_AGG_MIN) v = hs_fold_units_seq<HS_AGG_MIN, true>(in, M, cap, sl, nord, a, kind);
+                            else v = hs_fold_units_seq<HS_AGG_MAX, true>(in, M, cap, sl, nord, a, kind);
+                        } else {
+                            if (op == HS_AGG_SUM) v = hs_fold_units_seq<HS_AGG_SUM, false>(in, M, cap, sl, nord, a, kind);
+                            else if (op == HS_AGG_MIN) v = hs_fold_units_seq<HS_AGG_MIN, false>(in, M, cap, sl, nord, a, kind);
+                            else v = hs_fold_units_seq<HS_AGG_MAX, false>(in, M, cap, sl, nord, a, kind);
+                        }
+                        out_acc[(int64_t)a * cap + g] = v;
+                    }
+                }
+                HS_STAMP(7);
+                return ngroups;
+            }
             // One fold per (group, aggregate), by a lane group of 16 / 32 / 64 lanes: as wide as possible while all folds
             // still fit one round of the workgroup's waves, and no wider than the sequence is long.  A further task per
             // group finds its first row (the representative the key is copied from).

@@ -38,7 +38,7 @@ def _query(api, path):
         F.min(C("i")).alias("mn_i"), F.max(C("i")).alias("mx_i"), F.count())
 
 
-@pytest.mark.parametrize(("blocks", "rows_per_block"), [(150, 300), (40, 1000), (333, 64)])
+@pytest.mark.parametrize(("blocks", "rows_per_block"), [(150, 300), (40, 1000), (333, 64), (600, 40), (30, 900)])  # <= 64 units: a lane per (group, aggregate) runs the chain; more: the lane-group protocol
 def test_long_buckets_fold_like_the_reference(tmp_path, blocks, rows_per_block):
     import struct
 
