@@ -1729,7 +1729,7 @@ extern "C" int hs_expand_by_bounds(void* stream, const int64_t* bounds, const in
 //      included) leaves with coalesced stores.
 // The probe is then one or two adjacent 4-byte reads per row (starts[s], starts[s + 1]) instead of a hash probe over
 // three arrays: count -> exclusive scan -> fill, pairs ordered by probe row, then build row (tasks.py:224-240).
-constexpr int JD_MAX_L = 13;  // slots of one partition: 2^L cursors + 2^L first rows (uint32) in LDS per wave (64 KB at most)
+constexpr int JD_MAX_L = 13;  // slots of one partition: 2^L cursors + 2^L first rows (uint32) + 2^L tag bytes in LDS per wave (72 KB at most)
 constexpr uint32_t JD_EMPTY = 0xffffffffu;  // slot word: no build row has this key
 constexpr uint32_t JD_MULTI = 0x80000000u;  // slot word: several - the low 31 bits are the start of the key's list in rows[]
 
@@ -1751,8 +1751,9 @@ __global__ void __launch_bounds__(256) k_jd_assemble(const JdAssemble A) {
     extern __shared__ __align__(16) uint32_t jd_lds[];
     const int lane = threadIdx.x & (HS_WAVE - 1), w = threadIdx.x / HS_WAVE, wpb = blockDim.x / HS_WAVE;
     const int W = 1 << A.L;
-    uint32_t* cur = jd_lds + (size_t)w * 2 * W;  // counts, then list cursors
+    uint32_t* cur = jd_lds + (size_t)w * (2 * W + W / 4);  // counts, then list cursors
     uint32_t* head = cur + W;                    // the first (= lowest) build row of every slot
+    uint8_t* tag = (uint8_t*)(head + W);         // placement: the lane that came by last in this step
     const uint64_t below = (1ull << lane) - 1ull;
     const int per = W / HS_WAVE;  // consecutive slots of a lane in the scan (W >= 64)
     const uint32_t wmask = (uint32_t)(W - 1), kmin = (uint32_t)A.key_min;
@@ -1794,7 +1795,10 @@ __global__ void __launch_bounds__(256) k_jd_assemble(const JdAssemble A) {
             run += c;
         }
         rx_wave_handover();
-        // ordered placement: tuples arrive in row order; within a step, equal slots take consecutive places in lane order
+        // ordered placement: tuples arrive in row order; within a step, equal slots take consecutive places in lane order.
+        // Usually the 64 tuples of a step fall into 64 DIFFERENT slots (unique or nearly unique build keys): every lane
+        // leaves its number in a tag byte of its slot and reads it back - all lanes find their own: no ranking needed (the
+        // ten ballots per step were a third of this kernel).
         nkey = b + lane < e ? A.keys[b + lane] : 0;
         uint32_t nrow = b + lane < e ? A.rows[b + lane] : 0u;
         for (int64_t base = b; base < e; base += HS_WAVE) {
@@ -1805,6 +1809,20 @@ __global__ void __launch_bounds__(256) k_jd_assemble(const JdAssemble A) {
                 nkey = A.keys[base + HS_WAVE + lane];
                 nrow = A.rows[base + HS_WAVE + lane];
             }
+            if (valid) tag[s] = (uint8_t)lane;
+            rx_wave_handover();
+            const bool shared_slot = valid && tag[s] != (uint8_t)lane;
+            const uint32_t at = valid ? cur[s] : 0u;
+            const uint32_t first = valid ? head[s] : 0u;
+            if (__ballot(shared_slot) == 0) {  // wave-uniform
+                if (valid) {
+                    A.out_rows[b + at] = row;
+                    cur[s] = at + 1u;
+                    if (first == JD_EMPTY) head[s] = row;
+                }
+                rx_wave_handover();
+                continue;
+            }
             uint64_t peers = __ballot(valid);
             for (int bit = 0; bit < A.L; ++bit) {
                 const bool on = (s >> bit) & 1u;
@@ -1812,8 +1830,6 @@ __global__ void __launch_bounds__(256) k_jd_assemble(const JdAssemble A) {
                 peers &= on ? bal : ~bal;
             }
             const uint32_t rank = (uint32_t)__popcll(peers & below);
-            const uint32_t at = valid ? cur[s] : 0u;
-            const uint32_t first = valid ? head[s] : 0u;
             rx_wave_handover();  // every lane has read its slot's cursor before a leader moves it
             if (valid) {
                 A.out_rows[b + at + rank] = row;
@@ -1984,13 +2000,13 @@ extern "C" int hs_join_dense_build(void* stream_, const int32_t* build_keys, int
     A.list_count = list_count;
     A.n = n;
     A.flags = flags;
-    const size_t per_wave = (size_t)8 << Y.L;
+    const size_t per_wave = (size_t)9 << Y.L;  // cursors + first rows (uint32) + tag bytes
     int wpb = (int)(65536 / per_wave);
     wpb = wpb < 1 ? 1 : (wpb > 4 ? 4 : wpb);
     int64_t g = (A.parts + wpb - 1) / wpb;
     if (g > 256 * 32) g = 256 * 32;
     static unsigned long long attr_set = 0;
-    if (hs_first_on_device(attr_set)) (void)hipFuncSetAttribute((const void*)k_jd_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    if (hs_first_on_device(attr_set)) (void)hipFuncSetAttribute((const void*)k_jd_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, 9 << JD_MAX_L);
     hipLaunchKernelGGL(k_jd_assemble, dim3((unsigned)g), dim3(HS_WAVE * wpb), per_wave * wpb, stream, A);
     RX_CHECK_LAUNCH("hs_join_dense_build (assemble)");
     return HS_OK;
@@ -2162,6 +2178,8 @@ struct JhAssemble {
     uint2* table;              // [windows << JH_L] {key, word}
     uint32_t* out_rows;        // [n]: build rows window by window, slot by slot, ascending within a slot
     uint32_t* list_count;      // [n]: at the start of a list of several rows, its length
+    uint16_t* slot_of;         // [n] scratch: the slot every tuple found in the counting pass (the placement pass reads it back
+                               // with coalesced loads instead of walking the LDS window again)
     uint32_t* flags;
 };
 
@@ -2188,9 +2206,10 @@ __global__ void __launch_bounds__(256) k_jh_assemble(const JhAssemble A) {
     extern __shared__ __align__(16) uint64_t jh_lds[];
     constexpr int W = 1 << JH_L, per = W / HS_WAVE;
     const int lane = threadIdx.x & (HS_WAVE - 1), w = threadIdx.x / HS_WAVE, wpb = blockDim.x / HS_WAVE;
-    uint64_t* cell = jh_lds + (size_t)w * 2 * W;   // key cells
+    uint64_t* cell = jh_lds + (size_t)w * (2 * W + W / 8);   // key cells
     uint32_t* cur = (uint32_t*)(cell + W);         // counts, then list cursors
     uint32_t* head = cur + W;                      // the first (= lowest) build row of every slot
+    uint8_t* tag = (uint8_t*)(head + W);           // placement: the lane that came by last in this step
     const uint64_t below = (1ull << lane) - 1ull;
     uint32_t err = 0;
     for (int64_t p = (int64_t)blockIdx.x * wpb + w; p < A.parts; p += (int64_t)gridDim.x * wpb) {
@@ -2215,6 +2234,7 @@ __global__ void __launch_bounds__(256) k_jh_assemble(const JhAssemble A) {
                 const int s = jh_slot<true>(cell, key, rx_mix32(key));
                 if (s < 0) full = true;
                 else atomicAdd(&cur[s], 1u);
+                A.slot_of[base + lane] = (uint16_t)s;
             }
         }
         rx_wave_handover();
@@ -2237,16 +2257,29 @@ __global__ void __launch_bounds__(256) k_jh_assemble(const JhAssemble A) {
             run += c;
         }
         rx_wave_handover();
-        nkey = b + lane < e ? A.keys[b + lane] : 0;
+        uint32_t nslot = b + lane < e ? A.slot_of[b + lane] : 0u;
         uint32_t nrow = b + lane < e ? A.rows[b + lane] : 0u;
         for (int64_t base = b; base < e; base += HS_WAVE) {  // ordered placement (see k_jd_assemble)
             const bool valid = base + lane < e;
-            const uint32_t key = (uint32_t)nkey, row = nrow;
+            const uint32_t s = nslot, row = nrow;
             if (base + HS_WAVE + lane < e) {
-                nkey = A.keys[base + HS_WAVE + lane];
+                nslot = A.slot_of[base + HS_WAVE + lane];
                 nrow = A.rows[base + HS_WAVE + lane];
             }
-            const uint32_t s = valid ? (uint32_t)jh_slot<false>(cell, key, rx_mix32(key)) : 0u;
+            if (valid) tag[s] = (uint8_t)lane;
+            rx_wave_handover();
+            const bool shared_slot = valid && tag[s] != (uint8_t)lane;
+            const uint32_t at = valid ? cur[s] : 0u;
+            const uint32_t first = valid ? head[s] : 0u;
+            if (__ballot(shared_slot) == 0) {  // (wave-uniform) 64 different slots: nothing to rank
+                if (valid) {
+                    A.out_rows[b + at] = row;
+                    cur[s] = at + 1u;
+                    if (first == JD_EMPTY) head[s] = row;
+                }
+                rx_wave_handover();
+                continue;
+            }
             uint64_t peers = __ballot(valid);
             for (int bit = 0; bit < JH_L; ++bit) {
                 const bool on = (s >> bit) & 1u;
@@ -2254,8 +2287,6 @@ __global__ void __launch_bounds__(256) k_jh_assemble(const JhAssemble A) {
                 peers &= on ? bal : ~bal;
             }
             const uint32_t rank = (uint32_t)__popcll(peers & below);
-            const uint32_t at = valid ? cur[s] : 0u;
-            const uint32_t first = valid ? head[s] : 0u;
             rx_wave_handover();
             if (valid) {
                 A.out_rows[b + at + rank] = row;
@@ -2284,7 +2315,7 @@ __global__ void __launch_bounds__(256) k_jh_assemble(const JhAssemble A) {
 }
 
 struct JhLayout {
-    size_t keys_a, rows_a, keys_b, rows_b, iota, seg0, seg1, seg2, tb0, tb1, cnt, scan, scan_ws, total;
+    size_t keys_a, rows_a, keys_b, rows_b, iota, slot_of, seg0, seg1, seg2, tb0, tb1, cnt, scan, scan_ws, total;
     int64_t tiles1, tiles2, nseg1, parts, counters, windows;
     int bits1, bits2;
 };
@@ -2313,6 +2344,7 @@ static bool jh_layout(int64_t n, JhLayout& Y) {
     Y.keys_b = take(Y.bits2 ? (size_t)n * 4 + 64 : 0);
     Y.rows_b = take(Y.bits2 ? (size_t)n * 4 + 64 : 0);
     Y.iota = take(Y.bits1 ? 64 : (size_t)n * 4 + 64);
+    Y.slot_of = take((size_t)n * 2 + 64);
     Y.seg0 = take(16);
     Y.seg1 = take((size_t)(Y.nseg1 + 1) * 8);
     Y.seg2 = take((size_t)(Y.parts + 1) * 8);
@@ -2408,8 +2440,9 @@ extern "C" int hs_join_hash_build(void* stream_, const int32_t* build_keys, int6
     A.table = (uint2*)table;
     A.out_rows = rows;
     A.list_count = list_count;
+    A.slot_of = (uint16_t*)(ws + Y.slot_of);
     A.flags = flags;
-    constexpr size_t per_wave = (size_t)16 << JH_L;
+    constexpr size_t per_wave = (size_t)17 << JH_L;  // key cells (8 B) + cursors + first rows (4 B each) + tag bytes
     constexpr int wpb = 4;
     int64_t g = (A.parts + wpb - 1) / wpb;
     if (g > 256 * 32) g = 256 * 32;
