@@ -1350,7 +1350,7 @@ extern "C" int hs_group_radix_plan(int32_t key_kind, int64_t n, int32_t n_units,
     take(PL_OFF_PACC, (size_t)NA * rx_align((size_t)n * f[PL_OSIZE]));
     take(PL_OFF_PCOUNT, (size_t)f[PL_PARTS] * 8);
     take(PL_OFF_PSCAN, (size_t)(f[PL_PARTS] + 1) * 8);
-    take(PL_OFF_OVERFLOW, (size_t)(f[PL_PARTS] + 1) * 8);
+    take(PL_OFF_OVERFLOW, (size_t)(f[PL_PARTS] + 1) * 16);  // two lists: past the 256-slot tables, past the 512-slot tables
     f[PL_WS] = (int64_t)off;
     return HS_OK;
 }
@@ -1464,7 +1464,9 @@ extern "C" int hs_group_radix_run(void* stream_, const hs_radix_plan* plan, cons
     static const bool stamps = getenv("HIPSPARK_RADIX_STAMPS") != nullptr;
     G.debug = stamps ? 1 : 0;
     int64_t* overflow = (int64_t*)(ws + f[PL_OFF_OVERFLOW]);  // [0] = count, [1 ..] = partitions
+    int64_t* overflow2 = overflow + f[PL_PARTS] + 1;           // the same for the next table size
     hs_memset_async(overflow, 0, 8, stream);
+    hs_memset_async(overflow2, 0, 8, stream);
     // every aggregate a SUM over an f32 / i32 column or an integer constant: the specialised fold (k_rx_fold_sum)
     int sum_cls = NA >= 1 && NA <= 3 ? 0 : -1;
     for (int a = 0; a < NA && sum_cls >= 0; ++a) {
@@ -1481,13 +1483,14 @@ extern "C" int hs_group_radix_run(void* stream_, const hs_radix_plan* plan, cons
         hs_set_error("hs_group_radix_run: a wide STRING key needs the SUM-specialised fold");
         return HS_E_LIMIT;
     }
-    auto fold = [&](int cap, bool listed) {
+    // todo: the partitions this launch works on (NULL: all), left: where it notes the ones that outgrow its tables
+    auto fold = [&](int cap, int64_t* todo, int64_t* left) {
         G.cap = cap;
         G.last = cap == (int)f[PL_CAP] ? 1 : 0;
-        G.list = listed ? overflow + 1 : nullptr;
-        G.list_count = listed ? overflow : nullptr;
-        G.overflow = overflow + 1;
-        G.overflow_count = overflow;
+        G.list = todo ? todo + 1 : nullptr;
+        G.list_count = todo;
+        G.overflow = left + 1;
+        G.overflow_count = left;
         const size_t per_wave = ((size_t)cap * ((wide ? 2 : 1) + NA) + (size_t)cap / 4) * 8;
         int wpb = (int)(65536 / per_wave);
         wpb = wpb < 1 ? 1 : (wpb > 4 ? 4 : wpb);
@@ -1555,13 +1558,25 @@ extern "C" int hs_group_radix_run(void* stream_, const hs_radix_plan* plan, cons
         }
 #undef RX_FOLD
     };
-    const int big = (int)f[PL_CAP], small = big > 512 ? 512 : big;
-    if (small < big) {
-        fold(small, false);
+    // Three table sizes, smallest first: a partition is cut to hold ~half the LARGE table's slots in ROWS, and usually holds far
+    // fewer distinct keys.  The fold is a chain of LDS round trips per 64-row step, one wave per partition - what it needs is
+    // waves: 256-slot tables leave room for 28 per CU (512: 16), and a partition that outgrows 3/4 of a table moves to the next
+    // size's list (round 4; 64 Mi rows / 4 Mi groups: fold 0.52 -> see profiles/r04_radix_tier_64M.txt).
+    const int big = (int)f[PL_CAP], small = big > 512 ? 512 : big, tiny = small > 256 ? 256 : small;
+    if (tiny < small) {
+        fold(tiny, nullptr, overflow);
         RX_CHECK_LAUNCH("hs_group_radix_run (fold)");
-        fold(big, true);
+        fold(small, overflow, overflow2);
+        if (small < big) {
+            RX_CHECK_LAUNCH("hs_group_radix_run (fold)");
+            fold(big, overflow2, overflow2);
+        }
+    } else if (small < big) {
+        fold(small, nullptr, overflow);
+        RX_CHECK_LAUNCH("hs_group_radix_run (fold)");
+        fold(big, overflow, overflow);
     } else {
-        fold(big, false);  // nothing can overflow into a list: a full table raises HS_FLAG_DICT_FULL ...
+        fold(big, nullptr, overflow);  // nothing can overflow into a list: a full table raises HS_FLAG_DICT_FULL ...
     }
     RX_CHECK_LAUNCH("hs_group_radix_run (fold)");
     int64_t* pscan = (int64_t*)(ws + f[PL_OFF_PSCAN]);
