@@ -434,8 +434,8 @@ int hs_join_dense_fill(void* stream, int64_t n_probe, const uint32_t* rows, cons
                        int64_t* out_left, int64_t* out_right);
 /* ---- the general inner join on ANY INTEGER keys (round 4; csrc/hs_radix.hip) -------------------------------------------
  * The same reference loop (tasks.py:201-240) for keys the dense form does not hold: a sparse or huge key range, negative
- * keys.  table = hs_join_hash_slots(n_build) 8-byte slots {key, word} (word as in the dense form), cut into windows of 1024
- * slots; a key hashes to ONE window and probes linearly inside it.  Build: two stable partition passes bring the (key, row)
+ * keys.  table = hs_join_hash_slots(n_build) 8-byte slots {key, word} (word as in the dense form), cut into windows of 512
+ * slots (1024 past 19 M build rows); a key hashes to ONE window and probes linearly inside it.  Build: two stable partition passes bring the (key, row)
  * tuples into window order, one wave per window inserts / counts / scans / places them in LDS and stores the finished window
  * with coalesced stores - no global atomic, no scattered store, lists ascending without a sort.  hs_join_hash_count: one
  * scattered 8-byte read per probe row in the usual case (~1.7 slots from the start at the table's load of 0.57, nearly always

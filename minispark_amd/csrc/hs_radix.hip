@@ -1887,8 +1887,8 @@ __global__ void __launch_bounds__(256) k_jd_setup(uint32_t* iota, int64_t n_iota
 static void jd_geometry(int64_t slots, int& L, int& bits1, int& bits2) {
     int S = 0;
     while (S < 31 && ((int64_t)1 << S) < slots) ++S;
-    L = 10;
-    if (S - L > 2 * RX_MAX_BITS) L = S - 2 * RX_MAX_BITS;
+    L = 9;  // 512 slots: 4.5 KB of LDS per wave in the assembly (it runs on the number of waves a CU holds) ...
+    if (S - L > 2 * RX_MAX_BITS) L = S - 2 * RX_MAX_BITS;  // ... more when 65 536 partitions would not cover the range
     const int bits = S > L ? S - L : 0;
     bits1 = bits <= RX_MAX_BITS ? bits : (bits + 1) / 2;
     bits2 = bits - bits1;
@@ -2177,11 +2177,14 @@ extern "C" int hs_join_dense_fill(void* stream, int64_t n_probe, const uint32_t*
 //     present key sits 1.7 slots from its start on average - the same 64-byte line nearly always).
 // The slot word is the dense form's (JD_EMPTY / the one build row / JD_MULTI + list start), rows[] and list_count[] too, so
 // the probe's second pass IS hs_join_dense_fill.
-constexpr int JH_L = 10;                       // slots per window: 8 KB of keys + 8 KB of cursors / first rows in LDS per wave
+// slots per window, log2: 512 (8.5 KB of LDS per wave: key cells, cursors, first rows, tag bytes - 18 waves per CU) while
+// 65 536 windows hold the build side (19 M rows), else 1024 (17 KB: 9 waves per CU; 38 M rows).  The assembly is a chain of LDS
+// round trips per 64-tuple step, one wave per window: it runs on the number of waves a CU holds.
+constexpr int JH_L_SMALL = 9, JH_L_LARGE = 10;
 constexpr uint64_t JH_FREE = ~0ull;            // LDS key cell: nobody here yet (a key occupies the low 32 bits only)
 
-static int64_t jh_windows(int64_t n_build) {   // ~1.75 slots per build row: distinct keys <= rows
-    const int64_t w = (n_build * 7 / 4 + (1 << JH_L) - 1) >> JH_L;
+static int64_t jh_windows(int64_t n_build, int L) {   // ~1.75 slots per build row: distinct keys <= rows
+    const int64_t w = (n_build * 7 / 4 + ((int64_t)1 << L) - 1) >> L;
     return w < 1 ? 1 : w;
 }
 
@@ -2190,7 +2193,7 @@ struct JhAssemble {
     int64_t parts, windows;
     const int32_t* keys;       // tuples, window by window, in row order inside a window
     const uint32_t* rows;
-    uint2* table;              // [windows << JH_L] {key, word}
+    uint2* table;              // [windows << L] {key, word}
     uint32_t* out_rows;        // [n]: build rows window by window, slot by slot, ascending within a slot
     uint32_t* list_count;      // [n]: at the start of a list of several rows, its length
     uint16_t* slot_of;         // [n] scratch: the slot every tuple found in the counting pass (the placement pass reads it back
@@ -2200,7 +2203,7 @@ struct JhAssemble {
 
 // slot of `key` in the wave's LDS window, claiming a free cell on the way when INSERT; -1: the window is full (more
 // distinct keys than slots - jh_windows leaves 1.75x room over the AVERAGE window; the caller falls back)
-template <bool INSERT>
+template <bool INSERT, int JH_L>
 __device__ __forceinline__ int jh_slot(uint64_t* cell, uint32_t key, uint32_t start) {
     constexpr uint32_t wmask = (1u << JH_L) - 1u;
     uint32_t s = start & wmask;
@@ -2217,6 +2220,7 @@ __device__ __forceinline__ int jh_slot(uint64_t* cell, uint32_t key, uint32_t st
     return -1;
 }
 
+template <int JH_L>
 __global__ void __launch_bounds__(256) k_jh_assemble(const JhAssemble A) {
     extern __shared__ __align__(16) uint64_t jh_lds[];
     constexpr int W = 1 << JH_L, per = W / HS_WAVE;
@@ -2246,7 +2250,7 @@ __global__ void __launch_bounds__(256) k_jh_assemble(const JhAssemble A) {
             const bool valid = base + lane < e;
             if (base + HS_WAVE + lane < e) nkey = A.keys[base + HS_WAVE + lane];
             if (valid) {
-                const int s = jh_slot<true>(cell, key, rx_mix32(key));
+                const int s = jh_slot<true, JH_L>(cell, key, rx_mix32(key));
                 if (s < 0) full = true;
                 else atomicAdd(&cur[s], 1u);
                 A.slot_of[base + lane] = (uint16_t)s;
@@ -2332,11 +2336,12 @@ __global__ void __launch_bounds__(256) k_jh_assemble(const JhAssemble A) {
 struct JhLayout {
     size_t keys_a, rows_a, keys_b, rows_b, iota, slot_of, seg0, seg1, seg2, tb0, tb1, cnt, scan, scan_ws, total;
     int64_t tiles1, tiles2, nseg1, parts, counters, windows;
-    int bits1, bits2;
+    int bits1, bits2, L;
 };
 static bool jh_layout(int64_t n, JhLayout& Y) {
     if (n < 0 || n >= 0x7fffffffll) return false;  // a slot word holds a row in 31 bits
-    Y.windows = jh_windows(n);
+    Y.L = jh_windows(n, JH_L_SMALL) <= ((int64_t)1 << (2 * RX_MAX_BITS)) ? JH_L_SMALL : JH_L_LARGE;
+    Y.windows = jh_windows(n, Y.L);
     int bits = 0;
     while (((int64_t)1 << bits) < Y.windows) ++bits;
     if (bits > 2 * RX_MAX_BITS) return false;  // 65 536 windows = 38 M build rows per call
@@ -2378,7 +2383,7 @@ extern "C" size_t hs_join_hash_ws_bytes(int64_t n_build) {
 }
 extern "C" int64_t hs_join_hash_slots(int64_t n_build) {
     JhLayout Y;
-    return jh_layout(n_build, Y) ? Y.windows << JH_L : 0;
+    return jh_layout(n_build, Y) ? Y.windows << Y.L : 0;
 }
 
 extern "C" int hs_join_hash_build(void* stream_, const int32_t* build_keys, int64_t n_build, void* table, uint32_t* rows,
@@ -2457,13 +2462,15 @@ extern "C" int hs_join_hash_build(void* stream_, const int32_t* build_keys, int6
     A.list_count = list_count;
     A.slot_of = (uint16_t*)(ws + Y.slot_of);
     A.flags = flags;
-    constexpr size_t per_wave = (size_t)17 << JH_L;  // key cells (8 B) + cursors + first rows (4 B each) + tag bytes
+    const size_t per_wave = (size_t)17 << Y.L;  // key cells (8 B) + cursors + first rows (4 B each) + tag bytes
     constexpr int wpb = 4;
     int64_t g = (A.parts + wpb - 1) / wpb;
     if (g > 256 * 32) g = 256 * 32;
     static unsigned long long attr_set = 0;
-    if (hs_first_on_device(attr_set)) (void)hipFuncSetAttribute((const void*)k_jh_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(per_wave * wpb));
-    hipLaunchKernelGGL(k_jh_assemble, dim3((unsigned)g), dim3(HS_WAVE * wpb), per_wave * wpb, stream, A);
+    if (hs_first_on_device(attr_set))
+        (void)hipFuncSetAttribute((const void*)k_jh_assemble<JH_L_LARGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (17 << JH_L_LARGE) * wpb);
+    if (Y.L == JH_L_SMALL) hipLaunchKernelGGL(k_jh_assemble<JH_L_SMALL>, dim3((unsigned)g), dim3(HS_WAVE * wpb), per_wave * wpb, stream, A);
+    else hipLaunchKernelGGL(k_jh_assemble<JH_L_LARGE>, dim3((unsigned)g), dim3(HS_WAVE * wpb), per_wave * wpb, stream, A);
     RX_CHECK_LAUNCH("hs_join_hash_build (assemble)");
     return HS_OK;
 }
@@ -2481,6 +2488,7 @@ struct JhProbe {
 
 // Probe, pass 1 (the hashed twin of k_jd_count): four keys per lane, their first slots in flight together; a slot that
 // holds another key sends the lane to the next one of the window.  counts / aux as hs_join_dense_count writes them.
+template <int JH_L>
 __global__ void __launch_bounds__(256) k_jh_count(const JhProbe A) {
     constexpr uint32_t wmask = (1u << JH_L) - 1u;
     const int64_t nq = (A.n + 3) / 4;
@@ -2545,7 +2553,8 @@ extern "C" int hs_join_hash_count(void* stream, const int32_t* probe_keys, int64
     JhProbe A{probe_keys, n_probe, (uint32_t)Y.windows, 0, (const uint2*)table, rows, list_count, counts, (uint32_t*)aux};
     int64_t g = ((n_probe + 3) / 4 + 255) / 256;
     if (g > 256 * 64) g = 256 * 64;
-    hipLaunchKernelGGL(k_jh_count, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, A);
+    if (Y.L == JH_L_SMALL) hipLaunchKernelGGL(k_jh_count<JH_L_SMALL>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, A);
+    else hipLaunchKernelGGL(k_jh_count<JH_L_LARGE>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, A);
     RX_CHECK_LAUNCH("hs_join_hash_count");
     return HS_OK;
 }

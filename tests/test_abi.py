@@ -77,11 +77,12 @@ def test_shared_tier_geometry_fits_its_rounds_of_workgroups():
 
 def test_join_table_geometries_without_a_gpu():
     """The partitioned joins size their tables and workspaces on the host: the hashed form leaves ~1.75 slots per build row
-    in whole 1024-slot windows and holds up to 65 536 windows; the dense form refuses key ranges past 2^29 slots."""
+    in whole windows (512 slots while 65 536 windows hold the build side, else 1024); the dense form refuses key ranges past
+    2^29 slots."""
     lib = hs.load_library()
     for n in (0, 1, 585, 586, 1_000_000, 16 * 1024 * 1024, 38_000_000):
         slots = lib.hs_join_hash_slots(n)
-        assert slots % 1024 == 0 and slots >= max(1024, n * 7 // 4), (n, slots)
+        assert slots % 512 == 0 and slots >= max(512, n * 7 // 4), (n, slots)
         assert slots <= n * 7 // 4 + 1024
         assert lib.hs_join_hash_ws_bytes(n) >= 2 * n  # (at least the slot scratch)
     assert lib.hs_join_hash_slots(40_000_000) == 0 and lib.hs_join_hash_ws_bytes(40_000_000) == 0

@@ -220,7 +220,7 @@ def test_dense_integer_join_matches_reference_order(dev, n_left, n_right, spread
                                                  (2_000_000, 3_000_000, 4), (9_000_000, 1_000_000, 5)])
 def test_sparse_integer_join_takes_the_hash_windows_and_matches_reference_order(dev, n_left, n_right, seed):
     """Round 4: INTEGER keys that are NOT dense (the whole int32 range, negative values) take hs_join_hash_* - the build
-    rows moved into hash-window order by zero / one / two stable partition passes, every 1024-slot window of the {key, word}
+    rows moved into hash-window order by zero / one / two stable partition passes, every 512-slot window of the {key, word}
     table assembled in LDS, probe by one 8-byte slot read, second pass shared with the dense form.  Duplicates on both sides
     (one key many times), probe keys without a partner, INT32_MIN / INT32_MAX / 0 / -1 as keys: pairs must come out ordered by
     right row, then left row ascending (reference tasks.py:224-240)."""
@@ -256,7 +256,7 @@ def test_sparse_integer_join_takes_the_hash_windows_and_matches_reference_order(
 
 
 def test_a_hash_window_that_overflows_hands_the_join_to_the_global_table(dev):
-    """More distinct keys in ONE 1024-slot window than it has slots (keys picked by brute force to share a window - a
+    """More distinct keys in ONE 512-slot window than it has slots (keys picked by brute force to share a window - a
     degenerate hash, not a data pattern): the build leaves that window empty and says so, the engine's join falls back to
     hs_join_build and the pairs are still the reference's."""
     from minispark_amd.constants import ColumnType
@@ -269,7 +269,7 @@ def test_a_hash_window_that_overflows_hands_the_join_to_the_global_table(dev):
         return h ^ (h >> np.uint64(16))
 
     n_left = 4000
-    windows = (n_left * 7 // 4 + 1023) >> 10
+    windows = (n_left * 7 // 4 + 511) >> 9  # (tables of up to 19 M build rows are cut into 512-slot windows)
     cand = np.arange(0, 4_000_000, dtype=np.int64)
     in_window_0 = cand[((mix32(cand) * np.uint64(windows)) >> np.uint64(32)) == 0]
     assert len(in_window_0) >= 1100
