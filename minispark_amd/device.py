@@ -260,6 +260,7 @@ class Device:
         self.rec: Recording | None = None
         self.scan_events = None
         self.exchange_events = None
+        self.exchange_begins_at_scan_end = False  # the slab exchange's begin event is the timed scan launch's end event
         self.join_events = None
 
     def native_engine(self) -> Any:
@@ -340,7 +341,8 @@ class Device:
         for ev in self.exchange_events:
             ev.synchronize()
         ev = self.exchange_events
-        return ev[0].elapsed_time(ev[1]) + ev[2].elapsed_time(ev[3])
+        begin = self.scan_events[1] if self.exchange_begins_at_scan_end and self.scan_events is not None else ev[0]
+        return begin.elapsed_time(ev[1]) + ev[2].elapsed_time(ev[3])
 
     def time_join(self, enable: bool = True) -> None:
         """Bracket the in-place join operator (table build + probe) of every following query with events on the
