@@ -99,6 +99,24 @@ __global__ __launch_bounds__(256) void k_read(Cols c, int64_t rows, int steps, d
     if ((threadIdx.x & 63) == 0) atomicAdd(&out[blockIdx.x & 1023], acc);
 }
 
+// ONE stream of the same number of bytes: does reading seven columns side by side cost anything against the plainest read?
+__global__ __launch_bounds__(256) void k_read_one(const f32x4* p, int64_t n16, int steps, double* out) {
+    const int64_t stride = 256;
+    const int64_t c0 = (int64_t)blockIdx.x * steps * stride * 6;
+    int64_t c1 = c0 + (int64_t)steps * stride * 6;
+    if (c1 > n16) c1 = n16;
+    double acc = 0;
+    for (int64_t base = c0 + threadIdx.x; base < c1; base += stride * 6) {
+        f32x4 v[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v[k] = base + k * stride < c1 ? __builtin_nontemporal_load(p + base + k * stride) : f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc += (double)v[k][0] + (double)v[k][1] + (double)v[k][2] + (double)v[k][3];
+    }
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_down(acc, d);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&out[blockIdx.x & 1023], acc);
+}
+
 template <int DEPTH, bool NT>
 static double run(const Cols& c, int64_t rows, int steps, size_t lds, double* out, hipStream_t s, int reps = 7) {
     CHECK(hipFuncSetAttribute((const void*)k_read<DEPTH, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -165,6 +183,30 @@ int main(int argc, char** argv) {
             if (si == 0 && wgs[w] == 3) ROW(1, false)
             if (si == 0 && wgs[w] == 3) ROW(2, false)
 #undef ROW
+        }
+    }
+    {   // one stream: the four f32 columns are allocated one after the other? no - use the biggest single buffer: ship (8 B/row)
+        const int64_t n16 = padded * 8 / 16;  // 16-byte words of the shipdate column
+        const double gb1 = (double)n16 * 16 / 1e9;
+        for (int steps : {32, 128}) {
+            const int64_t per = (int64_t)steps * 256 * 6;
+            const unsigned grid = (unsigned)((n16 + per - 1) / per);
+            hipEvent_t a, b;
+            CHECK(hipEventCreate(&a));
+            CHECK(hipEventCreate(&b));
+            std::vector<float> ms;
+            for (int r = 0; r < 9; ++r) {
+                CHECK(hipEventRecord(a, s));
+                hipLaunchKernelGGL(k_read_one, dim3(grid), dim3(256), 0, s, (const f32x4*)ship, n16, steps, out);
+                CHECK(hipEventRecord(b, s));
+                CHECK(hipStreamSynchronize(s));
+                float t;
+                CHECK(hipEventElapsedTime(&t, a, b));
+                if (r >= 2) ms.push_back(t);
+            }
+            std::sort(ms.begin(), ms.end());
+            printf("one stream of %.3f GB, 6 x 16 B per lane in flight, %d steps per workgroup: %9.4f ms %10.1f GB/s (%.4f of 8 TB/s)\n", gb1, steps,
+                   ms[ms.size() / 2], gb1 / ms[ms.size() / 2] * 1e3, gb1 / ms[ms.size() / 2] * 1e3 / 8000.0);
         }
     }
     return 0;
