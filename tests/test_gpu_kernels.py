@@ -217,7 +217,8 @@ def test_dense_integer_join_matches_reference_order(dev, n_left, n_right, spread
 
 
 @pytest.mark.parametrize("n_left,n_right,seed", [(1, 5, 0), (700, 5000, 1), (3000, 900, 2), (70_000, 200_000, 3),
-                                                 (2_000_000, 3_000_000, 4), (9_000_000, 1_000_000, 5)])
+                                                 (2_000_000, 3_000_000, 4), (9_000_000, 1_000_000, 5),
+                                                 (20_000_000, 500_000, 6)])  # (past 19 M build rows: 1024-slot windows)
 def test_sparse_integer_join_takes_the_hash_windows_and_matches_reference_order(dev, n_left, n_right, seed):
     """Round 4: INTEGER keys that are NOT dense (the whole int32 range, negative values) take hs_join_hash_* - the build
     rows moved into hash-window order by zero / one / two stable partition passes, every 512-slot window of the {key, word}
